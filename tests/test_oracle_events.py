@@ -1,0 +1,59 @@
+"""The events oracle against the golden vectors produced by the reference's vis.py."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import event_fixture_paths, load_event_fixture
+from oracle import events as oe
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('path', event_fixture_paths(), ids=os.path.basename)
+def test_oracle_matches_reference_fixture(path):
+    ev, shape, kw, exp = load_event_fixture(path)
+    frames, raw, kept = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape,
+                                         return_counts=True, **kw)
+    assert frames.shape[0] == exp['n_frames']
+    assert frames.dtype == np.uint8 and frames.shape[1:] == (*shape, 3)
+    assert sha(raw.astype(np.int32)) == exp['raw_sha256']
+    assert sha(frames) == exp['frames_sha256']
+    if 'frames' in exp:
+        np.testing.assert_array_equal(frames, exp['frames'])
+        np.testing.assert_array_equal(raw, exp['raw'])
+    assert (kept <= raw).all()
+
+
+def test_fixture_count():
+    assert len(event_fixture_paths()) >= 30
+
+
+@pytest.mark.parametrize('tot,N,exp0,exp1', [
+    (5, 10, [0], [5]),                       # fewer than N: one chunk (vis.py:60-61)
+    (10, 10, [0], [10]),
+    (14, 10, [0], [10]),                     # remainder 4 <= N/2 dropped
+    (15, 10, [0], [10]),                     # remainder exactly N/2 dropped
+    (16, 10, [0, 6], [10, 16]),              # remainder > N/2: overlapping last chunk (vis.py:67-69)
+    (30, 10, [0, 10, 20], [10, 20, 30]),
+])
+def test_split_event_count(tot, N, exp0, exp1):
+    i0, i1 = oe.split_event_count(tot, N)
+    assert i0 == exp0 and i1 == exp1
+
+
+def test_out_of_sensor_raises():
+    ev = np.array([[5, 5, 0, 1], [300, 5, 0.1, 1]], dtype=np.float32)
+    with pytest.raises(ValueError):
+        oe.events2frames(ev, 'event_count', 'event_histogram', shape=(36, 52), N=10)
+
+
+def test_numpy_sum_order():
+    # the std() restatement depends on numpy's reduction order staying what it was
+    rng = np.random.default_rng(3)
+    for n in (5, 100, 129, 8192, 8200, 86400):
+        a = rng.random(n) ** 3 * 1e3
+        assert oe.np_sum(a) == a.sum()
