@@ -1,0 +1,89 @@
+"""ctypes binding of libeventclip_hip.so (the C ABI declared in include/eventclip_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the
+callers raise.  torch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeventclip_hip.so')
+
+EC_F16, EC_BF16 = 0, 1
+
+c_void_p, c_int, c_long, c_double, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long,
+                                              ctypes.c_double, ctypes.c_float)
+
+
+class EcFrameStats(ctypes.Structure):
+    _fields_ = [('sum', ctypes.c_uint64), ('sumsq', ctypes.c_uint64), ('nnz', ctypes.c_uint32),
+                ('max_kept', ctypes.c_uint32), ('dropped', ctypes.c_uint32),
+                ('ambiguous', ctypes.c_uint32), ('thr', ctypes.c_double)]
+
+
+class EcEventsParams(ctypes.Structure):
+    _fields_ = [('H', c_int), ('W', c_int), ('thresh', c_double), ('count_non_zero', c_int),
+                ('background_mask', c_int), ('red', ctypes.c_uint8 * 3),
+                ('blue', ctypes.c_uint8 * 3)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check that every
+# symbol of the header is exported.
+SIGNATURES = {
+    'ec_last_error': (ctypes.c_char_p, []),
+    'ec_version': (c_int, []),
+    'ec_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library once.  Raises HipLibraryError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f'{LIB_PATH} is missing: build it with `python -m eventclip_amd.build` '
+                '(hipcc --offload-arch=gfx950).  eventclip_amd has no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().ec_last_error()
+        raise RuntimeError(f'{what or "libeventclip_hip"} failed ({rc}): '
+                           f'{msg.decode() if msg else ""}')
+
+
+def require_gpu():
+    """The device every op runs on; raises when there is none."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HipLibraryError('eventclip_amd needs an MI355X (gfx950) device: '
+                              'torch.cuda.is_available() is False and there is no CPU fallback.')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,341 @@
+// events -> polarity-histogram frames on gfx950.
+//
+// Replaces /root/reference/datasets/vis.py make_event_histogram (:6-41) +
+// parse_events (:44-52) as driven by events2frames (:75-117).
+//
+// One 1024-thread workgroup owns one frame.  The [rows, W, 2] uint32 histogram
+// of a row band lives in LDS (up to 156 KiB of the CU's 160 KiB) and is filled
+// with LDS atomics; a frame that does not fit is walked band by band.  The
+// reference needs two frame-wide reductions before it can colour a pixel (the
+// hot-pixel threshold from mean/std, vis.py:17-24, then the max of what is
+// left, vis.py:27), so a multi-band frame re-bins its events for each of the
+// three passes instead of spilling a histogram to HBM: the events of a frame
+// (16 B each) are re-read from L2/Infinity Cache, HBM sees them once, and the
+// only HBM write is the uint8 frame itself.  Frames that fit one band (N-Cars)
+// bin once.
+//
+// Exactness: counts are integers.  mean/std come from exact integer sums
+// (numpy's float64 pairwise summation agrees to ~1e-15 relative; bins whose
+// count sits within 1e-9 of the threshold are reported in stats.ambiguous).
+// The float stage is the float64 sequence numpy >= 2 executes for
+// vis.py:27-39, including the fused multiply-add of the dgemm behind
+// `hist @ cmap`, with FP contraction disabled everywhere else.
+#include "common.h"
+
+namespace {
+
+constexpr int EV_THREADS = 1024;
+constexpr int EV_WAVES = EV_THREADS / 64;
+constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
+constexpr int EV_SCRATCH_BYTES = 8 * EV_WAVES * 2; // block-reduction scratch (u64 per wave, 2 slots)
+
+struct EvArgs {
+    const float4 *events;
+    const long long *range;  // [F,2]
+    int H, W;
+    double thresh;
+    int count_non_zero, background_mask;
+    double red[3], blue[3];
+    uint8_t *frames;
+    int *raw;
+    int *kept;
+    ec_frame_stats *stats;
+    int rows_per_band, bands;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned t = __shfl_down(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// Sum over the workgroup, result in every thread.  scratch: EV_WAVES u64.
+__device__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum_u64(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < EV_WAVES; w++) t += scratch[w];
+    return t;
+}
+
+__device__ unsigned block_max_u32(unsigned v, unsigned long long *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_max_u32(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    unsigned t = 0;
+#pragma unroll
+    for (int w = 0; w < EV_WAVES; w++) t = scratch[w] > t ? (unsigned)scratch[w] : t;
+    return t;
+}
+
+// vis.py:10-14 restricted to rows [y0, y1): LDS atomics, one per in-band event.
+__device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, int W, unsigned *bins,
+                                        unsigned &dropped)
+{
+    // parse_events, vis.py:50: astype(int32) truncates toward zero
+    const int x = (int)e.x, y = (int)e.y, p = (int)e.w;
+    if (p == 0) return;  // counted in neither channel (vis.py:10,12)
+    if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
+        dropped++;
+        return;
+    }
+    if (y >= y0 && y < y1) atomicAdd(&bins[((y - y0) * W + x) * 2 + (p < 0 ? 1 : 0)], 1u);
+}
+
+__device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, int W, unsigned *bins,
+                         unsigned &dropped)
+{
+    const int nb = (y1 - y0) * W * 2;
+    for (int i = threadIdx.x; i < nb; i += EV_THREADS) bins[i] = 0;
+    __syncthreads();
+    long long i = threadIdx.x;
+    for (; i + 3 * EV_THREADS < n; i += 4 * EV_THREADS) {
+        const float4 e0 = ev[i], e1 = ev[i + EV_THREADS], e2 = ev[i + 2 * EV_THREADS],
+                     e3 = ev[i + 3 * EV_THREADS];
+        bin_one(e0, y0, y1, H, W, bins, dropped);
+        bin_one(e1, y0, y1, H, W, bins, dropped);
+        bin_one(e2, y0, y1, H, W, bins, dropped);
+        bin_one(e3, y0, y1, H, W, bins, dropped);
+    }
+    for (; i < n; i += EV_THREADS) bin_one(ev[i], y0, y1, H, W, bins, dropped);
+    __syncthreads();
+}
+
+// vis.py:27-39 for one pixel, float64, numpy's operation order.
+#pragma clang fp contract(off)
+__device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dmx, const EvArgs &a,
+                                             uint8_t out[3])
+{
+    const double p = (double)(float)c0 / dmx;  // vis.py:27 (astype(float32) then / int64 max)
+    const double q = (double)(float)c1 / dmx;
+    double w = 0.;
+    if (a.background_mask) {                   // vis.py:35
+        w = p + q;
+        if (w < 0.) w = 0.;
+        if (w > 1.) w = 1.;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double t = p * a.red[c];
+        double v = __builtin_fma(q, a.blue[c], t);  // vis.py:31 (dgemm inner product)
+        if (a.background_mask) {                     // vis.py:36-37
+            const double t1 = v * w;
+            const double om = 1. - w;
+            const double t2 = 255. * om;
+            v = t1 + t2;
+        }
+        const double r = __builtin_rint(v);          // vis.py:39, half to even
+        out[c] = (r != r) ? (uint8_t)0 : (uint8_t)(int)r;
+    }
+}
+
+__global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *bins = reinterpret_cast<unsigned *>(smem);
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + EV_BIN_BYTES);
+
+    const int f = blockIdx.x;
+    const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
+    const float4 *ev = a.events + e0;
+    const long long n = e1 - e0;
+    const int H = a.H, W = a.W;
+    const long long M2 = (long long)H * W * 2;
+    const int rpb = a.rows_per_band, bands = a.bands;
+
+    // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
+    unsigned long long s1 = 0, s2 = 0;
+    unsigned nnz = 0, dropped = 0;
+    for (int b = 0; b < bands; b++) {
+        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
+        unsigned dr = 0;
+        bin_band(ev, n, y0, y1, H, W, bins, dr);
+        if (b == 0) dropped = dr;
+        const int nb = (y1 - y0) * W * 2;
+        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
+            const unsigned h = bins[i];
+            s1 += h;
+            s2 += (unsigned long long)h * h;
+            nnz += h > 0;
+            if (a.raw) a.raw[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
+        }
+    }
+    s1 = block_sum_u64(s1, scratch);
+    s2 = block_sum_u64(s2, scratch);
+    nnz = (unsigned)block_sum_u64(nnz, scratch);
+    dropped = (unsigned)block_sum_u64(dropped, scratch);
+
+    // ---- hot-pixel threshold, vis.py:17-24 ----
+    // mean = S1/cnt; sum of squared deviations = S2 - S1^2/cnt = (cnt*S2 - S1^2)/cnt, exact
+    // in 128-bit integers, then numpy's own sequence: /cnt, sqrt, thresh*std + mean.
+    double thr = __builtin_inf();
+    bool use_thr = a.thresh > 0.;
+    if (use_thr) {
+        const unsigned long long cnt = a.count_non_zero ? (unsigned long long)nnz
+                                                        : (unsigned long long)M2;
+        if (cnt == 0) {
+            thr = __builtin_nan("");  // empty population: comparisons are all false
+        } else {
+            const unsigned __int128 num =
+                (unsigned __int128)cnt * s2 - (unsigned __int128)s1 * s1;
+            const double mean = (double)s1 / (double)cnt;
+            const double ss = (double)num / (double)cnt;
+            const double var = ss / (double)cnt;
+            const double sd = __builtin_sqrt(var);
+            const double tsd = a.thresh * sd;
+            thr = tsd + mean;
+        }
+    }
+
+    // ---- pass 2: max of the counts that survive (vis.py:24,27) ----
+    unsigned mx = 0, amb = 0;
+    for (int b = 0; b < bands; b++) {
+        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
+        unsigned dr = 0;
+        if (bands > 1) bin_band(ev, n, y0, y1, H, W, bins, dr);
+        const int nb = (y1 - y0) * W * 2;
+        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
+            unsigned h = bins[i];
+            if (use_thr) {
+                const double dh = (double)h;
+                if (dh > thr) h = 0;
+                if (__builtin_fabs(dh - thr) <= 1e-9 * __builtin_fabs(thr)) amb++;
+            }
+            mx = h > mx ? h : mx;
+            if (bands == 1) bins[i] = h;  // single band: keep the thresholded counts for pass 3
+            if (a.kept) a.kept[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
+        }
+    }
+    mx = block_max_u32(mx, scratch);
+    amb = (unsigned)block_sum_u64(amb, scratch);
+    const double dmx = (double)mx;
+
+    if (a.stats && threadIdx.x == 0) {
+        ec_frame_stats st;
+        st.sum = s1;
+        st.sumsq = s2;
+        st.nnz = nnz;
+        st.max_kept = mx;
+        st.dropped = dropped;
+        st.ambiguous = amb;
+        st.thr = use_thr ? thr : __builtin_nan("");
+        a.stats[f] = st;
+    }
+
+    // ---- pass 3: normalise, colour, blend, round -> uint8 (vis.py:27-39) ----
+    uint8_t *out = a.frames + (long long)f * H * W * 3;
+    for (int b = 0; b < bands; b++) {
+        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
+        unsigned dr = 0;
+        if (bands > 1) bin_band(ev, n, y0, y1, H, W, bins, dr);
+        __syncthreads();
+        const int npix = (y1 - y0) * W;
+        uint8_t *o = out + (long long)y0 * W * 3;
+        if ((W & 3) == 0) {
+            // 4 pixels = 12 bytes = three dwords per thread, 4-byte aligned
+            for (int g = threadIdx.x; g < npix / 4; g += EV_THREADS) {
+                unsigned words[3];
+                uint8_t *bytes = reinterpret_cast<uint8_t *>(words);
+                const uint4 ca = *reinterpret_cast<const uint4 *>(&bins[g * 8]);
+                const uint4 cb = *reinterpret_cast<const uint4 *>(&bins[g * 8 + 4]);
+                unsigned c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    unsigned h0 = c[2 * k], h1 = c[2 * k + 1];
+                    if (use_thr && bands > 1) {
+                        if ((double)h0 > thr) h0 = 0;
+                        if ((double)h1 > thr) h1 = 0;
+                    }
+                    colour_pixel(h0, h1, dmx, a, bytes + 3 * k);
+                }
+                unsigned *dst = reinterpret_cast<unsigned *>(o + (long long)g * 12);
+                dst[0] = words[0];
+                dst[1] = words[1];
+                dst[2] = words[2];
+            }
+        } else {
+            for (int q = threadIdx.x; q < npix; q += EV_THREADS) {
+                unsigned h0 = bins[2 * q], h1 = bins[2 * q + 1];
+                if (use_thr && bands > 1) {
+                    if ((double)h0 > thr) h0 = 0;
+                    if ((double)h1 > thr) h1 = 0;
+                }
+                uint8_t px[3];
+                colour_pixel(h0, h1, dmx, a, px);
+                o[3 * q] = px[0];
+                o[3 * q + 1] = px[1];
+                o[3 * q + 2] = px[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
+                                          const ec_events_params *prm, uint8_t *frames,
+                                          int32_t *raw_counts, int32_t *kept_counts,
+                                          ec_frame_stats *stats, ec_stream_t stream)
+{
+    EC_REQUIRE(prm != nullptr, "ec_events_to_frames: params is null");
+    EC_REQUIRE(F >= 0, "ec_events_to_frames: F=%d", F);
+    if (F == 0) return EC_OK;
+    EC_REQUIRE(events && frame_range && frames, "ec_events_to_frames: null buffer");
+    EC_REQUIRE(prm->H > 0 && prm->W > 0, "ec_events_to_frames: bad shape (%d,%d)", prm->H, prm->W);
+    EC_REQUIRE(((uintptr_t)events & 15) == 0, "ec_events_to_frames: events must be 16-byte aligned");
+    const int row_bytes = prm->W * 2 * 4;
+    EC_REQUIRE(row_bytes <= EV_BIN_BYTES, "ec_events_to_frames: W=%d too wide for one LDS row band",
+               prm->W);
+
+    EvArgs a;
+    a.events = reinterpret_cast<const float4 *>(events);
+    a.range = reinterpret_cast<const long long *>(frame_range);
+    a.H = prm->H;
+    a.W = prm->W;
+    a.thresh = prm->thresh;
+    a.count_non_zero = prm->count_non_zero;
+    a.background_mask = prm->background_mask;
+    for (int c = 0; c < 3; c++) {
+        a.red[c] = (double)(float)prm->red[c];    // cmap.astype(float32), vis.py:30
+        a.blue[c] = (double)(float)prm->blue[c];
+    }
+    a.frames = frames;
+    a.raw = raw_counts;
+    a.kept = kept_counts;
+    a.stats = stats;
+    const int max_rows = EV_BIN_BYTES / row_bytes;
+    a.bands = ec::ceil_div(prm->H, max_rows);
+    a.rows_per_band = ec::ceil_div(prm->H, a.bands);
+
+    static bool attr_set = false;
+    const int lds = EV_BIN_BYTES + EV_SCRATCH_BYTES;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(events_to_frames_kernel, dim3(F), dim3(EV_THREADS), lds,
+                       static_cast<hipStream_t>(stream), a);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}

@@ -1,0 +1,107 @@
+"""HIP events->frames kernel against the oracle and the reference's golden vectors (MI355X)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import event_fixture_paths, load_event_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_hip(ev, shape, kw):
+    import torch
+    from eventclip_amd import vis
+    idx0, idx1 = vis.chunk_bounds(ev.shape[0], kw['N'])
+    ev_d = torch.from_numpy(np.ascontiguousarray(ev, dtype=np.float32)).cuda()
+    rng = torch.tensor(np.stack([idx0, idx1], 1), dtype=torch.int64).cuda()
+    frames, raw, kept, stats = vis.events_to_frames_device(
+        ev_d, rng, shape, grayscale=kw['grayscale'], count_non_zero=kw['count_non_zero'],
+        background_mask=kw['background_mask'], return_counts=True, return_stats=True)
+    torch.cuda.synchronize()
+    return frames.cpu().numpy(), raw.cpu().numpy(), kept.cpu().numpy(), stats
+
+
+@pytest.mark.parametrize('path', event_fixture_paths(), ids=os.path.basename)
+def test_hip_matches_reference_fixture(path, hip):
+    from oracle import events as oe
+    ev, shape, kw, exp = load_event_fixture(path)
+    frames, raw, kept, stats = run_hip(ev, shape, kw)
+    o_frames, o_raw, o_kept = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape,
+                                               return_counts=True, **kw)
+    assert frames.shape == o_frames.shape and frames.shape[0] == exp['n_frames']
+    np.testing.assert_array_equal(raw, o_raw)             # bit-exact counts
+    assert sha(raw.astype(np.int32)) == exp['raw_sha256']
+    assert int(stats['ambiguous'].sum()) == 0
+    np.testing.assert_array_equal(kept, o_kept)           # same hot pixels removed
+    np.testing.assert_array_equal(frames, o_frames)       # bit-exact uint8 frames
+    assert sha(frames) == exp['frames_sha256']
+    assert int(stats['dropped'].sum()) == 0
+    np.testing.assert_array_equal(stats['sum'], o_raw.reshape(o_raw.shape[0], -1).sum(1))
+
+
+def test_numpy_api_drop_in(hip):
+    """events2frames(events, split_method, convert_method, shape, **kw) like vis.py:75."""
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import make_events
+    from oracle import events as oe
+    ev = make_events(70000, (100, 120), seed=9)
+    kw = dict(N=30000, grayscale=False, count_non_zero=True, background_mask=False, max_imgs=2)
+    got = vis.events2frames(ev, 'event_count', 'event_histogram', shape=(100, 120), **dict(kw))
+    want = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(100, 120), **dict(kw))
+    assert got.dtype == np.uint8
+    np.testing.assert_array_equal(got, want)
+    # dict input (vis.py:46-47)
+    d = dict(x=ev[:, 0], y=ev[:, 1], t=ev[:, 2], p=ev[:, 3])
+    got2 = vis.events2frames(d, 'event_count', 'event_histogram', shape=(100, 120), **dict(kw))
+    np.testing.assert_array_equal(got2, want)
+    with pytest.raises(NotImplementedError):
+        vis.events2frames(ev, 'event_count', 'voxel', shape=(100, 120), N=30000)
+    with pytest.raises(AssertionError):
+        vis.events2frames(ev, 'time', 'event_histogram', shape=(100, 120), N=30000)
+
+
+def test_out_of_sensor_is_dropped_and_reported(hip):
+    from eventclip_amd import vis
+    ev = np.array([[5, 5, 0, 1], [300, 5, 0.1, 1], [-3, 2, 0.2, -1], [6, 5, 0.3, -1]], np.float32)
+    with pytest.raises(ValueError):
+        vis.events2frames(ev, 'event_count', 'event_histogram', shape=(36, 52), N=10)
+
+
+@pytest.mark.parametrize('geom', ['n_caltech', 'n_cars', 'n_imagenet'])
+def test_full_size_batch_properties(geom, hip):
+    """BASELINE-sized batch: counts sum to the event count and match the oracle on a sample."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import GEOMETRY, make_events
+    from oracle import events as oe
+    g = GEOMETRY[geom]
+    shape, N = g['resolution'], g['N']
+    B = 16
+    n_ev = g['max_n'] if geom != 'n_caltech' else 10 * N
+    evs = [make_events(n_ev, shape, seed=100 + i) for i in range(B)]
+    ranges, off = [], 0
+    for e in evs:
+        i0, i1 = vis.chunk_bounds(e.shape[0], N)
+        ranges += [(off + a, off + b) for a, b in zip(i0, i1)]
+        off += e.shape[0]
+    ev_d = torch.from_numpy(np.concatenate(evs)).cuda()
+    rng = torch.tensor(ranges, dtype=torch.int64).cuda()
+    kw = dict(grayscale=False, count_non_zero=g['count_non_zero'],
+              background_mask=g['background_mask'])
+    frames, raw, kept, stats = vis.events_to_frames_device(ev_d, rng, shape, return_counts=True,
+                                                           return_stats=True, **kw)
+    torch.cuda.synchronize()
+    lens = np.array([b - a for a, b in ranges])
+    np.testing.assert_array_equal(stats['sum'], lens)            # every event lands in one bin
+    np.testing.assert_array_equal(raw.sum(dim=(1, 2, 3)).cpu().numpy(), lens)
+    assert (kept <= raw).all()
+    for s in (0, B - 1):
+        want = oe.events2frames(evs[s], 'event_count', 'event_histogram', shape=shape, N=N, **kw)
+        f0 = sum(len(vis.chunk_bounds(e.shape[0], N)[0]) for e in evs[:s])
+        np.testing.assert_array_equal(frames[f0:f0 + want.shape[0]].cpu().numpy(), want)
