@@ -27,6 +27,14 @@ class EcEventsParams(ctypes.Structure):
                 ('blue', ctypes.c_uint8 * 3)]
 
 
+class EcGemmArgs(ctypes.Structure):
+    _fields_ = [('M', c_int), ('N', c_int), ('K', c_int), ('dtype', c_int), ('epilogue', c_int),
+                ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
+                ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long)]
+
+
+EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
+
 # name -> (restype, argtypes); kept in one table so tests can check that every
 # symbol of the header is exported.
 SIGNATURES = {
@@ -35,6 +43,7 @@ SIGNATURES = {
     'ec_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
     'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
 }
 
 _lib = None
@@ -52,6 +61,14 @@ def lib():
             raise HipLibraryError(
                 f'{LIB_PATH} is missing: build it with `python -m eventclip_amd.build` '
                 '(hipcc --offload-arch=gfx950).  eventclip_amd has no CPU fallback.')
+        # One HIP runtime per process: torch bundles its own libamdhip64 (soname
+        # libamdhip64.so.7).  Load it first so that this library's NEEDED entry
+        # binds to the same runtime instead of pulling a second copy from
+        # /opt/rocm, whose streams and device state torch would not share.
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

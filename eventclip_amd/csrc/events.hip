@@ -189,6 +189,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     // in 128-bit integers, then numpy's own sequence: /cnt, sqrt, thresh*std + mean.
     double thr = __builtin_inf();
     bool use_thr = a.thresh > 0.;
+    bool spread = false;  // population not constant: numpy's summation order can matter
     if (use_thr) {
         const unsigned long long cnt = a.count_non_zero ? (unsigned long long)nnz
                                                         : (unsigned long long)M2;
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         } else {
             const unsigned __int128 num =
                 (unsigned __int128)cnt * s2 - (unsigned __int128)s1 * s1;
+            spread = num != 0;
             const double mean = (double)s1 / (double)cnt;
             const double ss = (double)num / (double)cnt;
             const double var = ss / (double)cnt;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
             if (use_thr) {
                 const double dh = (double)h;
                 if (dh > thr) h = 0;
-                if (__builtin_fabs(dh - thr) <= 1e-9 * __builtin_fabs(thr)) amb++;
+                if (spread && __builtin_fabs(dh - thr) <= 1e-9 * __builtin_fabs(thr)) amb++;
             }
             mx = h > mx ? h : mx;
             if (bands == 1) bins[i] = h;  // single band: keep the thresholded counts for pass 3

@@ -80,6 +80,36 @@ EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, 
                                const ec_events_params *prm, uint8_t *frames, int32_t *raw_counts,
                                int32_t *kept_counts, ec_frame_stats *stats, ec_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 16-bit MFMA GEMM with fused epilogue: C[M,N] = epi(A[M,K] . W[N,K]^T + bias).
+ * The building block behind every nn.Linear / in_proj / out_proj / conv1 /
+ * projection of the CLIP towers the reference calls through
+ * clip_model.encode_image / encode_text (models/clip_cls.py:84,101; module
+ * structure from un-vendored openai/CLIP clip/model.py).  Exposed for unit
+ * tests and micro-benchmarks; ec_vit_encode / ec_text_encode drive it.
+ * ------------------------------------------------------------------------ */
+enum {
+    EC_EPI_STORE16 = 0, /* C16 = acc + bias */
+    EC_EPI_GELU16 = 1,  /* C16 = QuickGELU(acc + bias), x * sigmoid(1.702 x) */
+    EC_EPI_RESID32 = 2, /* C32 += acc + bias   (fp32 residual stream, in place) */
+    EC_EPI_STORE32 = 3, /* C32 = acc + bias */
+};
+
+typedef struct {
+    int M, N, K;       /* K % 64 == 0, N % 16 == 0 */
+    int dtype;         /* EC_F16 / EC_BF16: A, W and 16-bit outputs */
+    int epilogue;      /* EC_EPI_* */
+    int variant;       /* 0 = default tiling; others select tilings for A/B runs */
+    const void *A;     /* [M, K] 16-bit, row stride lda elements (0 = K) */
+    long lda;
+    const void *W;     /* [N, K] 16-bit, dense (nn.Linear weight layout) */
+    const float *bias; /* [N] fp32 or NULL */
+    void *C;           /* [M, N] 16-bit or fp32 by epilogue, row stride ldc (0 = N) */
+    long ldc;
+} ec_gemm_args;
+
+EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

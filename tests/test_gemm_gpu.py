@@ -1,0 +1,74 @@
+"""MFMA GEMM + fused epilogues against a plain torch fp32 reference (MI355X)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_gemm(A, W, bias, epilogue, resid=None):
+    import torch
+    y = A.float() @ W.float().t()
+    if bias is not None:
+        y = y + bias
+    if epilogue == 'gelu16':
+        y = y * torch.sigmoid(1.702 * y)
+    if epilogue == 'resid32':
+        y = y + resid
+    return y
+
+
+@pytest.mark.parametrize('variant', [0, 2, 3])
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 3072, 1024), (513, 1024, 4096),
+                                   (77, 768, 640), (5, 512, 64), (256, 256, 128), (300, 48, 64)])
+@pytest.mark.parametrize('epilogue', ['store16', 'gelu16', 'resid32', 'store32'])
+def test_gemm_matches_torch(M, N, K, dt, epilogue, variant, hip):
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, device='cuda', generator=g).to(dtype)
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, device='cuda', generator=g)
+    resid = torch.randn(M, N, device='cuda', generator=g)
+    out = resid.clone() if epilogue == 'resid32' else None
+    got = ops.gemm(A, W, bias, epilogue, out=out, variant=variant)
+    want = ref_gemm(A, W, bias, epilogue, resid)
+    torch.cuda.synchronize()
+    # inputs are identical 16-bit values on both sides; fp32 accumulation order differs,
+    # 16-bit outputs add one rounding (2^-11 f16, 2^-8 bf16)
+    out16 = epilogue in ('store16', 'gelu16')
+    rtol = (2e-3 if dt == 'float16' else 1.6e-2) if out16 else 1e-4
+    torch.testing.assert_close(got.float(), want, rtol=rtol, atol=rtol)
+
+
+def test_gemm_exact_integer_layout(hip):
+    """A = I-like selector with an asymmetric integer W catches swapped fragment maps."""
+    import torch
+    from eventclip_amd import ops
+    M, N, K = 256, 256, 256
+    A = torch.zeros(M, K, device='cuda', dtype=torch.float16)
+    A[torch.arange(M), (torch.arange(M) * 7) % K] = 1.
+    W = ((torch.arange(N, device='cuda')[:, None] * 3 + torch.arange(K, device='cuda')[None] * 5)
+         % 61).to(torch.float16)
+    got = ops.gemm(A, W, None, 'store32')
+    want = A.float() @ W.float().t()
+    assert torch.equal(got, want)
+
+
+def test_gemm_no_bias_and_strided_A(hip):
+    import torch
+    from eventclip_amd import ops
+    big = torch.randn(64, 2048, device='cuda').half()
+    A = big[:, :1024]                      # lda = 2048
+    W = torch.randn(768, 1024, device='cuda').half() / 32
+    got = ops.gemm(A, W, None, 'store32')
+    torch.testing.assert_close(got, A.float() @ W.float().t(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    import torch
+    from eventclip_amd import ops
+    A = torch.zeros(8, 100, device='cuda', dtype=torch.float16)
+    W = torch.zeros(64, 100, device='cuda', dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W)
