@@ -34,6 +34,32 @@ class EcGemmArgs(ctypes.Structure):
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
+EC_PRE_CHW_F32, EC_PRE_PATCHES16, EC_PRE_HWC_U8 = 0, 1, 2
+EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
+
+
+class EcBlockWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        'ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
+        'fc2_w', 'fc2_b')]
+
+
+class EcVitWeights(ctypes.Structure):
+    _fields_ = [('dtype', c_int), ('image_size', c_int), ('patch', c_int), ('width', c_int),
+                ('layers', c_int), ('heads', c_int), ('out_dim', c_int), ('kpad', c_int),
+                ('conv_w', c_void_p), ('cls', c_void_p), ('pos', c_void_p),
+                ('ln_pre_g', c_void_p), ('ln_pre_b', c_void_p), ('ln_post_g', c_void_p),
+                ('ln_post_b', c_void_p), ('proj_w', c_void_p),
+                ('blocks', ctypes.POINTER(EcBlockWeights))]
+
+
+class EcTextWeights(ctypes.Structure):
+    _fields_ = [('dtype', c_int), ('ctx', c_int), ('vocab', c_int), ('width', c_int),
+                ('layers', c_int), ('heads', c_int), ('out_dim', c_int),
+                ('token_embedding', c_void_p), ('pos', c_void_p), ('ln_final_g', c_void_p),
+                ('ln_final_b', c_void_p), ('proj_w', c_void_p),
+                ('blocks', ctypes.POINTER(EcBlockWeights))]
+
 
 # name -> (restype, argtypes); kept in one table so tests can check that every
 # symbol of the header is exported.
@@ -44,6 +70,27 @@ SIGNATURES = {
     'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
+    'ec_preprocess_plan_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
+    'ec_preprocess_plan': (c_int, [c_int, c_int, c_int, c_void_p, ctypes.c_size_t]),
+    'ec_preprocess': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_int, c_void_p]),
+    'ec_patchify': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'ec_layernorm': (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                             c_void_p, c_long, c_int, c_void_p]),
+    'ec_vit_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_float, c_void_p, c_void_p]),
+    'ec_text_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                              c_void_p]),
+    'ec_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_void_p]),
+    'ec_vit_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcVitWeights), c_int]),
+    'ec_text_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcTextWeights), c_int]),
+    'ec_vit_encode': (c_int, [ctypes.POINTER(EcVitWeights), c_void_p, c_int, c_void_p, c_void_p,
+                              ctypes.c_size_t, c_int, c_void_p]),
+    'ec_text_encode': (c_int, [ctypes.POINTER(EcTextWeights), c_void_p, c_int, c_void_p, c_void_p,
+                               ctypes.c_size_t, c_int, c_void_p]),
+    'ec_classify': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,496 @@
+"""The `clip` module surface the reference uses, backed by the HIP towers.
+
+The reference imports OpenAI's ``clip`` package (un-vendored) and touches exactly
+this much of it:
+
+* ``clip.load(arch, device) -> (model, preprocess)``          test.py:26
+* ``clip.tokenize(str) -> IntTensor[1, 77]``                   models/clip_cls.py:81-83
+* ``model.encode_image(FloatTensor[N,3,R,R]) -> [N, D]``      models/clip_cls.py:101
+* ``model.encode_text(IntTensor[K,77]) -> [K, D]``            models/clip_cls.py:84
+* ``model.logit_scale`` (0-dim Parameter), ``model.visual.output_dim``,
+  ``.parameters()``, ``.eval()``, ``.state_dict()``           models/clip_cls.py:40-44,217; test.py:44
+
+``CLIP`` below provides the same, with OpenAI's state-dict key names so released
+checkpoints load unchanged.  The parameters are fp32 masters; 16-bit copies for
+the MFMA GEMMs are packed once per device/dtype.  Only ViT backbones are
+supported (the ResNet variants are outside the north-star path).  Everything
+numeric runs in libeventclip_hip.so; there is no CPU fallback.
+"""
+import ctypes
+import gzip
+import html
+import os
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .preprocess import Preprocess
+
+# (image_size, patch, vision width, vision layers, embed dim, text width, text heads, text layers)
+ARCHS = {
+    'ViT-B/32': dict(image_size=224, patch=32, width=768, layers=12, embed_dim=512,
+                     text_width=512, text_heads=8, text_layers=12),
+    'ViT-B/16': dict(image_size=224, patch=16, width=768, layers=12, embed_dim=512,
+                     text_width=512, text_heads=8, text_layers=12),
+    'ViT-L/14': dict(image_size=224, patch=14, width=1024, layers=24, embed_dim=768,
+                     text_width=768, text_heads=12, text_layers=12),
+    'ViT-L/14@336px': dict(image_size=336, patch=14, width=1024, layers=24, embed_dim=768,
+                           text_width=768, text_heads=12, text_layers=12),
+}
+CONTEXT_LENGTH = 77
+VOCAB_SIZE = 49408
+_RESNETS = ('RN50', 'RN101', 'RN50x4', 'RN50x16', 'RN50x64')
+
+
+def available_models():
+    return list(ARCHS)
+
+
+def arch_config(arch, **override):
+    if arch in _RESNETS:
+        raise NotImplementedError(f'{arch}: ResNet CLIP backbones are not built for MI355X; '
+                                  f'use one of {available_models()}')
+    if arch not in ARCHS:
+        raise RuntimeError(f'Model {arch} not found; available models = {available_models()}')
+    cfg = dict(ARCHS[arch], context_length=CONTEXT_LENGTH, vocab_size=VOCAB_SIZE)
+    cfg.update(override)
+    return cfg
+
+
+def _block_keys(prefix, i):
+    p = f'{prefix}.resblocks.{i}.'
+    return [p + k for k in ('ln_1.weight', 'ln_1.bias', 'attn.in_proj_weight', 'attn.in_proj_bias',
+                            'attn.out_proj.weight', 'attn.out_proj.bias', 'ln_2.weight',
+                            'ln_2.bias', 'mlp.c_fc.weight', 'mlp.c_fc.bias', 'mlp.c_proj.weight',
+                            'mlp.c_proj.bias')]
+
+
+def random_state_dict(cfg, seed=0):
+    """Seeded random weights with OpenAI CLIP's key names and init scales (fp32, CPU).
+    Biases and LayerNorm affine terms are perturbed too so every code path carries signal."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    sd = {}
+
+    def blocks(prefix, width, layers):
+        attn_std = width ** -0.5
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        fc_std = (2 * width) ** -0.5
+        for i in range(layers):
+            p = f'{prefix}.resblocks.{i}.'
+            sd[p + 'ln_1.weight'] = 1 + rn(width, std=0.1)
+            sd[p + 'ln_1.bias'] = rn(width, std=0.1)
+            sd[p + 'attn.in_proj_weight'] = rn(3 * width, width, std=attn_std)
+            sd[p + 'attn.in_proj_bias'] = rn(3 * width, std=0.02)
+            sd[p + 'attn.out_proj.weight'] = rn(width, width, std=proj_std)
+            sd[p + 'attn.out_proj.bias'] = rn(width, std=0.02)
+            sd[p + 'ln_2.weight'] = 1 + rn(width, std=0.1)
+            sd[p + 'ln_2.bias'] = rn(width, std=0.1)
+            sd[p + 'mlp.c_fc.weight'] = rn(4 * width, width, std=fc_std)
+            sd[p + 'mlp.c_fc.bias'] = rn(4 * width, std=0.02)
+            sd[p + 'mlp.c_proj.weight'] = rn(width, 4 * width, std=proj_std)
+            sd[p + 'mlp.c_proj.bias'] = rn(width, std=0.02)
+
+    W, P, R = cfg['width'], cfg['patch'], cfg['image_size']
+    scale = W ** -0.5
+    sd['visual.conv1.weight'] = rn(W, 3, P, P, std=(3 * P * P) ** -0.5)
+    sd['visual.class_embedding'] = rn(W, std=scale)
+    sd['visual.positional_embedding'] = rn((R // P) ** 2 + 1, W, std=scale)
+    sd['visual.ln_pre.weight'] = 1 + rn(W, std=0.1)
+    sd['visual.ln_pre.bias'] = rn(W, std=0.1)
+    blocks('visual.transformer', W, cfg['layers'])
+    sd['visual.ln_post.weight'] = 1 + rn(W, std=0.1)
+    sd['visual.ln_post.bias'] = rn(W, std=0.1)
+    sd['visual.proj'] = rn(W, cfg['embed_dim'], std=scale)
+    TW = cfg['text_width']
+    sd['token_embedding.weight'] = rn(cfg['vocab_size'], TW, std=0.02)
+    sd['positional_embedding'] = rn(cfg['context_length'], TW, std=0.01)
+    blocks('transformer', TW, cfg['text_layers'])
+    sd['ln_final.weight'] = 1 + rn(TW, std=0.1)
+    sd['ln_final.bias'] = rn(TW, std=0.1)
+    sd['text_projection'] = rn(TW, cfg['embed_dim'], std=TW ** -0.5)
+    sd['logit_scale'] = torch.tensor(float(np.log(100.0)))   # exp() = 100 for released weights
+    return sd
+
+
+def config_from_state_dict(sd):
+    """Recover the architecture from an OpenAI-format state dict (ViT only)."""
+    if 'visual.proj' not in sd:
+        raise NotImplementedError('only ViT CLIP checkpoints are supported')
+    W = sd['visual.conv1.weight'].shape[0]
+    P = sd['visual.conv1.weight'].shape[-1]
+    g = round((sd['visual.positional_embedding'].shape[0] - 1) ** 0.5)
+    layers = len({k.split('.')[3] for k in sd if k.startswith('visual.transformer.resblocks.')})
+    TW = sd['ln_final.weight'].shape[0]
+    return dict(image_size=g * P, patch=P, width=W, layers=layers,
+                embed_dim=sd['text_projection'].shape[1], text_width=TW, text_heads=TW // 64,
+                text_layers=len({k.split('.')[2] for k in sd
+                                 if k.startswith('transformer.resblocks.')}),
+                context_length=sd['positional_embedding'].shape[0],
+                vocab_size=sd['token_embedding.weight'].shape[0])
+
+
+class _Holder(nn.Module):
+    """Plain container so parameters appear under OpenAI's dotted key names."""
+
+
+def _assign(root, key, tensor):
+    parts = key.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], nn.Parameter(tensor.clone().float(), requires_grad=False))
+
+
+class CLIP(nn.Module):
+    """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
+
+    def __init__(self, cfg, state_dict, dtype='float16', chunk=256):
+        super().__init__()
+        self.cfg = dict(cfg)
+        for k in ('input_resolution', 'context_length', 'vocab_size'):
+            state_dict = {a: b for a, b in state_dict.items() if a != k}
+        for k, v in state_dict.items():
+            _assign(self, k, v)
+        self.visual.output_dim = cfg['embed_dim']
+        self.visual.input_resolution = cfg['image_size']
+        self.compute_dtype = {'float16': torch.float16, 'fp16': torch.float16,
+                              'bfloat16': torch.bfloat16, 'bf16': torch.bfloat16}[str(dtype)]
+        self.chunk = int(chunk)
+        self._packed = None
+        self._ws = None
+
+    # ---- protocol bits the reference's classifiers read ----
+    @property
+    def dtype(self):
+        return self.logit_scale.dtype
+
+    @property
+    def device(self):
+        return self.logit_scale.device
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None          # .cuda() / .to(): repack lazily
+        self._ws = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, sd, strict=True):
+        self._packed = None
+        return super().load_state_dict(sd, strict=strict)
+
+    # ---- device packing ----
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        dev = _lib.require_gpu()
+        if self.logit_scale.device.type != 'cuda':
+            raise _lib.HipLibraryError('CLIP weights are on the CPU: call model.cuda() first '
+                                       '(there is no CPU fallback)')
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        cd = self.compute_dtype
+        code = _lib.EC_F16 if cd == torch.float16 else _lib.EC_BF16
+        keep = []   # owns every device tensor the structs point to
+
+        def dev32(t):
+            t = t.to(dev, torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def dev16(t):
+            t = t.to(dev, torch.float32).to(cd).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def blocks(prefix, layers):
+            arr = (_lib.EcBlockWeights * layers)()
+            for i in range(layers):
+                ks = _block_keys(prefix, i)
+                b = arr[i]
+                b.ln1_g, b.ln1_b = dev32(sd[ks[0]]), dev32(sd[ks[1]])
+                b.qkv_w, b.qkv_b = dev16(sd[ks[2]]), dev32(sd[ks[3]])
+                b.out_w, b.out_b = dev16(sd[ks[4]]), dev32(sd[ks[5]])
+                b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
+                b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
+                b.fc2_w, b.fc2_b = dev16(sd[ks[10]]), dev32(sd[ks[11]])
+            return arr
+
+        c = self.cfg
+        P, W = c['patch'], c['width']
+        k = 3 * P * P
+        kpad = ((k + 63) // 64) * 64
+        conv = torch.zeros(W, kpad)
+        conv[:, :k] = sd['visual.conv1.weight'].reshape(W, k).float().cpu()
+        v = _lib.EcVitWeights()
+        v.dtype, v.image_size, v.patch, v.width = code, c['image_size'], P, W
+        v.layers, v.heads, v.out_dim, v.kpad = c['layers'], W // 64, c['embed_dim'], kpad
+        v.conv_w = dev16(conv)
+        v.cls, v.pos = dev32(sd['visual.class_embedding']), dev32(sd['visual.positional_embedding'])
+        v.ln_pre_g, v.ln_pre_b = dev32(sd['visual.ln_pre.weight']), dev32(sd['visual.ln_pre.bias'])
+        v.ln_post_g, v.ln_post_b = (dev32(sd['visual.ln_post.weight']),
+                                    dev32(sd['visual.ln_post.bias']))
+        v.proj_w = dev16(sd['visual.proj'].t())
+        vb = blocks('visual.transformer', c['layers'])
+        v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
+        t = _lib.EcTextWeights()
+        t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']
+        t.layers, t.heads, t.out_dim = c['text_layers'], c['text_heads'], c['embed_dim']
+        t.token_embedding = dev32(sd['token_embedding.weight'])
+        t.pos = dev32(sd['positional_embedding'])
+        t.ln_final_g, t.ln_final_b = dev32(sd['ln_final.weight']), dev32(sd['ln_final.bias'])
+        t.proj_w = dev16(sd['text_projection'].t())
+        tb = blocks('transformer', c['text_layers'])
+        t.blocks = ctypes.cast(tb, ctypes.POINTER(_lib.EcBlockWeights))
+        self._packed = dict(vit=v, text=t, keep=keep, vb=vb, tb=tb, kpad=kpad, code=code, dev=dev)
+        return self._packed
+
+    def _workspace(self, nbytes, dev):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return self._ws
+
+    @property
+    def kpad(self):
+        return self._pack()['kpad']
+
+    @property
+    def dtype_code(self):
+        return self._pack()['code']
+
+    # ---- towers ----
+    @torch.no_grad()
+    def encode_patches(self, patches, n_img=None):
+        """patches: 16-bit CUDA tensor [N, G, kpad] (ec_preprocess / ec_patchify layout)."""
+        pk = self._pack()
+        n = int(patches.shape[0]) if n_img is None else int(n_img)
+        feats = torch.empty((n, self.cfg['embed_dim']), dtype=torch.float32, device=pk['dev'])
+        chunk = max(1, min(self.chunk, n))
+        need = _lib.lib().ec_vit_workspace_bytes(ctypes.byref(pk['vit']), chunk)
+        ws = self._workspace(need, pk['dev'])
+        assert patches.dtype == self.compute_dtype and patches.is_contiguous()
+        rc = _lib.lib().ec_vit_encode(ctypes.byref(pk['vit']), _lib.ptr(patches), n,
+                                      _lib.ptr(feats), _lib.ptr(ws), ws.numel(), chunk,
+                                      _lib.stream_ptr())
+        _lib.check(rc, 'ec_vit_encode')
+        return feats
+
+    @torch.no_grad()
+    def encode_image(self, image):
+        """image: float tensor [N, 3, R, R] as CLIP's preprocess produces -> fp32 [N, D]."""
+        pk = self._pack()
+        c = self.cfg
+        R, P = c['image_size'], c['patch']
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != R or image.shape[3] != R:
+            raise ValueError(f'encode_image expects [N, 3, {R}, {R}], got {tuple(image.shape)}')
+        img = image.to(pk['dev'], torch.float32).contiguous()
+        n = img.shape[0]
+        patches = torch.empty((n, (R // P) ** 2, pk['kpad']), dtype=self.compute_dtype,
+                              device=pk['dev'])
+        rc = _lib.lib().ec_patchify(_lib.ptr(img), n, R, P, pk['kpad'], _lib.ptr(patches),
+                                    pk['code'], _lib.stream_ptr())
+        _lib.check(rc, 'ec_patchify')
+        return self.encode_patches(patches)
+
+    @torch.no_grad()
+    def encode_text(self, text):
+        """text: int tensor [K, 77] of BPE ids -> fp32 [K, D] (not normalised)."""
+        pk = self._pack()
+        c = self.cfg
+        if text.dim() != 2 or text.shape[1] != c['context_length']:
+            raise ValueError(f'encode_text expects [K, {c["context_length"]}]')
+        tok = text.to(pk['dev'], torch.int32).contiguous()
+        n = tok.shape[0]
+        feats = torch.empty((n, c['embed_dim']), dtype=torch.float32, device=pk['dev'])
+        chunk = max(1, min(512, n))
+        need = _lib.lib().ec_text_workspace_bytes(ctypes.byref(pk['text']), chunk)
+        ws = self._workspace(need, pk['dev'])
+        rc = _lib.lib().ec_text_encode(ctypes.byref(pk['text']), _lib.ptr(tok), n, _lib.ptr(feats),
+                                       _lib.ptr(ws), ws.numel(), chunk, _lib.stream_ptr())
+        _lib.check(rc, 'ec_text_encode')
+        return feats
+
+    def forward(self, image, text):
+        """Cosine-similarity logits, as OpenAI's CLIP.forward."""
+        i = self.encode_image(image)
+        t = self.encode_text(text)
+        i = i / i.norm(dim=1, keepdim=True)
+        t = t / t.norm(dim=1, keepdim=True)
+        li = self.logit_scale.exp() * i @ t.t()
+        return li, li.t()
+
+
+def build_random(arch, seed=0, dtype='float16', device='cuda', chunk=256, **override):
+    """Random-weight CLIP of a named architecture (benchmarks / tests: no checkpoints ship)."""
+    cfg = arch_config(arch, **override)
+    model = CLIP(cfg, random_state_dict(cfg, seed), dtype=dtype, chunk=chunk)
+    if device is not None:
+        model = model.to(device)
+    return model.eval()
+
+
+def build_from_state_dict(sd, dtype='float16', device='cuda', chunk=256):
+    sd = {k: v for k, v in sd.items() if k not in ('input_resolution', 'context_length',
+                                                   'vocab_size')}
+    cfg = config_from_state_dict(sd)
+    model = CLIP(cfg, sd, dtype=dtype, chunk=chunk)
+    if device is not None:
+        model = model.to(device)
+    return model.eval()
+
+
+def load(name, device='cuda', jit=False, download_root=None, dtype='float16'):
+    """``clip.load`` of the reference (test.py:26) -> (model, preprocess).
+
+    ``name`` is an architecture name whose checkpoint ``<name with / -> ->.pt`` sits in
+    ``download_root`` (default ``~/.cache/clip``), or a path to a checkpoint (TorchScript
+    archive or plain state dict in OpenAI's key layout).  Nothing is downloaded."""
+    path = name
+    if not os.path.isfile(path):
+        cfg = arch_config(name)   # raises for unknown / ResNet names
+        root = download_root or os.path.expanduser('~/.cache/clip')
+        path = os.path.join(root, name.replace('/', '-') + '.pt')
+        if not os.path.isfile(path):
+            raise FileNotFoundError(
+                f'CLIP checkpoint {path} not found and this build never downloads; place the '
+                f'OpenAI checkpoint there or use eventclip_amd.clip.build_random({name!r}) '
+                f'(image {cfg["image_size"]}px) for synthetic weights')
+    try:
+        sd = torch.jit.load(path, map_location='cpu').state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location='cpu')
+        if isinstance(sd, dict) and 'state_dict' in sd:
+            sd = sd['state_dict']
+    model = build_from_state_dict(sd, dtype=dtype, device=device)
+    return model, Preprocess(model.cfg['image_size'])
+
+
+# ------------------------------------------------------------------------------------------
+# tokenizer: byte-level BPE of OpenAI CLIP.  Needs the published vocabulary file
+# bpe_simple_vocab_16e6.txt.gz, which does not ship here (no network); benchmarks use
+# synthetic token ids instead (synthetic_tokens).
+# ------------------------------------------------------------------------------------------
+def _bytes_to_unicode():
+    bs = list(range(ord('!'), ord('~') + 1)) + list(range(ord('¡'), ord('¬') + 1)) + \
+        list(range(ord('®'), ord('ÿ') + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
+class SimpleTokenizer:
+    def __init__(self, bpe_path):
+        import regex as re
+        self.byte_encoder = _bytes_to_unicode()
+        merges = gzip.open(bpe_path).read().decode('utf-8').split('\n')
+        merges = [tuple(m.split()) for m in merges[1:49152 - 256 - 2 + 1]]
+        vocab = list(self.byte_encoder.values())
+        vocab = vocab + [v + '</w>' for v in vocab]
+        vocab += [''.join(m) for m in merges]
+        vocab += ['<|startoftext|>', '<|endoftext|>']
+        self.encoder = dict(zip(vocab, range(len(vocab))))
+        self.bpe_ranks = dict(zip(merges, range(len(merges))))
+        self.cache = {'<|startoftext|>': '<|startoftext|>', '<|endoftext|>': '<|endoftext|>'}
+        self.pat = re.compile(
+            r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""",
+            re.IGNORECASE)
+        self._re = re
+
+    def bpe(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        word = tuple(token[:-1]) + (token[-1] + '</w>',)
+        pairs = set(zip(word[:-1], word[1:]))
+        if not pairs:
+            return token + '</w>'
+        while True:
+            bigram = min(pairs, key=lambda p: self.bpe_ranks.get(p, float('inf')))
+            if bigram not in self.bpe_ranks:
+                break
+            first, second = bigram
+            new, i = [], 0
+            while i < len(word):
+                try:
+                    j = word.index(first, i)
+                except ValueError:
+                    new.extend(word[i:])
+                    break
+                new.extend(word[i:j])
+                i = j
+                if word[i] == first and i < len(word) - 1 and word[i + 1] == second:
+                    new.append(first + second)
+                    i += 2
+                else:
+                    new.append(word[i])
+                    i += 1
+            word = tuple(new)
+            if len(word) == 1:
+                break
+            pairs = set(zip(word[:-1], word[1:]))
+        out = ' '.join(word)
+        self.cache[token] = out
+        return out
+
+    def encode(self, text):
+        text = html.unescape(html.unescape(text)).strip()
+        text = self._re.sub(r'\s+', ' ', text).strip().lower()
+        ids = []
+        for tok in self._re.findall(self.pat, text):
+            tok = ''.join(self.byte_encoder[b] for b in tok.encode('utf-8'))
+            ids.extend(self.encoder[t] for t in self.bpe(tok).split(' '))
+        return ids
+
+
+@lru_cache()
+def _tokenizer():
+    cands = [os.environ.get('EVENTCLIP_BPE_PATH', ''),
+             os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bpe_simple_vocab_16e6.txt.gz'),
+             os.path.expanduser('~/.cache/clip/bpe_simple_vocab_16e6.txt.gz')]
+    for p in cands:
+        if p and os.path.isfile(p):
+            return SimpleTokenizer(p)
+    raise FileNotFoundError(
+        'clip.tokenize needs OpenAI CLIP\'s bpe_simple_vocab_16e6.txt.gz (set EVENTCLIP_BPE_PATH); '
+        'it is not shipped and nothing is downloaded.  Pass token ids directly '
+        '(clip_dict["class_tokens"]) or use synthetic_tokens() for benchmarks.')
+
+
+def tokenize(texts, context_length=CONTEXT_LENGTH, truncate=False):
+    """``clip.tokenize``: str or list of str -> IntTensor [n, context_length]."""
+    if isinstance(texts, str):
+        texts = [texts]
+    tk = _tokenizer()
+    sot, eot = tk.encoder['<|startoftext|>'], tk.encoder['<|endoftext|>']
+    out = torch.zeros(len(texts), context_length, dtype=torch.int)
+    for i, t in enumerate(texts):
+        ids = [sot] + tk.encode(t) + [eot]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError(f'Input {t} is too long for context length {context_length}')
+            ids = ids[:context_length]
+            ids[-1] = eot
+        out[i, :len(ids)] = torch.tensor(ids)
+    return out
+
+
+def synthetic_tokens(n_classes, seed=0, context_length=CONTEXT_LENGTH):
+    """Stand-in prompts: SOT, 4-8 random ids < 49406, EOT, zero padding."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_classes, context_length), dtype=np.int32)
+    for i in range(n_classes):
+        n = int(rng.integers(4, 9))
+        out[i, 0] = 49406
+        out[i, 1:1 + n] = rng.integers(1, 49406, size=n)
+        out[i, 1 + n] = 49407
+    return torch.from_numpy(out)

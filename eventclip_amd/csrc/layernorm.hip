@@ -1,0 +1,197 @@
+// LayerNorm kernels of the CLIP towers (gfx950): HBM-bound, one wave per row.
+//
+//  * ec_layernorm: fp32 row -> LayerNorm (fp32 statistics, eps inside the sqrt,
+//    as the fp32-computing LayerNorm subclass of un-vendored openai/CLIP
+//    clip/model.py; call sites models/clip_cls.py:84,101) -> 16-bit GEMM operand.
+//    Row stride is free, so ln_post reads the CLS rows in place.
+//  * ec_vit_embed: x[n, 0] = class_embedding, x[n, 1+p] = patch GEMM row, plus
+//    positional_embedding, then ln_pre -> the fp32 residual stream.
+//  * ec_text_embed: token_embedding[token] + positional_embedding -> residual stream.
+//
+// Each lane keeps its slice of the row in registers (float4 x up to 8), two
+// shuffle reductions (mean, then centred variance), one write.
+#include "common.h"
+#include "mfma.h"
+
+namespace {
+
+using namespace ec;
+
+constexpr int LN_MAXV = 8;  // float4 per lane: width <= 2048
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// normalises the lane-resident row in place: v = (v - mean) * rstd * gamma + beta
+__device__ __forceinline__ void ln_row(float4 (&v)[LN_MAXV], int nv, int width, int lane,
+                                       const float *gamma, const float *beta, float eps)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    const float rstd = 1.f / __builtin_sqrtf(wave_sum(q) / (float)width + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+            v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
+            v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+            v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
+            v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+        }
+}
+
+// lanes cover the row in float4 units: unit u = i*64 + lane, valid if u*4 < width
+__device__ __forceinline__ int units(int width, int lane)
+{
+    const int total = width / 4;
+    return (total - lane + 63) / 64;  // number of i with i*64 + lane < total
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx,
+                                                        const int *row_idx, const float *gamma,
+                                                        const float *beta, int rows, int width,
+                                                        float eps, void *out, long ldo)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v4 v4;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = units(width, lane);
+    float4 v[LN_MAXV];
+    const float *xr = x + (row_idx ? (long)row_idx[row] : row) * ldx;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) v[i] = *reinterpret_cast<const float4 *>(xr + (i * 64 + lane) * 4);
+    ln_row(v, nv, width, lane, gamma, beta, eps);
+    elem *o = (elem *)out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            v4 p = {to16(v[i].x, elem()), to16(v[i].y, elem()), to16(v[i].z, elem()),
+                    to16(v[i].w, elem())};
+            *reinterpret_cast<v4 *>(o + (i * 64 + lane) * 4) = p;
+        }
+}
+
+// fp32 in -> fp32 out with an additive table (positional embedding) and a row
+// source that is either a broadcast vector (class token) or a GEMM output row.
+__global__ __launch_bounds__(256) void vit_embed_kernel(const float *patch, const float *cls,
+                                                        const float *pos, const float *gamma,
+                                                        const float *beta, int n_img, int seq,
+                                                        int width, float eps, float *x)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)n_img * seq) return;
+    const int n = (int)(row / seq), s = (int)(row % seq);
+    const float *src = s == 0 ? cls : patch + ((long)n * (seq - 1) + (s - 1)) * width;
+    const float *pr = pos + (long)s * width;
+    const int nv = units(width, lane);
+    float4 v[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 a = *reinterpret_cast<const float4 *>(src + c);
+            const float4 p = *reinterpret_cast<const float4 *>(pr + c);
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        }
+    ln_row(v, nv, width, lane, gamma, beta, eps);
+    float *o = x + row * width;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) *reinterpret_cast<float4 *>(o + (i * 64 + lane) * 4) = v[i];
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int *tokens, const float *table,
+                                                         const float *pos, int n_txt, int ctx,
+                                                         int width, int vocab, float *x)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)n_txt * ctx) return;
+    const int s = (int)(row % ctx);
+    int tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const float *src = table + (long)tok * width, *pr = pos + (long)s * width;
+    float *o = x + row * width;
+    for (int c = lane * 4; c < width; c += 256) {
+        const float4 a = *reinterpret_cast<const float4 *>(src + c);
+        const float4 p = *reinterpret_cast<const float4 *>(pr + c);
+        *reinterpret_cast<float4 *>(o + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
+                        const float *beta, int rows, int width, float eps, void *out16, long ldo,
+                        int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && width <= LN_MAXV * 256,
+               "ec_layernorm: width=%d must be a multiple of 4 and <= %d", width, LN_MAXV * 256);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(x && gamma && beta && out16, "ec_layernorm: null buffer");
+    EC_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "ec_layernorm: strides must be multiples of 4");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(ec::ceil_div(rows, 4)), block(256);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(layernorm_kernel<EC_F16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
+                           width, eps, out16, ldo);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<EC_BF16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
+                           width, eps, out16, ldo);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_layernorm: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, const float *gamma,
+                        const float *beta, int n_img, int seq, int width, float eps, float *x,
+                        ec_stream_t stream)
+{
+    EC_REQUIRE(width % 4 == 0 && width <= LN_MAXV * 256 && seq >= 2, "ec_vit_embed: bad shape");
+    if (n_img == 0) return EC_OK;
+    const long rows = (long)n_img * seq;
+    hipLaunchKernelGGL(vit_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), patch, cls, pos, gamma, beta, n_img, seq,
+                       width, eps, x);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_text_embed(const int32_t *tokens, const float *table, const float *pos, int n_txt,
+                         int ctx, int width, int vocab, float *x, ec_stream_t stream)
+{
+    EC_REQUIRE(width % 4 == 0 && ctx > 0 && vocab > 0, "ec_text_embed: bad shape");
+    if (n_txt == 0) return EC_OK;
+    const long rows = (long)n_txt * ctx;
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tokens, table, pos, n_txt, ctx, width,
+                       vocab, x);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// Host-side drivers of the two CLIP towers: enqueue the per-block kernel chain on
+// the caller's stream.  No allocation, no synchronisation; scratch comes from the
+// caller.  Replaces clip_model.encode_image / encode_text as the reference calls
+// them (models/clip_cls.py:101, :84; structure of un-vendored openai/CLIP
+// clip/model.py: ln_pre -> L x {x += MHA(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))}
+// -> ln_post(CLS) @ proj, and the causal text twin ending in ln_final(EOT) @
+// text_projection).
+//
+// Residual stream fp32; every GEMM operand 16-bit; seven launches per block:
+//   LN -> GEMM(qkv) -> attention -> GEMM(out, +=x) -> LN -> GEMM(fc1, QuickGELU) -> GEMM(fc2, +=x)
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Scratch {
+    unsigned char *base;
+    size_t off, cap;
+    void *take(size_t bytes)
+    {
+        void *p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    }
+};
+
+struct BlockBufs {
+    float *x;     // [rows, W] fp32 residual stream
+    void *h;      // [rows, W] 16-bit: LN output / attention output
+    void *qkv;    // [rows, 3W] 16-bit
+    void *mlp;    // [rows, 4W] 16-bit
+};
+
+int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
+         void *C, ec_stream_t s)
+{
+    ec_gemm_args g;
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = N;
+    return ec_gemm(&g, s);
+}
+
+#define EC_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != EC_OK) return _rc; \
+    } while (0)
+
+int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
+               int causal, int dtype, const BlockBufs &b, ec_stream_t s)
+{
+    const int rows = n_seq * S;
+    for (int l = 0; l < layers; l++) {
+        const ec_block_weights &w = blocks[l];
+        EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, W, dtype, s));
+        EC_TRY(gemm(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s));
+        EC_TRY(ec_attention(b.qkv, b.h, n_seq, S, W, heads, causal, dtype, s));
+        EC_TRY(gemm(rows, W, W, dtype, EC_EPI_RESID32, b.h, w.out_w, w.out_b, b.x, s));
+        EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, W, dtype, s));
+        EC_TRY(gemm(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, w.fc1_w, w.fc1_b, b.mlp, s));
+        EC_TRY(gemm(rows, W, 4 * W, dtype, EC_EPI_RESID32, b.mlp, w.fc2_w, w.fc2_b, b.x, s));
+    }
+    return EC_OK;
+}
+
+// carve the scratch for `chunk` sequences of length S; patch_rows > 0 adds the fp32
+// patch-GEMM output (aliased onto the mlp buffer: both are dead at the same time)
+size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs &b, void **small16,
+             int **idx)
+{
+    const size_t rows = (size_t)chunk * S;
+    b.x = (float *)sc.take(rows * W * 4);
+    b.h = sc.take(rows * W * 2);
+    b.qkv = sc.take(rows * 3 * W * 2);
+    b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
+    *small16 = sc.take((size_t)chunk * W * 2);
+    *idx = (int *)sc.take((size_t)chunk * 4 + (size_t)out_rows_extra);
+    return sc.off;
+}
+
+__global__ void eot_index_kernel(const int *tokens, int n_txt, int ctx, int *idx)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_txt) return;
+    const int *t = tokens + (long)n * ctx;
+    int best = 0, bv = t[0];
+    for (int s = 1; s < ctx; s++)
+        if (t[s] > bv) bv = t[s], best = s;   // first maximum, as torch.argmax
+    idx[n] = n * ctx + best;
+}
+
+}  // namespace
+
+extern "C" {
+
+EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
+{
+    if (!w || chunk <= 0) return 0;
+    const int g = w->image_size / w->patch;
+    Scratch sc{nullptr, 0, 0};
+    BlockBufs b;
+    void *s16;
+    int *idx;
+    return carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
+}
+
+EC_API size_t ec_text_workspace_bytes(const ec_text_weights *w, int chunk)
+{
+    if (!w || chunk <= 0) return 0;
+    Scratch sc{nullptr, 0, 0};
+    BlockBufs b;
+    void *s16;
+    int *idx;
+    return carve(sc, chunk, w->ctx, w->width, 0, b, &s16, &idx);
+}
+
+EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img, float *feats,
+                         void *workspace, size_t workspace_bytes, int chunk, ec_stream_t stream)
+{
+    EC_REQUIRE(w && w->blocks, "ec_vit_encode: weights are null");
+    EC_REQUIRE(n_img >= 0 && chunk > 0, "ec_vit_encode: n_img=%d chunk=%d", n_img, chunk);
+    if (n_img == 0) return EC_OK;
+    EC_REQUIRE(patches && feats && workspace, "ec_vit_encode: null buffer");
+    EC_REQUIRE(w->image_size % w->patch == 0, "ec_vit_encode: image %d not a multiple of patch %d",
+               w->image_size, w->patch);
+    EC_REQUIRE(w->width == w->heads * 64, "ec_vit_encode: head dim must be 64");
+    EC_REQUIRE(w->kpad % 64 == 0 && w->kpad >= 3 * w->patch * w->patch, "ec_vit_encode: bad kpad %d",
+               w->kpad);
+    EC_REQUIRE(w->out_dim % 16 == 0, "ec_vit_encode: out_dim %d", w->out_dim);
+    const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype;
+    if (chunk > n_img) chunk = n_img;
+    Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    BlockBufs b;
+    void *cls16;
+    int *idx;
+    const size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx);
+    if (need > workspace_bytes)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes", workspace_bytes,
+                        need);
+    const size_t esz = 2;
+    for (int i0 = 0; i0 < n_img; i0 += chunk) {
+        const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
+        const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
+        float *patch_out = (float *)b.mlp;
+        // conv1 (kernel = stride = patch, no bias) as a GEMM over im2col rows
+        EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_STORE32, p, w->conv_w, nullptr, patch_out, stream));
+        EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, b.x,
+                            stream));
+        EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream));
+        // ln_post on the CLS rows (row stride S*W), then @ proj
+        EC_TRY(ec_layernorm(b.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16,
+                            W, dt, stream));
+        EC_TRY(gemm(n, w->out_dim, W, dt, EC_EPI_STORE32, cls16, w->proj_w, nullptr,
+                    feats + (size_t)i0 * w->out_dim, stream));
+    }
+    return EC_OK;
+}
+
+EC_API int ec_text_encode(const ec_text_weights *w, const int32_t *tokens, int n_txt, float *feats,
+                          void *workspace, size_t workspace_bytes, int chunk, ec_stream_t stream)
+{
+    EC_REQUIRE(w && w->blocks, "ec_text_encode: weights are null");
+    EC_REQUIRE(n_txt >= 0 && chunk > 0, "ec_text_encode: n_txt=%d chunk=%d", n_txt, chunk);
+    if (n_txt == 0) return EC_OK;
+    EC_REQUIRE(tokens && feats && workspace, "ec_text_encode: null buffer");
+    EC_REQUIRE(w->width == w->heads * 64, "ec_text_encode: head dim must be 64");
+    EC_REQUIRE(w->out_dim % 16 == 0, "ec_text_encode: out_dim %d", w->out_dim);
+    const int S = w->ctx, W = w->width, dt = w->dtype;
+    if (chunk > n_txt) chunk = n_txt;
+    Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    BlockBufs b;
+    void *eot16;
+    int *idx;
+    const size_t need = carve(sc, chunk, S, W, 0, b, &eot16, &idx);
+    if (need > workspace_bytes)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_text_encode: workspace %zu < %zu bytes",
+                        workspace_bytes, need);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    for (int i0 = 0; i0 < n_txt; i0 += chunk) {
+        const int n = (n_txt - i0 < chunk) ? n_txt - i0 : chunk;
+        const int32_t *tok = tokens + (size_t)i0 * S;
+        EC_TRY(ec_text_embed(tok, w->token_embedding, w->pos, n, S, W, w->vocab, b.x, stream));
+        EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 1, dt, b, stream));
+        hipLaunchKernelGGL(eot_index_kernel, dim3((n + 255) / 256), dim3(256), 0, hs, tok, n, S, idx);
+        EC_CHECK_HIP(hipGetLastError());
+        EC_TRY(ec_layernorm(b.x, W, idx, w->ln_final_g, w->ln_final_b, n, W, LN_EPS, eot16, W, dt,
+                            stream));
+        EC_TRY(gemm(n, w->out_dim, W, dt, EC_EPI_STORE32, eot16, w->proj_w, nullptr,
+                    feats + (size_t)i0 * w->out_dim, stream));
+    }
+    return EC_OK;
+}
+
+}  // extern "C"

@@ -81,6 +81,29 @@ EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, 
                                int32_t *kept_counts, ec_frame_stats *stats, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * CLIP image preprocess: uint8 frames -> model input.
+ * Replaces `self.transforms(img)` per frame (datasets/event2img.py:119-122,
+ * transforms = clip.load's preprocess, test.py:26-29): torchvision
+ * Resize(n_px, BICUBIC) + CenterCrop(n_px) + ToTensor + Normalize over PIL.
+ * The plan holds Pillow's fixed-point bicubic coefficients for one geometry.
+ * ------------------------------------------------------------------------ */
+enum {
+    EC_PRE_CHW_F32 = 0,   /* float32 [F, 3, n_px, n_px]: the reference's tensor */
+    EC_PRE_PATCHES16 = 1, /* 16-bit [F, G, kpad] im2col rows for ec_vit_encode */
+    EC_PRE_HWC_U8 = 2,    /* uint8 [F, n_px, n_px, 3]: resized + cropped, before ToTensor */
+};
+
+EC_API size_t ec_preprocess_plan_bytes(int in_h, int in_w, int n_px);
+/* fills a HOST buffer; the caller uploads a copy and passes both to ec_preprocess */
+EC_API int ec_preprocess_plan(int in_h, int in_w, int n_px, void *host_plan, size_t cap);
+EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, const void *plan_dev,
+                         void *out, int mode, int patch, int kpad, int dtype, ec_stream_t stream);
+/* float32 [N, 3, n_px, n_px] (what the reference feeds encode_image) -> 16-bit
+ * im2col rows [N, G, kpad] in conv1.weight's (c, i, j) order, zero padded. */
+EC_API int ec_patchify(const float *img, int n_img, int n_px, int patch, int kpad, void *out16,
+                       int dtype, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * 16-bit MFMA GEMM with fused epilogue: C[M,N] = epi(A[M,K] . W[N,K]^T + bias).
  * The building block behind every nn.Linear / in_proj / out_proj / conv1 /
  * projection of the CLIP towers the reference calls through
@@ -109,6 +132,102 @@ typedef struct {
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
+
+/* LayerNorm (fp32 statistics, eps inside the sqrt) of fp32 rows into the 16-bit
+ * GEMM operand.  row_idx (optional, device int32 [rows]) gathers source rows:
+ * used for ln_post on the CLS rows and ln_final on the EOT rows. */
+EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
+                        const float *beta, int rows, int width, float eps, void *out16, long ldo,
+                        int dtype, ec_stream_t stream);
+
+/* x[n, 0] = class_embedding, x[n, 1 + p] = patch[n * (seq - 1) + p]; + positional
+ * embedding; ln_pre -> fp32 residual stream x [n_img, seq, width]. */
+EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, const float *gamma,
+                        const float *beta, int n_img, int seq, int width, float eps, float *x,
+                        ec_stream_t stream);
+
+/* x[n, s] = token_embedding[tokens[n, s]] + positional_embedding[s]. */
+EC_API int ec_text_embed(const int32_t *tokens, const float *table, const float *pos, int n_txt,
+                         int ctx, int width, int vocab, float *x, ec_stream_t stream);
+
+/* Multi-head self-attention, head dim 64 (nn.MultiheadAttention of the CLIP
+ * blocks).  qkv: 16-bit [n_seq * S, 3 * width] = q | k | v; out: 16-bit
+ * [n_seq * S, width].  causal != 0 applies the text tower's mask. */
+EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width, int heads,
+                        int causal, int dtype, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * CLIP towers.  Replace clip_model.encode_image / encode_text as called from
+ * models/clip_cls.py:101 / :84 (module structure: un-vendored openai/CLIP
+ * clip/model.py VisionTransformer / Transformer / ResidualAttentionBlock).
+ * Weight pointers are borrowed device memory; 16-bit tensors are in `dtype`.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    const float *ln1_g, *ln1_b; /* ln_1 [W] */
+    const void *qkv_w;          /* attn.in_proj_weight [3W, W] 16-bit */
+    const float *qkv_b;         /* attn.in_proj_bias [3W] */
+    const void *out_w;          /* attn.out_proj.weight [W, W] 16-bit */
+    const float *out_b;
+    const float *ln2_g, *ln2_b; /* ln_2 [W] */
+    const void *fc1_w;          /* mlp.c_fc.weight [4W, W] 16-bit */
+    const float *fc1_b;
+    const void *fc2_w;          /* mlp.c_proj.weight [W, 4W] 16-bit */
+    const float *fc2_b;
+} ec_block_weights;
+
+typedef struct {
+    int dtype;                  /* EC_F16 / EC_BF16 */
+    int image_size, patch, width, layers, heads, out_dim;
+    int kpad;                   /* 3 * patch * patch rounded up to a multiple of 64 */
+    const void *conv_w;         /* visual.conv1.weight as [W, kpad] 16-bit, (c, i, j) order, zero padded */
+    const float *cls, *pos;     /* class_embedding [W], positional_embedding [S, W] */
+    const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    const void *proj_w;         /* visual.proj transposed: [out_dim, W] 16-bit */
+    const ec_block_weights *blocks; /* host array [layers] */
+} ec_vit_weights;
+
+typedef struct {
+    int dtype;
+    int ctx, vocab, width, layers, heads, out_dim;
+    const float *token_embedding;   /* [vocab, W] fp32 */
+    const float *pos;               /* [ctx, W] */
+    const float *ln_final_g, *ln_final_b;
+    const void *proj_w;             /* text_projection transposed: [out_dim, W] 16-bit */
+    const ec_block_weights *blocks; /* host array [layers] */
+} ec_text_weights;
+
+/* bytes of scratch needed to push `chunk` images (or texts) through at once */
+EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk);
+EC_API size_t ec_text_workspace_bytes(const ec_text_weights *w, int chunk);
+
+/* patches: 16-bit [n_img, G, kpad] with G = (image_size / patch)^2 (what
+ * ec_preprocess or ec_patchify writes); feats: fp32 [n_img, out_dim] (out).
+ * Images are processed `chunk` at a time through `workspace`. */
+EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img, float *feats,
+                         void *workspace, size_t workspace_bytes, int chunk, ec_stream_t stream);
+
+/* tokens: int32 [n_txt, ctx]; feats: fp32 [n_txt, out_dim] = ln_final(x)[EOT] @
+ * text_projection, EOT = argmax of the token ids (not yet L2-normalised). */
+EC_API int ec_text_encode(const ec_text_weights *w, const int32_t *tokens, int n_txt, float *feats,
+                          void *workspace, size_t workspace_bytes, int chunk, ec_stream_t stream);
+
+
+/* ------------------------------------------------------------------------
+ * Logits and view aggregation.  Replaces ZSCLIPClassifier.forward
+ * (models/clip_cls.py:131-162: logits :148, scatter :151-152,
+ * _aggregate_logits :104-121, _aggregate_probs :123-129) and the tail of
+ * FSCLIPClassifier.forward (:326-343: F.normalize, mask, logits).
+ * ------------------------------------------------------------------------ */
+enum { EC_AGG_SUM = 0, EC_AGG_MEAN = 1, EC_AGG_MAX = 2 };
+
+/* feats:   fp32 [n_rows, C] image features (compact over valid views, or full).
+ * row_idx: int32 [B, T]: row of feats for view (b, t), or -1 for an invalid view.
+ * text_t:  fp32 [C, K] text features, transposed.
+ * normalize != 0: L2-normalise each view's features first (F.normalize, eps 1e-12).
+ * Outputs fp32: full_logits [B, T, K] (invalid views 0), logits [B, K], probs [B, K]. */
+EC_API int ec_classify(const float *feats, const int32_t *row_idx, const float *text_t, int B, int T,
+                       int C, int K, float logit_scale, int agg, int normalize, float *full_logits,
+                       float *logits, float *probs, ec_stream_t stream);
 
 #ifdef __cplusplus
 }

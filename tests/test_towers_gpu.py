@@ -1,0 +1,173 @@
+"""LayerNorm, attention and the two CLIP towers on the MI355X against torch fp32."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('width', [256, 512, 640, 768, 1024])
+def test_layernorm(width, dt, hip):
+    import torch
+    import torch.nn.functional as F
+    from eventclip_amd import _lib
+    dtype = getattr(torch, dt)
+    x = torch.randn(301, width, device='cuda') * 3 + 1
+    g, b = torch.randn(width, device='cuda'), torch.randn(width, device='cuda')
+    out = torch.empty(301, width, dtype=dtype, device='cuda')
+    _lib.check(_lib.lib().ec_layernorm(_lib.ptr(x), width, None, _lib.ptr(g), _lib.ptr(b), 301, width,
+                                       1e-5, _lib.ptr(out), width,
+                                       _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16,
+                                       _lib.stream_ptr()))
+    want = F.layer_norm(x, (width,), g, b, 1e-5)
+    tol = 2e-3 if dt == 'float16' else 1.6e-2
+    torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
+    # gathered rows (ln_post on CLS rows / ln_final on EOT rows)
+    idx = torch.tensor([5, 0, 300, 17], dtype=torch.int32, device='cuda')
+    out2 = torch.empty(4, width, dtype=dtype, device='cuda')
+    _lib.check(_lib.lib().ec_layernorm(_lib.ptr(x), width, _lib.ptr(idx), _lib.ptr(g), _lib.ptr(b), 4,
+                                       width, 1e-5, _lib.ptr(out2), width,
+                                       _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16,
+                                       _lib.stream_ptr()))
+    torch.testing.assert_close(out2.float(), want[idx.long()], rtol=tol, atol=tol)
+
+
+def ref_attention(qkv, n_seq, S, W, heads, causal):
+    import torch
+    q, k, v = qkv.float().view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        att = att + torch.full((S, S), float('-inf'), device=qkv.device).triu_(1)
+    out = att.softmax(-1) @ v
+    return out.permute(0, 2, 1, 3).reshape(n_seq * S, W)
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('S,heads,causal', [(50, 12, 0), (77, 8, 1), (77, 12, 1), (197, 12, 0),
+                                            (257, 16, 0), (577, 16, 0), (17, 1, 0), (1, 2, 1)])
+def test_attention(S, heads, causal, dt, hip):
+    import torch
+    from eventclip_amd import _lib
+    dtype = getattr(torch, dt)
+    n_seq, W = 3, heads * 64
+    qkv = (torch.randn(n_seq * S, 3 * W, device='cuda') * 1.5).to(dtype)
+    out = torch.empty(n_seq * S, W, dtype=dtype, device='cuda')
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, causal,
+                                       _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16,
+                                       _lib.stream_ptr()))
+    want = ref_attention(qkv, n_seq, S, W, heads, causal)
+    tol = 4e-3 if dt == 'float16' else 2.5e-2     # P and the output are rounded to 16 bit
+    torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
+
+
+def test_attention_exact_selector(hip):
+    """One-hot softmax (huge matching score) must copy the right V row for every query:
+    catches any mismatch between the P^T and V^T operand permutations."""
+    import torch
+    from eventclip_amd import _lib
+    S, heads, W = 257, 2, 128
+    perm = torch.randperm(S)
+    q = torch.zeros(S, W)
+    k = torch.zeros(S, W)
+    code = (torch.arange(S)[:, None] >> torch.arange(9)[None]) & 1      # 9-bit binary codes
+    code = code.float() * 2 - 1
+    for h in range(heads):
+        q[:, h * 64:h * 64 + 9] = code[perm] * 16
+        k[:, h * 64:h * 64 + 9] = code * 16
+    v = torch.arange(S)[:, None].float() + torch.arange(W)[None].float() / 256
+    qkv = torch.cat([q, k, v], 1).half().cuda()
+    out = torch.empty(S, W, dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), 1, S, W, heads, 0, _lib.EC_F16,
+                                       _lib.stream_ptr()))
+    want = v.half()[perm]
+    assert torch.equal(out.cpu(), want)
+
+
+def load_tiny():
+    import torch
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'clip_tiny.npz'))
+    cfg = {str(k): int(v) for k, v in zip(z['cfg_keys'], z['cfg_vals'])}
+    sd = {k[2:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith('w:')}
+    sd['logit_scale'] = torch.tensor(float(np.log(100.0)))
+    return cfg, sd, z
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+def test_tiny_clip_matches_hf_fixture(dt, hip):
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg, sd, z = load_tiny()
+    model = eclip.CLIP(cfg, sd, dtype=dt).cuda().eval()
+    img = torch.from_numpy(z['img'].astype(np.float32)).cuda()
+    tok = torch.from_numpy(z['tok']).cuda()
+    gi = model.encode_image(img).cpu()
+    gt = model.encode_text(tok).cpu()
+    tol = 2e-3 if dt == 'float16' else 1.5e-2
+    assert rel_err(gi, torch.from_numpy(z['hf_img'])) < tol
+    assert rel_err(gt, torch.from_numpy(z['hf_txt'])) < tol
+
+
+@pytest.mark.parametrize('arch,layers,n', [('ViT-B/32', 12, 5), ('ViT-B/16', 3, 3),
+                                           ('ViT-L/14', 24, 3), ('ViT-L/14@336px', 2, 2)])
+def test_image_tower_matches_oracle(arch, layers, n, hip):
+    """Full-width towers, seeded random weights, identical inputs on both sides.
+    Tolerance: north_star's 1e-3 relative (max |diff| / max |ref|), f16 operands."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config(arch, layers=layers, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=11)
+    model = eclip.CLIP(cfg, sd, dtype='float16').cuda().eval()
+    R = cfg['image_size']
+    img = torch.randn(n, 3, R, R, generator=torch.Generator().manual_seed(5))
+    got = model.encode_image(img.cuda()).cpu()
+    torch.set_num_threads(os.cpu_count() or 8)
+    want = clip_ref.encode_image(sd, cfg, img)
+    assert got.shape == want.shape == (n, cfg['embed_dim'])
+    assert rel_err(got, want) < 1e-3
+    # against the oracle fed the same 16-bit-rounded weights the error is pure arithmetic
+    want16 = clip_ref.encode_image(clip_ref.round_weights(sd, torch.float16), cfg, img)
+    assert rel_err(got, want16) < 1e-3
+
+
+@pytest.mark.parametrize('arch', ['ViT-B/32', 'ViT-L/14'])
+def test_text_tower_matches_oracle(arch, hip):
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config(arch, layers=1)
+    sd = eclip.random_state_dict(cfg, seed=12)
+    model = eclip.CLIP(cfg, sd, dtype='float16').cuda().eval()
+    tok = eclip.synthetic_tokens(7, seed=3)
+    got = model.encode_text(tok.cuda()).cpu()
+    want = clip_ref.encode_text(sd, cfg, tok)
+    assert rel_err(got, want) < 1e-3
+
+
+def test_chunked_encode_is_batch_invariant(hip):
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=2, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=1)
+    img = torch.randn(7, 3, 224, 224).cuda()
+    a = eclip.CLIP(cfg, sd, chunk=256).cuda().encode_image(img)
+    b = eclip.CLIP(cfg, sd, chunk=3).cuda().encode_image(img)
+    assert torch.equal(a, b)
+
+
+def test_cpu_model_fails_loudly(hip):
+    import torch
+    from eventclip_amd import _lib
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=1, text_layers=1, vocab_size=1024)
+    m = eclip.CLIP(cfg, eclip.random_state_dict(cfg, 0))
+    with pytest.raises(_lib.HipLibraryError):
+        m.encode_image(torch.zeros(1, 3, 224, 224))
