@@ -27,6 +27,23 @@ class EcEventsParams(ctypes.Structure):
                 ('blue', ctypes.c_uint8 * 3)]
 
 
+class EcAdapterLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('ln1_g', 'ln1_b', 'qkv_w_t', 'qkv_b', 'o_w_t', 'o_b',
+                                        'ln2_g', 'ln2_b', 'w1_t', 'b1', 'w2_t', 'b2')]
+
+
+class EcAdapterWeights(ctypes.Structure):
+    _fields_ = [('in_dim', c_int), ('d_model', c_int), ('heads', c_int), ('ffn', c_int),
+                ('layers', c_int), ('residual', c_float), ('in_w_t', c_void_p), ('in_b', c_void_p),
+                ('out_w_t', c_void_p), ('out_b', c_void_p),
+                ('layer', ctypes.POINTER(EcAdapterLayer))]
+
+
+class EcProfileEntry(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 64), ('launches', c_long), ('total_ms', c_double),
+                ('flops', c_double), ('bytes', c_double)]
+
+
 class EcGemmArgs(ctypes.Structure):
     _fields_ = [('M', c_int), ('N', c_int), ('K', c_int), ('dtype', c_int), ('epilogue', c_int),
                 ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
@@ -67,6 +84,8 @@ SIGNATURES = {
     'ec_last_error': (ctypes.c_char_p, []),
     'ec_version': (c_int, []),
     'ec_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'ec_profile_begin': (c_int, []),
+    'ec_profile_end': (c_int, [ctypes.POINTER(EcProfileEntry), c_int, ctypes.POINTER(c_int)]),
     'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
@@ -89,6 +108,8 @@ SIGNATURES = {
                               ctypes.c_size_t, c_int, c_void_p]),
     'ec_text_encode': (c_int, [ctypes.POINTER(EcTextWeights), c_void_p, c_int, c_void_p, c_void_p,
                                ctypes.c_size_t, c_int, c_void_p]),
+    'ec_adapter_forward': (c_int, [ctypes.POINTER(EcAdapterWeights), c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p]),
     'ec_classify': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
@@ -151,3 +172,17 @@ def ptr(t):
     if t is None:
         return None
     return ctypes.c_void_p(t.data_ptr())
+
+
+def profile_begin():
+    check(lib().ec_profile_begin(), 'ec_profile_begin')
+
+
+def profile_end():
+    """-> list of dicts (name, launches, total_ms, flops, bytes), one per kernel symbol."""
+    arr = (EcProfileEntry * 32)()
+    n = c_int(0)
+    check(lib().ec_profile_end(arr, 32, ctypes.byref(n)), 'ec_profile_end')
+    return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches),
+                 total_ms=float(arr[i].total_ms), flops=float(arr[i].flops),
+                 bytes=float(arr[i].bytes)) for i in range(n.value)]

@@ -1,0 +1,318 @@
+"""Zero-shot / few-shot classifiers with the reference's API, running on HIP kernels.
+
+Mirror of /root/reference/models/clip_cls.py: ``ZSCLIPClassifier`` (:14-219) and
+``FSCLIPClassifier`` (:222-354) take the same ``clip_dict`` / ``adapter_dict`` /
+``loss_dict``, expose ``forward(data_dict) -> out_dict`` with the same four keys,
+``get_img_feats``, ``get_text_feats``, ``state_dict`` / ``load_state_dict`` that
+leave the frozen CLIP weights out, and ``load_weight``.  The arithmetic (image tower,
+text tower, adapter, logits, aggregation) is done by libeventclip_hip.so; torch is
+used for tensors and the nn.Module plumbing only.  Inference only: the training
+losses of the reference (calc_train_loss, :164-175) are outside the accelerated path.
+
+``forward`` accepts the reference's batch (``img`` [B, T, 3, R, R] + ``valid_mask``)
+or the fused batch of ``Event2ImagePipeline`` (``patches`` + ``row_idx`` +
+``valid_mask``), which skips the padded fp32 image tensor.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import clip as eclip
+from .adapter import IdentityAdapter, TransformerAdapter
+
+_AGG = {'sum': _lib.EC_AGG_SUM, 'mean': _lib.EC_AGG_MEAN, 'max': _lib.EC_AGG_MAX}
+
+
+def _l2_normalize(x):
+    """F.normalize(x, p=2, dim=-1): x / max(||x||, 1e-12)."""
+    return x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+
+
+class ZSCLIPClassifier(nn.Module):
+    """CLIP model for **zero-shot** classification (clip_cls.py:14-219)."""
+
+    def __init__(
+            self,
+            clip_dict=dict(
+                clip_model=None,
+                prompt='a point cloud image of a {}',
+                class_names=None,
+                agg_func='sum',
+            ),
+            loss_dict=dict(
+                use_logits_loss=True,
+                use_probs_loss=False,
+            ),
+    ):
+        super().__init__()
+        self.clip_dict = clip_dict
+        self.loss_dict = loss_dict
+        self._build_clip()
+        self._build_loss()
+
+    def _build_clip(self):
+        model = self.clip_dict['clip_model']
+        for p in model.parameters():                                     # clip_cls.py:41-42
+            p.requires_grad = False
+        self.model = model.eval()
+        self.logit_scale = model.logit_scale.exp().item()                # clip_cls.py:44
+        self.prompt = self.clip_dict['prompt']
+        self.class_names = self.clip_dict['class_names']
+        # token ids [K, 77] for the class prompts, for when the BPE vocabulary file is not
+        # available to clip.tokenize (it does not ship with this repo)
+        self.class_tokens = self.clip_dict.get('class_tokens', None)
+        self.text_feats = None
+        self._text_t = None
+        self.agg_func = self.clip_dict['agg_func']
+        assert self.agg_func in ['sum', 'mean', 'max']                   # clip_cls.py:53
+
+    def _build_loss(self):
+        self.use_logits_loss = self.loss_dict['use_logits_loss']
+        self.use_probs_loss = self.loss_dict['use_probs_loss']
+        assert int(self.use_logits_loss) + int(self.use_probs_loss) == 1
+
+    def _same_class_names(self, class_names):
+        return all([c1 == c2 for c1, c2 in zip(class_names, self.class_names)])
+
+    def _tokenize(self, class_names):
+        if self.class_tokens is not None and (class_names is self.class_names or
+                                              self._same_class_names(class_names)):
+            return self.class_tokens
+        names = [c.lower().replace('_', ' ') for c in class_names]      # clip_cls.py:80
+        return torch.cat([eclip.tokenize(self.prompt.format(c)) for c in names])
+
+    def get_text_feats(self, class_names=None):
+        """Text prompt features, L2-normalised and cached (clip_cls.py:64-93).  Unlike the
+        reference this does not crash when called with explicit ``class_names`` and an
+        empty cache (its ``no_cls_flag`` is unbound there, :74/:90)."""
+        no_cls_flag = class_names is None
+        if no_cls_flag:
+            class_names = self.class_names
+        if (no_cls_flag or self._same_class_names(class_names)) and self.text_feats is not None:
+            return self.text_feats
+        prompts = self._tokenize(class_names).to(self.device)
+        text_feats = self.model.encode_text(prompts)                     # clip_cls.py:84
+        text_feats = _l2_normalize(text_feats)                           # clip_cls.py:85
+        if no_cls_flag or self._same_class_names(class_names):
+            self.text_feats = text_feats
+            self._text_t = None
+        return text_feats
+
+    def _text_transposed(self):
+        t = self.get_text_feats()
+        if self._text_t is None or self._text_t.shape[1] != t.shape[0]:
+            self._text_t = t.detach().float().t().contiguous()
+        return self._text_t
+
+    def get_img_feats(self, imgs):
+        """imgs [N, 3, R, R] -> [N, C] (clip_cls.py:95-102)."""
+        return self.model.encode_image(imgs)
+
+    # torch restatements kept for API parity (the HIP path aggregates in ec_classify)
+    def _aggregate_logits(self, logits, valid_masks):
+        if self.agg_func == 'sum':
+            return logits.sum(1)
+        if self.agg_func == 'mean':
+            return logits.sum(1) / valid_masks.float().sum(1, keepdim=True)
+        if self.agg_func == 'max':
+            logits = logits - (1. - valid_masks.float())[..., None] * 1e6
+            return logits.max(1)[0]
+        raise NotImplementedError
+
+    def _aggregate_probs(self, logits, valid_masks):
+        valid_masks = valid_masks.detach().float()
+        probs = logits.softmax(dim=-1) * valid_masks[..., None]
+        return probs.sum(1) / valid_masks.sum(1, keepdim=True)
+
+    # ---- shared pieces of forward ----
+    def _view_feats(self, data_dict):
+        """Features of the valid views [Nv, C] fp32 plus row_idx [B, T] int32 (CUDA)."""
+        valid_masks = data_dict['valid_mask']
+        if 'patches' in data_dict:
+            feats = self.model.encode_patches(data_dict['patches'])
+            row_idx = data_dict['row_idx']
+        else:
+            imgs = data_dict['img']                                      # [B, T, C, H, W]
+            valid_imgs = imgs[valid_masks]                               # clip_cls.py:139
+            feats = self.get_img_feats(valid_imgs)
+            flat = valid_masks.reshape(-1)
+            row_idx = torch.where(flat, torch.cumsum(flat.int(), 0) - 1,
+                                  torch.full_like(flat, -1, dtype=torch.int64))
+            row_idx = row_idx.to(torch.int32).reshape(valid_masks.shape)
+        return feats.float().contiguous(), row_idx.contiguous(), valid_masks
+
+    def _classify(self, feats, row_idx, normalize):
+        B, T = row_idx.shape
+        text_t = self._text_transposed()
+        C, K = text_t.shape
+        dev = feats.device
+        full = torch.empty((B, T, K), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+        probs = torch.empty((B, K), dtype=torch.float32, device=dev)
+        rc = _lib.lib().ec_classify(_lib.ptr(feats), _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C, K,
+                                    float(self.logit_scale), _AGG[self.agg_func], int(normalize),
+                                    _lib.ptr(full), _lib.ptr(logits), _lib.ptr(probs),
+                                    _lib.stream_ptr())
+        _lib.check(rc, 'ec_classify')
+        return full, logits, probs
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        """clip_cls.py:131-162."""
+        feats, row_idx, valid_masks = self._view_feats(data_dict)
+        # logits = logit_scale * img_feats @ text_feats.T with UN-normalised image feats (:148)
+        full_logits, logits, probs = self._classify(feats, row_idx, normalize=False)
+        return {
+            'full_logits': full_logits,  # [B, T, n_classes]
+            'valid_masks': valid_masks,  # [B, T]
+            'logits': logits,  # [B, n_classes]
+            'probs': probs,  # [B, n_classes]
+        }
+
+    @torch.no_grad()
+    def calc_eval_loss(self, data_dict, out_dict):
+        """Accuracies of clip_cls.py:177-192 (the CE terms belong to training)."""
+        labels = data_dict['label']
+        return {
+            'probs_acc': (out_dict['probs'].argmax(dim=-1) == labels).float().mean(),
+            'logits_acc': (out_dict['logits'].argmax(dim=-1) == labels).float().mean(),
+        }
+
+    @property
+    def dtype(self):
+        return self.model.logit_scale.dtype
+
+    @property
+    def device(self):
+        return self.model.logit_scale.device
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        self.model.eval()                                                # clip_cls.py:202-206
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        """Frozen CLIP weights are not part of a checkpoint (clip_cls.py:208-212)."""
+        w = super().state_dict(*args, **kwargs)
+        return {k: v for k, v in w.items() if not k.startswith('model.')}
+
+    def load_state_dict(self, state_dict, strict=True):
+        clip_w = {f'model.{k}': v for k, v in self.model.state_dict().items()}   # :214-219
+        state_dict = {**clip_w, **state_dict}
+        self.text_feats_dirty = True
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._text_t = None
+        return out
+
+    def load_weight(self, ckp_path, strict=True):
+        """nerv BaseModel.load_weight (test.py:50): checkpoint file with a ``state_dict`` entry."""
+        ckp = torch.load(ckp_path, map_location='cpu')
+        sd = ckp['state_dict'] if isinstance(ckp, dict) and 'state_dict' in ckp else ckp
+        self.load_state_dict(sd, strict=strict)
+
+
+class FSCLIPClassifier(ZSCLIPClassifier):
+    """CLIP model for **few-shot** classification (clip_cls.py:222-354)."""
+
+    def __init__(
+            self,
+            adapter_dict=dict(
+                adapter_type='trans',
+                residual=True,
+            ),
+            clip_dict=dict(
+                clip_model=None,
+                prompt='a point cloud image of a {}',
+                class_names=None,
+                agg_func='sum',
+            ),
+            loss_dict=dict(
+                use_logits_loss=False,
+                use_probs_loss=True,
+            ),
+    ):
+        super().__init__(clip_dict=clip_dict, loss_dict=loss_dict)
+        self.adapter_dict = copy.deepcopy(adapter_dict)
+        self._build_adapter()
+
+    def _build_prompts(self, adapter_type):
+        with torch.no_grad():
+            text_feats = ZSCLIPClassifier.get_text_feats(self).float()   # [n_classes, C]
+        self.text_feats = nn.Parameter(text_feats.clone(), requires_grad=True)
+        return adapter_type[5:]
+
+    def _build_adapter(self):
+        adapter_type = self.adapter_dict.pop('adapter_type').lower()
+        if adapter_type.startswith('text-'):                             # clip_cls.py:263-266
+            self.prompt_tuning = True
+            adapter_type = self._build_prompts(adapter_type)
+        else:
+            self.prompt_tuning = False
+        self.adapter_type = adapter_type
+        if adapter_type == 'identity':
+            model = IdentityAdapter
+        elif adapter_type == 'trans':
+            model = TransformerAdapter
+        else:
+            raise NotImplementedError(f'adapter {adapter_type} not supported!')
+        self.adapter = model(**self.adapter_dict)
+
+    def _adjust_dtype(self, x):
+        if self.training:
+            return x
+        return x.type(self.dtype)
+
+    def get_text_feats(self, class_names=None):
+        if self.prompt_tuning:                                           # clip_cls.py:292-295
+            text_feats = _l2_normalize(self.text_feats)
+        else:
+            with torch.no_grad():
+                text_feats = super().get_text_feats(class_names)
+        return self._adjust_dtype(text_feats)
+
+    def _text_transposed(self):
+        # learned text features can change under load_state_dict: rebuild when asked
+        if self.prompt_tuning:
+            return self.get_text_feats().detach().float().t().contiguous()
+        return super()._text_transposed()
+
+    def get_img_feats(self, imgs):
+        with torch.no_grad():
+            img_feats = super().get_img_feats(imgs)
+        return self._adjust_dtype(img_feats)
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        """clip_cls.py:308-350."""
+        feats, row_idx, valid_masks = self._view_feats(data_dict)
+        B, T = valid_masks.shape
+        C = feats.shape[-1]
+        # scatter to [B, T, C] with zero rows for padded views (:319-321), adapter (:322)
+        full_img_feats = self.adapter.forward_rows(feats, row_idx)       # [B, T, C] fp32
+        # F.normalize + mask + logits + aggregation (:326-343) in ec_classify
+        idx = torch.where(valid_masks, torch.arange(B * T, device=feats.device).view(B, T),
+                          torch.full((B, T), -1, device=feats.device)).to(torch.int32)
+        full_logits, logits, probs = self._classify(full_img_feats.reshape(B * T, C).contiguous(),
+                                                    idx.contiguous(), normalize=True)
+        return {
+            'full_logits': full_logits,
+            'valid_masks': valid_masks,
+            'logits': logits,
+            'probs': probs,
+        }
+
+    @property
+    def dtype(self):
+        return self.adapter.dtype
+
+
+def build_model(params):
+    """models/__init__.py:5-21 (FTCLIP = fine-tuning of CLIP itself, is out of scope)."""
+    if params.model == 'ZSCLIP':
+        return ZSCLIPClassifier(clip_dict=params.clip_dict)
+    elif params.model == 'FSCLIP':
+        return FSCLIPClassifier(adapter_dict=params.adapter_dict, clip_dict=params.clip_dict,
+                                loss_dict=params.loss_dict)
+    raise NotImplementedError(f'{params.model} is not implemented.')

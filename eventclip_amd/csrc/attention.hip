@@ -187,6 +187,9 @@ template <int DT, int NT2> int launch(const AttnArgs &a, int n_seq, int heads, h
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    // algorithmic work: QK^T and PV, 2 * 2 * S^2 * 64 flops per head; bytes: read qkv, write out
+    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.S * a.S * 64.0 * heads * n_seq,
+                       (double)n_seq * a.S * a.W * 2.0 * 4.0);
     hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(256), lds, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;

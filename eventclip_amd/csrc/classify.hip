@@ -180,6 +180,7 @@ extern "C" EC_API int ec_classify(const float *feats, const int32_t *row_idx, co
     a.full_logits = full_logits, a.logits = logits, a.probs = probs;
     const int lds = (T * C + 4 * CL_MAXT) * 4;
     EC_REQUIRE(lds <= 64 * 1024, "ec_classify: T*C=%d too large for LDS", T * C);
+    ec::ProfScope prof(ec::PROF_CLASSIFY, static_cast<hipStream_t>(stream), 2.0 * B * T * C * K, 0);
     hipLaunchKernelGGL(classify_kernel, dim3(B), dim3(CL_THREADS), lds,
                        static_cast<hipStream_t>(stream), a);
     EC_CHECK_HIP(hipGetLastError());

@@ -26,6 +26,21 @@ int fail(int code, const char *fmt, ...);
         if (!(cond)) return ::ec::fail(EC_ERR_INVALID, __VA_ARGS__);                        \
     } while (0)
 
+// Optional launch profiler behind ec_profile_begin / ec_profile_end: when enabled, every
+// instrumented launch is bracketed by a pair of hipEvents on its own stream.  Classes
+// are the kernel symbols a rocprofv3 --kernel-trace lists.
+enum ProfClass {
+    PROF_EVENTS = 0, PROF_PREPROCESS, PROF_PATCHIFY, PROF_GEMM_STORE16, PROF_GEMM_GELU16,
+    PROF_GEMM_RESID32, PROF_GEMM_STORE32, PROF_LAYERNORM, PROF_ATTENTION, PROF_EMBED, PROF_CLASSIFY,
+    PROF_ADAPTER, PROF_NCLASS
+};
+struct ProfScope {
+    ProfScope(int cls, hipStream_t s, double flops, double bytes);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

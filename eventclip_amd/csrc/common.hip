@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace ec {
 
@@ -20,9 +22,92 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+namespace {
+struct ProfRec {
+    int cls;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;   // events are recycled across begin/end cycles
+size_t g_pool_used = 0;
+std::mutex g_prof_mu;
+constexpr size_t PROF_MAX = 1 << 16;
+const char *const kProfNames[PROF_NCLASS] = {
+    "events_to_frames_kernel", "preprocess_kernel", "patchify_kernel", "gemm_kernel<STORE16>",
+    "gemm_kernel<GELU16>", "gemm_kernel<RESID32>", "gemm_kernel<STORE32>", "layernorm_kernel",
+    "attention_kernel", "embed_kernel", "classify_kernel", "adapter_kernels"};
+
+hipEvent_t take_event()
+{
+    if (g_pool_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_used++];
+}
+}  // namespace
+
+ProfScope::ProfScope(int cls, hipStream_t s, double flops, double bytes) : slot(-1), stream(s)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_recs.size() >= PROF_MAX) return;
+    ProfRec r{cls, flops, bytes, take_event(), take_event()};
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, s);
+    slot = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_recs[slot].e1, stream);
+}
+
 }  // namespace ec
 
 extern "C" {
+
+EC_API int ec_profile_begin(void)
+{
+    std::lock_guard<std::mutex> lk(ec::g_prof_mu);
+    ec::g_recs.clear();
+    ec::g_pool_used = 0;
+    ec::g_prof_on = true;
+    return EC_OK;
+}
+
+EC_API int ec_profile_end(ec_profile_entry *out, int cap, int *n_out)
+{
+    std::lock_guard<std::mutex> lk(ec::g_prof_mu);
+    ec::g_prof_on = false;
+    ec_profile_entry acc[ec::PROF_NCLASS];
+    for (int c = 0; c < ec::PROF_NCLASS; c++) {
+        memset(&acc[c], 0, sizeof(acc[c]));
+        snprintf(acc[c].name, sizeof(acc[c].name), "%s", ec::kProfNames[c]);
+    }
+    for (auto &r : ec::g_recs) {
+        EC_CHECK_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        EC_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        acc[r.cls].launches += 1;
+        acc[r.cls].total_ms += ms;
+        acc[r.cls].flops += r.flops;
+        acc[r.cls].bytes += r.bytes;
+    }
+    int n = 0;
+    for (int c = 0; c < ec::PROF_NCLASS; c++)
+        if (acc[c].launches > 0 && out && n < cap) out[n++] = acc[c];
+    if (n_out) *n_out = n;
+    ec::g_recs.clear();
+    return EC_OK;
+}
+
 
 EC_API const char *ec_last_error(void) { return ec::err_buf(); }
 

@@ -336,6 +336,11 @@ extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *fr
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    // algorithmic bytes: 16 B per event in + 3*H*W out; the event count
+    // is only known on the device, so the call site reports the output part and the
+    // caller adds 16 B x events
+    ec::ProfScope prof(ec::PROF_EVENTS, static_cast<hipStream_t>(stream), 0,
+                       (double)F * prm->H * prm->W * 3.0);
     hipLaunchKernelGGL(events_to_frames_kernel, dim3(F), dim3(EV_THREADS), lds,
                        static_cast<hipStream_t>(stream), a);
     EC_CHECK_HIP(hipGetLastError());

@@ -224,6 +224,13 @@ int launch(const GemmArgs &g0, hipStream_t stream)
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, stream, g);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;

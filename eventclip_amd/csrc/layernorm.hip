@@ -155,6 +155,7 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
     EC_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "ec_layernorm: strides must be multiples of 4");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(ec::ceil_div(rows, 4)), block(256);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 6.0);
     if (dtype == EC_F16)
         hipLaunchKernelGGL(layernorm_kernel<EC_F16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
                            width, eps, out16, ldo);
@@ -174,6 +175,7 @@ EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, 
     EC_REQUIRE(width % 4 == 0 && width <= LN_MAXV * 256 && seq >= 2, "ec_vit_embed: bad shape");
     if (n_img == 0) return EC_OK;
     const long rows = (long)n_img * seq;
+    ec::ProfScope prof(ec::PROF_EMBED, static_cast<hipStream_t>(stream), 0, (double)rows * width * 8.0);
     hipLaunchKernelGGL(vit_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), patch, cls, pos, gamma, beta, n_img, seq,
                        width, eps, x);
@@ -187,6 +189,7 @@ EC_API int ec_text_embed(const int32_t *tokens, const float *table, const float 
     EC_REQUIRE(width % 4 == 0 && ctx > 0 && vocab > 0, "ec_text_embed: bad shape");
     if (n_txt == 0) return EC_OK;
     const long rows = (long)n_txt * ctx;
+    ec::ProfScope prof(ec::PROF_EMBED, static_cast<hipStream_t>(stream), 0, (double)rows * width * 8.0);
     hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), tokens, table, pos, n_txt, ctx, width,
                        vocab, x);

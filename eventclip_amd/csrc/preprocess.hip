@@ -311,6 +311,11 @@ EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, co
     if (lds > 64 * 1024)
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    // algorithmic bytes: uint8 frame in, n_px^2 x 3 values out
+    const double out_bytes = mode == EC_PRE_CHW_F32 ? 12.0 * R * R
+                             : mode == EC_PRE_HWC_U8 ? 3.0 * R * R
+                                                     : 2.0 * (R / a.patch) * (R / a.patch) * a.kpad;
+    ec::ProfScope prof(ec::PROF_PREPROCESS, s, 0, F * (3.0 * a.in_h * a.in_w + out_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)F * a.bands), dim3(256), lds, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
@@ -326,6 +331,7 @@ EC_API int ec_patchify(const float *img, int n_img, int n_px, int patch, int kpa
     const long total = (long)n_img * (n_px / patch) * (n_px / patch) * kpad;
     const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_PATCHIFY, s, 0, 12.0 * n_img * n_px * n_px + 2.0 * total);
     if (dtype == EC_F16)
         hipLaunchKernelGGL(patchify_kernel<EC_F16>, dim3(grid), dim3(256), 0, s, img, out16, n_img,
                            n_px, patch, kpad);

@@ -1,0 +1,132 @@
+"""Events -> model-ready views on the MI355X: device-side mirror of the reference's
+``Event2ImageDataset`` (datasets/event2img.py:14-145) plus the DataLoader collate.
+
+The reference converts ONE sample per ``__getitem__`` in CPU worker processes:
+``events2frames`` (:118) -> PIL -> ``self.transforms`` per frame (:119-122) ->
+``_subsample_imgs`` (:80-92, pad with zero tensors / random subset to ``max_imgs``)
+and the loader stacks samples into ``img [B, T, 3, R, R]``, ``valid_mask [B, T]``.
+Here a whole batch goes through two kernels (events->frames, preprocess) with the
+chunk bookkeeping (``split_event_count``, ``max_imgs``, padding, masks) done on the
+host from event counts alone.  No CPU fallback.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import vis
+from .preprocess import preprocess_frames
+
+
+class Event2ImagePipeline:
+    """Batched ``_event2img`` (event2img.py:114-128).
+
+    resolution, max_n: the event dataset's constants (caltech.py:52-58 etc.).
+    quantize_args: same dict as the reference's configs (``max_imgs``, ``N``,
+        ``split_method``, ``convert_method``, ``grayscale``, ``count_non_zero``,
+        ``background_mask``).
+    n_px: CLIP input resolution.  patch/kpad/dtype: when given, ``__call__`` emits the
+        16-bit im2col rows for ``CLIP.encode_patches`` instead of fp32 images.
+    """
+
+    def __init__(self, resolution, max_n, quantize_args, n_px=224, patch=None, kpad=None,
+                 dtype=torch.float16, generator=None):
+        qa = copy.deepcopy(quantize_args)
+        self.resolution = tuple(resolution)
+        self.split_method = qa['split_method']
+        self.event_rep = qa['convert_method']
+        assert self.split_method == 'event_count'                       # event2img.py:69
+        if self.event_rep != 'event_histogram':                          # vis.py:113
+            raise NotImplementedError(f'{self.event_rep} not implemented!')
+        self.N = int(qa['N'])
+        max_imgs = round(max_n / self.N)                                 # event2img.py:70
+        max_max_imgs = qa.pop('max_imgs', 10)                            # event2img.py:71
+        self.max_imgs = max(min(max_imgs, max_max_imgs), 1)              # event2img.py:72
+        self.grayscale = qa.get('grayscale', True)
+        self.thresh = float(qa.get('thresh', 10.))
+        self.count_non_zero = bool(qa.get('count_non_zero', False))
+        self.background_mask = bool(qa.get('background_mask', True))
+        self.n_px, self.patch, self.kpad, self.dtype = int(n_px), patch, kpad, dtype
+        self.generator = generator
+        self.strict = True   # raise on events outside the sensor, as the reference does
+
+    # ---- host bookkeeping: which event rows make which view ----
+    def plan(self, n_events):
+        """n_events: per-sample event counts.  Returns (frame_range int64 [Fv, 2],
+        row_idx int32 [B, T], valid_mask bool [B, T]) as CPU tensors; row_idx[b, t] is the
+        compact frame number of view t of sample b, or -1 for a padded view."""
+        T = self.max_imgs
+        B = len(n_events)
+        ranges, row_idx = [], np.full((B, T), -1, dtype=np.int32)
+        off = 0
+        for b, n in enumerate(n_events):
+            n = int(n)
+            if n <= 0:
+                raise IndexError('sample with no events (the reference resamples these upstream, '
+                                 'caltech.py:181-182)')
+            idx0, idx1 = vis.chunk_bounds(n, self.N)
+            sel = list(range(len(idx0)))
+            if len(sel) > T:                                             # event2img.py:83-86
+                sel = torch.randperm(len(sel), generator=self.generator)[:T].tolist()
+            for t, f in enumerate(sel):                                  # event2img.py:87-91
+                row_idx[b, t] = len(ranges)
+                ranges.append((off + idx0[f], off + idx1[f]))
+            off += n
+        fr = torch.tensor(ranges, dtype=torch.int64).reshape(-1, 2)
+        ri = torch.from_numpy(row_idx)
+        return fr, ri, ri >= 0
+
+    def frames(self, events, frame_range):
+        """uint8 [Fv, H, W, 3] for the planned views (vis.events2frames, batched)."""
+        out = vis.events_to_frames_device(
+            events, frame_range, self.resolution, grayscale=self.grayscale, thresh=self.thresh,
+            count_non_zero=self.count_non_zero, background_mask=self.background_mask,
+            return_stats=self.strict)
+        if self.strict:
+            frames, stats = out
+            if int(stats['dropped'].sum()) > 0:
+                raise ValueError('events outside the sensor '
+                                 f'({int(stats["dropped"].sum())} dropped; vis.py:11 would raise)')
+            return frames
+        return out
+
+    def __call__(self, events, n_events=None):
+        """events: list of per-sample float32 [n_i, 4] arrays/tensors, or one CUDA tensor
+        [sum n_i, 4] with ``n_events`` giving the per-sample counts.
+
+        Returns a dict with ``valid_mask`` [B, T] (CUDA bool), ``row_idx`` [B, T] (CUDA
+        int32) and either ``patches`` [Fv, G, kpad] (fused path) or ``img``
+        [B, T, 3, R, R] float32 (the reference's batch layout, padded views all-zero)."""
+        dev = _lib.require_gpu()
+        if isinstance(events, (list, tuple)):
+            n_events = [int(e.shape[0]) for e in events]
+            cat = np.concatenate([vis.parse_events(e.cpu().numpy() if torch.is_tensor(e) else e)
+                                  for e in events], axis=0)
+            events = torch.from_numpy(cat).to(dev)
+        assert events.is_cuda and events.dtype == torch.float32 and n_events is not None
+        fr, ri, vm = self.plan(n_events)
+        fr_d = fr.to(dev)
+        frames = self.frames(events, fr_d)
+        out = dict(valid_mask=vm.to(dev), row_idx=ri.to(dev))
+        if self.patch:
+            out['patches'] = preprocess_frames(frames, self.n_px, mode='patches', patch=self.patch,
+                                               kpad=self.kpad, dtype=self.dtype)
+        else:
+            chw = preprocess_frames(frames, self.n_px, mode='chw')
+            B, T = ri.shape
+            img = torch.zeros((B, T, 3, self.n_px, self.n_px), dtype=torch.float32, device=dev)
+            img[out['valid_mask']] = chw                                 # event2img.py:88-91
+            out['img'] = img
+        return out
+
+
+def build_event2img_pipeline(params, resolution, max_n, clip_model=None):
+    """Counterpart of build_event2img_dataset (event2img.py:148-156) for the device path."""
+    kw = {}
+    n_px = 224
+    if clip_model is not None:
+        c = clip_model.cfg
+        n_px = c['image_size']
+        kw = dict(patch=c['patch'], kpad=clip_model.kpad, dtype=clip_model.compute_dtype)
+    return Event2ImagePipeline(resolution, max_n, params.quantize_args, n_px=n_px, **kw)

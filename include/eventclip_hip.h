@@ -41,6 +41,20 @@ EC_API int ec_version(void);
 /* number of CUs / name of the current device, for reports */
 EC_API int ec_device_info(int *cu_count, char *name, int name_len);
 
+/* Launch profiler: between begin and end every kernel launch this library makes is
+ * bracketed by hipEvents on its own stream; end() waits for them and returns one
+ * entry per kernel symbol (launch count, summed duration, algorithmic flops / bytes
+ * as the call sites state them).  bench.py's `roofline` comes from here. */
+typedef struct {
+    char name[64];
+    long launches;
+    double total_ms;
+    double flops; /* algorithmic FLOPs (2*M*N*K per GEMM launch, ...) */
+    double bytes; /* algorithmic HBM bytes where the call site states them, else 0 */
+} ec_profile_entry;
+EC_API int ec_profile_begin(void);
+EC_API int ec_profile_end(ec_profile_entry *out, int cap, int *n_out);
+
 /* ------------------------------------------------------------------------
  * events -> histogram frames.
  * Replaces datasets/vis.py: events2frames (:75-117) = parse_events (:44-52) +
@@ -228,6 +242,35 @@ enum { EC_AGG_SUM = 0, EC_AGG_MEAN = 1, EC_AGG_MAX = 2 };
 EC_API int ec_classify(const float *feats, const int32_t *row_idx, const float *text_t, int B, int T,
                        int C, int K, float logit_scale, int agg, int normalize, float *full_logits,
                        float *logits, float *probs, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Few-shot feature adapter.  Replaces TransformerAdapter.forward
+ * (models/adapter.py:82-105) + Adapter.residual_add (:22-25) including the
+ * scatter of view features into a zero [B, T, C] tensor (models/clip_cls.py:319-321).
+ * fp32.  All Linear weights are handed over TRANSPOSED ([in, out] row-major).
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    const float *ln1_g, *ln1_b;    /* norm1 [d_model] */
+    const float *qkv_w_t, *qkv_b;  /* self_attn.in_proj_weight^T [d_model, 3 d_model], bias */
+    const float *o_w_t, *o_b;      /* self_attn.out_proj.weight^T [d_model, d_model] */
+    const float *ln2_g, *ln2_b;    /* norm2 */
+    const float *w1_t, *b1;        /* linear1.weight^T [d_model, ffn] */
+    const float *w2_t, *b2;        /* linear2.weight^T [ffn, d_model] */
+} ec_adapter_layer;
+
+typedef struct {
+    int in_dim, d_model, heads, ffn, layers;
+    float residual;                /* r of in * r + new * (1 - r) */
+    const float *in_w_t, *in_b;    /* in_proj.weight^T [in_dim, d_model] */
+    const float *out_w_t, *out_b;  /* out_proj.weight^T [d_model, in_dim] */
+    const ec_adapter_layer *layer; /* host array [layers] */
+} ec_adapter_weights;
+
+/* feats: fp32 [n_rows, in_dim]; row_idx: int32 [B, T] (row of feats or -1 = padded
+ * view, which enters as a zero row and is masked as an attention key);
+ * out: fp32 [B, T, in_dim]. */
+EC_API int ec_adapter_forward(const ec_adapter_weights *w, const float *feats,
+                              const int32_t *row_idx, int B, int T, float *out, ec_stream_t stream);
 
 #ifdef __cplusplus
 }

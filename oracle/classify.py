@@ -17,6 +17,8 @@ def aggregate_logits(logits, valid_masks, agg_func):
     if agg_func == 'mean':
         return logits.sum(1) / valid_masks.float().sum(1, keepdim=True)
     if agg_func == 'max':
+        # the reference subtracts the [B, T] mask without unsqueezing (clip_cls.py:117),
+        # which cannot broadcast against [B, T, K] and raises; this is the evident intent
         logits = logits - (1. - valid_masks.float())[..., None] * 1e6
         return logits.max(1)[0]
     raise NotImplementedError(agg_func)

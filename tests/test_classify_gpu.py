@@ -20,6 +20,16 @@ def run_classify(feats, row_idx, text, scale, agg, normalize):
     return full, logits, probs
 
 
+def check(full, logits, probs, want, T):
+    """fp32 on both sides; only the summation order differs, so the tolerance is a few
+    ulp of the largest logit (x T for the view sums)."""
+    import torch
+    mag = float(want['full_logits'].abs().max())
+    torch.testing.assert_close(full.cpu(), want['full_logits'], rtol=1e-5, atol=2e-6 * mag)
+    torch.testing.assert_close(logits.cpu(), want['logits'], rtol=1e-5, atol=2e-6 * mag * T)
+    torch.testing.assert_close(probs.cpu(), want['probs'], rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('agg', ['sum', 'mean', 'max'])
 @pytest.mark.parametrize('B,T,C,K', [(6, 10, 768, 101), (4, 1, 768, 2), (3, 5, 512, 1000),
                                      (5, 2, 64, 7)])
@@ -37,9 +47,7 @@ def test_zero_shot_matches_oracle(B, T, C, K, agg, hip):
     idx = torch.full((B, T), -1, dtype=torch.int32)
     idx[valid] = torch.arange(nv, dtype=torch.int32)
     full, logits, probs = run_classify(feats.cuda(), idx.cuda(), text.cuda(), 100.0, agg, False)
-    torch.testing.assert_close(full.cpu(), want['full_logits'], rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(logits.cpu(), want['logits'], rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(probs.cpu(), want['probs'], rtol=1e-4, atol=1e-6)
+    check(full, logits, probs, want, T)
 
 
 @pytest.mark.parametrize('agg', ['sum', 'mean', 'max'])
@@ -57,6 +65,4 @@ def test_few_shot_tail_matches_oracle(agg, hip):
     idx = torch.where(valid, torch.arange(B * T).view(B, T), torch.tensor(-1)).to(torch.int32)
     full, logits, probs = run_classify(feats.view(B * T, C).cuda(), idx.cuda(), text.cuda(), 100.0,
                                        agg, True)
-    torch.testing.assert_close(full.cpu(), want['full_logits'], rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(logits.cpu(), want['logits'], rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(probs.cpu(), want['probs'], rtol=1e-4, atol=1e-6)
+    check(full, logits, probs, want, T)

@@ -115,41 +115,58 @@ def test_tiny_clip_matches_hf_fixture(dt, hip):
     assert rel_err(gt, torch.from_numpy(z['hf_txt'])) < tol
 
 
-@pytest.mark.parametrize('arch,layers,n', [('ViT-B/32', 12, 5), ('ViT-B/16', 3, 3),
-                                           ('ViT-L/14', 24, 3), ('ViT-L/14@336px', 2, 2)])
-def test_image_tower_matches_oracle(arch, layers, n, hip):
-    """Full-width towers, seeded random weights, identical inputs on both sides.
-    Tolerance: north_star's 1e-3 relative (max |diff| / max |ref|), f16 operands."""
+def seeded(name):
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, 'towers_seeded.npz'))[name]
+
+
+@pytest.mark.parametrize('name,arch,ov,n', [
+    ('vitl14', 'ViT-L/14', dict(text_layers=1, vocab_size=1024), 2),
+    ('vitb32', 'ViT-B/32', dict(text_layers=1, vocab_size=1024), 3),
+    ('vitl14_336', 'ViT-L/14@336px', dict(layers=4, text_layers=1, vocab_size=1024), 1)])
+@pytest.mark.parametrize('dt,tol', [('float16', 1e-3), ('bfloat16', 1e-2)])
+def test_image_tower_matches_oracle_fixture(name, arch, ov, n, dt, tol, hip):
+    """Full-width (and for L/14, B/32 full-depth) towers with seeded random weights against
+    the fp32 CPU oracle's stored outputs (tools/make_golden_vit.py).  Tolerance: north_star's
+    1e-3 relative (max |diff| / max |ref|) with f16 operands; bf16 operands are ~8x coarser."""
     import torch
     from eventclip_amd import clip as eclip
-    from oracle import clip_ref
-    cfg = eclip.arch_config(arch, layers=layers, text_layers=1, vocab_size=1024)
+    cfg = eclip.arch_config(arch, **ov)
     sd = eclip.random_state_dict(cfg, seed=11)
-    model = eclip.CLIP(cfg, sd, dtype='float16').cuda().eval()
+    model = eclip.CLIP(cfg, sd, dtype=dt).cuda().eval()
     R = cfg['image_size']
     img = torch.randn(n, 3, R, R, generator=torch.Generator().manual_seed(5))
+    assert abs(float(img.double().sum()) - float(seeded(name + '_img_checksum'))) < 1e-6
     got = model.encode_image(img.cuda()).cpu()
-    torch.set_num_threads(os.cpu_count() or 8)
-    want = clip_ref.encode_image(sd, cfg, img)
+    want = torch.from_numpy(seeded(name))
     assert got.shape == want.shape == (n, cfg['embed_dim'])
-    assert rel_err(got, want) < 1e-3
-    # against the oracle fed the same 16-bit-rounded weights the error is pure arithmetic
-    want16 = clip_ref.encode_image(clip_ref.round_weights(sd, torch.float16), cfg, img)
-    assert rel_err(got, want16) < 1e-3
+    assert rel_err(got, want) < tol
+    if dt == 'float16':   # same 16-bit-rounded weights on both sides: arithmetic error only
+        assert rel_err(got, torch.from_numpy(seeded(name + '_w16'))) < tol
 
 
-@pytest.mark.parametrize('arch', ['ViT-B/32', 'ViT-L/14'])
-def test_text_tower_matches_oracle(arch, hip):
+def test_small_tower_matches_live_oracle(hip):
     import torch
     from eventclip_amd import clip as eclip
     from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-B/16', layers=2, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=4)
+    model = eclip.CLIP(cfg, sd, dtype='float16').cuda().eval()
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    got = model.encode_image(img.cuda()).cpu()
+    assert rel_err(got, clip_ref.encode_image(sd, cfg, img)) < 1e-3
+
+
+@pytest.mark.parametrize('name,arch', [('text_l14', 'ViT-L/14'), ('text_b32', 'ViT-B/32')])
+def test_text_tower_matches_oracle_fixture(name, arch, hip):
+    import torch
+    from eventclip_amd import clip as eclip
     cfg = eclip.arch_config(arch, layers=1)
     sd = eclip.random_state_dict(cfg, seed=12)
     model = eclip.CLIP(cfg, sd, dtype='float16').cuda().eval()
-    tok = eclip.synthetic_tokens(7, seed=3)
+    tok = eclip.synthetic_tokens(9, seed=3)
     got = model.encode_text(tok.cuda()).cpu()
-    want = clip_ref.encode_text(sd, cfg, tok)
-    assert rel_err(got, want) < 1e-3
+    assert rel_err(got, torch.from_numpy(seeded(name))) < 1e-3
 
 
 def test_chunked_encode_is_batch_invariant(hip):
