@@ -44,17 +44,18 @@ def parse():
     ap.add_argument('--chunk', type=int, default=256, help='frames per pass through the tower')
     ap.add_argument('--classes', type=int, default=101)
     ap.add_argument('--cpu-baseline-samples', type=int, default=1)
+    ap.add_argument('--cpu-baseline-frames', type=int, default=4, help='views per baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples):
+def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames):
     """The CPU oracle chain on a bounded sample of the same workload (rank 0, N=1 only)."""
     from oracle import classify as oc
     from oracle import clip_ref
     from oracle import events as oe
     from oracle import preprocess as op
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 64)   # more threads than this slow torch's CPU GEMMs down
     torch.set_num_threads(threads)
     qa = {k: v for k, v in quantize_args.items()
           if k not in ('max_imgs', 'split_method', 'convert_method')}
@@ -62,6 +63,7 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples):
     t0 = time.perf_counter()
     n_frames = 0
     for ev in events[:n_samples]:
+        ev = ev[:max_frames * qa['N']]
         frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
         imgs = torch.from_numpy(op.preprocess(frames, cfg['image_size']))
         feats = clip_ref.encode_image(sd, cfg, imgs)
@@ -70,7 +72,7 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples):
         n_frames += frames.shape[0]
     dt = time.perf_counter() - t0
     return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_samples} sample(s) = {n_frames} frames of the same workload through the '
+            'sample': f'{n_samples} sample(s) cut to {n_frames} frames of the same workload through the '
                       f'CPU oracle (C events2frames + numpy Pillow-bicubic + torch fp32 '
                       f'{threads}-thread ViT), {dt:.1f} s'}
 
@@ -193,7 +195,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
-                                               a.cpu_baseline_samples)
+                                               a.cpu_baseline_samples, a.cpu_baseline_frames)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
