@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
     ap.add_argument('--arch', default='ViT-L/14')
     ap.add_argument('--dtype', default='float16', choices=['float16', 'bfloat16'])
-    ap.add_argument('--chunk', type=int, default=256, help='frames per pass through the tower')
+    ap.add_argument('--chunk', type=int, default=2560, help='frames per pass through the tower')
     ap.add_argument('--classes', type=int, default=101)
     ap.add_argument('--cpu-baseline-samples', type=int, default=3)
     ap.add_argument('--cpu-baseline-frames', type=int, default=10, help='views per baseline sample')

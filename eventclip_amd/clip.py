@@ -153,7 +153,7 @@ def _assign(root, key, tensor):
 class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
-    def __init__(self, cfg, state_dict, dtype='float16', chunk=256):
+    def __init__(self, cfg, state_dict, dtype='float16', chunk=2560):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -165,6 +165,7 @@ class CLIP(nn.Module):
         self.compute_dtype = {'float16': torch.float16, 'fp16': torch.float16,
                               'bfloat16': torch.bfloat16, 'bf16': torch.bfloat16}[str(dtype)]
         self.chunk = int(chunk)
+        self.workspace_budget = 24 << 30   # bytes of tower scratch at most
         self._packed = None
         self._ws = None
 
@@ -273,6 +274,9 @@ class CLIP(nn.Module):
         feats = torch.empty((n, self.cfg['embed_dim']), dtype=torch.float32, device=pk['dev'])
         chunk = max(1, min(self.chunk, n))
         need = _lib.lib().ec_vit_workspace_bytes(ctypes.byref(pk['vit']), chunk)
+        if need > self.workspace_budget:     # keep the scratch bounded (e.g. 336-px inputs)
+            chunk = max(1, int(chunk * self.workspace_budget / need))
+            need = _lib.lib().ec_vit_workspace_bytes(ctypes.byref(pk['vit']), chunk)
         ws = self._workspace(need, pk['dev'])
         assert patches.dtype == self.compute_dtype and patches.is_contiguous()
         rc = _lib.lib().ec_vit_encode(ctypes.byref(pk['vit']), _lib.ptr(patches), n,
@@ -326,7 +330,7 @@ class CLIP(nn.Module):
         return li, li.t()
 
 
-def build_random(arch, seed=0, dtype='float16', device='cuda', chunk=256, **override):
+def build_random(arch, seed=0, dtype='float16', device='cuda', chunk=2560, **override):
     """Random-weight CLIP of a named architecture (benchmarks / tests: no checkpoints ship)."""
     cfg = arch_config(arch, **override)
     model = CLIP(cfg, random_state_dict(cfg, seed), dtype=dtype, chunk=chunk)
@@ -335,7 +339,7 @@ def build_random(arch, seed=0, dtype='float16', device='cuda', chunk=256, **over
     return model.eval()
 
 
-def build_from_state_dict(sd, dtype='float16', device='cuda', chunk=256):
+def build_from_state_dict(sd, dtype='float16', device='cuda', chunk=2560):
     sd = {k: v for k, v in sd.items() if k not in ('input_resolution', 'context_length',
                                                    'vocab_size')}
     cfg = config_from_state_dict(sd)

@@ -5,8 +5,9 @@
 // models/clip_cls.py:84 encode_text / :101 encode_image).  Sequences are short
 // and fixed (50..577 vision tokens, 77 text tokens), so one workgroup owns one
 // (sequence, head): the head's whole K and V (<= 608 x 64 x 16 bit each) sit in
-// LDS, every wave takes 16-query tiles, and the full score row lives in
-// registers -- no online-softmax rescaling is needed.
+// LDS and every wave takes 16-query tiles.  Keys are walked in 64-key blocks with
+// an online softmax (running max / sum per query, O rescaled per block: 16
+// registers), which keeps the kernel near 100 VGPRs for any sequence length.
 //
 //  * S^T = K . Q^T with v_mfma_f32_16x16x32: K rows from LDS (ds_read_b128,
 //    XOR-swizzled 128-B rows), Q straight from HBM as the B operand.  A lane then
@@ -26,6 +27,9 @@ namespace {
 
 using namespace ec;
 
+constexpr int AT_WAVES = 8;            // waves per workgroup (two workgroups fit a CU's LDS)
+constexpr int AT_THREADS = AT_WAVES * 64;
+
 struct AttnArgs {
     const void *qkv;  // [n_seq * S, 3W] 16-bit: q | k | v, heads are 64-wide column blocks
     void *out;        // [n_seq * S, W] 16-bit
@@ -33,27 +37,135 @@ struct AttnArgs {
     float scale_log2e;
 };
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the
+// gfx950 row-swap VALU ops instead of ds_bpermute round trips through LDS:
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
+// second, v_permlane32_swap the upper half of the first with the lower half of the second.
+// (Written as inline asm: hipcc folds max / add over the two results of the swap builtins
+// to one operand.  s_nop 1 covers the VALU-write -> v_permlane-read hazard.)
 __device__ __forceinline__ float xor_max(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32 %0, %0, %1\n\t"
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32 %0, %0, %1"
+                 : "+v"(a), "+v"(b));
+    return a;
 }
 __device__ __forceinline__ float xor_sum(float v)
 {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %1\n\t"
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %1"
+                 : "+v"(a), "+v"(b));
+    return a;
 }
 
-template <int DT, int NT2>  // NT2 = number of 32-key steps; keys padded to 32 * NT2
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
+// One 64-key (or, for the last odd step, 32-key) block of the online softmax:
+// scores -> running max / sum -> P^T as the B operand -> O^T += V^T . P^T.
+template <int DT, int KSTEPS, bool MASK>  // KSTEPS = 32-key steps in this block (2 or 1)
+__device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsigned char *ldsV,
+                                           int key0, int klimit, const typename T16<DT>::v8 (&qf)[2],
+                                           float scale_log2e, float &m_run, float &l_run,
+                                           f32x4 (&o)[4], int g, int c16)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     typedef typename T16<DT>::v4 v4;
-    constexpr int NT = 2 * NT2;    // 16-key score tiles
-    constexpr int SP = 32 * NT2;   // padded key count
+    constexpr int NT = 2 * KSTEPS;
+    // ---- scores: acc[kt][r] = <k[key0 + 16 kt + 4 g + r], q[c16]> ----
+    f32x4 acc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = key0 + kt * 16 + c16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const v8 kf = *reinterpret_cast<const v8 *>(ldsK + row * 128 +
+                                                        (((ks * 4 + g) ^ (row & 7)) << 4));
+            acc[kt] = mfma16(kf, qf[ks], acc[kt]);
+        }
+    }
+    // ---- (mask,) block max, rescale factor ----
+    float mx = m_run;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (MASK) {   // only blocks that reach past klimit (padding, causal diagonal)
+                const int key = key0 + kt * 16 + 4 * g + r;
+                acc[kt][r] = key < klimit ? acc[kt][r] : -INFINITY;
+            }
+            mx = fmaxf(mx, acc[kt][r]);
+        }
+    mx = xor_max(mx);   // the four lane groups hold different keys of the same query
+    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);
+    m_run = mx;
+    const float mc = -mx * scale_log2e;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kt][r], scale_log2e, mc));
+            acc[kt][r] = p;
+            psum += p;
+        }
+    l_run = l_run * alpha + psum;   // per-lane partial; summed over the lane groups at the end
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+        // B operand element j <-> key key0 + 32 s + 16 (j >> 2) + 4 g + (j & 3)
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            pf[r] = to16(acc[2 * s][r], elem());
+            pf[4 + r] = to16(acc[2 * s + 1][r], elem());
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            // A operand row i <-> head dim (i >> 2) * 16 + 4 dt + (i & 3), same key order
+            v8 vf;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int row = key0 + 32 * s + 16 * hh + 4 * g + (c16 >> 2);
+                const int u = ((c16 & 3) * 4 + dt) ^ ((row >> 1) & 3);
+                const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(ldsV + row * 128 + u * 8));
+                const v4 tv = __builtin_bit_cast(v4, t);
+                vf[4 * hh] = tv[0], vf[4 * hh + 1] = tv[1], vf[4 * hh + 2] = tv[2],
+                        vf[4 * hh + 3] = tv[3];
+            }
+            o[dt] = mfma16(vf, pf, o[dt]);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(const AttnArgs a)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = a.S, W = a.W;
+    const int n32 = (S + 31) / 32;       // 32-key steps; keys padded to 32 * n32
+    const int SP = 32 * n32;
     unsigned char *ldsK = smem;
     unsigned char *ldsV = smem + SP * 128;
 
@@ -61,16 +173,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c16 = lane & 15;
     const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
-    const int S = a.S, W = a.W;
     const long ld = 3L * W;
     const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
 
-    // ---- stage K and V of this head: 32 rows x 8 chunks of 16 B per pass ----
+    // ---- stage K and V of this head: AT_THREADS / 8 rows x 8 chunks of 16 B per pass ----
     {
         const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
-#pragma unroll 2
-        for (int it = 0; it < NT2; it++) {
-            const int row = it * 32 + r_in;
+        for (int row = r_in; row < SP; row += AT_THREADS / 8) {
             const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
             const elem *src = base + (long)srow * ld + ch * 8;
             const u32x4 kv = *reinterpret_cast<const u32x4 *>(src + W);
@@ -81,90 +190,49 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
             *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
         }
     }
-    __syncthreads();
-
+    // first Q tile of this wave, issued before the barrier so its latency hides behind staging
     const int n_qt = (S + 15) / 16;
-    for (int qt = wave; qt < n_qt; qt += 4) {
-        // ---- Q tile as the MFMA B operand: lane -> query c16, d = 32 ks + 8 g + j ----
-        const int qrow = qt * 16 + c16;
-        const int qsrc = qrow < S ? qrow : S - 1;
-        v8 qf[2];
+    v8 qf[2], qn[2];
+    auto load_q = [&](int qt, v8(&dst)[2]) {
+        int qsrc = qt * 16 + c16;
+        qsrc = qsrc < S ? qsrc : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
-            qf[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 32 + g * 8);
+            dst[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 32 + g * 8);
+    };
+    if (wave < n_qt) load_q(wave, qn);
+    __syncthreads();
 
-        // ---- scores: acc[kt][r] = <k[16 kt + 4 g + r], q[c16]> ----
-        f32x4 acc[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++) {
-            acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row = kt * 16 + c16;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const v8 kf = *reinterpret_cast<const v8 *>(
-                    ldsK + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4));
-                acc[kt] = mfma16(kf, qf[ks], acc[kt]);
-            }
-        }
-
-        // ---- mask + softmax over keys (fp32) ----
+    for (int qt = wave; qt < n_qt; qt += AT_WAVES) {
+        qf[0] = qn[0], qf[1] = qn[1];
+        if (qt + AT_WAVES < n_qt) load_q(qt + AT_WAVES, qn);   // prefetch the next tile's Q
+        const int qrow = qt * 16 + c16;
         const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;  // keys < klimit are visible
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 16 + 4 * g + r;
-                const float s = key < klimit ? acc[kt][r] : -INFINITY;
-                acc[kt][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        mx = xor_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float p = __builtin_amdgcn_exp2f((acc[kt][r] - mx) * a.scale_log2e);
-                acc[kt][r] = p;
-                sum += p;
-            }
-        sum = xor_sum(sum);
-
-        // ---- O^T = V^T . P^T over 32-key steps ----
+        // causal rows of this tile see no key beyond 16 qt + 15: skip the blocks past it
+        const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
+        float m_run = -1e30f, l_run = 0.f;
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NT2; s++) {
-            // B operand element j <-> key 32 s + 16 (j >> 2) + 4 g + (j & 3)
-            v8 pf;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                pf[r] = to16(acc[2 * s][r], elem());
-                pf[4 + r] = to16(acc[2 * s + 1][r], elem());
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++) {
-                // A operand row i <-> head dim (i >> 2) * 16 + 4 dt + (i & 3), same key order
-                v8 vf;
-#pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    const int row = 32 * s + 16 * hh + 4 * g + (c16 >> 2);
-                    const int u = ((c16 & 3) * 4 + dt) ^ ((row >> 1) & 3);
-                    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(ldsV + row * 128 + u * 8));
-                    const v4 tv = __builtin_bit_cast(v4, t);
-                    vf[4 * hh] = tv[0], vf[4 * hh + 1] = tv[1], vf[4 * hh + 2] = tv[2],
-                            vf[4 * hh + 3] = tv[3];
-                }
-                o[dt] = mfma16(vf, pf, o[dt]);
-            }
+        // blocks entirely below every lane's klimit need no masking: klimit >= kfree for all
+        // 16 queries of the tile (causal: 16 qt + 1 .. ; otherwise S)
+        const int kfree = a.causal ? qt * 16 + 1 : S;
+        int key0 = 0;
+        for (; key0 + 64 <= kend; key0 += 64) {
+            if (key0 + 64 <= kfree)
+                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
+                                         g, c16);
+            else
+                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
+                                        g, c16);
         }
+        if (key0 < kend)
+            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o, g,
+                                    c16);
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
+        const float inv = 1.f / xor_sum(l_run);
         if (qrow < S) {
-            const float inv = 1.f / sum;
             elem ov[16];
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
@@ -177,33 +245,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
     }
 }
 
-template <int DT, int NT2> int launch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
+template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
 {
-    constexpr int lds = 32 * NT2 * 128 * 2;
-    auto kern = attention_kernel<DT, NT2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const int n32 = (a.S + 31) / 32;
+    const int lds = 32 * n32 * 128 * 2;
+    if (lds > 160 * 1024)
+        return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d > 640", a.S);
+    auto kern = attention_kernel<DT>;
+    static int attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_lds = lds;
     }
     // algorithmic work: QK^T and PV, 2 * 2 * S^2 * 64 flops per head; bytes: read qkv, write out
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.S * a.S * 64.0 * heads * n_seq,
                        (double)n_seq * a.S * a.W * 2.0 * 4.0);
-    hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(AT_THREADS), lds, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
-}
-
-template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
-{
-    const int nt2 = (a.S + 31) / 32;
-    if (nt2 <= 2) return launch<DT, 2>(a, n_seq, heads, s);    // S <= 64  (ViT-B/32: 50)
-    if (nt2 <= 3) return launch<DT, 3>(a, n_seq, heads, s);    // S <= 96  (text: 77)
-    if (nt2 <= 7) return launch<DT, 7>(a, n_seq, heads, s);    // S <= 224 (ViT-B/16: 197)
-    if (nt2 <= 9) return launch<DT, 9>(a, n_seq, heads, s);    // S <= 288 (ViT-L/14: 257)
-    if (nt2 <= 19) return launch<DT, 19>(a, n_seq, heads, s);  // S <= 608 (ViT-L/14@336: 577)
-    return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d > 608", a.S);
 }
 
 }  // namespace

@@ -47,8 +47,9 @@ __device__ __forceinline__ int swz_key(int row) { return (row & 7) ^ ((row >> 3)
 
 __device__ __forceinline__ float quick_gelu(float x)
 {
-    // QuickGELU of openai/CLIP: x * sigmoid(1.702 x)
-    return x / (1.f + __expf(-1.702f * x));
+    // QuickGELU of openai/CLIP: x * sigmoid(1.702 x); v_exp_f32 + v_rcp_f32 (1 ulp each),
+    // far inside the 16-bit rounding of the output
+    return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
 }
 
 // bijective XCD remap (blocks b and b+8 share an XCD): XCD x gets a contiguous id range
@@ -57,6 +58,60 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
     const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + (bid >> 3);
+}
+
+// Epilogue shared by the GEMM kernels.  acc[i][j][r]: row m_base + 16 i + (lane & 15),
+// column n_base + 16 (lane >> 4) + 4 j + r  (see the weight-row permutation above).
+template <int DT, int EPI, int TM>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
+                                         int n_base, int lane)
+{
+    typedef typename T16<DT>::elem elem;
+    const int nb = n_base + (lane >> 4) * 16;
+    if (nb >= g.N) return;
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) bias[c] = 0.f;
+    if (g.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 b = *reinterpret_cast<const float4 *>(g.bias + nb + 4 * c);
+            bias[4 * c] = b.x, bias[4 * c + 1] = b.y, bias[4 * c + 2] = b.z, bias[4 * c + 3] = b.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m_base + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
+        if constexpr (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) {
+            elem o[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                float x = v[c];
+                if constexpr (EPI == EC_EPI_GELU16) x = quick_gelu(x);
+                o[c] = to16(x, elem());
+            }
+            elem *dst = (elem *)g.C + (long)m * g.ldc + nb;
+            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&o[0]);
+            *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&o[8]);
+        } else {
+            float *dst = (float *)g.C + (long)m * g.ldc + nb;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float4 o = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+                if constexpr (EPI == EC_EPI_RESID32) {
+                    const float4 x = *reinterpret_cast<const float4 *>(dst + 4 * c);
+                    o.x += x.x, o.y += x.y, o.z += x.z, o.w += x.w;
+                }
+                *reinterpret_cast<float4 *>(dst + 4 * c) = o;
+            }
+        }
+    }
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int EPI>
@@ -162,52 +217,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs g)
         cur ^= 1;
     }
 
-    // ---- epilogue: lane owns row m = .. + (lane&15), columns nb .. nb+15 ----
-    const int nb = n0 + wn * 64 + (lane >> 4) * 16;
-    if (nb >= g.N) return;
-    float bias[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) bias[c] = 0.f;
-    if (g.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float4 b = *reinterpret_cast<const float4 *>(g.bias + nb + 4 * c);
-            bias[4 * c] = b.x, bias[4 * c + 1] = b.y, bias[4 * c + 2] = b.z, bias[4 * c + 3] = b.w;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
-        if constexpr (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) {
-            elem o[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                float x = v[c];
-                if constexpr (EPI == EC_EPI_GELU16) x = quick_gelu(x);
-                o[c] = to16(x, elem());
-            }
-            elem *dst = (elem *)g.C + (long)m * g.ldc + nb;
-            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&o[0]);
-            *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&o[8]);
-        } else {
-            float *dst = (float *)g.C + (long)m * g.ldc + nb;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float4 o = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-                if constexpr (EPI == EC_EPI_RESID32) {
-                    const float4 x = *reinterpret_cast<const float4 *>(dst + 4 * c);
-                    o.x += x.x, o.y += x.y, o.z += x.z, o.w += x.w;
-                }
-                *reinterpret_cast<float4 *>(dst + 4 * c) = o;
-            }
-        }
-    }
+    epilogue<DT, EPI, TM>(g, acc, m0 + wm * (BM / WM), n0 + wn * 64, lane);
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int EPI>
@@ -236,13 +246,448 @@ int launch(const GemmArgs &g0, hipStream_t stream)
     return EC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves, four phases per K tile, LDS-DMA kept in flight across raw
+// barriers, the two wave groups staggered by one barrier interval.
+//
+// Per wave the 128 x 64 output splits into 2 x 2 quadrants of 64 rows x 32 columns; one
+// phase = one quadrant x the whole K tile = 16 MFMAs, quadrant order (m0,n0) (m0,n1)
+// (m1,n1) (m1,n0) so each phase needs at most one new operand set (12 / 4 / 8 / 0
+// ds_read_b128).  A K tile sits in LDS as four 16-KiB regions laid out by what a phase
+// reads -- Am0, Am1 (rows of quadrant row 0 / 1 of both wave rows), Bn0, Bn1 (the weight
+// rows of quadrant column 0 / 1 of all four wave columns) -- two K tiles deep (128 KiB).
+// Every phase has a load segment (ds_reads for this phase, one region of DMA for three
+// phases ahead = 2 global_load_lds_dwordx4 per lane, a counted s_waitcnt that retires only
+// the region the NEXT phase reads) and a compute segment (16 MFMAs), each closed by a raw
+// s_barrier.  Waves 4-7 (the second wave row; they share SIMDs with waves 0-3) run one
+// interval behind, so on every SIMD one wave computes while its partner loads.
+//
+// Hazards (intervals between barriers, group 0 loads phase p in interval 2p, group 1 in
+// 2p+1): a region read in phase q is waited for by every wave in its load segment of phase
+// q-1 (intervals 2q-2 and 2q-1), i.e. behind at least one barrier before the first read
+// (interval 2q); it is overwritten again 8 phases after it was staged, 5 phases after its
+// last read.
+// ---------------------------------------------------------------------------------------
+#define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(512) void gemm4p_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::v8 v8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int REGION = 128 * 128;     // 128 rows x 128 B
+    constexpr int KT = 4 * REGION;        // one K tile: Am0 | Am1 | Bn0 | Bn1
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int m0 = (tile / g.tiles_n) * BM;
+    const int n0 = (tile % g.tiles_n) * BN;
+
+    auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
+
+    // ---- DMA sources: region r (0 Am0, 1 Am1, 2 Bn0, 3 Bn1), instruction i (0, 1) ----
+    // piece = 8 i + wave covers region rows 8 piece .. 8 piece + 7
+    const unsigned char *src[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int rr = (i * 8 + wave) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ key(rr);
+            if (r < 2) {
+                // region row rr = (wave row) * 64 + row within the 64-row quadrant
+                int m = m0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
+                m = m < g.M ? m : g.M - 1;
+                src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+            } else {
+                // region row rr = (wave column) * 32 + p; output column c of the wave's 64 with
+                // bit 3 = quadrant column: c = (p >> 3) * 16 + nq * 8 + (p & 7)
+                const int p = rr & 31;
+                int n = n0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
+                n = n < g.N ? n : g.N - 1;
+                src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+            }
+        }
+    auto issue = [&](int r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
+            src[r][i] += BK * 2;
+        }
+    };
+
+    // ---- fragment read offsets inside a region (k-substep 0) ----
+    int offM[4], offN[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        const int row = wm * 64 + mt * 16 + (lane & 15);
+        offM[mt] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+        // MFMA A row i of tile j = 2 nq + jj is wave column (i >> 2) * 16 + 4 j + (i & 3)
+        const int i = lane & 15;
+        const int row = wn * 32 + ((i >> 2) << 3) + (jj << 2) + (i & 3);
+        offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    v8 fm[4][2], fn0[2][2], fn1[2][2];
+    auto load_m = [&](int buf, int mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
+                                                           (offM[mt] ^ (ks << 6)));
+    };
+    auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
+                                                           (offN[jj] ^ (ks << 6)));
+    };
+    auto mma = [&](int mq, int nq, v8(&fn)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nq * 2 + jj] =
+                        mfma16(fn[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nq * 2 + jj]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nk = g.K / BK;
+    // prologue: the four regions of K tile 0; Am0 and Bn0 must have landed before phase 1
+    issue(0, 0);
+    issue(2, 0);
+    issue(3, 0);
+    issue(1, 0);
+    EC_VMCNT(4);
+    bar();
+    if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
+
+    for (int t = 0; t < nk; t++) {
+        const int buf = t & 1, nxt = buf ^ 1;
+        const bool more = t + 1 < nk;
+        // ---- phase 1: quadrant (m0, n0) ----
+        load_m(buf, 0);
+        load_n(fn0, buf, 0);
+        if (more) {
+            issue(0, nxt);      // Am0 of the next K tile
+            EC_VMCNT(4);        // retires Bn1 of this tile (phase 2)
+        } else {
+            EC_VMCNT(2);
+        }
+        bar();
+        mma(0, 0, fn0);
+        bar();
+        // ---- phase 2: quadrant (m0, n1) ----
+        load_n(fn1, buf, 1);
+        if (more) {
+            issue(2, nxt);      // Bn0 of the next K tile
+            EC_VMCNT(4);        // retires Am1 of this tile (phase 3)
+        } else {
+            EC_VMCNT(0);
+        }
+        bar();
+        mma(0, 1, fn1);
+        bar();
+        // ---- phase 3: quadrant (m1, n1) ----
+        load_m(buf, 1);
+        if (more) issue(3, nxt);   // Bn1 of the next K tile; nothing new is read in phase 4
+        bar();
+        mma(1, 1, fn1);
+        bar();
+        // ---- phase 4: quadrant (m1, n0), operands already in registers ----
+        if (more) {
+            issue(1, nxt);      // Am1 of the next K tile
+            EC_VMCNT(4);        // retires Am0 and Bn0 of the next tile (its phase 1)
+        }
+        bar();
+        mma(1, 0, fn0);
+        bar();
+    }
+    if (wm == 0) bar();   // balance the stagger barrier
+
+    epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+template <int DT, int EPI> int launch4p(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    g.tiles_m = ec::ceil_div(g.M, 256);
+    g.tiles_n = ec::ceil_div(g.N, 256);
+    constexpr int lds = 2 * 4 * 128 * 128;
+    auto kern = gemm4p_kernel<DT, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+template <int DT, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::v8 v8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int REGION = 128 * 128;     // 128 rows x 128 B
+    constexpr int KT = 4 * REGION;        // one K tile: Am0 | Am1 | Bn0 | Bn1
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int m0 = (tile / g.tiles_n) * BM;
+    const int n0 = (tile % g.tiles_n) * BN;
+    const int lm0 = DBG == 2 ? 0 : m0, ln0 = DBG == 2 ? 0 : n0;   // timing experiments only
+
+    auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
+
+    // ---- DMA sources: region r (0 Am0, 1 Am1, 2 Bn0, 3 Bn1), instruction i (0, 1) ----
+    // piece = 8 i + wave covers region rows 8 piece .. 8 piece + 7
+    const unsigned char *src[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int rr = (i * 8 + wave) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ key(rr);
+            if (r < 2) {
+                // region row rr = (wave row) * 64 + row within the 64-row quadrant
+                int m = lm0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
+                m = m < g.M ? m : g.M - 1;
+                src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+            } else {
+                // region row rr = (wave column) * 32 + p; output column c of the wave's 64 with
+                // bit 3 = quadrant column: c = (p >> 3) * 16 + nq * 8 + (p & 7)
+                const int p = rr & 31;
+                int n = ln0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
+                n = n < g.N ? n : g.N - 1;
+                src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+            }
+        }
+    auto issue = [&](int r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
+            src[r][i] += BK * 2;
+        }
+    };
+
+    // ---- fragment read offsets inside a region (k-substep 0) ----
+    int offM[4], offN[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        const int row = wm * 64 + mt * 16 + (lane & 15);
+        offM[mt] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+        // MFMA A row i of tile j = 2 nq + jj is wave column (i >> 2) * 16 + 4 j + (i & 3)
+        const int i = lane & 15;
+        const int row = wn * 32 + ((i >> 2) << 3) + (jj << 2) + (i & 3);
+        offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    v8 fm[4][2], fn0[2][2], fn1[2][2];
+    auto load_m = [&](int buf, int mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
+                                                           (offM[mt] ^ (ks << 6)));
+    };
+    auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
+                                                           (offN[jj] ^ (ks << 6)));
+    };
+    auto mma = [&](int mq, int nq, v8(&fn)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nq * 2 + jj] =
+                        mfma16(fn[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nq * 2 + jj]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto mma2 = [&](int mq, int nqa, v8(&fa)[2][2], int nqb, v8(&fb)[2][2]) {
+        if (DBG != 3 && DBG != 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqa * 2 + jj] =
+                        mfma16(fa[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqa * 2 + jj]);
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqb * 2 + jj] =
+                        mfma16(fb[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqb * 2 + jj]);
+            }
+        if (DBG != 3 && DBG != 4) __builtin_amdgcn_s_setprio(0);
+        if (DBG == 4) __builtin_amdgcn_s_setprio(1);   // the load segment that follows runs at priority
+    };
+    // end of a load segment: this wave's LDS reads have returned (the regions they came
+    // from may be re-staged by the other wave group in the very next interval)
+    auto bar_l = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (DBG == 4) __builtin_amdgcn_s_setprio(0);
+        bar();
+    };
+
+    // Two phases per K tile (32 MFMAs each): A = quadrants (m0,n0) (m0,n1), B = (m1,n1)
+    // (m1,n0).  Phase A reads Am0, Bn0, Bn1 of the tile, phase B reads Am1.  DMA runs a
+    // whole tile ahead: load segment B(t) stages {Am0, Bn0, Bn1} of tile t+2 into the
+    // regions phase A(t) has just drained, load segment A(t) stages Am1 of tile t+1.
+    const int nk = g.K / BK;
+    issue(0, 0);
+    issue(2, 0);
+    issue(3, 0);
+    issue(1, 0);
+    if (nk > 1) {
+        issue(0, 1);
+        issue(2, 1);
+        issue(3, 1);
+        EC_VMCNT(8);      // {Am0, Bn0, Bn1}(0) landed; Am1(0) and the three of tile 1 in flight
+    } else {
+        EC_VMCNT(2);
+    }
+    bar();
+    if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
+
+    for (int t = 0; t < nk; t++) {
+        const int buf = t & 1, nxt = buf ^ 1;
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+        // ---- phase A ----
+        load_m(buf, 0);
+        load_n(fn0, buf, 0);
+        load_n(fn1, buf, 1);
+        if (has1) {
+            if (DBG != 1) issue(1, nxt);      // Am1 of tile t+1
+            if (DBG != 1) EC_VMCNT(8);        // retires Am1 of this tile (phase B)
+        } else {
+            EC_VMCNT(0);
+        }
+        bar_l();
+        mma2(0, 0, fn0, 1, fn1);
+        bar();
+        // ---- phase B ----
+        load_m(buf, 1);
+        if (has2) {
+            if (DBG != 1) {
+                issue(0, buf);      // {Am0, Bn0, Bn1} of tile t+2 replace what phase A consumed
+                issue(2, buf);
+                issue(3, buf);
+                EC_VMCNT(8);        // retires {Am0, Bn0, Bn1} of tile t+1
+            }
+        } else if (has1) {
+            EC_VMCNT(2);
+        }
+        bar_l();
+        mma2(1, 1, fn1, 0, fn0);
+        bar();
+    }
+    if (wm == 0) bar();   // balance the stagger barrier
+
+    epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    g.tiles_m = ec::ceil_div(g.M, 256);
+    g.tiles_n = ec::ceil_div(g.N, 256);
+    constexpr int lds = 2 * 4 * 128 * 128;
+    auto kern = gemm2p_kernel<DT, EPI, DBG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, hipStream_t s)
 {
     switch (variant) {
-    case 0:
+    case 0: return launch2p<DT, EPI>(g, s);                      // default: staggered 2-phase
     case 1: return launch<DT, 256, 256, 2, 4, EPI>(g, s);
     case 2: return launch<DT, 128, 128, 2, 2, EPI>(g, s);
     case 3: return launch<DT, 128, 256, 1, 4, EPI>(g, s);
+    case 4: return launch4p<DT, EPI>(g, s);
+    case 5: return launch2p<DT, EPI>(g, s);
+    case 6: return launch2p<DT, EPI, 1>(g, s);   // timing experiment: no DMA in the loop (wrong results)
+    case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)
+    case 8: return launch2p<DT, EPI, 3>(g, s);   // no s_setprio
+    case 9: return launch2p<DT, EPI, 4>(g, s);   // priority on the load segments
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
     }
 }

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--iters', type=int, default=10)
-    ap.add_argument('--variants', type=int, nargs='+', default=[1, 2, 3])
+    ap.add_argument('--variants', type=int, nargs='+', default=[1, 4, 5])
     ap.add_argument('--dtypes', nargs='+', default=['float16', 'bfloat16'])
     a = ap.parse_args()
     M = a.frames * 257
@@ -31,7 +31,7 @@ def main():
             out = torch.zeros(M, N, device='cuda',
                               dtype=torch.float32 if epi == 'resid32' else dtype)
             for v in a.variants:
-                for _ in range(2):
+                for _ in range(10):
                     ops.gemm(A, W, bias, epi, out=out, variant=v)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
