@@ -1,0 +1,156 @@
+"""Host-side logic on CPU: chunking, view planning, meters, and the data-parallel
+shard / all-gather path over gloo with world_size 2 (the oracle stands in for the GPU
+forward here -- this tests the sharding harness, not the kernels)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eventclip_amd import harness, vis
+
+
+def test_chunk_bounds_match_oracle_split():
+    from oracle import events as oe
+    for tot in [1, 5, 10, 14, 15, 16, 20, 25, 26, 30, 100, 104, 105, 106, 20000, 225000]:
+        for N in (10, 7, 20000):
+            assert vis.chunk_bounds(tot, N) == oe.split_event_count(tot, N)
+
+
+def test_split_event_count_signature():
+    t = np.linspace(0, 1, 26)
+    i0, i1, t0, t1 = vis.split_event_count(t, 10)
+    assert i0 == [0, 10, 16] and i1 == [10, 20, 26]
+    np.testing.assert_array_equal(t0, t[[0, 10, 16]])
+    np.testing.assert_array_equal(t1, t[[9, 19, 25]])
+
+
+def test_colour_map():
+    from oracle import events as oe
+    for g in (True, False, 200, [90, 127, 255]):
+        a, b = vis.colour_map(g), oe.colour_map(g)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_pipeline_plan_padding_and_subsampling():
+    from eventclip_amd.event2img import Event2ImagePipeline
+    qa = dict(max_imgs=3, N=100, split_method='event_count', convert_method='event_histogram',
+              grayscale=True, count_non_zero=False, background_mask=True)
+    pipe = Event2ImagePipeline((36, 52), 1000, qa, generator=torch.Generator().manual_seed(0))
+    assert pipe.max_imgs == 3                       # min(round(1000/100), 3), event2img.py:70-72
+    fr, ri, vm = pipe.plan([250, 60, 1000])
+    # sample 0: 2 chunks + dropped remainder; sample 1: one short chunk; sample 2: 10 chunks -> 3
+    assert vm.tolist() == [[True, True, False], [True, False, False], [True, True, True]]
+    assert fr[:3].tolist() == [[0, 100], [100, 200], [250, 310]]
+    sel = fr[3:] - 310
+    assert all((b - a) == 100 and a % 100 == 0 for a, b in sel.tolist())
+    assert ri.tolist()[0] == [0, 1, -1] and ri.tolist()[1] == [2, -1, -1]
+    with pytest.raises(IndexError):
+        pipe.plan([0])
+    qa2 = dict(qa, convert_method='voxel')
+    with pytest.raises(NotImplementedError):
+        Event2ImagePipeline((36, 52), 1000, qa2)
+    # N-Cars: round(12500 / 30000) = 0 -> at least one view (event2img.py:72)
+    assert Event2ImagePipeline((100, 120), 12500, dict(qa, N=30000)).max_imgs == 1
+
+
+def test_average_meter_and_accuracies():
+    m = harness.AverageMeter()
+    m.update(1.0, 3)
+    m.update(0.0, 1)
+    assert abs(m.avg - 0.75) < 1e-12                # sum(acc*n)/sum(n), test.py:67
+    probs = torch.tensor([[0.1, 0.9], [0.8, 0.2]])
+    out = dict(probs=probs, logits=probs.flip(1))
+    acc = harness.batch_accuracies(out, torch.tensor([1, 1]))
+    assert acc == {'probs_acc': 0.5, 'logits_acc': 0.5}
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 256, 257):
+        for w in (1, 2, 3, 8):
+            spans = [harness.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import classify as oc
+    g = torch.Generator().manual_seed(0)
+    B, T, C, K = 7, 3, 16, 5                        # uneven shards on purpose
+    valid = torch.rand(B, T, generator=g) < 0.7
+    valid[:, 0] = True
+    feats = torch.randn(B, T, C, generator=g)
+    text = torch.nn.functional.normalize(torch.randn(K, C, generator=g), dim=-1)
+    lo, hi = harness.shard_range(B, rank, world)
+    local = oc.zs_forward(feats[lo:hi][valid[lo:hi]], valid[lo:hi], text, 100.0, 'mean')
+    sizes = [harness.shard_range(B, r, world)[1] - harness.shard_range(B, r, world)[0]
+             for r in range(world)]
+    gathered = harness.gather_out_dict(local, sizes)
+    full = oc.zs_forward(feats[valid], valid, text, 100.0, 'mean')
+    ok = all(torch.allclose(gathered[k], full[k], atol=1e-5) for k in ('logits', 'probs'))
+    # even shards take the single all_gather_into_tensor path
+    even = harness.all_gather_rows(torch.full((2, 3), float(rank)))
+    ok = ok and even.shape == (2 * world, 3) and even[2 * rank].eq(rank).all().item()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_forward_and_all_gather_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_product_fails_loudly_without_gpu():
+    from eventclip_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.HipLibraryError):
+        vis.events2frames(np.zeros((4, 4), np.float32), 'event_count', 'event_histogram', N=2)
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=1, text_layers=1, vocab_size=64)
+    m = eclip.CLIP(cfg, eclip.random_state_dict(cfg, 0))
+    with pytest.raises(_lib.HipLibraryError):
+        m.encode_image(torch.zeros(1, 3, 224, 224))
+
+
+def test_clip_surface_without_gpu():
+    from eventclip_amd import clip as eclip
+    assert 'ViT-L/14' in eclip.available_models()
+    with pytest.raises(NotImplementedError):
+        eclip.arch_config('RN50')
+    with pytest.raises(RuntimeError):
+        eclip.arch_config('ViT-Z/1')
+    cfg = eclip.arch_config('ViT-B/32', layers=2, text_layers=1, vocab_size=64)
+    sd = eclip.random_state_dict(cfg, 0)
+    m = eclip.CLIP(cfg, sd)
+    assert m.visual.output_dim == 512 and m.logit_scale.ndim == 0
+    assert abs(m.logit_scale.exp().item() - 100.0) < 1e-3
+    assert set(m.state_dict()) == set(sd)           # OpenAI's key names round-trip
+    assert eclip.config_from_state_dict(sd)['layers'] == 2
+    tok = eclip.synthetic_tokens(4, seed=1)
+    assert tok.shape == (4, 77) and (tok.argmax(-1) >= 5).all()
+    with pytest.raises(FileNotFoundError):
+        eclip.load('ViT-B/32', download_root='/nonexistent')
