@@ -58,7 +58,7 @@ EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
 class EcBlockWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
-        'fc2_w', 'fc2_b')]
+        'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo')]
 
 
 class EcVitWeights(ctypes.Structure):
@@ -67,7 +67,8 @@ class EcVitWeights(ctypes.Structure):
                 ('conv_w', c_void_p), ('cls', c_void_p), ('pos', c_void_p),
                 ('ln_pre_g', c_void_p), ('ln_pre_b', c_void_p), ('ln_post_g', c_void_p),
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
-                ('blocks', ctypes.POINTER(EcBlockWeights))]
+                ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
+                ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p)]
 
 
 class EcTextWeights(ctypes.Structure):
@@ -75,7 +76,8 @@ class EcTextWeights(ctypes.Structure):
                 ('layers', c_int), ('heads', c_int), ('out_dim', c_int),
                 ('token_embedding', c_void_p), ('pos', c_void_p), ('ln_final_g', c_void_p),
                 ('ln_final_b', c_void_p), ('proj_w', c_void_p),
-                ('blocks', ctypes.POINTER(EcBlockWeights))]
+                ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
+                ('proj_w_lo', c_void_p)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every
@@ -96,6 +98,11 @@ SIGNATURES = {
     'ec_patchify': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'ec_layernorm': (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                              c_void_p, c_long, c_int, c_void_p]),
+    'ec_layernorm_split': (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_float, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    'ec_split16': (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'ec_attention_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_void_p]),
     'ec_vit_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_float, c_void_p, c_void_p]),
     'ec_text_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -153,7 +153,8 @@ def _assign(root, key, tensor):
 class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
-    def __init__(self, cfg, state_dict, dtype='float16', chunk=2560):
+    def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
+                 image_precise=False):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -165,6 +166,9 @@ class CLIP(nn.Module):
         self.compute_dtype = {'float16': torch.float16, 'fp16': torch.float16,
                               'bfloat16': torch.bfloat16, 'bf16': torch.bfloat16}[str(dtype)]
         self.chunk = int(chunk)
+        # split-precision (~fp32) arithmetic: on for the text tower (run once, cached by the
+        # classifiers), off for the image tower (3x the GEMM work; validation only)
+        self.text_precise, self.image_precise = bool(text_precise), bool(image_precise)
         self.workspace_budget = 24 << 30   # bytes of tower scratch at most
         self._packed = None
         self._ws = None
@@ -210,7 +214,13 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def blocks(prefix, layers):
+        def dev16_lo(t):    # w - round16(w), rounded to 16 bit
+            t = t.to(dev, torch.float32)
+            t = (t - t.to(cd).float()).to(cd).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def blocks(prefix, layers, precise):
             arr = (_lib.EcBlockWeights * layers)()
             for i in range(layers):
                 ks = _block_keys(prefix, i)
@@ -221,6 +231,9 @@ class CLIP(nn.Module):
                 b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
                 b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
                 b.fc2_w, b.fc2_b = dev16(sd[ks[10]]), dev32(sd[ks[11]])
+                if precise:
+                    b.qkv_w_lo, b.out_w_lo = dev16_lo(sd[ks[2]]), dev16_lo(sd[ks[4]])
+                    b.fc1_w_lo, b.fc2_w_lo = dev16_lo(sd[ks[8]]), dev16_lo(sd[ks[10]])
             return arr
 
         c = self.cfg
@@ -238,7 +251,10 @@ class CLIP(nn.Module):
         v.ln_post_g, v.ln_post_b = (dev32(sd['visual.ln_post.weight']),
                                     dev32(sd['visual.ln_post.bias']))
         v.proj_w = dev16(sd['visual.proj'].t())
-        vb = blocks('visual.transformer', c['layers'])
+        v.precise = int(self.image_precise)
+        if self.image_precise:
+            v.conv_w_lo, v.proj_w_lo = dev16_lo(conv), dev16_lo(sd['visual.proj'].t())
+        vb = blocks('visual.transformer', c['layers'], self.image_precise)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']
@@ -247,7 +263,10 @@ class CLIP(nn.Module):
         t.pos = dev32(sd['positional_embedding'])
         t.ln_final_g, t.ln_final_b = dev32(sd['ln_final.weight']), dev32(sd['ln_final.bias'])
         t.proj_w = dev16(sd['text_projection'].t())
-        tb = blocks('transformer', c['text_layers'])
+        t.precise = int(self.text_precise)
+        if self.text_precise:
+            t.proj_w_lo = dev16_lo(sd['text_projection'].t())
+        tb = blocks('transformer', c['text_layers'], self.text_precise)
         t.blocks = ctypes.cast(tb, ctypes.POINTER(_lib.EcBlockWeights))
         self._packed = dict(vit=v, text=t, keep=keep, vb=vb, tb=tb, kpad=kpad, code=code, dev=dev)
         return self._packed

@@ -266,6 +266,84 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     return EC_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 attention for the split-precision towers (text features are computed once and cached;
+// the image tower uses this only for validation).  One workgroup per (sequence, head,
+// 16-query tile); Q tile and the 16 x S score rows in LDS, K / V rows straight from L2.
+// Output is written as 16-bit hi + lo parts (x ~ hi + lo) for the split GEMMs that follow.
+// ---------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, void *out_hi,
+                                                            void *out_lo, int S, int W, int heads,
+                                                            int causal)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float *qs = fsm;            // [16][64], pre-scaled by 1/sqrt(64)
+    float *sc = fsm + 16 * 64;  // [16][S]
+    const int n_qt = (S + 15) / 16;
+    const int qt = blockIdx.x % n_qt, head = (blockIdx.x / n_qt) % heads;
+    const int seq = blockIdx.x / (n_qt * heads);
+    const long ld = 3L * W;
+    const float *base = qkv + (long)seq * S * ld + head * 64;
+    const int t = threadIdx.x, q = t >> 4, sub = t & 15;
+    const int qrow = qt * 16 + q, qsrc = qrow < S ? qrow : S - 1;
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (long)qsrc * ld + sub * 4);
+        *reinterpret_cast<float4 *>(qs + q * 64 + sub * 4) =
+            make_float4(v.x * 0.125f, v.y * 0.125f, v.z * 0.125f, v.w * 0.125f);
+    }
+    __syncthreads();
+    const int klimit = causal ? (qrow < S ? qrow + 1 : S) : S;
+    float mx = -INFINITY;
+    for (int key = sub; key < S; key += 16) {
+        const float *kr = base + (long)key * ld + W;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
+            const float4 qv = *reinterpret_cast<const float4 *>(qs + q * 64 + d);
+            s = fmaf(qv.x, kv.x, s), s = fmaf(qv.y, kv.y, s), s = fmaf(qv.z, kv.z, s),
+            s = fmaf(qv.w, kv.w, s);
+        }
+        s = key < klimit ? s : -INFINITY;
+        sc[q * S + key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float sum = 0.f;
+    for (int key = sub; key < S; key += 16) {
+        const float p = expf(sc[q * S + key] - mx);
+        sc[q * S + key] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int key = 0; key < S; key++) {
+        const float p = sc[q * S + key];
+        const float4 vv = *reinterpret_cast<const float4 *>(base + (long)key * ld + 2 * W + sub * 4);
+        acc.x = fmaf(p, vv.x, acc.x), acc.y = fmaf(p, vv.y, acc.y), acc.z = fmaf(p, vv.z, acc.z),
+        acc.w = fmaf(p, vv.w, acc.w);
+    }
+    if (qrow < S) {
+        const float inv = 1.f / sum;
+        const float o4[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+        v4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hi[i] = to16(o4[i], elem());
+            lo[i] = to16(o4[i] - (float)hi[i], elem());
+        }
+        const long off = ((long)seq * S + qrow) * W + head * 64 + sub * 4;
+        *reinterpret_cast<v4 *>((elem *)out_hi + off) = hi;
+        *reinterpret_cast<v4 *>((elem *)out_lo + off) = lo;
+    }
+}
+
 }  // namespace
 
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
@@ -283,4 +361,29 @@ extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S,
     if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
     if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);
     return ec::fail(EC_ERR_INVALID, "ec_attention: unknown dtype %d", dtype);
+}
+
+extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_seq, int S,
+                                       int width, int heads, int causal, int dtype,
+                                       ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention_f32: bad shape");
+    EC_REQUIRE(width == heads * 64, "ec_attention_f32: head dim must be 64");
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv && out_hi && out_lo, "ec_attention_f32: null buffer");
+    const int lds = (16 * 64 + 16 * S) * 4;
+    EC_REQUIRE(lds <= 64 * 1024, "ec_attention_f32: sequence length %d too long", S);
+    const unsigned grid = (unsigned)n_seq * heads * ((S + 15) / 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * S * S * 64.0 * heads * n_seq, 0);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(attention_f32_kernel<EC_F16>, dim3(grid), dim3(256), lds, s, qkv, out_hi,
+                           out_lo, S, width, heads, causal);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(attention_f32_kernel<EC_BF16>, dim3(grid), dim3(256), lds, s, qkv, out_hi,
+                           out_lo, S, width, heads, causal);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_attention_f32: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
 }

@@ -67,7 +67,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx,
                                                         const int *row_idx, const float *gamma,
                                                         const float *beta, int rows, int width,
-                                                        float eps, void *out, long ldo)
+                                                        float eps, void *out, long ldo, void *out_lo)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v4 v4;
@@ -88,7 +88,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx
             v4 p = {to16(v[i].x, elem()), to16(v[i].y, elem()), to16(v[i].z, elem()),
                     to16(v[i].w, elem())};
             *reinterpret_cast<v4 *>(o + (i * 64 + lane) * 4) = p;
+            if (out_lo) {   // split precision: lo = 16-bit(x - hi), x ~ hi + lo to ~2^-22
+                v4 q = {to16(v[i].x - (float)p[0], elem()), to16(v[i].y - (float)p[1], elem()),
+                        to16(v[i].z - (float)p[2], elem()), to16(v[i].w - (float)p[3], elem())};
+                *reinterpret_cast<v4 *>((elem *)out_lo + row * ldo + (i * 64 + lane) * 4) = q;
+            }
         }
+}
+
+// fp32 [n] -> (optionally QuickGELU) -> 16-bit hi and lo parts
+template <int DT>
+__global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, int gelu, void *hi,
+                                                      void *lo)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v4 v4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        float4 v = *reinterpret_cast<const float4 *>(x + i);
+        if (gelu) {
+            v.x = v.x / (1.f + expf(-1.702f * v.x));
+            v.y = v.y / (1.f + expf(-1.702f * v.y));
+            v.z = v.z / (1.f + expf(-1.702f * v.z));
+            v.w = v.w / (1.f + expf(-1.702f * v.w));
+        }
+        v4 p = {to16(v.x, elem()), to16(v.y, elem()), to16(v.z, elem()), to16(v.w, elem())};
+        v4 q = {to16(v.x - (float)p[0], elem()), to16(v.y - (float)p[1], elem()),
+                to16(v.z - (float)p[2], elem()), to16(v.w - (float)p[3], elem())};
+        *reinterpret_cast<v4 *>((elem *)hi + i) = p;
+        *reinterpret_cast<v4 *>((elem *)lo + i) = q;
+    }
 }
 
 // fp32 in -> fp32 out with an additive table (positional embedding) and a row
@@ -148,6 +176,34 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
                         const float *beta, int rows, int width, float eps, void *out16, long ldo,
                         int dtype, ec_stream_t stream)
 {
+    return ec_layernorm_split(x, ldx, row_idx, gamma, beta, rows, width, eps, out16, nullptr, ldo,
+                              dtype, stream);
+}
+
+EC_API int ec_split16(const float *x, long n, int gelu, void *hi16, void *lo16, int dtype,
+                      ec_stream_t stream)
+{
+    EC_REQUIRE(n >= 0 && n % 4 == 0, "ec_split16: n=%ld must be a multiple of 4", n);
+    if (n == 0) return EC_OK;
+    EC_REQUIRE(x && hi16 && lo16, "ec_split16: null buffer");
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 65536 ? (n / 4 + 255) / 256 : 65536);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)n * 8.0);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(split16_kernel<EC_F16>, dim3(grid), dim3(256), 0, s, x, n, gelu, hi16, lo16);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(split16_kernel<EC_BF16>, dim3(grid), dim3(256), 0, s, x, n, gelu, hi16,
+                           lo16);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_split16: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_layernorm_split(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
+                              const float *beta, int rows, int width, float eps, void *out16,
+                              void *out16_lo, long ldo, int dtype, ec_stream_t stream)
+{
     EC_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && width <= LN_MAXV * 256,
                "ec_layernorm: width=%d must be a multiple of 4 and <= %d", width, LN_MAXV * 256);
     if (rows == 0) return EC_OK;
@@ -158,10 +214,10 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
     ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 6.0);
     if (dtype == EC_F16)
         hipLaunchKernelGGL(layernorm_kernel<EC_F16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
-                           width, eps, out16, ldo);
+                           width, eps, out16, ldo, out16_lo);
     else if (dtype == EC_BF16)
         hipLaunchKernelGGL(layernorm_kernel<EC_BF16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
-                           width, eps, out16, ldo);
+                           width, eps, out16, ldo, out16_lo);
     else
         return ec::fail(EC_ERR_INVALID, "ec_layernorm: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());

@@ -66,6 +66,64 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
     return EC_OK;
 }
 
+// Split-precision chain: every GEMM is xh.wh + xh.wl + xl.wh accumulated in fp32, attention and
+// QuickGELU run in fp32, and every activation that feeds a GEMM is carried as hi + lo parts.
+struct PreciseBufs {
+    float *x;           // [rows, W] fp32 residual stream
+    void *h_hi, *h_lo;  // [rows, W] LN / attention output, split
+    float *wide;        // [rows, 4W] fp32: qkv (3W) or the c_fc output (4W)
+    void *m_hi, *m_lo;  // [rows, 4W] QuickGELU output, split
+};
+
+int gemm3(int M, int N, int K, int dtype, bool accumulate, const void *a_hi, const void *a_lo,
+          const void *w_hi, const void *w_lo, const float *bias, float *C, ec_stream_t s)
+{
+    EC_TRY(gemm(M, N, K, dtype, accumulate ? EC_EPI_RESID32 : EC_EPI_STORE32, a_hi, w_hi, bias, C, s));
+    EC_TRY(gemm(M, N, K, dtype, EC_EPI_RESID32, a_hi, w_lo, nullptr, C, s));
+    return gemm(M, N, K, dtype, EC_EPI_RESID32, a_lo, w_hi, nullptr, C, s);
+}
+
+int run_blocks_precise(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
+                       int causal, int dtype, const PreciseBufs &b, ec_stream_t s)
+{
+    const int rows = n_seq * S;
+    for (int l = 0; l < layers; l++) {
+        const ec_block_weights &w = blocks[l];
+        EC_REQUIRE(w.qkv_w_lo && w.out_w_lo && w.fc1_w_lo && w.fc2_w_lo,
+                   "precise tower: block %d has no lo weight parts", l);
+        EC_TRY(ec_layernorm_split(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h_hi, b.h_lo,
+                                  W, dtype, s));
+        EC_TRY(gemm3(rows, 3 * W, W, dtype, false, b.h_hi, b.h_lo, w.qkv_w, w.qkv_w_lo, w.qkv_b,
+                     b.wide, s));
+        EC_TRY(ec_attention_f32(b.wide, b.h_hi, b.h_lo, n_seq, S, W, heads, causal, dtype, s));
+        EC_TRY(gemm3(rows, W, W, dtype, true, b.h_hi, b.h_lo, w.out_w, w.out_w_lo, w.out_b, b.x, s));
+        EC_TRY(ec_layernorm_split(b.x, W, nullptr, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h_hi, b.h_lo,
+                                  W, dtype, s));
+        EC_TRY(gemm3(rows, 4 * W, W, dtype, false, b.h_hi, b.h_lo, w.fc1_w, w.fc1_w_lo, w.fc1_b,
+                     b.wide, s));
+        EC_TRY(ec_split16(b.wide, (long)rows * 4 * W, 1, b.m_hi, b.m_lo, dtype, s));
+        EC_TRY(gemm3(rows, W, 4 * W, dtype, true, b.m_hi, b.m_lo, w.fc2_w, w.fc2_w_lo, w.fc2_b, b.x,
+                     s));
+    }
+    return EC_OK;
+}
+
+size_t carve_precise(Scratch &sc, int chunk, int S, int W, PreciseBufs &b, void **s_hi, void **s_lo,
+                     int **idx)
+{
+    const size_t rows = (size_t)chunk * S;
+    b.x = (float *)sc.take(rows * W * 4);
+    b.h_hi = sc.take(rows * W * 2);
+    b.h_lo = sc.take(rows * W * 2);
+    b.wide = (float *)sc.take(rows * 4 * W * 4);
+    b.m_hi = sc.take(rows * 4 * W * 2);
+    b.m_lo = sc.take(rows * 4 * W * 2);
+    *s_hi = sc.take((size_t)chunk * W * 2);
+    *s_lo = sc.take((size_t)chunk * W * 2);
+    *idx = (int *)sc.take((size_t)chunk * 4);
+    return sc.off;
+}
+
 // carve the scratch for `chunk` sequences of length S; patch_rows > 0 adds the fp32
 // patch-GEMM output (aliased onto the mlp buffer: both are dead at the same time)
 size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs &b, void **small16,
@@ -101,9 +159,13 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
     if (!w || chunk <= 0) return 0;
     const int g = w->image_size / w->patch;
     Scratch sc{nullptr, 0, 0};
-    BlockBufs b;
-    void *s16;
+    void *s16, *s16b;
     int *idx;
+    if (w->precise) {
+        PreciseBufs pb;
+        return carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
+    }
+    BlockBufs b;
     return carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
 }
 
@@ -111,9 +173,13 @@ EC_API size_t ec_text_workspace_bytes(const ec_text_weights *w, int chunk)
 {
     if (!w || chunk <= 0) return 0;
     Scratch sc{nullptr, 0, 0};
-    BlockBufs b;
-    void *s16;
+    void *s16, *s16b;
     int *idx;
+    if (w->precise) {
+        PreciseBufs pb;
+        return carve_precise(sc, chunk, w->ctx, w->width, pb, &s16, &s16b, &idx);
+    }
+    BlockBufs b;
     return carve(sc, chunk, w->ctx, w->width, 0, b, &s16, &idx);
 }
 
@@ -133,6 +199,33 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype;
     if (chunk > n_img) chunk = n_img;
     Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    const size_t esz = 2;
+    if (w->precise) {
+        EC_REQUIRE(w->conv_w_lo && w->proj_w_lo, "ec_vit_encode: precise tower without lo weights");
+        PreciseBufs pb;
+        void *c_hi, *c_lo;
+        int *pidx;
+        const size_t pneed = carve_precise(sc, chunk, S, W, pb, &c_hi, &c_lo, &pidx);
+        if (pneed > workspace_bytes)
+            return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes",
+                            workspace_bytes, pneed);
+        for (int i0 = 0; i0 < n_img; i0 += chunk) {
+            const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
+            const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
+            // the 16-bit patch values are exact inputs: x.w = x.wh + x.wl
+            EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_STORE32, p, w->conv_w, nullptr, pb.wide, stream));
+            EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_RESID32, p, w->conv_w_lo, nullptr, pb.wide,
+                        stream));
+            EC_TRY(ec_vit_embed(pb.wide, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS,
+                                pb.x, stream));
+            EC_TRY(run_blocks_precise(w->blocks, w->layers, n, S, W, w->heads, 0, dt, pb, stream));
+            EC_TRY(ec_layernorm_split(pb.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W,
+                                      LN_EPS, c_hi, c_lo, W, dt, stream));
+            EC_TRY(gemm3(n, w->out_dim, W, dt, false, c_hi, c_lo, w->proj_w, w->proj_w_lo, nullptr,
+                         feats + (size_t)i0 * w->out_dim, stream));
+        }
+        return EC_OK;
+    }
     BlockBufs b;
     void *cls16;
     int *idx;
@@ -140,7 +233,6 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes", workspace_bytes,
                         need);
-    const size_t esz = 2;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
         const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
@@ -171,6 +263,31 @@ EC_API int ec_text_encode(const ec_text_weights *w, const int32_t *tokens, int n
     const int S = w->ctx, W = w->width, dt = w->dtype;
     if (chunk > n_txt) chunk = n_txt;
     Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (w->precise) {
+        EC_REQUIRE(w->proj_w_lo, "ec_text_encode: precise tower without lo weights");
+        PreciseBufs pb;
+        void *e_hi, *e_lo;
+        int *pidx;
+        const size_t pneed = carve_precise(sc, chunk, S, W, pb, &e_hi, &e_lo, &pidx);
+        if (pneed > workspace_bytes)
+            return ec::fail(EC_ERR_WORKSPACE, "ec_text_encode: workspace %zu < %zu bytes",
+                            workspace_bytes, pneed);
+        for (int i0 = 0; i0 < n_txt; i0 += chunk) {
+            const int n = (n_txt - i0 < chunk) ? n_txt - i0 : chunk;
+            const int32_t *tok = tokens + (size_t)i0 * S;
+            EC_TRY(ec_text_embed(tok, w->token_embedding, w->pos, n, S, W, w->vocab, pb.x, stream));
+            EC_TRY(run_blocks_precise(w->blocks, w->layers, n, S, W, w->heads, 1, dt, pb, stream));
+            hipLaunchKernelGGL(eot_index_kernel, dim3((n + 255) / 256), dim3(256), 0, hs, tok, n, S,
+                               pidx);
+            EC_CHECK_HIP(hipGetLastError());
+            EC_TRY(ec_layernorm_split(pb.x, W, pidx, w->ln_final_g, w->ln_final_b, n, W, LN_EPS, e_hi,
+                                      e_lo, W, dt, stream));
+            EC_TRY(gemm3(n, w->out_dim, W, dt, false, e_hi, e_lo, w->proj_w, w->proj_w_lo, nullptr,
+                         feats + (size_t)i0 * w->out_dim, stream));
+        }
+        return EC_OK;
+    }
     BlockBufs b;
     void *eot16;
     int *idx;
@@ -178,7 +295,6 @@ EC_API int ec_text_encode(const ec_text_weights *w, const int32_t *tokens, int n
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_text_encode: workspace %zu < %zu bytes",
                         workspace_bytes, need);
-    hipStream_t hs = static_cast<hipStream_t>(stream);
     for (int i0 = 0; i0 < n_txt; i0 += chunk) {
         const int n = (n_txt - i0 < chunk) ? n_txt - i0 : chunk;
         const int32_t *tok = tokens + (size_t)i0 * S;

@@ -154,6 +154,20 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
                         const float *beta, int rows, int width, float eps, void *out16, long ldo,
                         int dtype, ec_stream_t stream);
 
+/* Split-precision helpers ("precise" towers): a value is carried as two 16-bit numbers
+ * hi = round16(x), lo = round16(x - hi), and a product x.w as xh.wh + xh.wl + xl.wh with
+ * fp32 accumulation (three ec_gemm launches, EC_EPI_STORE32 then EC_EPI_RESID32), which
+ * reproduces fp32 arithmetic to ~1e-6 on the 16-bit MFMA path. */
+EC_API int ec_layernorm_split(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
+                              const float *beta, int rows, int width, float eps, void *out16,
+                              void *out16_lo, long ldo, int dtype, ec_stream_t stream);
+/* fp32 [n] -> (QuickGELU if gelu) -> hi / lo 16-bit parts */
+EC_API int ec_split16(const float *x, long n, int gelu, void *hi16, void *lo16, int dtype,
+                      ec_stream_t stream);
+/* fp32 attention over fp32 qkv [n_seq * S, 3 * width]; output as hi / lo parts [n_seq * S, width] */
+EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_seq, int S,
+                            int width, int heads, int causal, int dtype, ec_stream_t stream);
+
 /* x[n, 0] = class_embedding, x[n, 1 + p] = patch[n * (seq - 1) + p]; + positional
  * embedding; ln_pre -> fp32 residual stream x [n_img, seq, width]. */
 EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, const float *gamma,
@@ -187,6 +201,8 @@ typedef struct {
     const float *fc1_b;
     const void *fc2_w;          /* mlp.c_proj.weight [W, 4W] 16-bit */
     const float *fc2_b;
+    /* lo parts (w - round16(w)) of the four matrices; only read by precise towers, else NULL */
+    const void *qkv_w_lo, *out_w_lo, *fc1_w_lo, *fc2_w_lo;
 } ec_block_weights;
 
 typedef struct {
@@ -198,6 +214,8 @@ typedef struct {
     const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
     const void *proj_w;         /* visual.proj transposed: [out_dim, W] 16-bit */
     const ec_block_weights *blocks; /* host array [layers] */
+    int precise;                /* != 0: split-precision arithmetic (3x the GEMM work, ~fp32 results) */
+    const void *conv_w_lo, *proj_w_lo;
 } ec_vit_weights;
 
 typedef struct {
@@ -208,6 +226,8 @@ typedef struct {
     const float *ln_final_g, *ln_final_b;
     const void *proj_w;             /* text_projection transposed: [out_dim, W] 16-bit */
     const ec_block_weights *blocks; /* host array [layers] */
+    int precise;                    /* != 0: split-precision arithmetic (text features are cached) */
+    const void *proj_w_lo;
 } ec_text_weights;
 
 /* bytes of scratch needed to push `chunk` images (or texts) through at once */
