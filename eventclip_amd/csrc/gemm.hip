@@ -597,6 +597,20 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
     // (m1,n0).  Phase A reads Am0, Bn0, Bn1 of the tile, phase B reads Am1.  DMA runs a
     // whole tile ahead: load segment B(t) stages {Am0, Bn0, Bn1} of tile t+2 into the
     // regions phase A(t) has just drained, load segment A(t) stages Am1 of tile t+1.
+    // DBG == 5 (diagnostic build only): s_memtime stamps of waves 0 and 4 of workgroup 300 go to
+    // the buffer passed as `bias` (which is then not applied); layout [wave>>2][t][8 stamps]
+    unsigned long long *stamps = nullptr;
+    if (DBG == 5 && blockIdx.x == 300 && (wave & 3) == 0 && lane == 0)
+        stamps = (unsigned long long *)g.bias + (wave >> 2) * 64 * 8;
+    auto stamp = [&](int t, int i) {
+        if (DBG == 5) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamps && t < 64) stamps[t * 8 + i] = now;
+        }
+    };
     const int nk = g.K / BK;
     issue(0, 0);
     issue(2, 0);
@@ -617,19 +631,25 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         const int buf = t & 1, nxt = buf ^ 1;
         const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
         // ---- phase A ----
+        stamp(t, 0);
         load_m(buf, 0);
         load_n(fn0, buf, 0);
         load_n(fn1, buf, 1);
+        stamp(t, 1);
         if (has1) {
             if (DBG != 1) issue(1, nxt);      // Am1 of tile t+1
             if (DBG != 1) EC_VMCNT(8);        // retires Am1 of this tile (phase B)
         } else {
             EC_VMCNT(0);
         }
+        stamp(t, 2);
         bar_l();
+        stamp(t, 3);
         mma2(0, 0, fn0, 1, fn1);
+        stamp(t, 4);
         bar();
         // ---- phase B ----
+        stamp(t, 5);
         load_m(buf, 1);
         if (has2) {
             if (DBG != 1) {
@@ -641,12 +661,20 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         } else if (has1) {
             EC_VMCNT(2);
         }
+        stamp(t, 6);
         bar_l();
         mma2(1, 1, fn1, 0, fn0);
+        stamp(t, 7);
         bar();
     }
     if (wm == 0) bar();   // balance the stagger barrier
 
+    if (DBG == 5) {
+        GemmArgs g2 = g;
+        g2.bias = nullptr;
+        epilogue<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        return;
+    }
     epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
@@ -688,6 +716,7 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)
     case 8: return launch2p<DT, EPI, 3>(g, s);   // no s_setprio
     case 9: return launch2p<DT, EPI, 4>(g, s);   // priority on the load segments
+    case 10: return launch2p<DT, EPI, 5>(g, s);  // diagnostic: s_memtime stamps into the bias buffer
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
     }
 }
