@@ -24,7 +24,8 @@ class EcFrameStats(ctypes.Structure):
 class EcEventsParams(ctypes.Structure):
     _fields_ = [('H', c_int), ('W', c_int), ('thresh', c_double), ('count_non_zero', c_int),
                 ('background_mask', c_int), ('red', ctypes.c_uint8 * 3),
-                ('blue', ctypes.c_uint8 * 3)]
+                ('blue', ctypes.c_uint8 * 3), ('max_frame_events', c_int), ('flip_x', c_int),
+                ('negate_p', c_int)]
 
 
 class EcAdapterLayer(ctypes.Structure):
@@ -90,6 +91,7 @@ SIGNATURES = {
     'ec_profile_end': (c_int, [ctypes.POINTER(EcProfileEntry), c_int, ctypes.POINTER(c_int)]),
     'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_center_events': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
     'ec_preprocess_plan_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
     'ec_preprocess_plan': (c_int, [c_int, c_int, c_int, c_void_p, ctypes.c_size_t]),

@@ -4,15 +4,17 @@
 // parse_events (:44-52) as driven by events2frames (:75-117).
 //
 // One 1024-thread workgroup owns one frame.  The [rows, W, 2] uint32 histogram
-// of a row band lives in LDS (up to 156 KiB of the CU's 160 KiB) and is filled
-// with LDS atomics; a frame that does not fit is walked band by band.  The
-// reference needs two frame-wide reductions before it can colour a pixel (the
-// hot-pixel threshold from mean/std, vis.py:17-24, then the max of what is
-// left, vis.py:27), so a multi-band frame re-bins its events for each of the
-// three passes instead of spilling a histogram to HBM: the events of a frame
-// (16 B each) are re-read from L2/Infinity Cache, HBM sees them once, and the
-// only HBM write is the uint8 frame itself.  Frames that fit one band (N-Cars)
-// bin once.
+// of a row band lives in LDS and is filled with LDS atomics; a frame that does
+// not fit is walked band by band.  The reference needs two frame-wide
+// reductions before it can colour a pixel (the hot-pixel threshold from
+// mean/std, vis.py:17-24, then the max of what is left, vis.py:27), so a
+// multi-band frame re-bins its events for each of the three passes instead of
+// spilling a histogram to HBM.  To keep that off the memory system the events of
+// the frame are first reduced to 4-byte bin indices in an LDS cache (20 000
+// events = 80 KB beside a 36-row band for N-Caltech): HBM sees each event once,
+// the re-binning passes scan LDS, and the only HBM write is the uint8 frame.
+// Frames too long for the cache (N-ImageNet's 70 000 events) re-read their
+// events from L2 / Infinity Cache; frames that fit one band (N-Cars) bin once.
 //
 // Exactness: counts are integers.  mean/std come from exact integer sums
 // (numpy's float64 pairwise summation agrees to ~1e-15 relative; bins whose
@@ -21,6 +23,10 @@
 // vis.py:27-39, including the fused multiply-add of the dgemm behind
 // `hist @ cmap`, with FP contraction disabled everywhere else.
 #include "common.h"
+
+// numpy evaluates every ufunc with one rounding per operation: no FMA contraction anywhere in
+// this file (the one fused multiply-add of the reference is written out explicitly).
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -41,6 +47,9 @@ struct EvArgs {
     int *kept;
     ec_frame_stats *stats;
     int rows_per_band, bands;
+    int flip_x, negate_p; // test-time-augmentation views (utils.py:18-35)
+    int bin_bytes;       // LDS bytes of the histogram band (scratch and the event cache follow)
+    int cache_events;    // capacity of the LDS event cache, 0 = none
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -87,12 +96,21 @@ __device__ unsigned block_max_u32(unsigned v, unsigned long long *scratch)
     return t;
 }
 
-// vis.py:10-14 restricted to rows [y0, y1): LDS atomics, one per in-band event.
-__device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, int W, unsigned *bins,
-                                        unsigned &dropped)
+// parse_events (vis.py:50: astype(int32) truncates toward zero), after the optional TTA
+// transforms of utils.py: x -> W - 1 - x in float32 (:22), p -> -p (:34).
+__device__ __forceinline__ void parse(const float4 e, int W, int flip_x, int negate_p, int &x, int &y,
+                                      int &p)
 {
-    // parse_events, vis.py:50: astype(int32) truncates toward zero
-    const int x = (int)e.x, y = (int)e.y, p = (int)e.w;
+    const float xf = flip_x ? (float)(W - 1) - e.x : e.x;
+    x = (int)xf, y = (int)e.y, p = (int)(negate_p ? -e.w : e.w);
+}
+
+// vis.py:10-14 restricted to rows [y0, y1): LDS atomics, one per in-band event.
+__device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, int W, int flip_x,
+                                        int negate_p, unsigned *bins, unsigned &dropped)
+{
+    int x, y, p;
+    parse(e, W, flip_x, negate_p, x, y, p);
     if (p == 0) return;  // counted in neither channel (vis.py:10,12)
     if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
         dropped++;
@@ -101,8 +119,8 @@ __device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, i
     if (y >= y0 && y < y1) atomicAdd(&bins[((y - y0) * W + x) * 2 + (p < 0 ? 1 : 0)], 1u);
 }
 
-__device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, int W, unsigned *bins,
-                         unsigned &dropped)
+__device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, int W, int flip_x,
+                         int negate_p, unsigned *bins, unsigned &dropped)
 {
     const int nb = (y1 - y0) * W * 2;
     for (int i = threadIdx.x; i < nb; i += EV_THREADS) bins[i] = 0;
@@ -111,17 +129,52 @@ __device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, i
     for (; i + 3 * EV_THREADS < n; i += 4 * EV_THREADS) {
         const float4 e0 = ev[i], e1 = ev[i + EV_THREADS], e2 = ev[i + 2 * EV_THREADS],
                      e3 = ev[i + 3 * EV_THREADS];
-        bin_one(e0, y0, y1, H, W, bins, dropped);
-        bin_one(e1, y0, y1, H, W, bins, dropped);
-        bin_one(e2, y0, y1, H, W, bins, dropped);
-        bin_one(e3, y0, y1, H, W, bins, dropped);
+        bin_one(e0, y0, y1, H, W, flip_x, negate_p, bins, dropped);
+        bin_one(e1, y0, y1, H, W, flip_x, negate_p, bins, dropped);
+        bin_one(e2, y0, y1, H, W, flip_x, negate_p, bins, dropped);
+        bin_one(e3, y0, y1, H, W, flip_x, negate_p, bins, dropped);
     }
-    for (; i < n; i += EV_THREADS) bin_one(ev[i], y0, y1, H, W, bins, dropped);
+    for (; i < n; i += EV_THREADS) bin_one(ev[i], y0, y1, H, W, flip_x, negate_p, bins, dropped);
+    __syncthreads();
+}
+
+// Event cache: every event of the frame is read from HBM ONCE, reduced to its bin index
+// (((y * W + x) << 1) | channel, or EV_SKIP for p == 0 / outside the sensor) and kept in LDS,
+// so the band / pass loops below re-scan 4 B per event from LDS instead of 16 B from L2.
+constexpr unsigned EV_SKIP = 0xFFFFFFFFu;
+
+__device__ void fill_cache(const float4 *ev, long long n, int H, int W, int flip_x, int negate_p,
+                           unsigned *cache, unsigned &dropped)
+{
+    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
+        const float4 e = ev[i];
+        int x, y, p;
+        parse(e, W, flip_x, negate_p, x, y, p);
+        unsigned c = EV_SKIP;
+        if (p != 0) {
+            if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H)
+                dropped++;
+            else
+                c = ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+        }
+        cache[i] = c;
+    }
+}
+
+__device__ void bin_band_cached(const unsigned *cache, int n, int y0, int y1, int W, unsigned *bins)
+{
+    const int nb = (y1 - y0) * W * 2;
+    const unsigned lo = (unsigned)(y0 * W * 2);
+    for (int i = threadIdx.x; i < nb; i += EV_THREADS) bins[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += EV_THREADS) {
+        const unsigned c = cache[i] - lo;          // EV_SKIP and other bands wrap far above nb
+        if (c < (unsigned)nb) atomicAdd(&bins[c], 1u);
+    }
     __syncthreads();
 }
 
 // vis.py:27-39 for one pixel, float64, numpy's operation order.
-#pragma clang fp contract(off)
 __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dmx, const EvArgs &a,
                                              uint8_t out[3])
 {
@@ -152,7 +205,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *bins = reinterpret_cast<unsigned *>(smem);
-    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + EV_BIN_BYTES);
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + a.bin_bytes);
+    unsigned *cache = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_SCRATCH_BYTES);
 
     const int f = blockIdx.x;
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
@@ -162,14 +216,23 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     const long long M2 = (long long)H * W * 2;
     const int rpb = a.rows_per_band, bands = a.bands;
 
-    // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
+    // frames that fit the LDS event cache read their events from HBM exactly once
+    const bool cached = n <= (long long)a.cache_events;
     unsigned long long s1 = 0, s2 = 0;
     unsigned nnz = 0, dropped = 0;
+    if (cached) {
+        fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
+        __syncthreads();
+    }
+    // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
     for (int b = 0; b < bands; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
-        bin_band(ev, n, y0, y1, H, W, bins, dr);
-        if (b == 0) dropped = dr;
+        if (cached)
+            bin_band_cached(cache, (int)n, y0, y1, W, bins);
+        else
+            bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
+        if (b == 0 && !cached) dropped = dr;
         const int nb = (y1 - y0) * W * 2;
         for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
             const unsigned h = bins[i];
@@ -213,7 +276,12 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     for (int b = 0; b < bands; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
-        if (bands > 1) bin_band(ev, n, y0, y1, H, W, bins, dr);
+        if (bands > 1) {
+            if (cached)
+                bin_band_cached(cache, (int)n, y0, y1, W, bins);
+            else
+                bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
+        }
         const int nb = (y1 - y0) * W * 2;
         for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
             unsigned h = bins[i];
@@ -248,7 +316,12 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     for (int b = 0; b < bands; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
-        if (bands > 1) bin_band(ev, n, y0, y1, H, W, bins, dr);
+        if (bands > 1) {
+            if (cached)
+                bin_band_cached(cache, (int)n, y0, y1, W, bins);
+            else
+                bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
+        }
         __syncthreads();
         const int npix = (y1 - y0) * W;
         uint8_t *o = out + (long long)y0 * W * 3;
@@ -292,7 +365,62 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     }
 }
 
+// center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
+// t -= min t; x -= ((x_max + x_min + 1) - W) // 2; y likewise (float32 arithmetic).
+__global__ __launch_bounds__(256) void center_events_kernel(float4 *events, const long long *range,
+                                                            int H, int W)
+{
+    __shared__ float red[5][4];
+    const long long e0 = range[2 * blockIdx.x], e1 = range[2 * blockIdx.x + 1];
+    float4 *ev = events + e0;
+    const long long n = e1 - e0;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, tmin = INFINITY;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float4 e = ev[i];
+        xmin = fminf(xmin, e.x), xmax = fmaxf(xmax, e.x);
+        ymin = fminf(ymin, e.y), ymax = fmaxf(ymax, e.y);
+        tmin = fminf(tmin, e.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o, 64)), xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        ymin = fminf(ymin, __shfl_xor(ymin, o, 64)), ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        red[0][wave] = xmin, red[1][wave] = xmax, red[2][wave] = ymin, red[3][wave] = ymax,
+        red[4][wave] = tmin;
+    __syncthreads();
+    xmin = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    xmax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    ymin = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
+    ymax = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+    tmin = fminf(fminf(red[4][0], red[4][1]), fminf(red[4][2], red[4][3]));
+    const float xs = floorf(((xmax + xmin + 1.f) - (float)W) / 2.f);   // utils.py:53
+    const float ys = floorf(((ymax + ymin + 1.f) - (float)H) / 2.f);   // utils.py:54
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        float4 e = ev[i];
+        e.x -= xs, e.y -= ys, e.z -= tmin;
+        ev[i] = e;
+    }
+}
+
 }  // namespace
+
+extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_range, int B, int H, int W,
+                                       ec_stream_t stream)
+{
+    EC_REQUIRE(B >= 0 && H > 0 && W > 0, "ec_center_events: bad arguments");
+    if (B == 0) return EC_OK;
+    EC_REQUIRE(events && sample_range, "ec_center_events: null buffer");
+    EC_REQUIRE(((uintptr_t)events & 15) == 0, "ec_center_events: events must be 16-byte aligned");
+    hipLaunchKernelGGL(center_events_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float4 *>(events),
+                       reinterpret_cast<const long long *>(sample_range), H, W);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
 
 extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
                                           const ec_events_params *prm, uint8_t *frames,
@@ -316,6 +444,7 @@ extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *fr
     a.W = prm->W;
     a.thresh = prm->thresh;
     a.count_non_zero = prm->count_non_zero;
+    a.flip_x = prm->flip_x, a.negate_p = prm->negate_p;
     a.background_mask = prm->background_mask;
     for (int c = 0; c < 3; c++) {
         a.red[c] = (double)(float)prm->red[c];    // cmap.astype(float32), vis.py:30
@@ -325,12 +454,28 @@ extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *fr
     a.raw = raw_counts;
     a.kept = kept_counts;
     a.stats = stats;
-    const int max_rows = EV_BIN_BYTES / row_bytes;
+    // LDS plan: [histogram band | reduction scratch | event cache].  With the per-frame event
+    // count bounded (max_frame_events, known to the caller from split_event_count's N) the
+    // cache takes 4 B per event and the band gets what is left; frames longer than the bound,
+    // or geometries where no useful band fits beside the cache, re-read events from L2.
+    int cache_events = 0, bin_budget = EV_BIN_BYTES;
+    if (prm->max_frame_events > 0) {
+        const long cache_bytes = ((long)prm->max_frame_events * 4 + 15) / 16 * 16;
+        const long left = (long)EV_BIN_BYTES - cache_bytes;
+        // worth it when the whole frame then needs at most 8 bands
+        if (left >= row_bytes && ec::ceil_div(prm->H, (int)(left / row_bytes)) <= 8) {
+            cache_events = prm->max_frame_events;
+            bin_budget = (int)left;
+        }
+    }
+    const int max_rows = bin_budget / row_bytes;
     a.bands = ec::ceil_div(prm->H, max_rows);
     a.rows_per_band = ec::ceil_div(prm->H, a.bands);
+    a.bin_bytes = (a.rows_per_band * row_bytes + 15) / 16 * 16;
+    a.cache_events = cache_events;
 
     static bool attr_set = false;
-    const int lds = EV_BIN_BYTES + EV_SCRATCH_BYTES;
+    const int lds = EV_BIN_BYTES + EV_SCRATCH_BYTES;   // always the full carve: one attribute call
     if (!attr_set) {
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));

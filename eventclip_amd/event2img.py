@@ -52,10 +52,12 @@ class Event2ImagePipeline:
         self.strict = True   # raise on events outside the sensor, as the reference does
 
     # ---- host bookkeeping: which event rows make which view ----
-    def plan(self, n_events):
+    def plan(self, n_events, tflip=False):
         """n_events: per-sample event counts.  Returns (frame_range int64 [Fv, 2],
         row_idx int32 [B, T], valid_mask bool [B, T]) as CPU tensors; row_idx[b, t] is the
-        compact frame number of view t of sample b, or -1 for a padded view."""
+        compact frame number of view t of sample b, or -1 for a padded view.
+        tflip: chunk the time-reversed stream (utils.py:26-35): chunk [a, b) of the reversed
+        order covers rows [n - b, n - a) of the stored order (a histogram ignores order)."""
         T = self.max_imgs
         B = len(n_events)
         ranges, row_idx = [], np.full((B, T), -1, dtype=np.int32)
@@ -71,18 +73,21 @@ class Event2ImagePipeline:
                 sel = torch.randperm(len(sel), generator=self.generator)[:T].tolist()
             for t, f in enumerate(sel):                                  # event2img.py:87-91
                 row_idx[b, t] = len(ranges)
-                ranges.append((off + idx0[f], off + idx1[f]))
+                if tflip:
+                    ranges.append((off + n - idx1[f], off + n - idx0[f]))
+                else:
+                    ranges.append((off + idx0[f], off + idx1[f]))
             off += n
         fr = torch.tensor(ranges, dtype=torch.int64).reshape(-1, 2)
         ri = torch.from_numpy(row_idx)
         return fr, ri, ri >= 0
 
-    def frames(self, events, frame_range):
+    def frames(self, events, frame_range, hflip=False, tflip=False):
         """uint8 [Fv, H, W, 3] for the planned views (vis.events2frames, batched)."""
         out = vis.events_to_frames_device(
             events, frame_range, self.resolution, grayscale=self.grayscale, thresh=self.thresh,
             count_non_zero=self.count_non_zero, background_mask=self.background_mask,
-            return_stats=self.strict)
+            return_stats=self.strict, max_frame_events=self.N, flip_x=hflip, negate_p=tflip)
         if self.strict:
             frames, stats = out
             if int(stats['dropped'].sum()) > 0:
@@ -91,9 +96,12 @@ class Event2ImagePipeline:
             return frames
         return out
 
-    def __call__(self, events, n_events=None):
+    def __call__(self, events, n_events=None, hflip=False, tflip=False, center=False):
         """events: list of per-sample float32 [n_i, 4] arrays/tensors, or one CUDA tensor
         [sum n_i, 4] with ``n_events`` giving the per-sample counts.
+        hflip / tflip: the test-time-augmentation views of event2img.py:94-112;
+        center: apply center_events (utils.py:38-57, in place) first, as the N-Caltech /
+        N-ImageNet readers do (caltech.py:176).
 
         Returns a dict with ``valid_mask`` [B, T] (CUDA bool), ``row_idx`` [B, T] (CUDA
         int32) and either ``patches`` [Fv, G, kpad] (fused path) or ``img``
@@ -105,9 +113,13 @@ class Event2ImagePipeline:
                                   for e in events], axis=0)
             events = torch.from_numpy(cat).to(dev)
         assert events.is_cuda and events.dtype == torch.float32 and n_events is not None
-        fr, ri, vm = self.plan(n_events)
+        if center:
+            offs = np.concatenate([[0], np.cumsum(n_events)])
+            sr = torch.tensor(np.stack([offs[:-1], offs[1:]], 1), dtype=torch.int64, device=dev)
+            vis.center_events_device(events, sr, self.resolution)
+        fr, ri, vm = self.plan(n_events, tflip=tflip)
         fr_d = fr.to(dev)
-        frames = self.frames(events, fr_d)
+        frames = self.frames(events, fr_d, hflip=hflip, tflip=tflip)
         out = dict(valid_mask=vm.to(dev), row_idx=ri.to(dev))
         if self.patch:
             out['patches'] = preprocess_frames(frames, self.n_px, mode='patches', patch=self.patch,
@@ -119,6 +131,17 @@ class Event2ImagePipeline:
             img[out['valid_mask']] = chw                                 # event2img.py:88-91
             out['img'] = img
         return out
+
+
+    def tta(self, events, n_events=None):
+        """The four views of _load_tta_data (event2img.py:94-112): identity, h-flip, t-flip,
+        h+t-flip, as a list of batches in that order."""
+        if isinstance(events, (list, tuple)):
+            n_events = [int(e.shape[0]) for e in events]
+            cat = np.concatenate([vis.parse_events(e) for e in events], axis=0)
+            events = torch.from_numpy(cat).to(_lib.require_gpu())
+        return [self(events, n_events, hflip=h, tflip=t)
+                for h, t in ((False, False), (True, False), (False, True), (True, True))]
 
 
 def build_event2img_pipeline(params, resolution, max_n, clip_model=None):

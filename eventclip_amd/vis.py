@@ -64,7 +64,8 @@ def colour_map(grayscale=True):
     return red, blue
 
 
-def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, background_mask=True):
+def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, background_mask=True,
+                max_frame_events=0, flip_x=False, negate_p=False):
     H, W = shape
     red, blue = colour_map(grayscale)
     p = _lib.EcEventsParams()
@@ -72,6 +73,8 @@ def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, backgro
     p.thresh = float(thresh)
     p.count_non_zero = int(bool(count_non_zero))
     p.background_mask = int(bool(background_mask))
+    p.max_frame_events = int(max_frame_events)
+    p.flip_x, p.negate_p = int(bool(flip_x)), int(bool(negate_p))
     for c in range(3):
         p.red[c] = int(red[c])
         p.blue[c] = int(blue[c])
@@ -80,7 +83,8 @@ def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, backgro
 
 def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=10.,
                             count_non_zero=False, background_mask=True, return_counts=False,
-                            return_stats=False, out=None):
+                            return_stats=False, out=None, max_frame_events=0, flip_x=False,
+                            negate_p=False):
     """Batched device entry.
 
     events:      float32 CUDA tensor [n_total, 4].
@@ -101,7 +105,8 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
         kept = torch.empty((F, H, W, 2), dtype=torch.int32, device=dev)
     if return_stats:
         stats = torch.zeros((F, ctypes.sizeof(_lib.EcFrameStats)), dtype=torch.uint8, device=dev)
-    prm = make_params(shape, grayscale, thresh, count_non_zero, background_mask)
+    prm = make_params(shape, grayscale, thresh, count_non_zero, background_mask, max_frame_events,
+                      flip_x, negate_p)
     rc = _lib.lib().ec_events_to_frames(_lib.ptr(events), _lib.ptr(frame_range), F,
                                         ctypes.byref(prm), _lib.ptr(frames), _lib.ptr(raw),
                                         _lib.ptr(kept), _lib.ptr(stats), _lib.stream_ptr())
@@ -134,9 +139,33 @@ def events2frames(events, split_method, convert_method, shape=(180, 240), **kwar
     frames, stats = events_to_frames_device(
         ev_d, rng, shape, grayscale=grayscale, thresh=float(kwargs.get('thresh', 10.)),
         count_non_zero=kwargs.get('count_non_zero', False),
-        background_mask=kwargs.get('background_mask', True), return_stats=True)
+        background_mask=kwargs.get('background_mask', True), return_stats=True,
+        max_frame_events=max(b - a for a, b in zip(idx0, idx1)))
     if int(stats['dropped'].sum()) > 0:
         # the reference's bincount/reshape raises on such input (vis.py:11)
         raise ValueError('events2frames: events outside the sensor '
                          f'({int(stats["dropped"].sum())} dropped)')
     return frames.cpu().numpy()
+
+
+def center_events_device(events, sample_range, resolution):
+    """In-place center_events (datasets/utils.py:38-57) for a batch: events float32 CUDA
+    [n_total, 4], sample_range int64 CUDA [B, 2]."""
+    import torch
+    _lib.require_gpu()
+    assert events.is_cuda and events.dtype == torch.float32 and events.is_contiguous()
+    assert sample_range.is_cuda and sample_range.dtype == torch.int64
+    H, W = resolution
+    rc = _lib.lib().ec_center_events(_lib.ptr(events), _lib.ptr(sample_range.contiguous()),
+                                     int(sample_range.shape[0]), int(H), int(W), _lib.stream_ptr())
+    _lib.check(rc, 'ec_center_events')
+    return events
+
+
+def center_events(events, resolution=(180, 240)):
+    """Drop-in for datasets/utils.py center_events: numpy [n, 4] in, centred copy out."""
+    import torch
+    dev = _lib.require_gpu()
+    ev = torch.from_numpy(parse_events(events)).to(dev)
+    rng = torch.tensor([[0, ev.shape[0]]], dtype=torch.int64, device=dev)
+    return center_events_device(ev, rng, resolution).cpu().numpy()

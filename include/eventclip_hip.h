@@ -80,6 +80,11 @@ typedef struct {
     int count_non_zero;       /* statistics over non-zero bins only (vis.py:18-20) */
     int background_mask;      /* alpha-blend onto white (vis.py:34-37) */
     uint8_t red[3], blue[3];  /* colour of the positive / negative channel (vis.py:95-104) */
+    int max_frame_events;     /* upper bound of events per frame (N of split_event_count), 0 = unknown;
+                                 lets the kernel keep a frame's events in LDS and read HBM once */
+    int flip_x;               /* test-time augmentation: x -> W - 1 - x (datasets/utils.py:18-23) */
+    int negate_p;             /* test-time augmentation: p -> -p; together with frame ranges taken on
+                                 the reversed event order this is the time flip of utils.py:26-35 */
 } ec_events_params;
 
 /*
@@ -93,6 +98,12 @@ typedef struct {
 EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
                                const ec_events_params *prm, uint8_t *frames, int32_t *raw_counts,
                                int32_t *kept_counts, ec_frame_stats *stats, ec_stream_t stream);
+
+/* center_events (datasets/utils.py:38-57, applied to every N-Caltech / N-ImageNet sample at
+ * caltech.py:176), in place: t -= min t, x -= ((x_max + x_min + 1) - W) // 2, y likewise.
+ * sample_range: int64 [B, 2] (begin, end) event rows per sample. */
+EC_API int ec_center_events(float *events, const int64_t *sample_range, int B, int H, int W,
+                            ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CLIP image preprocess: uint8 frames -> model input.

@@ -1,0 +1,44 @@
+"""Oracle for the event-space transforms that run at test time (TEST INFRASTRUCTURE).
+
+Restates /root/reference/datasets/utils.py: center_events (:38-57, called for every
+N-Caltech / N-ImageNet sample at caltech.py:176), random_flip_events_along_x with p=1
+(:18-23) and random_time_flip_events with p=1 (:26-35) -- the two flips the reference
+composes into its 4-view test-time augmentation (datasets/event2img.py:94-112).
+Pinned by tests/golden/event_utils.npz, produced by importing the reference's utils.py
+(tools/make_golden_event_utils.py).
+"""
+import numpy as np
+
+
+def center_events(events, resolution=(180, 240)):
+    """utils.py:38-57 (in place on a float array, like the reference)."""
+    events[:, 2] -= events[:, 2].min()
+    H, W = resolution
+    x_min, x_max = events[:, 0].min(), events[:, 0].max()
+    y_min, y_max = events[:, 1].min(), events[:, 1].max()
+    x_shift = ((x_max + x_min + 1.) - W) // 2.
+    y_shift = ((y_max + y_min + 1.) - H) // 2.
+    events[:, 0] -= x_shift
+    events[:, 1] -= y_shift
+    return events
+
+
+def hflip_events(events, resolution=(180, 240)):
+    """utils.py:18-23 with p = 1."""
+    H, W = resolution
+    events[:, 0] = W - 1 - events[:, 0]
+    return events
+
+
+def tflip_events(events):
+    """utils.py:26-35 with p = 1: reverse order, t -> t[0] - t, p -> -p."""
+    events = np.ascontiguousarray(np.flip(events, axis=0))
+    events[:, 2] = events[0, 2] - events[:, 2]
+    events[:, 3] = -events[:, 3]
+    return events
+
+
+def tta_views(events, resolution):
+    """event2img.py:97-103: [events, h-flip, t-flip, h+t-flip]."""
+    h = hflip_events(events.copy(), resolution)
+    return [events, h, tflip_events(events.copy()), tflip_events(h.copy())]

@@ -14,7 +14,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def run_hip(ev, shape, kw):
+def run_hip(ev, shape, kw, max_frame_events=0):
     import torch
     from eventclip_amd import vis
     idx0, idx1 = vis.chunk_bounds(ev.shape[0], kw['N'])
@@ -22,7 +22,8 @@ def run_hip(ev, shape, kw):
     rng = torch.tensor(np.stack([idx0, idx1], 1), dtype=torch.int64).cuda()
     frames, raw, kept, stats = vis.events_to_frames_device(
         ev_d, rng, shape, grayscale=kw['grayscale'], count_non_zero=kw['count_non_zero'],
-        background_mask=kw['background_mask'], return_counts=True, return_stats=True)
+        background_mask=kw['background_mask'], return_counts=True, return_stats=True,
+        max_frame_events=max_frame_events)
     torch.cuda.synchronize()
     return frames.cpu().numpy(), raw.cpu().numpy(), kept.cpu().numpy(), stats
 
@@ -32,6 +33,13 @@ def test_hip_matches_reference_fixture(path, hip):
     from oracle import events as oe
     ev, shape, kw, exp = load_event_fixture(path)
     frames, raw, kept, stats = run_hip(ev, shape, kw)
+    # same frames through the LDS event cache (HBM reads each event once)
+    nmax = max(b - a for a, b in zip(*__import__('eventclip_amd.vis', fromlist=['x']).chunk_bounds(
+        ev.shape[0], kw['N'])))
+    c_frames, c_raw, c_kept, c_stats = run_hip(ev, shape, kw, max_frame_events=nmax)
+    np.testing.assert_array_equal(c_frames, frames)
+    np.testing.assert_array_equal(c_raw, raw)
+    np.testing.assert_array_equal(c_kept, kept)
     o_frames, o_raw, o_kept = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape,
                                                return_counts=True, **kw)
     assert frames.shape == o_frames.shape and frames.shape[0] == exp['n_frames']
@@ -95,7 +103,8 @@ def test_full_size_batch_properties(geom, hip):
     kw = dict(grayscale=False, count_non_zero=g['count_non_zero'],
               background_mask=g['background_mask'])
     frames, raw, kept, stats = vis.events_to_frames_device(ev_d, rng, shape, return_counts=True,
-                                                           return_stats=True, **kw)
+                                                           return_stats=True, max_frame_events=N,
+                                                           **kw)
     torch.cuda.synchronize()
     lens = np.array([b - a for a, b in ranges])
     np.testing.assert_array_equal(stats['sum'], lens)            # every event lands in one bin
@@ -105,3 +114,74 @@ def test_full_size_batch_properties(geom, hip):
         want = oe.events2frames(evs[s], 'event_count', 'event_histogram', shape=shape, N=N, **kw)
         f0 = sum(len(vis.chunk_bounds(e.shape[0], N)[0]) for e in evs[:s])
         np.testing.assert_array_equal(frames[f0:f0 + want.shape[0]].cpu().numpy(), want)
+
+
+def test_center_events_matches_reference_fixture(hip):
+    from conftest import GOLDEN
+    from eventclip_amd import vis
+    z = np.load(os.path.join(GOLDEN, 'event_utils.npz'))
+    res = tuple(int(v) for v in z['resolution'])
+    for i in range(int(z['n_cases'])):
+        got = vis.center_events(z[f'in{i}'].copy(), res)
+        np.testing.assert_array_equal(got, z[f'center{i}'])     # float32, bit for bit
+
+
+def test_tta_views_match_flipped_oracle(hip):
+    """h-/t-flip views (event2img.py:94-112) as kernel flags + reversed chunk ranges against
+    events2frames of the reference-style flipped copies."""
+    import torch
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    from oracle import event_utils as eu
+    from oracle import events as oe
+    res = (36, 52)
+    qa = dict(max_imgs=4, N=900, split_method='event_count', convert_method='event_histogram',
+              grayscale=False, count_non_zero=False, background_mask=True)
+    evs = make_batch(3, [2300, 700, 3151], res, seed=77)
+    pipe = Event2ImagePipeline(res, 3600, qa, n_px=224)
+    ev_d = torch.from_numpy(np.concatenate(evs)).cuda()
+    n_events = [e.shape[0] for e in evs]
+    combos = ((False, False), (True, False), (False, True), (True, True))
+    for (h, t) in combos:
+        fr, ri, vm = pipe.plan(n_events, tflip=t)
+        frames = pipe.frames(ev_d, fr.cuda(), hflip=h, tflip=t).cpu().numpy()
+        want = []
+        for ev in evs:
+            v = ev.copy()
+            if h:
+                v = eu.hflip_events(v, res)
+            if t:
+                v = eu.tflip_events(v)
+            want.append(oe.events2frames(v, 'event_count', 'event_histogram', shape=res, N=900,
+                                         grayscale=False, count_non_zero=False,
+                                         background_mask=True))
+        np.testing.assert_array_equal(frames, np.concatenate(want))
+    views = pipe.tta(ev_d, n_events)
+    assert len(views) == 4 and all(tuple(v['img'].shape) == (3, 4, 3, 224, 224) for v in views)
+
+
+def test_pipeline_center_flag(hip):
+    import torch
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    from oracle import event_utils as eu
+    from oracle import events as oe
+    res = (36, 52)
+    qa = dict(max_imgs=2, N=900, split_method='event_count', convert_method='event_histogram',
+              grayscale=True, count_non_zero=False, background_mask=True)
+    evs = make_batch(2, [1000, 1900], res, seed=5)
+    for e in evs:
+        e[:, 0] = 2 + e[:, 0] % 30       # off-centre window
+        e[:, 1] = 1 + e[:, 1] % 20
+    pipe = Event2ImagePipeline(res, 1800, qa, n_px=224)
+    ev_d = torch.from_numpy(np.concatenate(evs)).cuda()
+    fr, ri, vm = pipe.plan([1000, 1900])
+    from eventclip_amd import vis
+    offs = torch.tensor([[0, 1000], [1000, 2900]], dtype=torch.int64).cuda()
+    vis.center_events_device(ev_d, offs, res)
+    got = pipe.frames(ev_d, fr.cuda()).cpu().numpy()
+    want = np.concatenate([oe.events2frames(eu.center_events(e.copy(), res), 'event_count',
+                                            'event_histogram', shape=res, N=900, grayscale=True,
+                                            count_non_zero=False, background_mask=True)
+                           for e in evs])
+    np.testing.assert_array_equal(got, want)

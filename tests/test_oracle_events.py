@@ -57,3 +57,17 @@ def test_numpy_sum_order():
     for n in (5, 100, 129, 8192, 8200, 86400):
         a = rng.random(n) ** 3 * 1e3
         assert oe.np_sum(a) == a.sum()
+
+
+def test_event_utils_oracle_matches_reference():
+    from conftest import GOLDEN
+    from oracle import event_utils as eu
+    z = np.load(os.path.join(GOLDEN, 'event_utils.npz'))
+    res = tuple(int(v) for v in z['resolution'])
+    for i in range(int(z['n_cases'])):
+        ev = z[f'in{i}']
+        np.testing.assert_array_equal(eu.center_events(ev.copy(), res), z[f'center{i}'])
+        np.testing.assert_array_equal(eu.hflip_events(ev.copy(), res), z[f'hflip{i}'])
+        np.testing.assert_array_equal(eu.tflip_events(ev.copy()), z[f'tflip{i}'])
+        views = eu.tta_views(ev.copy(), res)
+        np.testing.assert_array_equal(views[3], z[f'htflip{i}'])
