@@ -632,13 +632,15 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
         // ---- phase A ----
         stamp(t, 0);
-        load_m(buf, 0);
-        load_n(fn0, buf, 0);
-        load_n(fn1, buf, 1);
+        if (DBG != 6 || t == 0) {
+            load_m(buf, 0);
+            load_n(fn0, buf, 0);
+            load_n(fn1, buf, 1);
+        }
         stamp(t, 1);
         if (has1) {
-            if (DBG != 1) issue(1, nxt);      // Am1 of tile t+1
-            if (DBG != 1) EC_VMCNT(8);        // retires Am1 of this tile (phase B)
+            if (DBG != 1 && DBG != 6) issue(1, nxt);      // Am1 of tile t+1
+            if (DBG != 1 && DBG != 6) EC_VMCNT(8);        // retires Am1 of this tile (phase B)
         } else {
             EC_VMCNT(0);
         }
@@ -650,9 +652,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         bar();
         // ---- phase B ----
         stamp(t, 5);
-        load_m(buf, 1);
+        if (DBG != 6 || t == 0) load_m(buf, 1);
         if (has2) {
-            if (DBG != 1) {
+            if (DBG != 1 && DBG != 6) {
                 issue(0, buf);      // {Am0, Bn0, Bn1} of tile t+2 replace what phase A consumed
                 issue(2, buf);
                 issue(3, buf);
@@ -703,6 +705,292 @@ template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStre
     return EC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Two workgroups per CU: 128 x 256 x 32 tiles, 4 waves (one per SIMD), each wave 128 x 64.
+// A 3-stage LDS-DMA ring of 24-KiB K tiles (72 KiB per workgroup, so two workgroups share a
+// CU's LDS and registers).  The SIMD partner of every wave belongs to the OTHER workgroup:
+// the two run unsynchronised, so one workgroup's prologue / epilogue (exposed for a third of a
+// tile's time at K = 1024 with one workgroup per CU) hides behind the other's MFMAs, and a
+// barrier only stalls four waves.
+// LDS rows are 64 B (4 chunks of 16 B); chunk ^= ((row >> 3) & 1) << 1 for the activation
+// rows (natural fragment order) and ((row >> 5) & 1) << 1 for the weight rows (permuted
+// order), which keeps every ds_read_b128 lane group on 16 distinct 16-B bank slots.
+// ---------------------------------------------------------------------------------------
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_b2_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::v8 v8;
+    constexpr int BM = 128, BN = 256, BK2 = 32, NSTAGE = 3;
+    constexpr int ROWB = BK2 * 2;                  // 64-byte rows
+    constexpr int STAGE = (BM + BN) * ROWB;        // 24 KiB
+    constexpr int PPW = STAGE / 1024 / 4;          // 6 DMA pieces (16 rows each) per wave
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int m0 = (tile / g.tiles_n) * BM;
+    const int n0 = (tile % g.tiles_n) * BN;
+
+    auto key_a = [](int row) { return ((row >> 3) & 1) << 1; };   // activation rows
+    auto key_w = [](int row) { return ((row >> 5) & 1) << 1; };   // weight rows
+
+    // piece p = i * 4 + wave covers stage rows 16 p .. 16 p + 15; lane -> row 16 p + (lane >> 2),
+    // physical chunk lane & 3
+    const unsigned char *src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; i++) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        if (row < BM) {
+            const int chunk = (lane & 3) ^ key_a(row);
+            int m = m0 + row;
+            m = m < g.M ? m : g.M - 1;
+            src[i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+        } else {
+            const int chunk = (lane & 3) ^ key_w(row - BM);
+            int n = n0 + (row - BM);
+            n = n < g.N ? n : g.N - 1;
+            src[i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+        }
+    }
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; i++) {
+            glds16(src[i], smem + slot * STAGE + (i * 4 + wave) * 1024);
+            src[i] += BK2 * 2;
+        }
+    };
+
+    // fragment offsets inside a stage: activation rows natural, weight rows permuted so that
+    // lane group g = lane >> 4 owns output columns 16 g .. 16 g + 15 of the wave's 64
+    int offB[8], offA[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = i * 16 + (lane & 15);
+        offB[i] = row * ROWB + (((lane >> 4) ^ key_a(row)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane & 15;
+        const int row = wave * 64 + (i >> 2) * 16 + j * 4 + (i & 3);
+        offA[j] = BM * ROWB + row * ROWB + (((lane >> 4) ^ key_w(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK2;
+    issue(0);
+    if (nk > 1) issue(1);
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt has landed (this wave's share) once at most one later stage is in flight
+        if (kt + 1 < nk) {
+            EC_VMCNT(6);
+        } else {
+            EC_VMCNT(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // everyone's share landed; stage kt-1 is drained
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(slot == 0 ? 2 : slot - 1);   // refill the slot of stage kt-1
+        const unsigned char *sb = smem + slot * STAGE;
+        v8 fa[4], fb[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const v8 *>(sb + offA[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fb[i] = *reinterpret_cast<const v8 *>(sb + offB[i]);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma16(fa[j], fb[i], acc[i][j]);
+        // the reads of this stage must have returned before the next barrier lets its slot be
+        // refilled one iteration later
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    }
+    epilogue<DT, EPI, 8>(g, acc, m0, n0 + wave * 64, lane);
+}
+
+template <int DT, int EPI> int launch_b2(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    g.tiles_m = ec::ceil_div(g.M, 128);
+    g.tiles_n = ec::ceil_div(g.N, 256);
+    constexpr int lds = 3 * (128 + 256) * 64;
+    auto kern = gemm_b2_kernel<DT, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_b2p_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::v8 v8;
+    constexpr int BM = 128, BN = 256, BK2 = 32, NSTAGE = 3;
+    constexpr int ROWB = BK2 * 2;                  // 64-byte rows
+    constexpr int STAGE = (BM + BN) * ROWB;        // 24 KiB
+    constexpr int PPW = STAGE / 1024 / 4;          // 6 DMA pieces (16 rows each) per wave
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int m0 = (tile / g.tiles_n) * BM;
+    const int n0 = (tile % g.tiles_n) * BN;
+
+    auto key_a = [](int row) { return ((row >> 3) & 1) << 1; };   // activation rows
+    auto key_w = [](int row) { return ((row >> 5) & 1) << 1; };   // weight rows
+
+    // piece p = i * 4 + wave covers stage rows 16 p .. 16 p + 15; lane -> row 16 p + (lane >> 2),
+    // physical chunk lane & 3
+    const unsigned char *src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; i++) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        if (row < BM) {
+            const int chunk = (lane & 3) ^ key_a(row);
+            int m = m0 + row;
+            m = m < g.M ? m : g.M - 1;
+            src[i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+        } else {
+            const int chunk = (lane & 3) ^ key_w(row - BM);
+            int n = n0 + (row - BM);
+            n = n < g.N ? n : g.N - 1;
+            src[i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+        }
+    }
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; i++) {
+            glds16(src[i], smem + slot * STAGE + (i * 4 + wave) * 1024);
+            src[i] += BK2 * 2;
+        }
+    };
+
+    // fragment offsets inside a stage: activation rows natural, weight rows permuted so that
+    // lane group g = lane >> 4 owns output columns 16 g .. 16 g + 15 of the wave's 64
+    int offB[8], offA[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = i * 16 + (lane & 15);
+        offB[i] = row * ROWB + (((lane >> 4) ^ key_a(row)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane & 15;
+        const int row = wave * 64 + (i >> 2) * 16 + j * 4 + (i & 3);
+        offA[j] = BM * ROWB + row * ROWB + (((lane >> 4) ^ key_w(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Register double-buffering: while the MFMAs of stage kt run on one fragment set, the
+    // ds_reads of stage kt+1 fill the other; the DMA ring runs two further stages ahead
+    // (stage kt+3 goes into the slot stage kt occupied, drained one iteration earlier).
+    v8 fa0[4], fb0[8], fa1[4], fb1[8];
+    auto read_frags = [&](int sl, v8(&fa)[4], v8(&fb)[8]) {
+        const unsigned char *sb = smem + sl * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const v8 *>(sb + offA[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fb[i] = *reinterpret_cast<const v8 *>(sb + offB[i]);
+    };
+    auto mma = [&](v8(&fa)[4], v8(&fb)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma16(fa[j], fb[i], acc[i][j]);
+    };
+    auto sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the previous stage are back
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nk = g.K / BK2;
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) {
+        EC_VMCNT(12);
+    } else if (nk > 1) {
+        EC_VMCNT(6);
+    } else {
+        EC_VMCNT(0);
+    }
+    sync();
+    read_frags(0, fa0, fb0);
+    // one step: stage kt is in (fa, fb); prefetch stage kt+1 into (na, nb)
+    auto step = [&](int kt, v8(&fa)[4], v8(&fb)[8], v8(&na)[4], v8(&nb)[8]) {
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) {
+                EC_VMCNT(6);      // stage kt+1 landed, kt+2 may still be in flight
+            } else {
+                EC_VMCNT(0);
+            }
+            sync();               // everyone's share of kt+1 landed; stage kt's slot is drained
+            if (kt + 3 < nk) issue(kt % NSTAGE);
+            read_frags((kt + 1) % NSTAGE, na, nb);
+        }
+        mma(fa, fb);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, fa0, fb0, fa1, fb1);
+        if (kt + 1 < nk) step(kt + 1, fa1, fb1, fa0, fb0);
+    }
+    epilogue<DT, EPI, 8>(g, acc, m0, n0 + wave * 64, lane);
+}
+
+template <int DT, int EPI> int launch_b2p(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    g.tiles_m = ec::ceil_div(g.M, 128);
+    g.tiles_n = ec::ceil_div(g.N, 256);
+    constexpr int lds = 3 * (128 + 256) * 64;
+    auto kern = gemm_b2p_kernel<DT, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, hipStream_t s)
 {
     switch (variant) {
@@ -716,7 +1004,10 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)
     case 8: return launch2p<DT, EPI, 3>(g, s);   // no s_setprio
     case 9: return launch2p<DT, EPI, 4>(g, s);   // priority on the load segments
-    case 10: return launch2p<DT, EPI, 5>(g, s);  // diagnostic: s_memtime stamps into the bias buffer
+    case 10: return launch2p<DT, EPI, 5>(g, s);
+    case 11: return launch2p<DT, EPI, 6>(g, s);
+    case 12: return launch_b2<DT, EPI>(g, s);     // two 4-wave workgroups per CU, 128x256x32
+    case 13: return launch_b2p<DT, EPI>(g, s);    // same with register-prefetched fragments  // timing experiment: MFMA + barrier skeleton only  // diagnostic: s_memtime stamps into the bias buffer
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
     }
 }
