@@ -1,0 +1,172 @@
+"""BASELINE.json configs as end-to-end parity cases (reduced batch / depth so the CPU oracle
+finishes in seconds): events -> frames -> preprocess -> CLIP tower -> (adapter) -> logits on the
+MI355X against the oracle chain.  configs[1] (the bench workload) is covered by
+test_models_gpu.py::test_end_to_end_events_to_logits_matches_oracle and bench.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_forward(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=None):
+    """Reference-order CPU chain; returns the out_dict of clip_cls.py."""
+    import torch
+    from oracle import adapter as oa
+    from oracle import classify as oc
+    from oracle import clip_ref
+    from oracle import events as oe
+    from oracle import preprocess as op
+    kw = {k: v for k, v in qa.items() if k not in ('max_imgs', 'split_method', 'convert_method')}
+    frames, valid = [], torch.zeros(len(evs), T, dtype=torch.bool)
+    for b, ev in enumerate(evs):
+        f = oe.events2frames(ev, 'event_count', 'event_histogram', shape=geo, **kw)
+        assert len(f) <= T
+        valid[b, :len(f)] = True
+        frames.append(f)
+    imgs = torch.from_numpy(op.preprocess(np.concatenate(frames), cfg['image_size']))
+    feats = clip_ref.encode_image(sd, cfg, imgs)
+    text = torch.nn.functional.normalize(clip_ref.encode_text(sd, cfg, tokens), dim=-1)
+    if adapter is None:
+        return oc.zs_forward(feats, valid, text, 100.0, agg), feats
+    ad_sd, heads, residual, text_param = adapter
+    full = torch.zeros(len(evs), T, feats.shape[-1])
+    full[valid] = feats
+    ad = oa.transformer_adapter(ad_sd, full, valid, heads, residual)
+    text = torch.nn.functional.normalize(text_param, dim=-1)
+    return oc.fs_tail(ad, valid, text, 100.0, agg), feats
+
+
+def check(out, want, feats_tol_info=None, logit_tol=2e-3):
+    import torch
+    assert torch.equal(out['valid_masks'].cpu(), want['valid_masks'])
+    mag = float(want['full_logits'].abs().max())
+    for k in ('full_logits', 'logits'):
+        err = float((out[k].cpu() - want[k]).abs().max()) / mag
+        assert err < logit_tol, (k, err)
+
+
+def quantize_args(geo_name, T, grayscale=True):
+    from eventclip_amd.synthetic import GEOMETRY
+    g = GEOMETRY[geo_name]
+    return g, dict(max_imgs=T, N=g['N'], split_method='event_count',
+                   convert_method='event_histogram', grayscale=grayscale,
+                   count_non_zero=g['count_non_zero'], background_mask=g['background_mask'])
+
+
+def test_config0_ncaltech_gray_vitb32_batch1(hip):
+    """configs[0]: N-Caltech101 zero-shot, ViT-B/32 (full depth), gray event2img, batch = 1."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    g, qa = quantize_args('n_caltech', 10)
+    cfg = eclip.arch_config('ViT-B/32', text_layers=2)
+    sd = eclip.random_state_dict(cfg, seed=31)
+    m = eclip.CLIP(cfg, sd).cuda().eval()
+    tokens = eclip.synthetic_tokens(101, seed=1)
+    evs = make_batch(1, [93000], g['resolution'], seed=1)          # 4 chunks + overlap chunk = 5 views
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                                            class_names=[str(i) for i in range(101)],
+                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=32, kpad=m.kpad)
+    assert pipe.max_imgs == 10
+    out = model(pipe(evs))
+    want, _ = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 10, 'mean')
+    assert int(want['valid_masks'].sum()) == 5
+    check(out, want)
+    assert torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
+
+
+def test_config2_ncars_fewshot_adapter_vitl14(hip):
+    """configs[2]: N-Cars few-shot with the text-trans adapter, ViT-L/14 (2 layers here), one
+    short view per sample (12 500 < N = 30 000 events), count_non_zero, no background mask."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import FSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    g, qa = quantize_args('n_cars', 2)
+    cfg = eclip.arch_config('ViT-L/14', layers=2, text_layers=1)
+    sd = eclip.random_state_dict(cfg, seed=32)
+    m = eclip.CLIP(cfg, sd).cuda().eval()
+    tokens = eclip.synthetic_tokens(2, seed=2)
+    evs = make_batch(6, 12500, g['resolution'], seed=2)
+    torch.manual_seed(0)
+    model = FSCLIPClassifier(
+        adapter_dict=dict(adapter_type='text-trans', in_dim=768, d_model=256, num_heads=4,
+                          ffn_dim=1024, norm_first=True, num_layers=2, residual=0.8),
+        clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                       class_names=['car', 'background'], agg_func='mean', class_tokens=tokens),
+        loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
+    with torch.no_grad():
+        for p in model.adapter.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    model = model.cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
+    assert pipe.max_imgs == 1                                      # round(12500 / 30000) = 0 -> 1
+    out = model(pipe(evs))
+    ad_sd = {k: v.detach().cpu() for k, v in model.adapter.state_dict().items()}
+    want, _ = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 1, 'mean',
+                             adapter=(ad_sd, 4, 0.8, model.text_feats.detach().cpu()))
+    check(out, want, logit_tol=3e-3)
+
+
+def test_config3_nimagenet_vitl14_336_k1000(hip):
+    """configs[3]: N-ImageNet zero-shot, ViT-L/14@336px (2 layers here), 1000 classes, two views
+    of 70 000 events on the 480 x 640 sensor (multi-band, uncached events path)."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    g, qa = quantize_args('n_imagenet', 2)
+    cfg = eclip.arch_config('ViT-L/14@336px', layers=2, text_layers=1)
+    sd = eclip.random_state_dict(cfg, seed=33)
+    m = eclip.CLIP(cfg, sd).cuda().eval()
+    tokens = eclip.synthetic_tokens(1000, seed=3)
+    evs = make_batch(2, [135000, 70000], g['resolution'], seed=3)
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                                            class_names=[str(i) for i in range(1000)],
+                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=336, patch=14, kpad=m.kpad)
+    assert pipe.max_imgs == 2
+    out = model(pipe(evs))
+    want, _ = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 2, 'mean')
+    assert want['valid_masks'].tolist() == [[True, True], [True, False]]
+    check(out, want)
+    top5 = out['logits'].topk(5, dim=-1).indices.cpu()              # test.py:76-81 top-5 path
+    assert all(int(want['logits'][b].argmax()) in top5[b].tolist() for b in range(2))
+
+
+def test_config4_nimagenet_fewshot_t5_k1000(hip):
+    """configs[4]: N-ImageNet few-shot adapter, ViT-L/14 (2 layers here), T = 5 views, 1000
+    classes, residual 0.95; ragged view counts."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import FSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    g, qa = quantize_args('n_imagenet', 5)
+    cfg = eclip.arch_config('ViT-L/14', layers=2, text_layers=1)
+    sd = eclip.random_state_dict(cfg, seed=34)
+    m = eclip.CLIP(cfg, sd).cuda().eval()
+    tokens = eclip.synthetic_tokens(1000, seed=4)
+    evs = make_batch(3, [350000, 150000, 69000], g['resolution'], seed=4)
+    torch.manual_seed(1)
+    model = FSCLIPClassifier(
+        adapter_dict=dict(adapter_type='text-trans', in_dim=768, d_model=256, num_heads=4,
+                          ffn_dim=1024, norm_first=True, num_layers=2, residual=0.95),
+        clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                       class_names=[str(i) for i in range(1000)], agg_func='mean',
+                       class_tokens=tokens),
+        loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda().eval()
+    # the reference derives max_imgs from max_n: round(135000 / 70000) = 2; T = 5 needs max_n = 350 k
+    pipe = Event2ImagePipeline(g['resolution'], 350000, qa, n_px=224, patch=14, kpad=m.kpad)
+    assert pipe.max_imgs == 5
+    out = model(pipe(evs))
+    ad_sd = {k: v.detach().cpu() for k, v in model.adapter.state_dict().items()}
+    want, _ = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 5, 'mean',
+                             adapter=(ad_sd, 4, 0.95, model.text_feats.detach().cpu()))
+    assert want['valid_masks'].sum(1).tolist() == [5, 2, 1]
+    check(out, want, logit_tol=3e-3)
