@@ -1,0 +1,122 @@
+"""Reference-API behaviour of the mirrors on the MI355X: caching, checkpoints, loaders, harness."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def small_clip(seed=3, **kw):
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=2, text_layers=2, vocab_size=49408)
+    sd = eclip.random_state_dict(cfg, seed=seed)
+    return cfg, sd, eclip.CLIP(cfg, sd, **kw).cuda().eval()
+
+
+def test_text_feats_cache_and_explicit_class_names(hip):
+    """clip_cls.py:64-93: cached when called without names or with matching names; explicit,
+    different names are computed but not cached (and do not crash as upstream does)."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    cfg, sd, m = small_clip()
+    names = ['a', 'b', 'c']
+    tokens = eclip.synthetic_tokens(3, seed=0)
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a {}', class_names=names,
+                                            agg_func='sum', class_tokens=tokens)).cuda().eval()
+    assert model.text_feats is None
+    t1 = model.get_text_feats()
+    assert model.text_feats is t1 and model.get_text_feats() is t1
+    assert model.get_text_feats(names) is t1
+    torch.testing.assert_close(t1.norm(dim=-1), torch.ones(3, device='cuda'), rtol=1e-5, atol=1e-5)
+    assert abs(model.logit_scale - 100.0) < 1e-3 and model.dtype == torch.float32
+    assert model.train() is model and not m.training             # CLIP stays in eval (:202-206)
+    with pytest.raises(AssertionError):
+        ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a {}', class_names=names,
+                                        agg_func='median'))
+
+
+def test_text_identity_adapter_and_checkpoint_round_trip(hip, tmp_path):
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import FSCLIPClassifier
+    from oracle import classify as oc
+    cfg, sd, m = small_clip(seed=4)
+    K, B, T, C = 4, 3, 2, 512
+    tokens = eclip.synthetic_tokens(K, seed=1)
+    mk = lambda: FSCLIPClassifier(                                   # noqa: E731
+        adapter_dict=dict(adapter_type='text-identity', in_dim=C, residual=False),
+        clip_dict=dict(clip_model=m, prompt='a {}', class_names=list('wxyz'), agg_func='mean',
+                       class_tokens=tokens),
+        loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda().eval()
+    model = mk()
+    assert sorted(model.state_dict()) == ['adapter.dummy', 'text_feats']
+    with torch.no_grad():
+        model.text_feats.add_(torch.randn_like(model.text_feats) * 0.05)
+    g = torch.Generator().manual_seed(0)
+    valid = torch.tensor([[True, True], [True, False], [True, True]])
+    imgs = torch.randn(B, T, 3, 224, 224, generator=g) * valid[:, :, None, None, None]
+    out = model({'img': imgs.cuda(), 'valid_mask': valid.cuda()})
+    feats = m.encode_image(imgs[valid].cuda()).cpu()
+    full = torch.zeros(B, T, C)
+    full[valid] = feats
+    text = torch.nn.functional.normalize(model.text_feats.detach().cpu(), dim=-1)
+    want = oc.fs_tail(full, valid, text, 100.0, 'mean')
+    for k in ('full_logits', 'logits', 'probs'):
+        torch.testing.assert_close(out[k].cpu(), want[k], rtol=1e-4, atol=1e-4)
+    # nerv-style checkpoint: {'state_dict': ...} without any CLIP weight (clip_cls.py:208-219)
+    path = os.path.join(tmp_path, 'model_1.pth')
+    torch.save({'state_dict': model.state_dict()}, path)
+    other = mk()
+    assert not torch.equal(other.text_feats, model.text_feats)
+    other.load_weight(path)
+    out2 = other({'img': imgs.cuda(), 'valid_mask': valid.cuda()})
+    assert torch.equal(out2['logits'], out['logits'])
+    with pytest.raises(NotImplementedError):
+        FSCLIPClassifier(adapter_dict=dict(adapter_type='mlp'),
+                         clip_dict=dict(clip_model=m, prompt='a {}', class_names=list('wxyz'),
+                                        agg_func='mean', class_tokens=tokens))
+
+
+def test_clip_load_from_state_dict_file(hip, tmp_path):
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg, sd, m = small_clip(seed=5)
+    path = os.path.join(tmp_path, 'ViT-B-32.pt')
+    torch.save(sd, path)
+    model, preprocess = eclip.load(path)
+    assert model.visual.output_dim == 512 and model.cfg['layers'] == 2
+    assert preprocess.n_px == 224
+    img = torch.randn(2, 3, 224, 224).cuda()
+    assert torch.equal(model.encode_image(img), m.encode_image(img))
+    model2, _ = eclip.load('ViT-B/32', download_root=str(tmp_path))   # arch name -> <root>/ViT-B-32.pt
+    assert torch.equal(model2.encode_image(img), m.encode_image(img))
+    li, lt = model(img, eclip.synthetic_tokens(3, seed=2).cuda())      # CLIP.forward
+    assert tuple(li.shape) == (2, 3) and torch.equal(li.t(), lt)
+
+
+def test_evaluate_harness_with_pipeline(hip):
+    """test.py:55-93 meters over two uneven batches of raw events."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.harness import evaluate
+    from eventclip_amd.synthetic import make_batch
+    cfg, sd, m = small_clip(seed=6)
+    K = 6
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a {}',
+                                            class_names=[str(i) for i in range(K)], agg_func='mean',
+                                            class_tokens=eclip.synthetic_tokens(K, seed=3))).cuda().eval()
+    qa = dict(max_imgs=2, N=30000, split_method='event_count', convert_method='event_histogram',
+              grayscale=True, count_non_zero=True, background_mask=False)
+    pipe = Event2ImagePipeline((100, 120), 60000, qa, n_px=224, patch=32, kpad=m.kpad)
+    b1, b2 = make_batch(3, 40000, (100, 120), seed=1), make_batch(1, 12500, (100, 120), seed=2)
+    preds = [model(pipe(b))['logits'].argmax(-1).cpu() for b in (b1, b2)]
+    labels = [preds[0].clone(), (preds[1] + 1) % K]                    # first batch right, second wrong
+    accs = evaluate(model, [dict(events=b1, label=labels[0]), dict(events=b2, label=labels[1])],
+                    is_nin=True, pipeline=pipe)
+    assert abs(accs['logits_acc'] - 0.75) < 1e-6                       # (1.0 * 3 + 0.0 * 1) / 4
+    assert set(accs) == {'probs_acc', 'logits_acc', 'probs_acc5', 'logits_acc5'}
+    assert accs['logits_acc5'] >= accs['logits_acc']
