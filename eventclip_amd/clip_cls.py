@@ -201,7 +201,6 @@ class ZSCLIPClassifier(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         clip_w = {f'model.{k}': v for k, v in self.model.state_dict().items()}   # :214-219
         state_dict = {**clip_w, **state_dict}
-        self.text_feats_dirty = True
         out = super().load_state_dict(state_dict, strict=strict)
         self._text_t = None
         return out

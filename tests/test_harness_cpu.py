@@ -154,3 +154,36 @@ def test_clip_surface_without_gpu():
     assert tok.shape == (4, 77) and (tok.argmax(-1) >= 5).all()
     with pytest.raises(FileNotFoundError):
         eclip.load('ViT-B/32', download_root='/nonexistent')
+
+
+def test_tokenize_with_synthetic_bpe_vocab(tmp_path, monkeypatch):
+    """clip.tokenize (models/clip_cls.py:81-83): byte-level BPE, <SOT> ... <EOT>, zero padding,
+    truncation rule.  The real vocabulary file is not shipped, so a tiny merges file stands in."""
+    import gzip
+    from eventclip_amd import clip as eclip
+    merges = ['#version: test', 'c a', 'ca t</w>', 'd o', 'do g</w>', 'a</w> x</w>']
+    path = tmp_path / 'bpe.txt.gz'
+    with gzip.open(path, 'wt', encoding='utf-8') as f:
+        f.write('\n'.join(merges) + '\n')
+    monkeypatch.setenv('EVENTCLIP_BPE_PATH', str(path))
+    eclip._tokenizer.cache_clear()
+    tk = eclip._tokenizer()
+    sot, eot = tk.encoder['<|startoftext|>'], tk.encoder['<|endoftext|>']
+    assert eot == sot + 1 == len(tk.encoder) - 1
+    out = eclip.tokenize(['a photo of a cat', 'DOG'])
+    assert out.shape == (2, 77) and out.dtype == torch.int32
+    assert out[0, 0] == sot and out[1, 0] == sot
+    assert int(out[1].argmax()) == 2 and out[1, 2] == eot            # <SOT> dog</w> <EOT>
+    assert out[1, 1] == tk.encoder['dog</w>'] and (out[1, 3:] == 0).all()
+    assert tk.encoder['cat</w>'] in out[0].tolist()
+    assert eclip.tokenize('cat').shape == (1, 77)                      # str input
+    long = ' '.join(['cat'] * 100)
+    with pytest.raises(RuntimeError):
+        eclip.tokenize(long)
+    t = eclip.tokenize(long, truncate=True)
+    assert t[0, 76] == eot and t[0, 0] == sot
+    eclip._tokenizer.cache_clear()
+    monkeypatch.delenv('EVENTCLIP_BPE_PATH')
+    with pytest.raises(FileNotFoundError):
+        eclip.tokenize('cat')
+    eclip._tokenizer.cache_clear()
