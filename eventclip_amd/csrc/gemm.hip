@@ -114,6 +114,26 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
     }
 }
 
+// Tile raster inside an XCD's contiguous id range: 8 row panels x 4 column tiles per group of
+// 32 ids (one per CU of the XCD), so the 32 workgroups an XCD runs at a time stream 8 + 4
+// distinct operand panels through its L2 instead of 2-3 + tiles_n.  Rows beyond the last full
+// group of 8 (and tilings whose column count is not a multiple of 4) keep the N-fastest order.
+__device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm, int &tn)
+{
+    const int full = (tiles_n & 3) == 0 ? (tiles_m >> 3) * 8 * tiles_n : 0;
+    if (id < full) {
+        const int per_group = 8 * tiles_n;
+        const int grp = id / per_group, r = id - grp * per_group;
+        const int chunk = r >> 5, w = r & 31;
+        tm = grp * 8 + (w >> 2);
+        tn = chunk * 4 + (w & 3);
+    } else {
+        const int r = id - full, base_m = full / tiles_n;
+        tm = base_m + r / tiles_n;
+        tn = r % tiles_n;
+    }
+}
+
 template <int DT, int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs g)
 {
@@ -474,8 +494,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
     const int wm = wave >> 2, wn = wave & 3;
 
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * BM;
-    const int n0 = (tile % g.tiles_n) * BN;
+    int tm, tn;
+    raster(tile, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
     const int lm0 = DBG == 2 ? 0 : m0, ln0 = DBG == 2 ? 0 : n0;   // timing experiments only
 
     auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
