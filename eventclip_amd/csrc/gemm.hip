@@ -66,7 +66,6 @@ template <int DT, int EPI, int TM>
 __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
                                          int n_base, int lane)
 {
-    typedef typename T16<DT>::elem elem;
     const int nb = n_base + (lane >> 4) * 16;
     if (nb >= g.N) return;
     float bias[16];
@@ -79,6 +78,38 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
             bias[4 * c] = b.x, bias[4 * c + 1] = b.y, bias[4 * c + 2] = b.z, bias[4 * c + 3] = b.w;
         }
     }
+    if constexpr (EPI == EC_EPI_RESID32) {
+        // fp32 residual read-modify-write.  The loads of tile row i + DEPTH are issued before
+        // row i is stored: the compiler cannot hoist them itself (same base pointer as the
+        // stores), and one row group in flight per wave leaves the epilogue latency-bound.
+        constexpr int DEPTH = TM < 4 ? TM : 4;
+        float4 x[DEPTH][4];
+        auto fetch = [&](int i) {
+            const int m = m_base + i * 16 + (lane & 15);
+            const float *src = (const float *)g.C + (long)(m < g.M ? m : g.M - 1) * g.ldc + nb;
+#pragma unroll
+            for (int c = 0; c < 4; c++) x[i % DEPTH][c] = *reinterpret_cast<const float4 *>(src + 4 * c);
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) fetch(i);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m_base + i * 16 + (lane & 15);
+            float *dst = (float *)g.C + (long)m * g.ldc + nb;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 r = x[i % DEPTH][c];
+                float4 o;
+                o.x = acc[i][c][0] + bias[4 * c] + r.x;
+                o.y = acc[i][c][1] + bias[4 * c + 1] + r.y;
+                o.z = acc[i][c][2] + bias[4 * c + 2] + r.z;
+                o.w = acc[i][c][3] + bias[4 * c + 3] + r.w;
+                if (m < g.M) *reinterpret_cast<float4 *>(dst + 4 * c) = o;
+            }
+            if (i + DEPTH < TM) fetch(i + DEPTH);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m_base + i * 16 + (lane & 15);
@@ -89,6 +120,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
 #pragma unroll
             for (int r = 0; r < 4; r++) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
         if constexpr (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) {
+            typedef typename T16<DT>::elem elem;
             elem o[16];
 #pragma unroll
             for (int c = 0; c < 16; c++) {
@@ -102,14 +134,123 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
         } else {
             float *dst = (float *)g.C + (long)m * g.ldc + nb;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float4 o = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-                if constexpr (EPI == EC_EPI_RESID32) {
-                    const float4 x = *reinterpret_cast<const float4 *>(dst + 4 * c);
-                    o.x += x.x, o.y += x.y, o.z += x.z, o.w += x.w;
-                }
-                *reinterpret_cast<float4 *>(dst + 4 * c) = o;
+            for (int c = 0; c < 4; c++)
+                *reinterpret_cast<float4 *>(dst + 4 * c) =
+                    make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+        }
+    }
+}
+
+// fp32 residual epilogue with a transpose through LDS.  In the accumulator layout a quad of
+// consecutive lanes owns four different rows, so every 16-byte access of a lane sits in its own
+// cache line and the texture path serves one quarter of its width (measured: 35 k cycles of
+// epilogue per 256 x 256 tile, as long as the 16 K-tile main loop).  Each wave passes one 16 x 64
+// row group at a time through a private LDS scratch (row pitch 68 dwords: conflict-free for both
+// the 16-B writes by (row, column group) and the 16-B reads by row) and comes back with 16
+// consecutive lanes covering 256 contiguous bytes of one row, for the residual loads and the stores.
+// scratch: 2 x 16 x 68 floats per wave.
+template <int EPI, int TM>
+__device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
+                                               int n_base, int lane, float *scratch)
+{
+    static_assert(EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32, "fp32 outputs only");
+    constexpr int PITCH = 68;
+    const int q = lane >> 4, lr = lane & 15;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nb = n_base + q * 16;
+    if (g.bias && nb < g.N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
+    }
+    const int col = n_base + lr * 4;          // this lane's 4 output columns after the transpose
+    const bool col_ok = col < g.N;
+    constexpr int DEPTH = EPI == EC_EPI_RESID32 ? (TM < 3 ? TM : 3) : 1;
+    f32x4 x[DEPTH][4];
+    auto fetch = [&](int i) {
+        if constexpr (EPI == EC_EPI_RESID32) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int m = m_base + i * 16 + q + 4 * p;
+                m = m < g.M ? m : g.M - 1;
+                const float *src = (const float *)g.C + (long)m * g.ldc + (col_ok ? col : 0);
+                x[i % DEPTH][p] = *reinterpret_cast<const f32x4 *>(src);
             }
+        }
+    };
+    if constexpr (EPI == EC_EPI_RESID32) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) fetch(i);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        float *buf = scratch + (i & 1) * 16 * PITCH;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
+        f32x4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            v[p] = *reinterpret_cast<const f32x4 *>(buf + (q + 4 * p) * PITCH + lr * 4);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int m = m_base + i * 16 + q + 4 * p;
+            f32x4 o = v[p];
+            if constexpr (EPI == EC_EPI_RESID32) o += x[i % DEPTH][p];
+            if (m < g.M && col_ok)
+                *reinterpret_cast<f32x4 *>((float *)g.C + (long)m * g.ldc + col) = o;
+        }
+        if constexpr (EPI == EC_EPI_RESID32) {
+            if (i + DEPTH < TM) fetch(i + DEPTH);
+        }
+    }
+}
+
+// 16-bit counterpart: a 16 x 64 row group is 16 rows of 128 B (pitch 144 B); after the transpose
+// 8 consecutive lanes cover one full 128-B row and a store instruction writes 8 whole lines.
+// scratch: 2 x 16 x 144 bytes per wave.
+template <int DT, int EPI, int TM>
+__device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
+                                               int n_base, int lane, unsigned char *scratch)
+{
+    typedef typename T16<DT>::elem elem;
+    static_assert(EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16, "16-bit outputs only");
+    constexpr int PITCH = 144;
+    const int q = lane >> 4, lr = lane & 15;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nb = n_base + q * 16;
+    if (g.bias && nb < g.N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
+    }
+    const int col = n_base + (lane & 7) * 8;   // this lane's 8 output columns after the transpose
+    const bool col_ok = col < g.N;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        unsigned char *buf = scratch + (i & 1) * 16 * PITCH;
+        elem o[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4 v = acc[i][j] + bias[j];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float y = v[r];
+                if constexpr (EPI == EC_EPI_GELU16) y = quick_gelu(y);
+                o[4 * j + r] = to16(y, elem());
+            }
+        }
+        *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
+        *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = (lane >> 3) + 8 * p;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(buf + row * PITCH + (lane & 7) * 16);
+            const int m = m_base + i * 16 + row;
+            if (m < g.M && col_ok)
+                *reinterpret_cast<u32x4 *>((elem *)g.C + (long)m * g.ldc + col) = v;
         }
     }
 }
@@ -137,7 +278,6 @@ __device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm
 template <int DT, int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs g)
 {
-    typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16;  // 16-row activation tiles per wave
@@ -570,18 +710,6 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
                 fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
                                                            (offN[jj] ^ (ks << 6)));
     };
-    auto mma = [&](int mq, int nq, v8(&fn)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    acc[mq * 4 + mt][nq * 2 + jj] =
-                        mfma16(fn[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nq * 2 + jj]);
-        __builtin_amdgcn_s_setprio(0);
-    };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -632,7 +760,38 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
             if (stamps && t < 64) stamps[t * 8 + i] = now;
         }
     };
+    // DBG == 9 (diagnostic build only): one record per workgroup in the buffer passed as `bias`
+    // (not applied): {HW_ID, start, prologue landed, loop done, epilogue issued, stores
+    // acknowledged, XCC_ID}, for the per-CU timeline of tools/timeline_gemm.py
+    unsigned long long *tl = nullptr;
+    auto tstamp = [&](int i) {
+        if (DBG == 9) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (tl) tl[i] = now;
+        }
+    };
+    if (DBG == 9 && threadIdx.x == 0) {
+        tl = (unsigned long long *)g.bias + (long)blockIdx.x * 8;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl[0] = hw;
+        tl[6] = xcc;
+    }
+    tstamp(1);
     const int nk = g.K / BK;
+    if ((DBG == 7 || DBG == 8) && gridDim.x > 512 && blockIdx.x < 256) {
+        // The first workgroup of every CU starts at a different point of one tile period, so
+        // the CUs' epilogues (HBM-bound bursts) land on other CUs' MFMA phases instead of
+        // all 256 alternating between a compute-only and a memory-only phase in lockstep.
+        const int slot = (blockIdx.x >> 3) & 31;
+        const int period = nk * 3200 + 8192;                    // cycles, measured (stamps)
+        const int n = (slot * period / 32) >> (DBG == 8 ? 11 : 10);
+        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(16);   // 1024 cycles each
+    }
     issue(0, 0);
     issue(2, 0);
     issue(3, 0);
@@ -646,6 +805,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         EC_VMCNT(2);
     }
     bar();
+    tstamp(2);
     if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
 
     for (int t = 0; t < nk; t++) {
@@ -692,13 +852,29 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
     }
     if (wm == 0) bar();   // balance the stagger barrier
 
-    if (DBG == 5) {
+    if (DBG == 5 || DBG == 9) {
         GemmArgs g2 = g;
         g2.bias = nullptr;
-        epilogue<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        tstamp(3);
+        if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32)
+            epilogue32_lds<EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane,
+                                   reinterpret_cast<float *>(smem) + wave * (2 * 16 * 68));
+        else if constexpr (DBG == 9)
+            epilogue16_lds<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
+        else
+            epilogue<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        tstamp(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp(5);
         return;
     }
-    epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32) {
+        // every wave is past the closing barrier of the last K tile: the staging buffers are free
+        epilogue32_lds<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane,
+                               reinterpret_cast<float *>(smem) + wave * (2 * 16 * 68));
+    } else {
+        epilogue16_lds<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
+    }
 }
 
 template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStream_t stream)
@@ -1028,7 +1204,10 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 10: return launch2p<DT, EPI, 5>(g, s);
     case 11: return launch2p<DT, EPI, 6>(g, s);
     case 12: return launch_b2<DT, EPI>(g, s);     // two 4-wave workgroups per CU, 128x256x32
-    case 13: return launch_b2p<DT, EPI>(g, s);    // same with register-prefetched fragments  // timing experiment: MFMA + barrier skeleton only  // diagnostic: s_memtime stamps into the bias buffer
+    case 13: return launch_b2p<DT, EPI>(g, s);    // same with register-prefetched fragments
+    case 14: return launch2p<DT, EPI, 7>(g, s);   // first-round start times spread over a tile period
+    case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
+    case 16: return launch2p<DT, EPI, 9>(g, s);   // diagnostic: per-workgroup timeline into the bias buffer
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
     }
 }

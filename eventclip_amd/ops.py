@@ -31,6 +31,9 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0):
         assert epilogue != 'resid32', 'resid32 needs the fp32 residual tensor as out'
         odt = A.dtype if epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16) else torch.float32
         out = torch.empty((M, N), dtype=odt, device=A.device)
+    want = A.dtype if epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16) else torch.float32
+    assert out.dtype == want and tuple(out.shape) == (M, N) and out.stride(1) == 1, \
+        f'{epilogue} writes a {want} [{M}, {N}] tensor, got {out.dtype} {tuple(out.shape)}'
     a = _lib.EcGemmArgs()
     a.M, a.N, a.K = M, N, K
     a.dtype, a.epilogue, a.variant = dtype_code(A.dtype), epi, variant
