@@ -148,8 +148,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
 // row group at a time through a private LDS scratch (row pitch 68 dwords: conflict-free for both
 // the 16-B writes by (row, column group) and the 16-B reads by row) and comes back with 16
 // consecutive lanes covering 256 contiguous bytes of one row, for the residual loads and the stores.
-// scratch: 2 x 16 x 68 floats per wave.
-template <int EPI, int TM>
+// scratch: NBUF x 16 x 68 floats per wave (one buffer is enough: a wave's LDS accesses execute in
+// program order).
+template <int EPI, int TM, int NBUF = 2>
 __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
                                                int n_base, int lane, float *scratch)
 {
@@ -185,7 +186,7 @@ __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[T
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-        float *buf = scratch + (i & 1) * 16 * PITCH;
+        float *buf = scratch + (i % NBUF) * 16 * PITCH;
 #pragma unroll
         for (int j = 0; j < 4; j++)
             *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
@@ -904,6 +905,274 @@ template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStre
 
 
 // ---------------------------------------------------------------------------------------
+// Persistent form of the staggered two-phase kernel: one workgroup per CU walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  (the same XCD / raster order as the one-tile-per-
+// workgroup launch, 256 tiles in flight at a time).  The first K tile of the next output tile
+// is on its way into staging buffer 0 while the epilogue drains the accumulators through a
+// scratch area in buffer 1, so neither the workgroup turnaround (~1.5 k cycles) nor the
+// prologue's HBM latency (~2.9 k cycles of a 48 k-cycle tile at K = 1024) is exposed.
+// TL: per-tile timeline records as in gemm2p_kernel<DBG = 9>.
+// ---------------------------------------------------------------------------------------
+template <int DT, int EPI, bool TL = false>
+__global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::v8 v8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int REGION = 128 * 128;
+    constexpr int KT = 4 * REGION;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int nk = g.K / BK;
+
+    auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
+
+    int m0 = 0, n0 = 0;
+    const unsigned char *src[4][2];
+    auto setup = [&](int id) {
+        int tm, tn;
+        raster(xcd_remap(id, ntiles), g.tiles_m, g.tiles_n, tm, tn);
+        m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int rr = (i * 8 + wave) * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ key(rr);
+                if (r < 2) {
+                    int m = m0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
+                    m = m < g.M ? m : g.M - 1;
+                    src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+                } else {
+                    const int p = rr & 31;
+                    int n = n0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
+                    n = n < g.N ? n : g.N - 1;
+                    src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+                }
+            }
+    };
+    auto issue = [&](int r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
+            src[r][i] += BK * 2;
+        }
+    };
+
+    int offM[4], offN[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        const int row = wm * 64 + mt * 16 + (lane & 15);
+        offM[mt] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+        const int i = lane & 15;
+        const int row = wn * 32 + ((i >> 2) << 3) + (jj << 2) + (i & 3);
+        offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+    v8 fm[4][2], fn0[2][2], fn1[2][2];
+    auto load_m = [&](int buf, int mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
+                                                           (offM[mt] ^ (ks << 6)));
+    };
+    auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
+                                                           (offN[jj] ^ (ks << 6)));
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma2 = [&](int mq, int nqa, v8(&fa)[2][2], int nqb, v8(&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqa * 2 + jj] =
+                        mfma16(fa[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqa * 2 + jj]);
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqb * 2 + jj] =
+                        mfma16(fb[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqb * 2 + jj]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar_l = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+    };
+
+    unsigned long long *tl = nullptr;
+    auto tstamp = [&](int i) {
+        if (TL) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (tl) tl[i] = now;
+        }
+    };
+    auto tl_open = [&](int id) {
+        if (TL && threadIdx.x == 0) {
+            tl = (unsigned long long *)g.bias + (long)id * 8;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tl[0] = hw;
+            tl[6] = xcc;
+        }
+    };
+    GemmArgs ge = g;
+    if (TL) ge.bias = nullptr;
+
+    int id = blockIdx.x;
+    tl_open(id);
+    tstamp(1);
+    setup(id);
+    issue(0, 0);
+    issue(2, 0);
+    issue(3, 0);
+    issue(1, 0);
+    if (nk > 1) {
+        issue(0, 1);
+        issue(2, 1);
+        issue(3, 1);
+        EC_VMCNT(8);
+    } else {
+        EC_VMCNT(2);
+    }
+    bar();
+    for (;;) {
+        tstamp(2);
+        if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < nk; t++) {
+            const int buf = t & 1, nxt = buf ^ 1;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            // ---- phase A ----
+            load_m(buf, 0);
+            load_n(fn0, buf, 0);
+            load_n(fn1, buf, 1);
+            if (has1) {
+                issue(1, nxt);
+                EC_VMCNT(8);
+            } else {
+                EC_VMCNT(0);
+            }
+            bar_l();
+            mma2(0, 0, fn0, 1, fn1);
+            bar();
+            // ---- phase B ----
+            load_m(buf, 1);
+            if (has2) {
+                issue(0, buf);
+                issue(2, buf);
+                issue(3, buf);
+                EC_VMCNT(8);
+            } else if (has1) {
+                EC_VMCNT(2);
+            }
+            bar_l();
+            mma2(1, 1, fn1, 0, fn0);
+            bar();
+        }
+        if (wm == 0) bar();   // balance the stagger barrier: every wave is out of the staging buffers
+
+        const int cm0 = m0, cn0 = n0;
+        const int next = id + gridDim.x;
+        const bool more = next < ntiles;
+        tstamp(3);
+        if (more) {
+            setup(next);
+            issue(0, 0);
+            issue(2, 0);
+            issue(3, 0);
+            issue(1, 0);
+        }
+        if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32)
+            epilogue32_lds<EPI, 8, 1>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                      reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+        else
+            epilogue16_lds<DT, EPI, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                       smem + KT + wave * (2 * 16 * 144));
+        tstamp(4);
+        if (!more) break;
+        // K tile 0 of the next output tile has landed, the stores are acknowledged (loads and
+        // stores share vmcnt and retire out of order with each other: only 0 is exact), and after
+        // the barrier no wave reads the scratch area any more
+        EC_VMCNT(0);
+        tstamp(5);
+        bar();
+        if (nk > 1) {
+            issue(0, 1);
+            issue(2, 1);
+            issue(3, 1);
+        }
+        id = next;
+        tl_open(id);
+        tstamp(1);
+    }
+    if (TL) {
+        EC_VMCNT(0);
+        tstamp(5);
+    }
+}
+
+template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    g.tiles_m = ec::ceil_div(g.M, 256);
+    g.tiles_n = ec::ceil_div(g.N, 256);
+    constexpr int lds = 2 * 4 * 128 * 128;
+    auto kern = gemm2pp_kernel<DT, EPI, TL>;
+    static bool attr_set = false;
+    static int cus = 0;
+    if (!attr_set) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        EC_CHECK_HIP(hipGetDevice(&dev));
+        EC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
+                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
+                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
+    const int tiles = g.tiles_m * g.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
 // Two workgroups per CU: 128 x 256 x 32 tiles, 4 waves (one per SIMD), each wave 128 x 64.
 // A 3-stage LDS-DMA ring of 24-KiB K tiles (72 KiB per workgroup, so two workgroups share a
 // CU's LDS and registers).  The SIMD partner of every wave belongs to the OTHER workgroup:
@@ -1191,12 +1460,12 @@ template <int DT, int EPI> int launch_b2p(const GemmArgs &g0, hipStream_t stream
 template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, hipStream_t s)
 {
     switch (variant) {
-    case 0: return launch2p<DT, EPI>(g, s);                      // default: staggered 2-phase
+    case 0: return launch2pp<DT, EPI>(g, s);                     // default: persistent staggered 2-phase
     case 1: return launch<DT, 256, 256, 2, 4, EPI>(g, s);
     case 2: return launch<DT, 128, 128, 2, 2, EPI>(g, s);
     case 3: return launch<DT, 128, 256, 1, 4, EPI>(g, s);
     case 4: return launch4p<DT, EPI>(g, s);
-    case 5: return launch2p<DT, EPI>(g, s);
+    case 5: return launch2p<DT, EPI>(g, s);                      // one tile per workgroup
     case 6: return launch2p<DT, EPI, 1>(g, s);   // timing experiment: no DMA in the loop (wrong results)
     case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)
     case 8: return launch2p<DT, EPI, 3>(g, s);   // no s_setprio
@@ -1208,6 +1477,8 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 14: return launch2p<DT, EPI, 7>(g, s);   // first-round start times spread over a tile period
     case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
     case 16: return launch2p<DT, EPI, 9>(g, s);   // diagnostic: per-workgroup timeline into the bias buffer
+    case 17: return launch2pp<DT, EPI>(g, s);        // persistent, next tile's first K tile prefetched
+    case 18: return launch2pp<DT, EPI, true>(g, s);  // ... with timeline records
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
     }
 }

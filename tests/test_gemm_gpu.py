@@ -16,7 +16,7 @@ def ref_gemm(A, W, bias, epilogue, resid=None):
     return y
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 12, 13])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 12, 13])
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 3072, 1024), (513, 1024, 4096),
                                    (77, 768, 640), (5, 512, 64), (256, 256, 128), (300, 48, 64)])
@@ -38,6 +38,25 @@ def test_gemm_matches_torch(M, N, K, dt, epilogue, variant, hip):
     # 16-bit outputs add one rounding (2^-11 f16, 2^-8 bf16)
     out16 = epilogue in ('store16', 'gelu16')
     rtol = (2e-3 if dt == 'float16' else 1.6e-2) if out16 else 1e-4
+    torch.testing.assert_close(got.float(), want, rtol=rtol, atol=rtol)
+
+
+@pytest.mark.parametrize('variant', [0, 5])
+@pytest.mark.parametrize('epilogue', ['store16', 'gelu16', 'resid32', 'store32'])
+@pytest.mark.parametrize('M,N,K', [(70001, 512, 256), (66000, 1024, 64), (40000, 784, 192)])
+def test_gemm_many_tiles(M, N, K, epilogue, variant, hip):
+    """More output tiles than CUs: several rounds of workgroups / a persistent workgroup's tile loop."""
+    import torch
+    from eventclip_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn(M, K, device='cuda', generator=g).half()
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, device='cuda', generator=g)
+    resid = torch.randn(M, N, device='cuda', generator=g)
+    out = resid.clone() if epilogue == 'resid32' else None
+    got = ops.gemm(A, W, bias, epilogue, out=out, variant=variant)
+    want = ref_gemm(A, W, bias, epilogue, resid)
+    rtol = 2e-3 if epilogue in ('store16', 'gelu16') else 1e-4
     torch.testing.assert_close(got.float(), want, rtol=rtol, atol=rtol)
 
 

@@ -22,7 +22,7 @@ out = torch.zeros(M, N, device='cuda', dtype=torch.float32 if epi.endswith('32')
 tiles = ((M + 255) // 256) * ((N + 255) // 256)
 dbg = torch.zeros(tiles * 8 * 2, device='cuda', dtype=torch.float32)
 for _ in range(2):
-    ops.gemm(A, W, dbg, epi, out=out, variant=16)
+    ops.gemm(A, W, dbg, epi, out=out, variant=int(os.environ.get('TL_VARIANT', '16')))
 torch.cuda.synchronize()
 r = dbg.cpu().numpy().view(np.uint64).reshape(tiles, 8).astype(np.int64)
 hw, xcc = r[:, 0], r[:, 6]
