@@ -192,6 +192,8 @@ def main():
                        'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': roof,
             'kernel_ms_per_step': breakdown, 'kernel_ms_per_step_total': gpu_ms,
+            'kernel_launches_per_step': {e['name']: e['launches'] / a.steps for e in prof},
+            'kernel_algorithmic_bytes_per_launch': {e['name']: e['bytes'] / e['launches'] for e in prof},
         }
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
