@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--classes', type=int, default=101)
     ap.add_argument('--cpu-baseline-samples', type=int, default=3)
     ap.add_argument('--cpu-baseline-frames', type=int, default=10, help='views per baseline sample')
+    ap.add_argument('--packed-events', action='store_true',
+                    help='feed the 8-byte packed event form (SURVEY 8(f)) instead of float32 [n, 4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -121,6 +123,9 @@ def main():
            for i in range(uniq)]
     n_events = [T * N] * a.batch
     events = torch.from_numpy(np.concatenate([evs[i % uniq] for i in range(a.batch)])).cuda()
+    if a.packed_events:
+        from eventclip_amd.vis import pack_events_device
+        events = pack_events_device(events)
     pipe = Event2ImagePipeline(geo['resolution'], geo['max_n'], quantize_args,
                                n_px=cfg['image_size'], patch=cfg['patch'], kpad=clip_model.kpad,
                                dtype=clip_model.compute_dtype)
@@ -188,6 +193,7 @@ def main():
                                    f'batch={a.batch} samples x {T} views per GPU (configs[1])',
                        'frames_per_step_per_gpu': frames_per_step, 'classes': a.classes,
                        'events_per_frame': N, 'resolution': list(geo['resolution']),
+                       'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
                        'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
                        'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': roof,

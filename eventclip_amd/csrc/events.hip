@@ -36,7 +36,7 @@ constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
 constexpr int EV_SCRATCH_BYTES = 8 * EV_WAVES * 2; // block-reduction scratch (u64 per wave, 2 slots)
 
 struct EvArgs {
-    const float4 *events;
+    const void *events;      // float4 (x, y, t, p) or packed 8-byte events
     const long long *range;  // [F,2]
     int H, W;
     double thresh;
@@ -105,8 +105,21 @@ __device__ __forceinline__ void parse(const float4 e, int W, int flip_x, int neg
     x = (int)xf, y = (int)e.y, p = (int)(negate_p ? -e.w : e.w);
 }
 
+// Packed 8-byte event (include/eventclip_hip.h, EC_PACKED_*): x and y are already the truncated
+// integers of parse_events, the polarity code is 0 (p == 0), 1 (p > 0) or 2 (p < 0).
+typedef unsigned long long packed_t;
+__device__ __forceinline__ void parse(const packed_t e, int W, int flip_x, int negate_p, int &x, int &y,
+                                      int &p)
+{
+    x = (int)(e & 0xffffu), y = (int)((e >> 16) & 0xffffu);
+    if (flip_x) x = W - 1 - x;
+    const int code = (int)((e >> 32) & 3u);
+    p = code == 0 ? 0 : ((code == 1) != (negate_p != 0) ? 1 : -1);
+}
+
 // vis.py:10-14 restricted to rows [y0, y1): LDS atomics, one per in-band event.
-__device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, int W, int flip_x,
+template <typename EV>
+__device__ __forceinline__ void bin_one(const EV e, int y0, int y1, int H, int W, int flip_x,
                                         int negate_p, unsigned *bins, unsigned &dropped)
 {
     int x, y, p;
@@ -119,7 +132,8 @@ __device__ __forceinline__ void bin_one(const float4 e, int y0, int y1, int H, i
     if (y >= y0 && y < y1) atomicAdd(&bins[((y - y0) * W + x) * 2 + (p < 0 ? 1 : 0)], 1u);
 }
 
-__device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, int W, int flip_x,
+template <typename EV>
+__device__ void bin_band(const EV *ev, long long n, int y0, int y1, int H, int W, int flip_x,
                          int negate_p, unsigned *bins, unsigned &dropped)
 {
     const int nb = (y1 - y0) * W * 2;
@@ -127,8 +141,8 @@ __device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, i
     __syncthreads();
     long long i = threadIdx.x;
     for (; i + 3 * EV_THREADS < n; i += 4 * EV_THREADS) {
-        const float4 e0 = ev[i], e1 = ev[i + EV_THREADS], e2 = ev[i + 2 * EV_THREADS],
-                     e3 = ev[i + 3 * EV_THREADS];
+        const EV e0 = ev[i], e1 = ev[i + EV_THREADS], e2 = ev[i + 2 * EV_THREADS],
+                 e3 = ev[i + 3 * EV_THREADS];
         bin_one(e0, y0, y1, H, W, flip_x, negate_p, bins, dropped);
         bin_one(e1, y0, y1, H, W, flip_x, negate_p, bins, dropped);
         bin_one(e2, y0, y1, H, W, flip_x, negate_p, bins, dropped);
@@ -143,11 +157,12 @@ __device__ void bin_band(const float4 *ev, long long n, int y0, int y1, int H, i
 // so the band / pass loops below re-scan 4 B per event from LDS instead of 16 B from L2.
 constexpr unsigned EV_SKIP = 0xFFFFFFFFu;
 
-__device__ void fill_cache(const float4 *ev, long long n, int H, int W, int flip_x, int negate_p,
+template <typename EV>
+__device__ void fill_cache(const EV *ev, long long n, int H, int W, int flip_x, int negate_p,
                            unsigned *cache, unsigned &dropped)
 {
     for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
-        const float4 e = ev[i];
+        const EV e = ev[i];
         int x, y, p;
         parse(e, W, flip_x, negate_p, x, y, p);
         unsigned c = EV_SKIP;
@@ -201,6 +216,7 @@ __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dm
     }
 }
 
+template <typename EV>
 __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     const int f = blockIdx.x;
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
-    const float4 *ev = a.events + e0;
+    const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
     const long long n = e1 - e0;
     const int H = a.H, W = a.W;
     const long long M2 = (long long)H * W * 2;
@@ -406,6 +422,81 @@ __global__ __launch_bounds__(256) void center_events_kernel(float4 *events, cons
     }
 }
 
+
+// center_events on packed events: the same shift in integers (coordinates are integral, so
+// utils.py:53-54's float floor-division equals the arithmetic shift of the integer sum);
+// a coordinate shifted below zero wraps to >= 32768 and is dropped by the binning kernel like
+// any other out-of-sensor event.  t is kept relative to the sample's first event.
+__global__ __launch_bounds__(256) void center_packed_kernel(packed_t *events, const long long *range,
+                                                            int H, int W)
+{
+    __shared__ unsigned red[5][4];
+    const long long e0 = range[2 * blockIdx.x], e1 = range[2 * blockIdx.x + 1];
+    packed_t *ev = events + e0;
+    const long long n = e1 - e0;
+    unsigned xmin = ~0u, xmax = 0, ymin = ~0u, ymax = 0, tmin = ~0u;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const packed_t e = ev[i];
+        const unsigned x = (unsigned)(e & 0xffffu), y = (unsigned)((e >> 16) & 0xffffu),
+                       t = (unsigned)(e >> 34);
+        xmin = min(xmin, x), xmax = max(xmax, x), ymin = min(ymin, y), ymax = max(ymax, y);
+        tmin = min(tmin, t);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = min(xmin, (unsigned)__shfl_xor((int)xmin, o, 64));
+        xmax = max(xmax, (unsigned)__shfl_xor((int)xmax, o, 64));
+        ymin = min(ymin, (unsigned)__shfl_xor((int)ymin, o, 64));
+        ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o, 64));
+        tmin = min(tmin, (unsigned)__shfl_xor((int)tmin, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        red[0][wave] = xmin, red[1][wave] = xmax, red[2][wave] = ymin, red[3][wave] = ymax,
+        red[4][wave] = tmin;
+    __syncthreads();
+    xmin = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+    xmax = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+    ymin = min(min(red[2][0], red[2][1]), min(red[2][2], red[2][3]));
+    ymax = max(max(red[3][0], red[3][1]), max(red[3][2], red[3][3]));
+    tmin = min(min(red[4][0], red[4][1]), min(red[4][2], red[4][3]));
+    const int xs = ((int)(xmax + xmin + 1) - W) >> 1;   // floor division by 2 (utils.py:53)
+    const int ys = ((int)(ymax + ymin + 1) - H) >> 1;   // utils.py:54
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const packed_t e = ev[i];
+        const unsigned x = ((unsigned)(e & 0xffffu) - (unsigned)xs) & 0xffffu;
+        const unsigned y = ((unsigned)((e >> 16) & 0xffffu) - (unsigned)ys) & 0xffffu;
+        const packed_t t = (e >> 34) - tmin;
+        ev[i] = (packed_t)x | ((packed_t)y << 16) | (e & (3ull << 32)) | (t << 34);
+    }
+}
+
+// float32 (x, y, t, p) -> packed: parse_events' truncating casts (vis.py:50), t in microseconds
+// rounded to nearest and saturated to 30 bits.  Events whose coordinates are not integral or do
+// not fit 16 bits cannot be represented: they are counted in *bad and packed with polarity code 0
+// (binned nowhere).
+__global__ __launch_bounds__(256) void pack_events_kernel(const float4 *events, long long n,
+                                                          packed_t *out, unsigned *bad)
+{
+    unsigned nbad = 0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const float4 e = events[i];
+        const int x = (int)e.x, y = (int)e.y, p = (int)e.w;
+        unsigned code = p == 0 ? 0u : (p > 0 ? 1u : 2u);
+        const bool ok = (float)x == e.x && (float)y == e.y && x >= 0 && y >= 0 && x < 65536 && y < 65536;
+        if (!ok) nbad++, code = 0;
+        double tu = __builtin_rint((double)e.z * 1e6);
+        tu = tu < 0. ? 0. : (tu > 1073741823. ? 1073741823. : tu);
+        out[i] = (packed_t)((unsigned)x & 0xffffu) | ((packed_t)((unsigned)y & 0xffffu) << 16) |
+                 ((packed_t)code << 32) | ((packed_t)(unsigned)tu << 34);
+    }
+    if (bad) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nbad += __shfl_down(nbad, o, 64);
+        if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(bad, nbad);
+    }
+}
+
 }  // namespace
 
 extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_range, int B, int H, int W,
@@ -422,23 +513,26 @@ extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_rang
     return EC_OK;
 }
 
-extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
-                                          const ec_events_params *prm, uint8_t *frames,
-                                          int32_t *raw_counts, int32_t *kept_counts,
-                                          ec_frame_stats *stats, ec_stream_t stream)
+namespace {
+
+template <typename EV>
+int launch_events(const void *events, const int64_t *frame_range, int F, const ec_events_params *prm,
+                  uint8_t *frames, int32_t *raw_counts, int32_t *kept_counts, ec_frame_stats *stats,
+                  ec_stream_t stream)
 {
     EC_REQUIRE(prm != nullptr, "ec_events_to_frames: params is null");
     EC_REQUIRE(F >= 0, "ec_events_to_frames: F=%d", F);
     if (F == 0) return EC_OK;
     EC_REQUIRE(events && frame_range && frames, "ec_events_to_frames: null buffer");
     EC_REQUIRE(prm->H > 0 && prm->W > 0, "ec_events_to_frames: bad shape (%d,%d)", prm->H, prm->W);
-    EC_REQUIRE(((uintptr_t)events & 15) == 0, "ec_events_to_frames: events must be 16-byte aligned");
+    EC_REQUIRE(((uintptr_t)events & (sizeof(EV) - 1)) == 0,
+               "ec_events_to_frames: events must be %d-byte aligned", (int)sizeof(EV));
     const int row_bytes = prm->W * 2 * 4;
     EC_REQUIRE(row_bytes <= EV_BIN_BYTES, "ec_events_to_frames: W=%d too wide for one LDS row band",
                prm->W);
 
     EvArgs a;
-    a.events = reinterpret_cast<const float4 *>(events);
+    a.events = events;
     a.range = reinterpret_cast<const long long *>(frame_range);
     a.H = prm->H;
     a.W = prm->W;
@@ -477,17 +571,69 @@ extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *fr
     static bool attr_set = false;
     const int lds = EV_BIN_BYTES + EV_SCRATCH_BYTES;   // always the full carve: one attribute call
     if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel),
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel<EV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    // algorithmic bytes: 16 B per event in + 3*H*W out; the event count
-    // is only known on the device, so the call site reports the output part and the
-    // caller adds 16 B x events
+    // algorithmic bytes: 16 B (packed: 8 B) per event in + 3*H*W out; the
+    // event count is only known on the device, so the call site reports the output part and
+    // the caller adds the event bytes
     ec::ProfScope prof(ec::PROF_EVENTS, static_cast<hipStream_t>(stream), 0,
                        (double)F * prm->H * prm->W * 3.0);
-    hipLaunchKernelGGL(events_to_frames_kernel, dim3(F), dim3(EV_THREADS), lds,
+    hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(F), dim3(EV_THREADS), lds,
                        static_cast<hipStream_t>(stream), a);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // namespace
+
+extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
+                                          const ec_events_params *prm, uint8_t *frames,
+                                          int32_t *raw_counts, int32_t *kept_counts,
+                                          ec_frame_stats *stats, ec_stream_t stream)
+{
+    return launch_events<float4>(events, frame_range, F, prm, frames, raw_counts, kept_counts, stats,
+                                 stream);
+}
+
+extern "C" EC_API int ec_events_to_frames_packed(const uint64_t *events, const int64_t *frame_range,
+                                                 int F, const ec_events_params *prm, uint8_t *frames,
+                                                 int32_t *raw_counts, int32_t *kept_counts,
+                                                 ec_frame_stats *stats, ec_stream_t stream)
+{
+    return launch_events<packed_t>(events, frame_range, F, prm, frames, raw_counts, kept_counts, stats,
+                                   stream);
+}
+
+extern "C" EC_API int ec_center_events_packed(uint64_t *events, const int64_t *sample_range, int B,
+                                              int H, int W, ec_stream_t stream)
+{
+    EC_REQUIRE(B >= 0 && H > 0 && W > 0, "ec_center_events_packed: bad arguments");
+    if (B == 0) return EC_OK;
+    EC_REQUIRE(events && sample_range, "ec_center_events_packed: null buffer");
+    EC_REQUIRE(((uintptr_t)events & 7) == 0, "ec_center_events_packed: events must be 8-byte aligned");
+    hipLaunchKernelGGL(center_packed_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<packed_t *>(events),
+                       reinterpret_cast<const long long *>(sample_range), H, W);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+extern "C" EC_API int ec_pack_events(const float *events, int64_t n, uint64_t *packed,
+                                     uint32_t *n_unrepresentable, ec_stream_t stream)
+{
+    EC_REQUIRE(n >= 0, "ec_pack_events: n=%lld", (long long)n);
+    if (n == 0) return EC_OK;
+    EC_REQUIRE(events && packed, "ec_pack_events: null buffer");
+    EC_REQUIRE(((uintptr_t)events & 15) == 0 && ((uintptr_t)packed & 7) == 0,
+               "ec_pack_events: events must be 16-byte and packed 8-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_unrepresentable) EC_CHECK_HIP(hipMemsetAsync(n_unrepresentable, 0, 4, s));
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(pack_events_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       s, reinterpret_cast<const float4 *>(events), (long long)n,
+                       reinterpret_cast<packed_t *>(packed), n_unrepresentable);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -96,9 +96,22 @@ class Event2ImagePipeline:
             return frames
         return out
 
+    @staticmethod
+    def _concat(samples, dev):
+        """Per-sample arrays -> one device tensor + counts.  Samples are float [n_i, 4] (or the
+        reference's dict form) or packed uint64 / int64 [n_i] (vis.pack_events)."""
+        n_events = [int(e.shape[0]) for e in samples]
+        host = [e.cpu().numpy() if torch.is_tensor(e) else e for e in samples]
+        if all(not isinstance(e, dict) and vis.is_packed(e) for e in host):
+            cat = np.concatenate([np.asarray(e).view(np.int64) for e in host])
+        else:
+            cat = np.concatenate([vis.parse_events(e) for e in host], axis=0)
+        return torch.from_numpy(cat).to(dev), n_events
+
     def __call__(self, events, n_events=None, hflip=False, tflip=False, center=False):
-        """events: list of per-sample float32 [n_i, 4] arrays/tensors, or one CUDA tensor
-        [sum n_i, 4] with ``n_events`` giving the per-sample counts.
+        """events: list of per-sample float32 [n_i, 4] arrays/tensors (or packed uint64 [n_i],
+        vis.pack_events), or one CUDA tensor [sum n_i, 4] (packed: int64 [sum n_i]) with
+        ``n_events`` giving the per-sample counts.
         hflip / tflip: the test-time-augmentation views of event2img.py:94-112;
         center: apply center_events (utils.py:38-57, in place) first, as the N-Caltech /
         N-ImageNet readers do (caltech.py:176).
@@ -108,11 +121,9 @@ class Event2ImagePipeline:
         [B, T, 3, R, R] float32 (the reference's batch layout, padded views all-zero)."""
         dev = _lib.require_gpu()
         if isinstance(events, (list, tuple)):
-            n_events = [int(e.shape[0]) for e in events]
-            cat = np.concatenate([vis.parse_events(e.cpu().numpy() if torch.is_tensor(e) else e)
-                                  for e in events], axis=0)
-            events = torch.from_numpy(cat).to(dev)
-        assert events.is_cuda and events.dtype == torch.float32 and n_events is not None
+            events, n_events = self._concat(events, dev)
+        assert events.is_cuda and n_events is not None
+        assert vis.is_packed(events) or events.dtype == torch.float32
         if center:
             offs = np.concatenate([[0], np.cumsum(n_events)])
             sr = torch.tensor(np.stack([offs[:-1], offs[1:]], 1), dtype=torch.int64, device=dev)
@@ -137,9 +148,7 @@ class Event2ImagePipeline:
         """The four views of _load_tta_data (event2img.py:94-112): identity, h-flip, t-flip,
         h+t-flip, as a list of batches in that order."""
         if isinstance(events, (list, tuple)):
-            n_events = [int(e.shape[0]) for e in events]
-            cat = np.concatenate([vis.parse_events(e) for e in events], axis=0)
-            events = torch.from_numpy(cat).to(_lib.require_gpu())
+            events, n_events = self._concat(events, _lib.require_gpu())
         return [self(events, n_events, hflip=h, tflip=t)
                 for h, t in ((False, False), (True, False), (False, True), (True, True))]
 

@@ -81,13 +81,79 @@ def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, backgro
     return p
 
 
+# ---- packed 8-byte events (include/eventclip_hip.h: x | y << 16 | code << 32 | t_us << 34) ----
+PACKED_T_MAX = (1 << 30) - 1
+
+
+def is_packed(events):
+    """Packed events travel as 1-D int64 (torch) / uint64 or int64 (numpy) arrays."""
+    return events.ndim == 1 and str(events.dtype).split('.')[-1] in ('int64', 'uint64')
+
+
+def pack_events(events):
+    """Host packer: float [n, 4] (x, y, t [s], p) -> uint64 [n].  Same bits as ec_pack_events.
+    Raises when a coordinate is not an integer in [0, 65535] (the float path flips x before it
+    truncates, datasets/utils.py:22, so such events have no packed equivalent)."""
+    ev = np.asarray(events)
+    if ev.dtype.names:   # structured (x, y, t, p) record array
+        ev = np.stack([ev['x'], ev['y'], ev['t'], ev['p']], 1)
+    ev = ev.astype(np.float32, copy=False)
+    x, y = ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32)     # vis.py:50
+    if not ((x == ev[:, 0]) & (y == ev[:, 1]) & (x >= 0) & (y >= 0) & (x < 65536) & (y < 65536)).all():
+        raise ValueError('pack_events: coordinates must be integers in [0, 65535]')
+    p = ev[:, 3].astype(np.int32)
+    code = np.where(p == 0, 0, np.where(p > 0, 1, 2)).astype(np.uint64)
+    t_us = np.clip(np.rint(ev[:, 2].astype(np.float64) * 1e6), 0, PACKED_T_MAX).astype(np.uint64)
+    return (x.astype(np.uint64) | (y.astype(np.uint64) << np.uint64(16)) | (code << np.uint64(32)) |
+            (t_us << np.uint64(34)))
+
+
+def pack_structured(x, y, t_us, p):
+    """Packed events straight from integer fields (N-ImageNet's event_data, imagenet.py:8-27:
+    t already in microseconds, polarity 0/1 where 0 means negative unless negatives are present)."""
+    x, y = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64)
+    if x.size and (x.min() < 0 or y.min() < 0 or x.max() > 65535 or y.max() > 65535):
+        raise ValueError('pack_structured: coordinates must lie in [0, 65535]')
+    p = np.asarray(p).astype(np.uint8).astype(np.float64)   # imagenet.py:15 (uint8 cast first)
+    if p.size and p.min() >= -0.5:                         # imagenet.py:24-25
+        p = np.where(p <= 0.5, -1., p)
+    code = np.where(p == 0, 0, np.where(p > 0, 1, 2)).astype(np.uint64)
+    t = np.clip(np.asarray(t_us).astype(np.int64), 0, PACKED_T_MAX).astype(np.uint64)
+    return (x.astype(np.uint64) | (y.astype(np.uint64) << np.uint64(16)) | (code << np.uint64(32)) |
+            (t << np.uint64(34)))
+
+
+def unpack_events(packed):
+    """uint64 [n] -> float32 [n, 4] (x, y, t [s], p in {-1, 0, +1})."""
+    e = np.asarray(packed).astype(np.uint64)
+    code = (e >> np.uint64(32)) & np.uint64(3)
+    p = np.where(code == 0, 0., np.where(code == 1, 1., -1.))
+    return np.stack([(e & np.uint64(0xffff)).astype(np.float64),
+                     ((e >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64),
+                     (e >> np.uint64(34)).astype(np.float64) / 1e6, p], 1).astype(np.float32)
+
+
+def pack_events_device(events, return_bad=False):
+    """float32 CUDA [n, 4] -> packed int64 CUDA [n] (ec_pack_events)."""
+    import torch
+    dev = _lib.require_gpu()
+    assert events.is_cuda and events.dtype == torch.float32 and events.is_contiguous()
+    n = int(events.shape[0])
+    out = torch.empty((n,), dtype=torch.int64, device=dev)
+    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rc = _lib.lib().ec_pack_events(_lib.ptr(events), n, _lib.ptr(out), _lib.ptr(bad), _lib.stream_ptr())
+    _lib.check(rc, 'ec_pack_events')
+    return (out, int(bad.item())) if return_bad else out
+
+
 def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=10.,
                             count_non_zero=False, background_mask=True, return_counts=False,
                             return_stats=False, out=None, max_frame_events=0, flip_x=False,
                             negate_p=False):
     """Batched device entry.
 
-    events:      float32 CUDA tensor [n_total, 4].
+    events:      float32 CUDA tensor [n_total, 4], or packed events: int64 CUDA tensor [n_total]
+                 (pack_events / pack_events_device, layout in include/eventclip_hip.h).
     frame_range: int64 CUDA tensor [F, 2] of (begin, end) rows per frame.
     Returns uint8 CUDA tensor [F, H, W, 3] (+ raw, kept int32 [F, H, W, 2] and a
     stats structured array when asked).
@@ -95,7 +161,9 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
     import torch
     dev = _lib.require_gpu()
     H, W = shape
-    assert events.is_cuda and events.dtype == torch.float32 and events.is_contiguous()
+    packed = is_packed(events)
+    assert events.is_cuda and events.is_contiguous()
+    assert packed or (events.dtype == torch.float32 and events.dim() == 2 and events.shape[1] == 4)
     assert frame_range.is_cuda and frame_range.dtype == torch.int64 and frame_range.is_contiguous()
     F = int(frame_range.shape[0])
     frames = out if out is not None else torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
@@ -107,9 +175,9 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
         stats = torch.zeros((F, ctypes.sizeof(_lib.EcFrameStats)), dtype=torch.uint8, device=dev)
     prm = make_params(shape, grayscale, thresh, count_non_zero, background_mask, max_frame_events,
                       flip_x, negate_p)
-    rc = _lib.lib().ec_events_to_frames(_lib.ptr(events), _lib.ptr(frame_range), F,
-                                        ctypes.byref(prm), _lib.ptr(frames), _lib.ptr(raw),
-                                        _lib.ptr(kept), _lib.ptr(stats), _lib.stream_ptr())
+    entry = _lib.lib().ec_events_to_frames_packed if packed else _lib.lib().ec_events_to_frames
+    rc = entry(_lib.ptr(events), _lib.ptr(frame_range), F, ctypes.byref(prm), _lib.ptr(frames),
+               _lib.ptr(raw), _lib.ptr(kept), _lib.ptr(stats), _lib.stream_ptr())
     _lib.check(rc, 'ec_events_to_frames')
     res = [frames]
     if return_counts:
@@ -150,14 +218,16 @@ def events2frames(events, split_method, convert_method, shape=(180, 240), **kwar
 
 def center_events_device(events, sample_range, resolution):
     """In-place center_events (datasets/utils.py:38-57) for a batch: events float32 CUDA
-    [n_total, 4], sample_range int64 CUDA [B, 2]."""
+    [n_total, 4] (or packed int64 [n_total]), sample_range int64 CUDA [B, 2]."""
     import torch
     _lib.require_gpu()
-    assert events.is_cuda and events.dtype == torch.float32 and events.is_contiguous()
+    packed = is_packed(events)
+    assert events.is_cuda and events.is_contiguous() and (packed or events.dtype == torch.float32)
     assert sample_range.is_cuda and sample_range.dtype == torch.int64
     H, W = resolution
-    rc = _lib.lib().ec_center_events(_lib.ptr(events), _lib.ptr(sample_range.contiguous()),
-                                     int(sample_range.shape[0]), int(H), int(W), _lib.stream_ptr())
+    entry = _lib.lib().ec_center_events_packed if packed else _lib.lib().ec_center_events
+    rc = entry(_lib.ptr(events), _lib.ptr(sample_range.contiguous()), int(sample_range.shape[0]),
+               int(H), int(W), _lib.stream_ptr())
     _lib.check(rc, 'ec_center_events')
     return events
 

@@ -105,6 +105,38 @@ EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, 
 EC_API int ec_center_events(float *events, const int64_t *sample_range, int B, int H, int W,
                             ec_stream_t stream);
 
+/* ---- packed event ingest ------------------------------------------
+ * The reference keeps events as float32 [n, 4] (x, y, t, p) (datasets/caltech.py:149-151; N-ImageNet's
+ * structured x, y, t [us], p [0/1] is converted to that at datasets/imagenet.py:8-27) and only ever
+ * reads int(x), int(y), sign(p) from them (datasets/vis.py:44-52).  The packed form carries exactly
+ * that in 8 bytes, so the upload and the binning kernel's HBM reads are halved:
+ *   bits  0..15  x   (parse_events' truncated integer)
+ *   bits 16..31  y
+ *   bits 32..33  polarity code: 0 = p == 0 (binned nowhere, vis.py:10,12), 1 = p > 0, 2 = p < 0
+ *   bits 34..63  t in microseconds (30 bits)
+ * Events with non-integral coordinates cannot be packed (the float path flips x before truncating,
+ * utils.py:22). */
+#define EC_PACKED_X(e) ((uint32_t)((e) & 0xffffu))
+#define EC_PACKED_Y(e) ((uint32_t)(((e) >> 16) & 0xffffu))
+#define EC_PACKED_P(e) ((uint32_t)(((e) >> 32) & 3u))
+#define EC_PACKED_T(e) ((uint32_t)((e) >> 34))
+
+/* float32 [n, 4] -> packed [n] on the device.  n_unrepresentable (optional, device uint32): number
+ * of events whose coordinates are not integers in [0, 65535]; those get polarity code 0. */
+EC_API int ec_pack_events(const float *events, int64_t n, uint64_t *packed,
+                          uint32_t *n_unrepresentable, ec_stream_t stream);
+
+/* ec_events_to_frames on packed events; every other argument as above. */
+EC_API int ec_events_to_frames_packed(const uint64_t *events, const int64_t *frame_range, int F,
+                                      const ec_events_params *prm, uint8_t *frames,
+                                      int32_t *raw_counts, int32_t *kept_counts,
+                                      ec_frame_stats *stats, ec_stream_t stream);
+
+/* ec_center_events on packed events (integer form of utils.py:53-54; t relative to the sample's
+ * first event).  A coordinate shifted below 0 wraps above 32767 and is dropped by the binning. */
+EC_API int ec_center_events_packed(uint64_t *events, const int64_t *sample_range, int B, int H, int W,
+                                   ec_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * CLIP image preprocess: uint8 frames -> model input.
  * Replaces `self.transforms(img)` per frame (datasets/event2img.py:119-122,

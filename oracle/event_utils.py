@@ -42,3 +42,27 @@ def tta_views(events, resolution):
     """event2img.py:97-103: [events, h-flip, t-flip, h+t-flip]."""
     h = hflip_events(events.copy(), resolution)
     return [events, h, tflip_events(events.copy()), tflip_events(h.copy())]
+
+
+def load_event_npz(path_or_records):
+    """N-ImageNet reader, datasets/imagenet.py:8-27: structured (x, y, t [us], p) records ->
+    float64 [n, 4] with t in seconds and polarity 0 mapped to -1 when no negative polarity is
+    present.  Pinned by tests/golden/ingest.npz (tools/make_golden_ingest.py runs the reference's
+    load_event on the same records)."""
+    rec = np.load(path_or_records)['event_data'] if isinstance(path_or_records, str) else path_or_records
+    event = np.stack([rec['x'], rec['y'], rec['t'], rec['p'].astype(np.uint8)], 1).astype(float)
+    event[:, 2] /= 1e6
+    if event[:, 3].min() >= -0.5:
+        event[:, 3][event[:, 3] <= 0.5] = -1
+    return event
+
+
+def packed_fields(events):
+    """What the 8-byte packed form (include/eventclip_hip.h) must carry for float events
+    [n, 4]: parse_events' truncated x, y (vis.py:50), the polarity code 0 / 1 / 2 for
+    p == 0 / p > 0 / p < 0 (vis.py:10,12) and t in whole microseconds."""
+    ev = np.asarray(events, dtype=np.float32)
+    p = ev[:, 3].astype(np.int32)
+    code = np.where(p == 0, 0, np.where(p > 0, 1, 2))
+    t_us = np.clip(np.rint(ev[:, 2].astype(np.float64) * 1e6), 0, (1 << 30) - 1).astype(np.int64)
+    return ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), code, t_us
