@@ -96,6 +96,8 @@ SIGNATURES = {
     'ec_events_to_frames_packed': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_center_events_packed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ec_pseudo_label': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
     'ec_preprocess_plan_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
     'ec_preprocess_plan': (c_int, [c_int, c_int, c_int, c_void_p, ctypes.c_size_t]),

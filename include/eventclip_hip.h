@@ -335,6 +335,16 @@ typedef struct {
 EC_API int ec_adapter_forward(const ec_adapter_weights *w, const float *feats,
                               const int32_t *row_idx, int B, int T, float *out, ec_stream_t stream);
 
+/* ---- pseudo-label selection (gen_data.py:132-164) -------------------
+ * probs: float32 [B, V, K], the classifier's `probs` for the V views of each sample (V = 4 with
+ * test-time augmentation, event2img.py:94-112; V = 1 without).  Outputs per sample: the view-mean
+ * distribution (optional, [B, K]), its argmax and maximum, and selected = 1 when
+ * max > conf_thresh, and (tta_consistent) every view predicts the same class, and (tta_min_prob)
+ * the smallest per-view top probability > conf_thresh. */
+EC_API int ec_pseudo_label(const float *probs, int B, int V, int K, float conf_thresh,
+                           int tta_consistent, int tta_min_prob, float *mean_probs, int32_t *pred,
+                           float *max_prob, uint8_t *selected, ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

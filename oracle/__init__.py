@@ -15,6 +15,11 @@ Pinning (what anchors each restatement):
 * ``oracle.classify`` / ``oracle.adapter`` -- pinned against the reference's
   ``models/clip_cls.py`` / ``models/adapter.py`` imported in the build
   container (``tools/make_golden_models.py``).
+* ``oracle.event_utils`` -- pinned: ``center_events`` / flips against the reference's
+  ``datasets/utils.py`` (``tools/make_golden_event_utils.py``) and the N-ImageNet reader against
+  the reference's ``datasets/imagenet.py:load_event`` (``tools/make_golden_ingest.py``).
+* ``oracle.pseudo_label`` -- PARITY UNPINNED: restates code that is inline in ``gen_data.py``'s
+  ``main()`` (lines 132-164, 196-215), which cannot run without clip / nerv / datasets.
 * ``oracle.preprocess`` -- the reference calls un-vendored ``clip._transform``
   (torchvision Resize/CenterCrop/ToTensor/Normalize over PIL).  Pinned against
   PIL itself (``Image.resize(BICUBIC)``), which is what torchvision calls.
