@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--packed-events', action='store_true',
                     help='feed the 8-byte packed event form (SURVEY 8(f)) instead of float32 [n, 4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dvfs', action='store_true', help='skip the clock / power sampling steps')
     return ap.parse_args()
 
 
@@ -77,6 +78,44 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames):
             'sample': f'{n_samples} sample(s) cut to {n_frames} frames of the same workload through the '
                       f'CPU oracle (C events2frames + numpy Pillow-bicubic + torch fp32 '
                       f'{threads}-thread ViT), {dt:.1f} s'}
+
+
+def sample_dvfs(step, fence, n_steps=6):
+    """Shader clock and socket power while the step runs (untimed extra steps, after the timed
+    region): `rocm-smi` is polled from a thread that never touches the HIP context.  The MFMA peak
+    in `roofline` is quoted at the 2.4 GHz boost clock; under its 1400 W cap the chip sustains less
+    on this workload, and `peak_at_sclk` restates the peak at the clock that was actually observed."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True,
+                                     text=True, timeout=20).stdout
+            except Exception:
+                return
+            clk = re.search(r'GPU\[0\].*sclk clock level.*\((\d+)Mhz\)', out)
+            pw = re.search(r'GPU\[0\].*Power \(W\): ([\d.]+)', out)
+            if clk and pw:
+                samples.append((int(clk.group(1)), float(pw.group(1))))
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    for _ in range(n_steps):
+        step()
+    fence()
+    stop.set()
+    th.join(timeout=30)
+    busy = [s for s in samples if s[1] > 600.]      # samples taken while the GPU was loaded
+    if not busy:
+        return None
+    sclk = sum(s[0] for s in busy) / len(busy)
+    return {'sclk_mhz': sclk, 'socket_power_w': sum(s[1] for s in busy) / len(busy),
+            'samples': len(busy), 'boost_mhz': 2400,
+            'peak_at_sclk': PEAK_MFMA_TFLOPS * sclk / 2400.}
 
 
 def main():
@@ -201,6 +240,12 @@ def main():
             'kernel_launches_per_step': {e['name']: e['launches'] / a.steps for e in prof},
             'kernel_algorithmic_bytes_per_launch': {e['name']: e['bytes'] / e['launches'] for e in prof},
         }
+        if world == 1 and not a.no_dvfs:
+            dv = sample_dvfs(step, fence)
+            if dv:
+                res['dvfs'] = dv
+                if roof['bound'] == 'mfma':
+                    roof['frac_of_peak_at_sclk'] = roof['achieved'] / dv['peak_at_sclk']
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
                                                a.cpu_baseline_samples, a.cpu_baseline_frames)
