@@ -1,7 +1,8 @@
 """BASELINE.json configs as end-to-end parity cases (reduced batch / depth so the CPU oracle
 finishes in seconds): events -> frames -> preprocess -> CLIP tower -> (adapter) -> logits on the
-MI355X against the oracle chain.  configs[1] (the bench workload) is covered by
-test_models_gpu.py::test_end_to_end_events_to_logits_matches_oracle and bench.py."""
+MI355X against the oracle chain.  configs[1] (the bench workload) is checked against the oracle at
+3 samples by test_models_gpu.py::test_end_to_end_events_to_logits_matches_oracle and at its full
+size through batch-independence properties below."""
 import numpy as np
 import pytest
 
@@ -51,6 +52,48 @@ def quantize_args(geo_name, T, grayscale=True):
     return g, dict(max_imgs=T, N=g['N'], split_method='event_count',
                    convert_method='event_histogram', grayscale=grayscale,
                    count_non_zero=g['count_non_zero'], background_mask=g['background_mask'])
+
+
+def test_config1_full_size_properties(hip):
+    """configs[1] at BASELINE size (256 samples x 10 views = 2560 frames, ViT-L/14 full depth) through
+    size-independent properties: a sample's outputs do not depend on what else is in the batch
+    (the same rows come back BIT-identical from a 3-sample batch, which is the size the oracle
+    checks), duplicated samples give identical rows, ragged view counts give the right masks, and
+    the probabilities are distributions."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_events
+    g, qa = quantize_args('n_caltech', 10, grayscale=False)
+    cfg = eclip.arch_config('ViT-L/14', text_layers=2)
+    sd = eclip.random_state_dict(cfg, seed=5)
+    m = eclip.CLIP(cfg, sd, chunk=2560).cuda().eval()
+    K = 101
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                                            class_names=[str(i) for i in range(K)], agg_func='mean',
+                                            class_tokens=eclip.synthetic_tokens(K, seed=2))).cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
+    N = g['N']
+    uniq = [make_events(10 * N, g['resolution'], seed=100 + i) for i in range(6)]
+    ragged = [make_events(n, g['resolution'], seed=200 + i) for i, n in enumerate((N // 3, 3 * N + N // 2 + 1, 7 * N))]
+    batch = [uniq[i % 6] for i in range(253)] + ragged            # 256 samples, 2530 + 1 + 4 + 7 frames
+    out = model(pipe(batch))
+    vm = out['valid_masks']
+    assert vm.shape == (256, 10) and int(vm.sum()) == 2530 + 1 + 4 + 7
+    assert vm[253].tolist() == [True] + [False] * 9 and int(vm[254].sum()) == 4 and int(vm[255].sum()) == 7
+    # duplicates of the same sample agree bit for bit wherever they sit in the batch
+    for i in range(6):
+        rows = out['logits'][i:253:6]
+        assert torch.equal(rows, rows[:1].expand_as(rows))
+    # ... and equal what a small batch of only those samples produces
+    small = model(pipe([uniq[0], ragged[1], uniq[5]]))
+    for k in ('logits', 'probs', 'full_logits'):
+        assert torch.equal(small[k][0], out[k][0]) and torch.equal(small[k][1], out[k][254])
+        assert torch.equal(small[k][2], out[k][5])
+    p = out['probs']
+    assert torch.isfinite(out['logits']).all() and float((p.sum(-1) - 1).abs().max()) < 1e-5
+    assert float(out['full_logits'][~vm].abs().max()) == 0.          # clip_cls.py:151-152
 
 
 def test_config0_ncaltech_gray_vitb32_batch1(hip):
