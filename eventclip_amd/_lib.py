@@ -25,7 +25,8 @@ class EcEventsParams(ctypes.Structure):
     _fields_ = [('H', c_int), ('W', c_int), ('thresh', c_double), ('count_non_zero', c_int),
                 ('background_mask', c_int), ('red', ctypes.c_uint8 * 3),
                 ('blue', ctypes.c_uint8 * 3), ('max_frame_events', c_int), ('flip_x', c_int),
-                ('negate_p', c_int)]
+                ('negate_p', c_int), ('sort_workspace', c_void_p),
+                ('sort_workspace_bytes', ctypes.c_size_t)]
 
 
 class EcAdapterLayer(ctypes.Structure):
@@ -91,6 +92,7 @@ SIGNATURES = {
     'ec_profile_end': (c_int, [ctypes.POINTER(EcProfileEntry), c_int, ctypes.POINTER(c_int)]),
     'ec_events_to_frames': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_events_sort_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcEventsParams)]),
     'ec_center_events': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ec_pack_events': (c_int, [c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     'ec_events_to_frames_packed': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),

@@ -50,6 +50,10 @@ struct EvArgs {
     int flip_x, negate_p; // test-time-augmentation views (utils.py:18-35)
     int bin_bytes;       // LDS bytes of the histogram band (scratch and the event cache follow)
     int cache_events;    // capacity of the LDS event cache, 0 = none
+    int F;               // frames; a workgroup takes frames blockIdx.x, + gridDim.x, ...
+    unsigned *sort_ws;   // band-sorted bin indices, sort_cap per workgroup (long frames), or null
+    int sort_cap;
+    unsigned band_magic; // ceil(2^32 / rows_per_band): y / rows_per_band == (y * magic) >> 32 for y < 2^16
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -189,6 +193,80 @@ __device__ void bin_band_cached(const unsigned *cache, int n, int y0, int y1, in
     __syncthreads();
 }
 
+// Long frames (more events than the LDS cache holds, several bands: N-ImageNet's 70 000 events
+// on 480 x 640) used to re-scan every event from L2 for each of the 3 passes x 16 bands.  Instead the
+// events are bucketed ONCE by band into a global scratch slot owned by the workgroup (4-B bin
+// indices; two scans of the events: count, then place), and each (pass, band) reads only its own
+// contiguous bucket.  Slots inside a bucket come from 16 sub-counters per band (one per wave), so
+// the LDS atomics that hand them out are spread like the binning atomics themselves.
+constexpr int EV_SORT_MAX_BANDS = 64;
+constexpr int EV_SORT_BYTES = (EV_SORT_MAX_BANDS * EV_WAVES + EV_SORT_MAX_BANDS + 1) * 4;
+
+template <typename EV>
+__device__ void sort_by_band(const EV *ev, long long n, int H, int W, int flip_x, int negate_p,
+                             int bands, unsigned magic, unsigned *cnt, unsigned *start, unsigned *ws,
+                             unsigned &dropped)
+{
+    const int wave = threadIdx.x >> 6;
+    const int entries = bands * EV_WAVES;
+    for (int i = threadIdx.x; i < entries; i += EV_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
+        int x, y, p;
+        parse(ev[i], W, flip_x, negate_p, x, y, p);
+        if (p == 0) continue;
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
+            dropped++;
+            continue;
+        }
+        const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
+        atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the (band, wave) counts by the first wave: lane l owns a run of entries
+    if (threadIdx.x < 64) {
+        const int per = (entries + 63) / 64;
+        const int lo = threadIdx.x * per, hi = min(entries, lo + per);
+        unsigned sum = 0;
+        for (int i = lo; i < hi; i++) sum += cnt[i];
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        unsigned run = incl - sum;
+        for (int i = lo; i < hi; i++) {
+            const unsigned c = cnt[i];
+            cnt[i] = run;
+            if ((i % EV_WAVES) == 0) start[i / EV_WAVES] = run;
+            run += c;
+        }
+        if (threadIdx.x == 63) start[bands] = incl;
+    }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
+        int x, y, p;
+        parse(ev[i], W, flip_x, negate_p, x, y, p);
+        if (p == 0 || (unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) continue;
+        const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
+        const unsigned slot = atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
+        ws[slot] = ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+    }
+    __syncthreads();   // the stores are visible to the whole workgroup (one CU, one L1)
+}
+
+__device__ void bin_band_sorted(const unsigned *ws, unsigned begin, unsigned end, int y0, int y1, int W,
+                                unsigned *bins)
+{
+    const int nb = (y1 - y0) * W * 2;
+    const unsigned lo = (unsigned)(y0 * W * 2);
+    for (int i = threadIdx.x; i < nb; i += EV_THREADS) bins[i] = 0;
+    __syncthreads();
+    for (unsigned i = begin + threadIdx.x; i < end; i += EV_THREADS) atomicAdd(&bins[ws[i] - lo], 1u);
+    __syncthreads();
+}
+
 // vis.py:27-39 for one pixel, float64, numpy's operation order.
 __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dmx, const EvArgs &a,
                                              uint8_t out[3])
@@ -223,8 +301,11 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     unsigned *bins = reinterpret_cast<unsigned *>(smem);
     unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + a.bin_bytes);
     unsigned *cache = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_SCRATCH_BYTES);
+    unsigned *sort_cnt = cache;                                   // sorted mode: no event cache
+    unsigned *sort_start = cache + EV_SORT_MAX_BANDS * EV_WAVES;
+    unsigned *ws = a.sort_ws ? a.sort_ws + (size_t)blockIdx.x * a.sort_cap : nullptr;
 
-    const int f = blockIdx.x;
+  for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
     const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
     const long long n = e1 - e0;
@@ -234,11 +315,16 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     // frames that fit the LDS event cache read their events from HBM exactly once
     const bool cached = n <= (long long)a.cache_events;
+    // longer multi-band frames are bucketed by band into this workgroup's scratch slot
+    const bool sorted = !cached && ws != nullptr && bands > 1 && n <= (long long)a.sort_cap;
     unsigned long long s1 = 0, s2 = 0;
     unsigned nnz = 0, dropped = 0;
     if (cached) {
         fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
         __syncthreads();
+    } else if (sorted) {
+        sort_by_band(ev, n, H, W, a.flip_x, a.negate_p, bands, a.band_magic, sort_cnt, sort_start, ws,
+                     dropped);
     }
     // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
     for (int b = 0; b < bands; b++) {
@@ -246,9 +332,11 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         unsigned dr = 0;
         if (cached)
             bin_band_cached(cache, (int)n, y0, y1, W, bins);
+        else if (sorted)
+            bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
         else
             bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
-        if (b == 0 && !cached) dropped = dr;
+        if (b == 0 && !cached && !sorted) dropped = dr;
         const int nb = (y1 - y0) * W * 2;
         for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
             const unsigned h = bins[i];
@@ -295,6 +383,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         if (bands > 1) {
             if (cached)
                 bin_band_cached(cache, (int)n, y0, y1, W, bins);
+            else if (sorted)
+                bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
             else
                 bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
         }
@@ -335,6 +425,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         if (bands > 1) {
             if (cached)
                 bin_band_cached(cache, (int)n, y0, y1, W, bins);
+            else if (sorted)
+                bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
             else
                 bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
         }
@@ -379,6 +471,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         }
         __syncthreads();
     }
+  }   // frames of this workgroup
 }
 
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
@@ -548,10 +641,13 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     a.raw = raw_counts;
     a.kept = kept_counts;
     a.stats = stats;
-    // LDS plan: [histogram band | reduction scratch | event cache].  With the per-frame event
-    // count bounded (max_frame_events, known to the caller from split_event_count's N) the
-    // cache takes 4 B per event and the band gets what is left; frames longer than the bound,
-    // or geometries where no useful band fits beside the cache, re-read events from L2.
+    // LDS plan: [histogram band | reduction scratch | event cache or sort counters].  With the
+    // per-frame event count bounded (max_frame_events, known to the caller from
+    // split_event_count's N) the cache takes 4 B per event and the band gets what is left.  Frames
+    // too long for that are bucketed by band in the caller's sort workspace (one slot of
+    // max_frame_events indices per resident workgroup, which then walks several frames); without
+    // a workspace, or for frames longer than the bound, every band pass re-reads the events from L2.
+    constexpr int LDS_TOTAL = 160 * 1024;
     int cache_events = 0, bin_budget = EV_BIN_BYTES;
     if (prm->max_frame_events > 0) {
         const long cache_bytes = ((long)prm->max_frame_events * 4 + 15) / 16 * 16;
@@ -562,14 +658,39 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
             bin_budget = (int)left;
         }
     }
+    int grid = F;
+    a.sort_ws = nullptr;
+    a.sort_cap = 0;
+    if (cache_events == 0 && prm->max_frame_events > 0 && prm->sort_workspace) {
+        const int sort_budget = (LDS_TOTAL - EV_SCRATCH_BYTES - EV_SORT_BYTES) / 16 * 16;
+        const int budget = sort_budget < EV_BIN_BYTES ? sort_budget : EV_BIN_BYTES;
+        const int rows = budget / row_bytes;
+        const size_t slot = (size_t)prm->max_frame_events * 4;
+        const size_t slots = prm->sort_workspace_bytes / slot;
+        if (rows >= 1 && ec::ceil_div(prm->H, rows) > 1 && ec::ceil_div(prm->H, rows) <= EV_SORT_MAX_BANDS &&
+            slots >= 1) {
+            EC_REQUIRE(((uintptr_t)prm->sort_workspace & 3) == 0, "ec_events_to_frames: sort workspace alignment");
+            bin_budget = budget;
+            a.sort_ws = static_cast<unsigned *>(prm->sort_workspace);
+            a.sort_cap = prm->max_frame_events;
+            int cus = 256;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            grid = F < cus ? F : cus;
+            if ((size_t)grid > slots) grid = (int)slots;
+        }
+    }
     const int max_rows = bin_budget / row_bytes;
     a.bands = ec::ceil_div(prm->H, max_rows);
     a.rows_per_band = ec::ceil_div(prm->H, a.bands);
     a.bin_bytes = (a.rows_per_band * row_bytes + 15) / 16 * 16;
     a.cache_events = cache_events;
+    a.F = F;
+    a.band_magic = (unsigned)((0x100000000ull + (unsigned)a.rows_per_band - 1) / (unsigned)a.rows_per_band);
 
     static bool attr_set = false;
-    const int lds = EV_BIN_BYTES + EV_SCRATCH_BYTES;   // always the full carve: one attribute call
+    const int lds = LDS_TOTAL;   // always the full carve: one attribute call, one workgroup per CU
     if (!attr_set) {
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel<EV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -580,13 +701,27 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     // the caller adds the event bytes
     ec::ProfScope prof(ec::PROF_EVENTS, static_cast<hipStream_t>(stream), 0,
                        (double)F * prm->H * prm->W * 3.0);
-    hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(F), dim3(EV_THREADS), lds,
+    hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(grid), dim3(EV_THREADS), lds,
                        static_cast<hipStream_t>(stream), a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
 
 }  // namespace
+
+extern "C" EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *prm)
+{
+    if (!prm || prm->max_frame_events <= 0 || prm->H <= 0 || prm->W <= 0) return 0;
+    const long row_bytes = (long)prm->W * 2 * 4;
+    const long cache_bytes = ((long)prm->max_frame_events * 4 + 15) / 16 * 16;
+    const long left = (long)EV_BIN_BYTES - cache_bytes;
+    if (left >= row_bytes && ec::ceil_div(prm->H, (int)(left / row_bytes)) <= 8) return 0;   // LDS cache
+    if (row_bytes * prm->H <= EV_BIN_BYTES) return 0;                                        // one band
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (size_t)cus * (size_t)prm->max_frame_events * 4;
+}
 
 extern "C" EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, int F,
                                           const ec_events_params *prm, uint8_t *frames,

@@ -81,6 +81,24 @@ def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, backgro
     return p
 
 
+_SORT_WS = {}   # device index -> uint8 CUDA tensor (grown as needed, reused by every call)
+
+
+def attach_sort_workspace(prm, device, enable=True):
+    """Long frames (N-ImageNet: 70 000 events on 480 x 640) are bucketed by row band in a device
+    scratch instead of being re-read for every band pass; the library says how much pays off."""
+    import torch
+    need = int(_lib.lib().ec_events_sort_workspace_bytes(ctypes.byref(prm))) if enable else 0
+    if need <= 0:
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _SORT_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _SORT_WS[key] = torch.empty((need,), dtype=torch.uint8, device=device)
+    prm.sort_workspace, prm.sort_workspace_bytes = ws.data_ptr(), ws.numel()
+    return ws
+
+
 # ---- packed 8-byte events (include/eventclip_hip.h: x | y << 16 | code << 32 | t_us << 34) ----
 PACKED_T_MAX = (1 << 30) - 1
 
@@ -149,7 +167,7 @@ def pack_events_device(events, return_bad=False):
 def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=10.,
                             count_non_zero=False, background_mask=True, return_counts=False,
                             return_stats=False, out=None, max_frame_events=0, flip_x=False,
-                            negate_p=False):
+                            negate_p=False, sort_workspace=True):
     """Batched device entry.
 
     events:      float32 CUDA tensor [n_total, 4], or packed events: int64 CUDA tensor [n_total]
@@ -175,6 +193,7 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
         stats = torch.zeros((F, ctypes.sizeof(_lib.EcFrameStats)), dtype=torch.uint8, device=dev)
     prm = make_params(shape, grayscale, thresh, count_non_zero, background_mask, max_frame_events,
                       flip_x, negate_p)
+    ws = attach_sort_workspace(prm, events.device, sort_workspace)   # noqa: F841 (kept alive over the call)
     entry = _lib.lib().ec_events_to_frames_packed if packed else _lib.lib().ec_events_to_frames
     rc = entry(_lib.ptr(events), _lib.ptr(frame_range), F, ctypes.byref(prm), _lib.ptr(frames),
                _lib.ptr(raw), _lib.ptr(kept), _lib.ptr(stats), _lib.stream_ptr())

@@ -85,7 +85,14 @@ typedef struct {
     int flip_x;               /* test-time augmentation: x -> W - 1 - x (datasets/utils.py:18-23) */
     int negate_p;             /* test-time augmentation: p -> -p; together with frame ranges taken on
                                  the reversed event order this is the time flip of utils.py:26-35 */
+    void *sort_workspace;     /* optional device scratch of ec_events_sort_workspace_bytes(): frames with
+                                 more events than the on-chip cache holds (N-ImageNet) are bucketed by row
+                                 band there once instead of being re-read for every band pass */
+    size_t sort_workspace_bytes;
 } ec_events_params;
+
+/* bytes of sort_workspace that pay off for this geometry / max_frame_events (0: not needed) */
+EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *prm);
 
 /*
  * events:      float32 [n_events_total, 4] rows (x, y, t, p), device.

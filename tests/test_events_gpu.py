@@ -185,3 +185,47 @@ def test_pipeline_center_flag(hip):
                                             count_non_zero=False, background_mask=True)
                            for e in evs])
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('packed', [False, True])
+@pytest.mark.parametrize('shape,n,frames', [((480, 640), 70000, 5), ((480, 640), 41234, 3), ((300, 640), 90001, 2)])
+def test_long_frames_band_sorted_path(shape, n, frames, packed, hip):
+    """Frames too long for the LDS event cache: the band-sorted scratch path, the streaming path
+    (no workspace) and the oracle all agree bit for bit, including TTA flags, polarity-0 events and
+    more frames than resident workgroups' slots are ever reused for."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import make_events
+    from oracle import events as oe
+    ev = np.concatenate([make_events(n, shape, seed=40 + i) for i in range(frames)])
+    ev[::97, 3] = 0                                                  # counted in neither channel
+    rng = torch.tensor([[i * n, (i + 1) * n] for i in range(frames)], dtype=torch.int64).cuda()
+    e = torch.from_numpy(vis.pack_events(ev).view(np.int64) if packed else ev).cuda()
+    for kw in (dict(), dict(flip_x=True, negate_p=True), dict(count_non_zero=True, background_mask=False)):
+        a = vis.events_to_frames_device(e, rng, shape, grayscale=False, return_counts=True, return_stats=True,
+                                        max_frame_events=n, **kw)
+        b = vis.events_to_frames_device(e, rng, shape, grayscale=False, return_counts=True, return_stats=True,
+                                        max_frame_events=n, sort_workspace=False, **kw)
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x, y)
+        for k in ('sum', 'sumsq', 'nnz', 'max_kept', 'dropped'):
+            np.testing.assert_array_equal(a[3][k], b[3][k])
+    want = oe.events2frames(ev[:n], 'event_count', 'event_histogram', shape=shape, N=n, grayscale=False)
+    got = vis.events_to_frames_device(e, rng, shape, grayscale=False, max_frame_events=n)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+
+
+def test_band_sorted_many_frames_reuse_slots(hip):
+    """More frames than CUs: every workgroup walks several frames through its one scratch slot."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import make_events
+    shape, n, frames = (480, 640), 30000, 600
+    base = [make_events(n, shape, seed=70 + i) for i in range(7)]
+    ev = np.concatenate([base[i % 7] for i in range(frames)])
+    rng = torch.tensor([[i * n, (i + 1) * n] for i in range(frames)], dtype=torch.int64).cuda()
+    e = torch.from_numpy(ev).cuda()
+    a = vis.events_to_frames_device(e, rng, shape, max_frame_events=n)
+    b = vis.events_to_frames_device(e, rng, shape, max_frame_events=n, sort_workspace=False)
+    assert torch.equal(a, b)
+    assert torch.equal(a[:7], a[7 * 84:7 * 85])
