@@ -234,6 +234,9 @@ def main():
                        'events_per_frame': N, 'resolution': list(geo['resolution']),
                        'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
                        'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
+                       'last_block': ('every token' if clip_model.full_last_block else
+                                      'keys/values for every token; query, out_proj, MLP for the class '
+                                      'token only (bit-identical encode_image output)'),
                        'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': roof,
             'kernel_ms_per_step': breakdown, 'kernel_ms_per_step_total': gpu_ms,

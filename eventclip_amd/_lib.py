@@ -70,7 +70,7 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_pre_g', c_void_p), ('ln_pre_b', c_void_p), ('ln_post_g', c_void_p),
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
-                ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p)]
+                ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):
@@ -119,6 +119,8 @@ SIGNATURES = {
                               c_void_p]),
     'ec_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
+    'ec_attention_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
     'ec_vit_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcVitWeights), c_int]),
     'ec_text_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcTextWeights), c_int]),
     'ec_vit_encode': (c_int, [ctypes.POINTER(EcVitWeights), c_void_p, c_int, c_void_p, c_void_p,

@@ -154,7 +154,7 @@ class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
-                 image_precise=False):
+                 image_precise=False, full_last_block=None):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -169,6 +169,12 @@ class CLIP(nn.Module):
         # split-precision (~fp32) arithmetic: on for the text tower (run once, cached by the
         # classifiers), off for the image tower (3x the GEMM work; validation only)
         self.text_precise, self.image_precise = bool(text_precise), bool(image_precise)
+        # encode_image returns ln_post(x[:, 0]) @ proj: of the last block only the class-token rows are
+        # read, so by default only those go through its attention query / out_proj / MLP (identical
+        # features); True (or EVENTCLIP_FULL_LAST_BLOCK=1) computes every token like the reference
+        if full_last_block is None:
+            full_last_block = os.environ.get('EVENTCLIP_FULL_LAST_BLOCK', '0') not in ('', '0')
+        self.full_last_block = bool(full_last_block)
         self.workspace_budget = 24 << 30   # bytes of tower scratch at most
         self._packed = None
         self._ws = None
@@ -252,6 +258,7 @@ class CLIP(nn.Module):
                                     dev32(sd['visual.ln_post.bias']))
         v.proj_w = dev16(sd['visual.proj'].t())
         v.precise = int(self.image_precise)
+        v.full_last_block = int(self.full_last_block)
         if self.image_precise:
             v.conv_w_lo, v.proj_w_lo = dev16_lo(conv), dev16_lo(sd['visual.proj'].t())
         vb = blocks('visual.transformer', c['layers'], self.image_precise)

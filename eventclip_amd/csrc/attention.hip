@@ -34,6 +34,8 @@ struct AttnArgs {
     const void *qkv;  // [n_seq * S, 3W] 16-bit: q | k | v, heads are 64-wide column blocks
     void *out;        // [n_seq * S, W] 16-bit
     int S, W, heads, causal;
+    int q_rows;       // only the first q_rows query rows of every sequence are computed; out is
+                      // [n_seq * q_rows, W] (q_rows = S: the whole sequence)
     float scale_log2e;
 };
 
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(const AttnArgs
         }
     }
     // first Q tile of this wave, issued before the barrier so its latency hides behind staging
-    const int n_qt = (S + 15) / 16;
+    const int n_qt = (a.q_rows + 15) / 16;
     v8 qf[2], qn[2];
     auto load_q = [&](int qt, v8(&dst)[2]) {
         int qsrc = qt * 16 + c16;
@@ -232,13 +234,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(const AttnArgs
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
         const float inv = 1.f / xor_sum(l_run);
-        if (qrow < S) {
+        if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) ov[4 * dt + r] = to16(o[dt][r] * inv, elem());
-            elem *dst = (elem *)a.out + ((long)seq * S + qrow) * W + head * 64 + g * 16;
+            elem *dst = (elem *)a.out + ((long)seq * a.q_rows + qrow) * W + head * 64 + g * 16;
             *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&ov[0]);
             *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
         }
@@ -259,8 +261,8 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
         attr_lds = lds;
     }
     // algorithmic work: QK^T and PV, 2 * 2 * S^2 * 64 flops per head; bytes: read qkv, write out
-    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.S * a.S * 64.0 * heads * n_seq,
-                       (double)n_seq * a.S * a.W * 2.0 * 4.0);
+    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.q_rows * a.S * 64.0 * heads * n_seq,
+                       (double)n_seq * a.W * 2.0 * (2.0 * a.S + 2.0 * a.q_rows));
     hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(AT_THREADS), lds, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
@@ -349,13 +351,22 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, vo
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
                                    int heads, int causal, int dtype, ec_stream_t stream)
 {
+    return ec_attention_rows(qkv, out, n_seq, S, width, heads, causal, S, dtype, stream);
+}
+
+extern "C" EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, int S, int width,
+                                        int heads, int causal, int q_rows, int dtype,
+                                        ec_stream_t stream)
+{
     EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention: bad shape");
+    EC_REQUIRE(q_rows >= 1 && q_rows <= S, "ec_attention: q_rows=%d outside 1..%d", q_rows, S);
     EC_REQUIRE(width == heads * 64, "ec_attention: head dim must be 64 (width %d, heads %d)", width,
                heads);
     if (n_seq == 0) return EC_OK;
     EC_REQUIRE(qkv && out, "ec_attention: null buffer");
     AttnArgs a;
     a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = causal;
+    a.q_rows = q_rows;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);

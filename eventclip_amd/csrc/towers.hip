@@ -35,11 +35,11 @@ struct BlockBufs {
 };
 
 int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
-         void *C, ec_stream_t s)
+         void *C, ec_stream_t s, long ldc = 0)
 {
     ec_gemm_args g;
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
-    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = N;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
     return ec_gemm(&g, s);
 }
 
@@ -49,12 +49,28 @@ int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, 
         if (_rc != EC_OK) return _rc; \
     } while (0)
 
+// first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
+// tower: ln_post(x[:, 0]) @ proj).  That block still needs every token's keys and values, but its
+// attention query, out_proj, ln_2 and MLP only for row 0: n_seq rows instead of n_seq * S, through the
+// same kernels with the residual stream addressed at row stride S * W.  Each output row of these
+// kernels depends on its own input row only, so the class-token features are bit-identical.
 int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
-               int causal, int dtype, const BlockBufs &b, ec_stream_t s)
+               int causal, int dtype, const BlockBufs &b, ec_stream_t s, bool first_only = false)
 {
     const int rows = n_seq * S;
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
+        if (first_only && l == layers - 1) {
+            const long ldx = (long)S * W;
+            EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, W, dtype, s));
+            EC_TRY(gemm(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s));
+            EC_TRY(ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, causal, 1, dtype, s));
+            EC_TRY(gemm(n_seq, W, W, dtype, EC_EPI_RESID32, b.h, w.out_w, w.out_b, b.x, s, ldx));
+            EC_TRY(ec_layernorm(b.x, ldx, nullptr, w.ln2_g, w.ln2_b, n_seq, W, LN_EPS, b.h, W, dtype, s));
+            EC_TRY(gemm(n_seq, 4 * W, W, dtype, EC_EPI_GELU16, b.h, w.fc1_w, w.fc1_b, b.mlp, s));
+            EC_TRY(gemm(n_seq, W, 4 * W, dtype, EC_EPI_RESID32, b.mlp, w.fc2_w, w.fc2_b, b.x, s, ldx));
+            break;
+        }
         EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, W, dtype, s));
         EC_TRY(gemm(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s));
         EC_TRY(ec_attention(b.qkv, b.h, n_seq, S, W, heads, causal, dtype, s));
@@ -241,7 +257,8 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_STORE32, p, w->conv_w, nullptr, patch_out, stream));
         EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, b.x,
                             stream));
-        EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream));
+        EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream,
+                          w->full_last_block == 0));
         // ln_post on the CLS rows (row stride S*W), then @ proj
         EC_TRY(ec_layernorm(b.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16,
                             W, dt, stream));

@@ -233,6 +233,11 @@ EC_API int ec_text_embed(const int32_t *tokens, const float *table, const float 
  * [n_seq * S, width].  causal != 0 applies the text tower's mask. */
 EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width, int heads,
                         int causal, int dtype, ec_stream_t stream);
+/* Same, computing only the first q_rows query rows of every sequence (keys and values still span the
+ * whole sequence); out is [n_seq * q_rows, width].  q_rows = 1 is what the LAST block of the vision
+ * tower needs: encode_image reads nothing but the class token of its output. */
+EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, int S, int width, int heads,
+                             int causal, int q_rows, int dtype, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CLIP towers.  Replace clip_model.encode_image / encode_text as called from
@@ -266,6 +271,11 @@ typedef struct {
     const ec_block_weights *blocks; /* host array [layers] */
     int precise;                /* != 0: split-precision arithmetic (3x the GEMM work, ~fp32 results) */
     const void *conv_w_lo, *proj_w_lo;
+    int full_last_block;        /* encode_image returns ln_post(x[:, 0]) @ proj (openai/CLIP model.py), so
+                                   of the last block's output only the class-token rows are ever read.
+                                   0 (default): that block computes keys / values for every token but the
+                                   attention query, out_proj, ln_2 and the MLP for the class token only --
+                                   the same features bit for bit.  != 0: every token, like the reference. */
 } ec_vit_weights;
 
 typedef struct {

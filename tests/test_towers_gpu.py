@@ -145,6 +145,42 @@ def test_image_tower_matches_oracle_fixture(name, arch, ov, n, dt, tol, hip):
         assert rel_err(got, torch.from_numpy(seeded(name + '_w16'))) < tol
 
 
+@pytest.mark.parametrize('S,heads,causal,q_rows', [(257, 16, 0, 1), (257, 16, 0, 20), (50, 12, 0, 1),
+                                                   (577, 16, 0, 1), (77, 8, 1, 5)])
+def test_attention_rows_is_a_prefix_of_full_attention(S, heads, causal, q_rows, hip):
+    """ec_attention_rows(q_rows) == the first q_rows rows of every sequence of ec_attention, bit for bit."""
+    import torch
+    from eventclip_amd import _lib
+    n_seq, W = 5, heads * 64
+    qkv = (torch.randn(n_seq * S, 3 * W, device='cuda') * 1.5).half()
+    full = torch.empty(n_seq * S, W, dtype=torch.float16, device='cuda')
+    part = torch.full((n_seq * q_rows, W), float('nan'), dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(full), n_seq, S, W, heads, causal, _lib.EC_F16,
+                                       _lib.stream_ptr()))
+    _lib.check(_lib.lib().ec_attention_rows(_lib.ptr(qkv), _lib.ptr(part), n_seq, S, W, heads, causal, q_rows,
+                                            _lib.EC_F16, _lib.stream_ptr()))
+    want = full.view(n_seq, S, W)[:, :q_rows].reshape(n_seq * q_rows, W)
+    assert torch.equal(part.view(torch.int16), want.contiguous().view(torch.int16))
+
+
+@pytest.mark.parametrize('arch,ov,n', [('ViT-L/14', dict(layers=3, text_layers=1, vocab_size=1024), 5),
+                                       ('ViT-B/32', dict(text_layers=1, vocab_size=1024), 7),
+                                       ('ViT-B/16', dict(layers=1, text_layers=1, vocab_size=1024), 2)])
+def test_class_token_only_last_block_is_bit_identical(arch, ov, n, hip):
+    """The default image tower sends only the class-token rows through the last block's attention
+    query / out_proj / MLP; computing every token (like the reference) gives the same features."""
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config(arch, **ov)
+    sd = eclip.random_state_dict(cfg, seed=21)
+    img = torch.randn(n, 3, cfg['image_size'], cfg['image_size'], generator=torch.Generator().manual_seed(8)).cuda()
+    fast = eclip.CLIP(cfg, sd).cuda().eval()
+    full = eclip.CLIP(cfg, sd, full_last_block=True).cuda().eval()
+    assert not fast.full_last_block and full.full_last_block
+    a, b = fast.encode_image(img), full.encode_image(img)
+    assert torch.equal(a, b)
+
+
 def test_small_tower_matches_live_oracle(hip):
     import torch
     from eventclip_amd import clip as eclip
