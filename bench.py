@@ -126,9 +126,16 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # one process per GPU over RCCL; EVENTCLIP_DIST_BACKEND=gloo lets two ranks share one GPU so the
+    # N > 1 code path can be exercised on a single-GPU box (a functional check, not a measurement)
+    backend = os.environ.get('EVENTCLIP_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     from eventclip_amd import _lib

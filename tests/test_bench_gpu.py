@@ -1,0 +1,48 @@
+"""bench.py's contract on the GPU box: one JSON line with the required fields, for one rank and for
+two ranks (the N > 1 code path; two gloo ranks sharing the single GPU, a functional check)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+            'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'}
+SMALL = ['--steps', '2', '--warmup', '1', '--batch', '4', '--arch', 'ViT-B/32', '--classes', '11',
+         '--cpu-baseline-samples', '1', '--cpu-baseline-frames', '2']
+
+
+def last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_line(hip):
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1'] + SMALL, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d) and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
+    assert d['value'] > 0 and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert abs(d['value'] - 4 * 10 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    roof = d['roofline']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(roof)
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['unit'] == 'frames/s'
+
+
+def test_two_ranks_share_the_gpu_over_gloo(hip):
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29533', 'bench.py', '--gpus', '2'] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['n_gpus'] == 2 and 'cpu_baseline' not in d
+    assert abs(d['value'] - 2 * 4 * 10 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']   # whole-job aggregate
+    assert d['config']['parallelism'].startswith('dp2')
