@@ -100,6 +100,12 @@ SIGNATURES = {
     'ec_center_events_packed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ec_pseudo_label': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_fs_text_train_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    'ec_fs_text_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     ctypes.c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     ctypes.c_size_t, c_void_p]),
+    'ec_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_float,
+                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),
     'ec_preprocess_plan_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
     'ec_preprocess_plan': (c_int, [c_int, c_int, c_int, c_void_p, ctypes.c_size_t]),

@@ -302,6 +302,15 @@ class FSCLIPClassifier(ZSCLIPClassifier):
             'probs': probs,
         }
 
+    @torch.no_grad()
+    def cache_feats(self, data_dict):
+        """Frozen-encoder outputs of a batch, scattered to [B, T, C] fp32 with zero rows for padded
+        views (clip_cls.py:313-321): what eventclip_amd.train consumes, computed once per sample."""
+        feats, row_idx, valid_masks = self._view_feats(data_dict)
+        B, T = valid_masks.shape
+        full = IdentityAdapter.forward_rows(None, feats.float(), row_idx)
+        return full.reshape(B, T, feats.shape[-1]), valid_masks
+
     @property
     def dtype(self):
         return self.adapter.dtype

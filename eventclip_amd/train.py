@@ -1,0 +1,100 @@
+"""Few-shot training on cached image features, `text-identity` adapters.
+
+The reference tunes `text_feats` (and, for `text-trans`, the transformer adapter) with the CLIP
+encoder frozen (train.py, method.py, models/clip_cls.py:164-175, 281-350); with the encoder's
+outputs cached per epoch one optimisation step is a few small fp32 kernels:
+``fs_text_loss_grad`` (forward + loss + d loss / d text_feats in closed form, ``ec_fs_text_loss_grad``)
+and ``adam_step`` (torch.optim.Adam, ``ec_adam_step``).  ``TextFeatTrainer`` strings them together with
+the warm-up + cosine schedule of method.py:82-98 and, across ranks, an all-reduce of the K x D
+gradient (the only trainable tensor of this adapter type).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_AGG = {'sum': _lib.EC_AGG_SUM, 'mean': _lib.EC_AGG_MEAN}
+_WS = {}
+
+
+def fs_text_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='sum', use_probs_loss=False,
+                      return_logits=False):
+    """img_feats fp32 CUDA [B, T, D] (raw encoder outputs), valid bool [B, T], labels int [B],
+    text_param fp32 [K, D] (raw parameter).  Returns (loss 0-dim tensor, grad [K, D][, logits [B, K]])."""
+    dev = _lib.require_gpu()
+    if agg not in _AGG:
+        raise NotImplementedError(f'agg_func {agg!r}: the reference trains with sum / mean')
+    f = img_feats.float().contiguous()
+    B, T, D = f.shape
+    t = text_param.detach().float().contiguous()
+    K = t.shape[0]
+    assert t.shape[1] == D and valid.shape == (B, T) and labels.shape == (B,)
+    v8 = valid.to(torch.uint8).contiguous()
+    lab = labels.to(torch.int32).contiguous()
+    need = int(_lib.lib().ec_fs_text_train_workspace_bytes(B, T, D, K))
+    ws = _WS.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = _WS[dev.index] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    grad = torch.empty((K, D), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, K), dtype=torch.float32, device=dev) if return_logits else None
+    rc = _lib.lib().ec_fs_text_loss_grad(_lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
+                                         float(logit_scale), _AGG[agg], int(bool(use_probs_loss)),
+                                         _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(logits), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, 'ec_fs_text_loss_grad')
+    return (loss[0], grad, logits) if return_logits else (loss[0], grad)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.):
+    """In-place torch.optim.Adam update of a contiguous fp32 CUDA tensor."""
+    _lib.require_gpu()
+    for x in (param, grad, exp_avg, exp_avg_sq):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == param.numel()
+    rc = _lib.lib().ec_adam_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                 param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                 float(weight_decay), int(step), _lib.stream_ptr())
+    _lib.check(rc, 'ec_adam_step')
+
+
+def cosine_warmup_lr(step, total_steps, max_lr, min_lr, warmup_steps):
+    """One cycle of linear warm-up then cosine decay (method.py:82-98: min_lr = lr / 100)."""
+    if step < warmup_steps:
+        return min_lr + (max_lr - min_lr) * step / max(warmup_steps, 1)
+    frac = (step - warmup_steps) / max(total_steps - warmup_steps, 1)
+    return min_lr + (max_lr - min_lr) * (1 + math.cos(math.pi * min(frac, 1.0))) / 2
+
+
+class TextFeatTrainer:
+    """Trains ``classifier.text_feats`` (FSCLIPClassifier built with adapter_type='text-identity')."""
+
+    def __init__(self, classifier, lr, total_steps, warmup_steps_pct=0.05, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.):
+        if getattr(classifier, 'adapter_type', None) != 'identity' or not getattr(classifier, 'prompt_tuning', False):
+            raise NotImplementedError("TextFeatTrainer handles adapter_type='text-identity'")
+        self.clf = classifier
+        self.lr, self.total_steps = float(lr), int(total_steps)
+        self.warmup_steps = warmup_steps_pct * self.total_steps          # method.py:86
+        self.betas, self.eps, self.weight_decay = betas, float(eps), float(weight_decay)
+        p = classifier.text_feats.data
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, img_feats, valid, labels):
+        """img_feats [B, T, D]: cached ``get_img_feats`` outputs scattered to [B, T] (zeros for padding)."""
+        clf = self.clf
+        loss, grad = fs_text_loss_grad(img_feats, valid, labels, clf.text_feats.data, clf.logit_scale,
+                                       clf.agg_func, clf.use_probs_loss)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(grad)                                        # DDP: mean of the rank gradients
+            grad /= dist.get_world_size()
+        lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
+        self.steps += 1
+        adam_step(clf.text_feats.data, grad, self.exp_avg, self.exp_avg_sq, self.steps, lr, self.betas,
+                  self.eps, self.weight_decay)
+        if hasattr(clf, '_invalidate_text_cache'):
+            clf._invalidate_text_cache()
+        return loss

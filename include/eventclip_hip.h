@@ -362,6 +362,27 @@ EC_API int ec_pseudo_label(const float *probs, int B, int V, int K, float conf_t
                            int tta_consistent, int tta_min_prob, float *mean_probs, int32_t *pred,
                            float *max_prob, uint8_t *selected, ec_stream_t stream);
 
+/* ---- few-shot `text-identity` training step ---------------------------
+ * One optimisation step of FSCLIPClassifier with adapter_type = 'text-identity'
+ * (configs/fsclip/text_adapter/) on cached image features: forward models/clip_cls.py:302-350,
+ * loss :164-175, d loss / d text_feats (torch autograd upstream), torch.optim.Adam.
+ *   img_feats   fp32 [B, T, D] encoder outputs, NOT normalised (any value on invalid views)
+ *   valid       uint8 [B, T];  labels int32 [B];  text_param fp32 [K, D] (the nn.Parameter, raw)
+ *   agg         EC_AGG_SUM / EC_AGG_MEAN;  use_probs_loss: 0 = CE on the aggregated logits,
+ *               1 = NLL of log(probs + 1e-6) (loss_dict.use_probs_loss)
+ *   loss        fp32 [1] (out, batch mean);  grad_text fp32 [K, D] (out)
+ *   agg_logits  optional fp32 [B, K] (out): the aggregated logits of the forward pass */
+EC_API size_t ec_fs_text_train_workspace_bytes(int B, int T, int D, int K);
+EC_API int ec_fs_text_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
+                                const float *text_param, int B, int T, int D, int K, float logit_scale,
+                                int agg, int use_probs_loss, float *loss, float *grad_text,
+                                float *agg_logits, void *workspace, size_t workspace_bytes,
+                                ec_stream_t stream);
+/* torch.optim.Adam (no amsgrad), in place; step counts from 1 */
+EC_API int ec_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                        ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ Pinning (what anchors each restatement):
   the reference's ``datasets/imagenet.py:load_event`` (``tools/make_golden_ingest.py``).
 * ``oracle.pseudo_label`` -- PARITY UNPINNED: restates code that is inline in ``gen_data.py``'s
   ``main()`` (lines 132-164, 196-215), which cannot run without clip / nerv / datasets.
+* ``oracle.train`` -- pinned: loss and d loss / d text_feats of the `text-identity` few-shot step
+  against the reference's own ``FSCLIPClassifier`` under torch autograd
+  (``tools/make_golden_train.py``); Adam against ``torch.optim.Adam``; the warm-up + cosine schedule is
+  PARITY UNPINNED (it lives in the absent ``nerv``).
 * ``oracle.preprocess`` -- the reference calls un-vendored ``clip._transform``
   (torchvision Resize/CenterCrop/ToTensor/Normalize over PIL).  Pinned against
   PIL itself (``Image.resize(BICUBIC)``), which is what torchvision calls.

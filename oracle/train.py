@@ -1,0 +1,82 @@
+"""Oracle for the few-shot `text-identity` training step (TEST INFRASTRUCTURE).
+
+Restates, with explicit formulas in float64 (no autograd), what the reference computes for
+adapter_type='text-identity' in train mode:
+  forward   models/clip_cls.py:302-350 (identity adapter, F.normalize of the image features, invalid
+            views zeroed, text_feats = F.normalize(parameter) :285-288, logits :332, aggregation
+            :104-129) and calc_train_loss :164-175 (cross-entropy on the aggregated logits, or NLL of
+            log(probs + 1e-6));
+  backward  d loss / d text_feats (what loss.backward() leaves in text_feats.grad).
+Pinned by tests/golden/train_text_identity.npz, produced by running the reference's own
+FSCLIPClassifier under torch autograd (tools/make_golden_train.py).
+adam_step / cosine_warmup_lr restate torch.optim.Adam (the `optimizer = 'Adam'` of the reference's
+configs) and the warm-up + cosine schedule of method.py:82-98; the latter lives in the absent `nerv`
+package: PARITY UNPINNED for the schedule.
+"""
+import math
+
+import numpy as np
+
+
+def _softmax(x):
+    x = x - x.max(-1, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(-1, keepdims=True)
+
+
+def fs_text_loss_and_grad(feats, valid, labels, text_param, logit_scale, agg='mean', probs_loss=False):
+    """feats [B, T, D] raw image features (any value on invalid views), valid [B, T] bool,
+    labels [B], text_param [K, D] -> (loss, grad [K, D], aggregated logits [B, K])."""
+    f = np.asarray(feats, dtype=np.float64)
+    m = np.asarray(valid, dtype=np.float64)
+    t = np.asarray(text_param, dtype=np.float64)
+    B, T, D = f.shape
+    fn = f / np.maximum(np.linalg.norm(f, axis=-1, keepdims=True), 1e-12)   # :325-327
+    fn = fn * m[..., None]                                                   # :329
+    tn_norm = np.maximum(np.linalg.norm(t, axis=-1, keepdims=True), 1e-12)
+    u = t / tn_norm                                                          # :287
+    L = logit_scale * fn @ u.T                                               # :332  [B, T, K]
+    n = m.sum(1, keepdims=True)
+    if agg == 'sum':
+        logits, w = L.sum(1), np.ones((B, T))
+    elif agg == 'mean':
+        logits, w = L.sum(1) / n, np.ones((B, T)) / n
+    else:
+        raise NotImplementedError(agg)          # 'max' raises upstream (clip_cls.py:117)
+    onehot = np.eye(t.shape[0])[np.asarray(labels)]
+    if not probs_loss:                                                       # :171
+        p = _softmax(logits)
+        loss = -np.log((p * onehot).sum(-1)).mean()
+        dL = ((p - onehot) / B)[:, None, :] * w[..., None]
+    else:                                                                    # :172-174
+        pv = _softmax(L)                                                     # per view, :125
+        P = (pv * m[..., None]).sum(1) / n
+        Py = (P * onehot).sum(-1)
+        loss = -np.log(Py + 1e-6).mean()
+        dPy = -1.0 / (B * (Py + 1e-6))
+        pvy = (pv * onehot[:, None, :]).sum(-1)                              # [B, T]
+        dL = (m / n * dPy[:, None] * pvy)[..., None] * (onehot[:, None, :] - pv)
+    dU = logit_scale * np.einsum('btk,btd->kd', dL, fn)
+    grad = (dU - u * (u * dU).sum(-1, keepdims=True)) / tn_norm
+    return float(loss), grad, logits
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.):
+    """torch.optim.Adam (no amsgrad), float64 in place; step counts from 1."""
+    if weight_decay:
+        grad = grad + weight_decay * param
+    exp_avg *= beta1
+    exp_avg += (1 - beta1) * grad
+    exp_avg_sq *= beta2
+    exp_avg_sq += (1 - beta2) * grad * grad
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    param -= lr / bc1 * exp_avg / (np.sqrt(exp_avg_sq) / math.sqrt(bc2) + eps)
+    return param
+
+
+def cosine_warmup_lr(step, total_steps, max_lr, min_lr, warmup_steps):
+    """One cycle of linear warm-up then cosine decay (method.py:82-98: max_lr = lr, min_lr = lr / 100)."""
+    if step < warmup_steps:
+        return min_lr + (max_lr - min_lr) * step / max(warmup_steps, 1)
+    frac = (step - warmup_steps) / max(total_steps - warmup_steps, 1)
+    return min_lr + (max_lr - min_lr) * (1 + math.cos(math.pi * min(frac, 1.0))) / 2

@@ -1,0 +1,50 @@
+"""The training-step oracle against the reference's own autograd (tests/golden/train_text_identity.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import train as ot
+
+
+def cases():
+    z = np.load(os.path.join(GOLDEN, 'train_text_identity.npz'))
+    for ci in range(len(z['cases'])):
+        for agg in ('sum', 'mean'):
+            for loss in ('logits', 'probs'):
+                yield z, ci, agg, loss
+
+
+@pytest.mark.parametrize('ci,agg,loss', [(c, a, l) for _, c, a, l in cases()])
+def test_loss_and_text_gradient_match_reference_autograd(ci, agg, loss):
+    z = np.load(os.path.join(GOLDEN, 'train_text_identity.npz'))
+    tag = f'c{ci}_{agg}_{loss}'
+    got_loss, got_grad, got_logits = ot.fs_text_loss_and_grad(
+        z[f'c{ci}_feats'], z[f'c{ci}_valid'], z[f'c{ci}_labels'], z[f'c{ci}_text_param'],
+        float(z[f'c{ci}_logit_scale']), agg, loss == 'probs')
+    np.testing.assert_allclose(got_logits, z[tag + '_logits'], rtol=2e-5, atol=2e-5)
+    assert abs(got_loss - float(z[tag + '_loss'])) < 2e-5 * max(1., abs(got_loss))
+    g = z[tag + '_grad']
+    assert np.abs(got_grad - g).max() < 2e-5 * max(np.abs(g).max(), 1e-3)
+
+
+def test_adam_matches_torch():
+    import torch
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal((7, 5))
+    p = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.Adam([p], lr=3e-3, weight_decay=0.01)
+    q, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 6):
+        g = rng.standard_normal(p0.shape)
+        p.grad = torch.tensor(g)
+        opt.step()
+        ot.adam_step(q, g, m, v, step, 3e-3, weight_decay=0.01)
+        np.testing.assert_allclose(q, p.detach().numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_cosine_warmup_shape():
+    lr = [ot.cosine_warmup_lr(s, 100, 1e-3, 1e-5, 10) for s in range(101)]
+    assert lr[0] == 1e-5 and abs(lr[10] - 1e-3) < 1e-12 and abs(lr[100] - 1e-5) < 1e-12
+    assert all(a <= b + 1e-15 for a, b in zip(lr[:10], lr[1:11])) and all(a >= b - 1e-15 for a, b in zip(lr[10:100], lr[11:]))
