@@ -63,6 +63,17 @@ class EcBlockWeights(ctypes.Structure):
         'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo')]
 
 
+class EcAdapterTrainLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'o_w', 'o_b', 'ln2_g', 'ln2_b',
+                                        'w1', 'b1', 'w2', 'b2')]
+
+
+class EcAdapterTrainParams(ctypes.Structure):
+    _fields_ = [('in_dim', c_int), ('d_model', c_int), ('heads', c_int), ('ffn_dim', c_int), ('layers', c_int),
+                ('residual', ctypes.c_float), ('in_w', c_void_p), ('in_b', c_void_p), ('out_w', c_void_p),
+                ('out_b', c_void_p), ('blocks', ctypes.POINTER(EcAdapterTrainLayer))]
+
+
 class EcVitWeights(ctypes.Structure):
     _fields_ = [('dtype', c_int), ('image_size', c_int), ('patch', c_int), ('width', c_int),
                 ('layers', c_int), ('heads', c_int), ('out_dim', c_int), ('kpad', c_int),
@@ -104,6 +115,11 @@ SIGNATURES = {
     'ec_fs_text_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      ctypes.c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      ctypes.c_size_t, c_void_p]),
+    'ec_fs_trans_train_workspace_bytes': (ctypes.c_size_t, [c_int] * 8),
+    'ec_fs_trans_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      ctypes.c_float, c_int, c_int, ctypes.POINTER(EcAdapterTrainParams),
+                                      ctypes.POINTER(EcAdapterTrainParams), c_void_p, c_void_p, c_void_p,
+                                      c_void_p, ctypes.c_size_t, c_void_p]),
     'ec_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),

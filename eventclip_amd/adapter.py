@@ -135,8 +135,9 @@ class TransformerAdapter(Adapter):
         B, T = row_idx.shape
         feats = feats.float().contiguous()
         out = torch.empty((B, T, self.in_dim), dtype=torch.float32, device=feats.device)
+        row_idx = row_idx.contiguous()
         rc = _lib.lib().ec_adapter_forward(ctypes.byref(pk['w']), _lib.ptr(feats),
-                                           _lib.ptr(row_idx.contiguous()), B, T, _lib.ptr(out),
+                                           _lib.ptr(row_idx), B, T, _lib.ptr(out),
                                            _lib.stream_ptr())
         _lib.check(rc, 'ec_adapter_forward')
         return out

@@ -243,6 +243,214 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     }
 }
 
+// ---- generic fp32 pieces of the transformer-adapter ('text-trans') step --------------------------
+// C[M, N] (row stride ldc) = alpha * sum_k A(m, k) B(k, n) + beta * C + bias[n], optional ReLU.
+// A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]: one kernel for x W^T, dy W and dy^T x.
+template <bool RELU>
+__global__ __launch_bounds__(256) void sgemm_kernel(const float *A, long sam, long sak, const float *Bm, long sbk,
+                                                    long sbn, int M, int N, int K, float alpha, float beta,
+                                                    const float *bias, float *C, long ldc)
+{
+    __shared__ float sa[16][65], sb[16][65];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+            // A: make the fast index follow the smaller stride so the reads coalesce in either layout
+            int kk, mm;
+            if (sak <= sam) kk = i & 15, mm = i >> 4; else mm = i & 63, kk = i >> 6;
+            sa[kk][mm] = (k0 + kk < K && m0 + mm < M) ? A[(long)(m0 + mm) * sam + (long)(k0 + kk) * sak] : 0.f;
+            int kb, nn;
+            if (sbn <= sbk) nn = i & 63, kb = i >> 6; else kb = i & 15, nn = i >> 4;
+            sb[kb][nn] = (k0 + kb < K && n0 + nn < N) ? Bm[(long)(k0 + kb) * sbk + (long)(n0 + nn) * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = sa[k][ty * 4 + i], b[i] = sb[k][tx * 4 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) {
+                float v = alpha * acc[i][j] + (bias ? bias[n] : 0.f);
+                if (beta != 0.f) v += beta * C[(long)m * ldc + n];
+                if (RELU) v = fmaxf(v, 0.f);
+                C[(long)m * ldc + n] = v;
+            }
+        }
+}
+
+// out[j] = sum_r X[r, j] (* Y[r, j] when Y): bias gradients and LayerNorm gamma / beta gradients
+__global__ __launch_bounds__(256) void colsum_kernel(const float *X, const float *Y, int R, int N, float *out)
+{
+    __shared__ float red[4][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (j < N)
+        for (int r = part; r < R; r += 4) s += Y ? X[(long)r * N + j] * Y[(long)r * N + j] : X[(long)r * N + j];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && j < N) out[j] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// LayerNorm over rows of width N <= 1024 (eps 1e-5, torch defaults): y, xhat, rstd; one wave per row
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *x, const float *g, const float *b, int R, int N,
+                                                     float *y, float *xhat, float *rstd)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float *xr = x + (long)r * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += xr[j];
+    const float mean = wave_sum_f(s) / (float)N;
+    float q = 0.f;
+    for (int j = lane; j < N; j += 64) q += (xr[j] - mean) * (xr[j] - mean);
+    const float rs = 1.f / __builtin_sqrtf(wave_sum_f(q) / (float)N + 1e-5f);
+    for (int j = lane; j < N; j += 64) {
+        const float h = (xr[j] - mean) * rs;
+        xhat[(long)r * N + j] = h;
+        y[(long)r * N + j] = h * g[j] + b[j];
+    }
+    if (lane == 0) rstd[r] = rs;
+}
+
+// dx[r, :] (+)= rstd * (gy - mean(gy) - xhat * mean(gy * xhat)), gy = dy * gamma
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *dy, const float *xhat, const float *rstd,
+                                                     const float *g, int R, int N, float *dx, int accumulate)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float gy = dy[(long)r * N + j] * g[j];
+        s1 += gy, s2 += gy * xhat[(long)r * N + j];
+    }
+    s1 = wave_sum_f(s1) / (float)N, s2 = wave_sum_f(s2) / (float)N;
+    const float rs = rstd[r];
+    for (int j = lane; j < N; j += 64) {
+        const float v = rs * (dy[(long)r * N + j] * g[j] - s1 - xhat[(long)r * N + j] * s2);
+        dx[(long)r * N + j] = accumulate ? dx[(long)r * N + j] + v : v;
+    }
+}
+
+// nn.MultiheadAttention over the T <= 16 views of a sample with src_key_padding_mask = ~valid
+// (adapter.py:97-99): one 64-thread block per (sample, head).  qkv [B*T, 3d]; P [B, heads, T, T].
+constexpr int AD_MAXT = 16;
+__global__ __launch_bounds__(64) void adapter_attn_fwd_kernel(const float *qkv, const unsigned char *valid, int T,
+                                                              int d, int heads, float *P, float *O)
+{
+    __shared__ float sp[AD_MAXT][AD_MAXT];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, hd = d / heads;
+    const float scale = 1.f / __builtin_sqrtf((float)hd);
+    const float *base = qkv + (long)b * T * 3 * d + h * hd;
+    for (int i = threadIdx.x; i < T * T; i += 64) {
+        const int t = i / T, j = i % T;
+        float s = 0.f;
+        for (int c = 0; c < hd; c++) s += base[(long)t * 3 * d + c] * base[(long)j * 3 * d + d + c];
+        sp[t][j] = valid[b * T + j] ? s * scale : -INFINITY;
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+        const int t = threadIdx.x;
+        float mx = -INFINITY, se = 0.f;
+        for (int j = 0; j < T; j++) mx = fmaxf(mx, sp[t][j]);
+        for (int j = 0; j < T; j++) se += __expf(sp[t][j] - mx);
+        for (int j = 0; j < T; j++) {
+            const float p = __expf(sp[t][j] - mx) / se;
+            sp[t][j] = p;
+            P[(((long)b * heads + h) * T + t) * T + j] = p;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * hd; i += 64) {
+        const int t = i / hd, c = i % hd;
+        float o = 0.f;
+        for (int j = 0; j < T; j++) o += sp[t][j] * base[(long)j * 3 * d + 2 * d + c];
+        O[((long)b * T + t) * d + h * hd + c] = o;
+    }
+}
+
+__global__ __launch_bounds__(64) void adapter_attn_bwd_kernel(const float *qkv, const float *P, const float *dO,
+                                                              int T, int d, int heads, float *dqkv)
+{
+    __shared__ float sp[AD_MAXT][AD_MAXT], ds[AD_MAXT][AD_MAXT];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, hd = d / heads;
+    const float scale = 1.f / __builtin_sqrtf((float)hd);
+    const float *base = qkv + (long)b * T * 3 * d + h * hd;
+    const float *dob = dO + (long)b * T * d + h * hd;
+    float *dq = dqkv + (long)b * T * 3 * d + h * hd;
+    for (int i = threadIdx.x; i < T * T; i += 64) {
+        const int t = i / T, j = i % T;
+        sp[t][j] = P[(((long)b * heads + h) * T + t) * T + j];
+        float dp = 0.f;
+        for (int c = 0; c < hd; c++) dp += dob[(long)t * d + c] * base[(long)j * 3 * d + 2 * d + c];
+        ds[t][j] = dp;                                   // dP for now
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+        const int t = threadIdx.x;
+        float dot = 0.f;
+        for (int j = 0; j < T; j++) dot += sp[t][j] * ds[t][j];
+        for (int j = 0; j < T; j++) ds[t][j] = sp[t][j] * (ds[t][j] - dot) * scale;   // dS (scaled)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * hd; i += 64) {
+        const int t = i / hd, c = i % hd;
+        float gq = 0.f, gk = 0.f, gv = 0.f;
+        for (int j = 0; j < T; j++) {
+            gq += ds[t][j] * base[(long)j * 3 * d + d + c];        // dQ[t] = sum_j dS[t, j] K[j]
+            gk += ds[j][t] * base[(long)j * 3 * d + c];            // dK[t] = sum_j dS[j, t] Q[j]
+            gv += sp[j][t] * dob[(long)j * d + c];                 // dV[t] = sum_j P[j, t] dO[j]
+        }
+        dq[(long)t * 3 * d + c] = gq;
+        dq[(long)t * 3 * d + d + c] = gk;
+        dq[(long)t * 3 * d + 2 * d + c] = gv;
+    }
+}
+
+// out = a * x + b * y (y may be null)
+__global__ __launch_bounds__(256) void axpby_kernel(const float *x, const float *y, long n, float a, float b, float *out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+// g[i] = f[i] > 0 ? g[i] : 0  (ReLU backward on the saved post-activation)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float *f, long n, float *g)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        if (!(f[i] > 0.f)) g[i] = 0.f;
+}
+// through F.normalize + the validity mask (clip_cls.py:325-329): dm = valid ? (dfn - fn (fn . dfn)) / |m| : 0,
+// scaled by `scale` (the (1 - residual) of Adapter.residual_add on the way to out_proj)
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *mixed, const float *fn, const float *dfn,
+                                                            const unsigned char *valid, int R, int D, float scale,
+                                                            float *dmixed)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float s = 0.f, dot = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const float m = mixed[(long)r * D + j];
+        s += m * m, dot += fn[(long)r * D + j] * dfn[(long)r * D + j];
+    }
+    const float inv = valid[r] ? scale / fmaxf(__builtin_sqrtf(wave_sum_f(s)), 1e-12f) : 0.f;
+    dot = wave_sum_f(dot);
+    for (int j = lane; j < D; j += 64)
+        dmixed[(long)r * D + j] = (dfn[(long)r * D + j] - fn[(long)r * D + j] * dot) * inv;
+}
+
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
@@ -314,6 +522,207 @@ extern "C" EC_API int ec_adam_step(float *param, const float *grad, float *exp_a
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1,
                        beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2));
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 'text-trans': TransformerAdapter (models/adapter.py:52-110) + text_feats.  Layer-wise over all
+// R = B * T view rows: every nn.Linear is one sgemm_kernel launch (x W^T forward, dy W and dy^T x
+// backward), the saved activations live in the workspace.  Dropout (p = 0.1 inside
+// nn.TransformerEncoderLayer) is not applied: this is the deterministic function the eval-mode module
+// computes, the same one the golden gradients differentiate.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Carve {
+    unsigned char *p;
+    size_t off;
+    float *f(size_t n)
+    {
+        float *r = p ? reinterpret_cast<float *>(p + off) : nullptr;
+        off += align256(n * 4);
+        return r;
+    }
+};
+
+struct LayerBufs {
+    float *xhat1, *rstd1, *a, *qkv, *P, *o, *h1, *xhat2, *rstd2, *bn, *f;
+};
+
+struct TransBufs {
+    float *h0, *hfin, *y, *mixed, *dfn, *dy, *dh, *dh1, *dtmp_d, *dqkv, *df;
+    LayerBufs L[8];
+    // shared with the text-identity path
+    float *Fn, *dL, *u, *dU, *inv_norm, *loss_b;
+};
+
+size_t carve_trans(Carve &c, int B, int T, int D, int K, int d, int ffn, int heads, int layers, TransBufs &t)
+{
+    const size_t R = (size_t)B * T;
+    t.Fn = c.f(R * D), t.dL = c.f(R * K), t.u = c.f((size_t)K * D), t.dU = c.f((size_t)K * D);
+    t.inv_norm = c.f(K), t.loss_b = c.f(B);
+    t.h0 = c.f(R * d), t.hfin = c.f(R * d), t.y = c.f(R * D), t.mixed = c.f(R * D), t.dfn = c.f(R * D);
+    t.dy = c.f(R * D), t.dh = c.f(R * d), t.dh1 = c.f(R * d), t.dtmp_d = c.f(R * d), t.dqkv = c.f(R * 3 * d);
+    t.df = c.f(R * ffn);
+    for (int l = 0; l < layers; l++) {
+        LayerBufs &b = t.L[l];
+        b.xhat1 = c.f(R * d), b.rstd1 = c.f(R), b.a = c.f(R * d), b.qkv = c.f(R * 3 * d);
+        b.P = c.f((size_t)B * heads * T * T), b.o = c.f(R * d), b.h1 = c.f(R * d), b.xhat2 = c.f(R * d);
+        b.rstd2 = c.f(R), b.bn = c.f(R * d), b.f = c.f(R * ffn);
+    }
+    return c.off;
+}
+
+void gemm(hipStream_t s, bool relu, const float *A, long sam, long sak, const float *Bm, long sbk, long sbn, int M,
+          int N, int K, float alpha, float beta, const float *bias, float *C)
+{
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    if (relu)
+        hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(256), 0, s, A, sam, sak, Bm, sbk, sbn, M, N, K, alpha, beta,
+                           bias, C, (long)N);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, s, A, sam, sak, Bm, sbk, sbn, M, N, K, alpha, beta,
+                           bias, C, (long)N);
+}
+// y[R, out] = x[R, in] W[out, in]^T + b (+ beta * y)
+void linear_fwd(hipStream_t s, const float *x, const float *W, const float *b, int R, int in, int out, float *y,
+                float beta = 0.f, bool relu = false)
+{
+    gemm(s, relu, x, in, 1, W, 1, in, R, out, in, 1.f, beta, b, y);
+}
+// dx[R, in] = dy[R, out] W (+ beta dx);  dW[out, in] = dy^T x;  db[out] = colsum(dy)
+void linear_bwd(hipStream_t s, const float *x, const float *W, const float *dy, int R, int in, int out, float *dx,
+                float dx_beta, float *dW, float *db)
+{
+    if (dx) gemm(s, false, dy, out, 1, W, in, 1, R, in, out, 1.f, dx_beta, nullptr, dx);
+    gemm(s, false, dy, 1, out, x, in, 1, out, in, R, 1.f, 0.f, nullptr, dW);
+    hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(256), 0, s, dy, (const float *)nullptr, R, out, db);
+}
+unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace
+
+extern "C" EC_API size_t ec_fs_trans_train_workspace_bytes(int B, int T, int D, int K, int d_model, int ffn_dim,
+                                                           int heads, int layers)
+{
+    if (B <= 0 || T <= 0 || D <= 0 || K <= 0 || d_model <= 0 || ffn_dim <= 0 || layers <= 0 || layers > 8) return 0;
+    Carve c{nullptr, 0};
+    TransBufs t;
+    return carve_trans(c, B, T, D, K, d_model, ffn_dim, heads, layers, t);
+}
+
+extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
+                                            const float *text_param, int B, int T, int D, int K, float logit_scale,
+                                            int agg, int use_probs_loss, const ec_adapter_train_params *w,
+                                            const ec_adapter_train_params *g, float *loss, float *grad_text,
+                                            float *agg_logits, void *workspace, size_t workspace_bytes,
+                                            ec_stream_t stream)
+{
+    EC_REQUIRE(B > 0 && T > 0 && D > 0 && K > 0, "ec_fs_trans_loss_grad: bad shape");
+    EC_REQUIRE(w && g && w->blocks && g->blocks, "ec_fs_trans_loss_grad: null parameter / gradient structs");
+    EC_REQUIRE(agg == EC_AGG_SUM || agg == EC_AGG_MEAN, "ec_fs_trans_loss_grad: agg must be sum or mean");
+    const int d = w->d_model, ffn = w->ffn_dim, heads = w->heads, layers = w->layers;
+    EC_REQUIRE(w->in_dim == D && d > 0 && d <= 1024 && heads > 0 && d % heads == 0 && layers >= 1 && layers <= 8 &&
+                   T <= AD_MAXT, "ec_fs_trans_loss_grad: unsupported adapter geometry (T <= %d, layers <= 8)", AD_MAXT);
+    EC_REQUIRE(img_feats && valid && labels && text_param && loss && grad_text && workspace,
+               "ec_fs_trans_loss_grad: null buffer");
+    Carve c{static_cast<unsigned char *>(workspace), 0};
+    TransBufs t;
+    const size_t need = carve_trans(c, B, T, D, K, d, ffn, heads, layers, t);
+    if (need > workspace_bytes)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_fs_trans_loss_grad: workspace %zu < %zu bytes", workspace_bytes, need);
+    const size_t lds = ((size_t)T * D + (size_t)T * K + TR_WAVES + 3 * (size_t)T) * 4;
+    EC_REQUIRE(lds <= 160 * 1024, "ec_fs_trans_loss_grad: T * (D + K) = %d floats exceed the LDS", T * (D + K));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_loss_grad_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int R = B * T;
+    const float r = w->residual;
+    const unsigned ln_grid = (unsigned)((R + 3) / 4);
+
+    // ---------------- forward (adapter.py:82-105) ----------------
+    linear_fwd(s, img_feats, w->in_w, w->in_b, R, D, d, t.h0);
+    const float *h = t.h0;
+    for (int l = 0; l < layers; l++) {
+        const ec_adapter_train_layer &p = w->blocks[l];
+        LayerBufs &b = t.L[l];
+        hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid), dim3(256), 0, s, h, p.ln1_g, p.ln1_b, R, d, b.a, b.xhat1, b.rstd1);
+        linear_fwd(s, b.a, p.qkv_w, p.qkv_b, R, d, 3 * d, b.qkv);
+        hipLaunchKernelGGL(adapter_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, s, b.qkv, valid, T, d, heads, b.P, b.o);
+        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, h, (const float *)nullptr,
+                           (long)R * d, 1.f, 0.f, b.h1);
+        linear_fwd(s, b.o, p.o_w, p.o_b, R, d, d, b.h1, 1.f);                       // h1 = h + out_proj(o)
+        hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid), dim3(256), 0, s, b.h1, p.ln2_g, p.ln2_b, R, d, b.bn, b.xhat2,
+                           b.rstd2);
+        linear_fwd(s, b.bn, p.w1, p.b1, R, d, ffn, b.f, 0.f, true);                   // relu(linear1)
+        float *hn = (l + 1 < layers) ? t.L[l + 1].h1 : t.hfin;   // next layer's h1 buffer is free until its own turn
+        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, b.h1, (const float *)nullptr,
+                           (long)R * d, 1.f, 0.f, hn);
+        linear_fwd(s, b.f, p.w2, p.b2, R, ffn, d, hn, 1.f);                           // h = h1 + linear2(f)
+        if (l + 1 < layers) {
+            // keep this layer's output where the next layer reads it, but its h1 slot must stay its own:
+            // copy into hfin as the running residual stream instead
+            hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, hn, (const float *)nullptr,
+                               (long)R * d, 1.f, 0.f, t.hfin);
+            h = t.hfin;
+        } else {
+            h = t.hfin;
+        }
+    }
+    linear_fwd(s, h, w->out_w, w->out_b, R, d, D, t.y);
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * D)), dim3(256), 0, s, img_feats, t.y, (long)R * D, r,
+                       1.f - r, t.mixed);                                           // Adapter.residual_add
+
+    // ---------------- loss, dL, text gradient (shared with 'text-identity') ----------------
+    hipLaunchKernelGGL(text_norm_kernel, dim3(K), dim3(64), 0, s, text_param, D, t.u, t.inv_norm);
+    hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, t.mixed, valid, labels, t.u, B, T, D, K,
+                       logit_scale, agg, use_probs_loss, t.Fn, t.dL, t.loss_b, agg_logits);
+    hipLaunchKernelGGL(sgemm_tn_kernel, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, t.dL, t.Fn, R, K, D,
+                       logit_scale, t.dU);
+    hipLaunchKernelGGL(text_grad_finish_kernel, dim3(K), dim3(64), 0, s, t.u, t.dU, t.inv_norm, D, t.loss_b, B,
+                       grad_text, loss);
+
+    // ---------------- backward into the adapter ----------------
+    gemm(s, false, t.dL, K, 1, t.u, D, 1, R, D, K, logit_scale, 0.f, nullptr, t.dfn);   // dFn = s dL u
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, t.mixed, t.Fn, t.dfn, valid, R, D, 1.f - r,
+                       t.dy);                                                        // dY = (1 - r) dMixed
+    linear_bwd(s, h, w->out_w, t.dy, R, d, D, t.dh, 0.f, g->out_w, g->out_b);
+    for (int l = layers - 1; l >= 0; l--) {
+        const ec_adapter_train_layer &p = w->blocks[l];
+        const ec_adapter_train_layer &q = g->blocks[l];
+        LayerBufs &b = t.L[l];
+        // h = h1 + linear2(relu(linear1(ln2(h1))))
+        linear_bwd(s, b.f, p.w2, t.dh, R, ffn, d, t.df, 0.f, const_cast<float *>(q.w2), const_cast<float *>(q.b2));
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for((long)R * ffn)), dim3(256), 0, s, b.f, (long)R * ffn, t.df);
+        linear_bwd(s, b.bn, p.w1, t.df, R, d, ffn, t.dtmp_d, 0.f, const_cast<float *>(q.w1), const_cast<float *>(q.b1));
+        hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, b.xhat2, R, d,
+                           const_cast<float *>(q.ln2_g));
+        hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, (const float *)nullptr, R, d,
+                           const_cast<float *>(q.ln2_b));
+        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, t.dh, (const float *)nullptr,
+                           (long)R * d, 1.f, 0.f, t.dh1);
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, t.dtmp_d, b.xhat2, b.rstd2, p.ln2_g, R, d, t.dh1,
+                           1);
+        // h1 = h + out_proj(attn(in_proj(ln1(h))))
+        linear_bwd(s, b.o, p.o_w, t.dh1, R, d, d, t.dtmp_d, 0.f, const_cast<float *>(q.o_w), const_cast<float *>(q.o_b));
+        hipLaunchKernelGGL(adapter_attn_bwd_kernel, dim3(B * heads), dim3(64), 0, s, b.qkv, b.P, t.dtmp_d, T, d, heads,
+                           t.dqkv);
+        linear_bwd(s, b.a, p.qkv_w, t.dqkv, R, d, 3 * d, t.dtmp_d, 0.f, const_cast<float *>(q.qkv_w),
+                   const_cast<float *>(q.qkv_b));
+        hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, b.xhat1, R, d,
+                           const_cast<float *>(q.ln1_g));
+        hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, (const float *)nullptr, R, d,
+                           const_cast<float *>(q.ln1_b));
+        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, t.dh1, (const float *)nullptr,
+                           (long)R * d, 1.f, 0.f, t.dh);
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, t.dtmp_d, b.xhat1, b.rstd1, p.ln1_g, R, d, t.dh, 1);
+    }
+    linear_bwd(s, img_feats, w->in_w, t.dh, R, D, d, nullptr, 0.f, g->in_w, g->in_b);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

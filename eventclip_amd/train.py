@@ -48,6 +48,68 @@ def fs_text_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='su
     return (loss[0], grad, logits) if return_logits else (loss[0], grad)
 
 
+_LAYER_FIELDS = (('ln1_g', 'norm1.weight'), ('ln1_b', 'norm1.bias'), ('qkv_w', 'self_attn.in_proj_weight'),
+                 ('qkv_b', 'self_attn.in_proj_bias'), ('o_w', 'self_attn.out_proj.weight'),
+                 ('o_b', 'self_attn.out_proj.bias'), ('ln2_g', 'norm2.weight'), ('ln2_b', 'norm2.bias'),
+                 ('w1', 'linear1.weight'), ('b1', 'linear1.bias'), ('w2', 'linear2.weight'), ('b2', 'linear2.bias'))
+
+
+def _adapter_struct(adapter, tensors):
+    """ec_adapter_train_params over `tensors` (name -> fp32 CUDA tensor, the adapter's state-dict names)."""
+    import ctypes
+    layers = (_lib.EcAdapterTrainLayer * adapter.num_layers)()
+    for i in range(adapter.num_layers):
+        for field, name in _LAYER_FIELDS:
+            setattr(layers[i], field, tensors[f'transformer_encoder.layers.{i}.{name}'].data_ptr())
+    p = _lib.EcAdapterTrainParams()
+    p.in_dim, p.d_model, p.heads = adapter.in_dim, adapter.d_model, adapter.num_heads
+    p.ffn_dim, p.layers, p.residual = adapter.ffn_dim, adapter.num_layers, float(adapter.residual)
+    p.in_w, p.in_b = tensors['in_proj.weight'].data_ptr(), tensors['in_proj.bias'].data_ptr()
+    p.out_w, p.out_b = tensors['out_proj.weight'].data_ptr(), tensors['out_proj.bias'].data_ptr()
+    p.blocks = ctypes.cast(layers, ctypes.POINTER(_lib.EcAdapterTrainLayer))
+    return p, layers
+
+
+def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapter, agg='sum',
+                       use_probs_loss=False, return_logits=False):
+    """The `text-trans` step: img_feats fp32 CUDA [B, T, D] with ZERO rows on invalid views
+    (clip_cls.py:319-321), ``adapter`` an eventclip_amd.adapter.TransformerAdapter on the GPU.
+    Returns (loss, grads) with grads = {adapter state-dict name: tensor, 'text_feats': [K, D]}
+    (the deterministic function: encoder-layer dropout is not applied)."""
+    import ctypes
+    dev = _lib.require_gpu()
+    if agg not in _AGG:
+        raise NotImplementedError(f'agg_func {agg!r}: the reference trains with sum / mean')
+    f = img_feats.float().contiguous()
+    B, T, D = f.shape
+    t = text_param.detach().float().contiguous()
+    K = t.shape[0]
+    params = {k: v.detach() for k, v in adapter.named_parameters()}
+    for k, v in params.items():
+        assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous(), k
+    grads = {k: torch.empty_like(v) for k, v in params.items()}
+    ps, keep_p = _adapter_struct(adapter, params)
+    gs, keep_g = _adapter_struct(adapter, grads)
+    need = int(_lib.lib().ec_fs_trans_train_workspace_bytes(B, T, D, K, adapter.d_model, adapter.ffn_dim,
+                                                            adapter.num_heads, adapter.num_layers))
+    ws = _WS.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = _WS[dev.index] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    gtext = torch.empty((K, D), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, K), dtype=torch.float32, device=dev) if return_logits else None
+    v8 = valid.to(torch.uint8).contiguous()       # named: a temporary's block would be handed to the next one
+    lab = labels.to(torch.int32).contiguous()
+    rc = _lib.lib().ec_fs_trans_loss_grad(
+        _lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab),
+        _lib.ptr(t), B, T, D, K, float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), ctypes.byref(ps),
+        ctypes.byref(gs), _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(logits), _lib.ptr(ws), ws.numel(),
+        _lib.stream_ptr())
+    _lib.check(rc, 'ec_fs_trans_loss_grad')
+    grads['text_feats'] = gtext
+    return (loss[0], grads, logits) if return_logits else (loss[0], grads)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.):
     """In-place torch.optim.Adam update of a contiguous fp32 CUDA tensor."""
     _lib.require_gpu()
@@ -97,4 +159,43 @@ class TextFeatTrainer:
                   self.eps, self.weight_decay)
         if hasattr(clf, '_invalidate_text_cache'):
             clf._invalidate_text_cache()
+        return loss
+
+
+class AdapterTrainer:
+    """Trains the TransformerAdapter (+ ``text_feats`` for 'text-trans') of an FSCLIPClassifier on
+    cached encoder features: ``fs_trans_loss_grad`` + one ``adam_step`` per tensor.  Encoder-layer
+    dropout is not applied (see ``fs_trans_loss_grad``)."""
+
+    def __init__(self, classifier, lr, total_steps, warmup_steps_pct=0.05, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.):
+        if getattr(classifier, 'adapter_type', None) != 'trans':
+            raise NotImplementedError("AdapterTrainer handles adapter_type='trans' / 'text-trans'")
+        self.clf = classifier
+        self.lr, self.total_steps = float(lr), int(total_steps)
+        self.warmup_steps = warmup_steps_pct * self.total_steps
+        self.betas, self.eps, self.weight_decay = betas, float(eps), float(weight_decay)
+        self.tensors = {k: p.data for k, p in classifier.adapter.named_parameters()}
+        if classifier.prompt_tuning:
+            self.tensors['text_feats'] = classifier.text_feats.data
+        self.state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.tensors.items()}
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, img_feats, valid, labels):
+        clf = self.clf
+        text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
+        loss, grads = fs_trans_loss_grad(img_feats, valid, labels, text, clf.logit_scale, clf.adapter,
+                                         clf.agg_func, clf.use_probs_loss)
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
+        self.steps += 1
+        for k, p in self.tensors.items():
+            g = grads[k]
+            if ddp:
+                dist.all_reduce(g)
+                g /= dist.get_world_size()
+            m, v = self.state[k]
+            adam_step(p, g.contiguous(), m, v, self.steps, lr, self.betas, self.eps, self.weight_decay)
+        clf.adapter._packed = None          # the forward kernel's transposed copies are stale now
         return loss

@@ -245,7 +245,8 @@ def center_events_device(events, sample_range, resolution):
     assert sample_range.is_cuda and sample_range.dtype == torch.int64
     H, W = resolution
     entry = _lib.lib().ec_center_events_packed if packed else _lib.lib().ec_center_events
-    rc = entry(_lib.ptr(events), _lib.ptr(sample_range.contiguous()), int(sample_range.shape[0]),
+    sample_range = sample_range.contiguous()
+    rc = entry(_lib.ptr(events), _lib.ptr(sample_range), int(sample_range.shape[0]),
                int(H), int(W), _lib.stream_ptr())
     _lib.check(rc, 'ec_center_events')
     return events

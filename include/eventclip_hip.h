@@ -383,6 +383,39 @@ EC_API int ec_adam_step(float *param, const float *grad, float *exp_avg, float *
                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                         ec_stream_t stream);
 
+/* 'text-trans' (configs/fsclip/joint_adapter/): the same step with the TransformerAdapter
+ * (models/adapter.py:52-110: in_proj -> nn.TransformerEncoder(norm_first, ReLU, key padding mask) ->
+ * out_proj -> residual mix) in front of the normalisation, differentiated with respect to every
+ * adapter parameter and text_feats.  Parameter tensors are passed in torch's own layouts
+ * ([out, in] weights, state-dict names in the comments), gradients come back in a second struct of the
+ * same shape.  Dropout inside the encoder layers is not applied (the deterministic, eval-mode
+ * function).  img_feats must hold ZERO rows for invalid views (clip_cls.py:319-321). */
+typedef struct {
+    float *ln1_g, *ln1_b;   /* norm1.weight / .bias [d] */
+    float *qkv_w, *qkv_b;   /* self_attn.in_proj_weight [3d, d] / in_proj_bias [3d] */
+    float *o_w, *o_b;       /* self_attn.out_proj.weight [d, d] / .bias */
+    float *ln2_g, *ln2_b;   /* norm2 */
+    float *w1, *b1;         /* linear1.weight [ffn, d] / .bias */
+    float *w2, *b2;         /* linear2.weight [d, ffn] / .bias */
+} ec_adapter_train_layer;
+
+typedef struct {
+    int in_dim, d_model, heads, ffn_dim, layers; /* layers <= 8 */
+    float residual;                              /* Adapter.residual (adapter.py:13-20) */
+    float *in_w, *in_b;                          /* in_proj.weight [d, in_dim] / .bias */
+    float *out_w, *out_b;                        /* out_proj.weight [in_dim, d] / .bias */
+    const ec_adapter_train_layer *blocks;        /* host array [layers] */
+} ec_adapter_train_params;
+
+EC_API size_t ec_fs_trans_train_workspace_bytes(int B, int T, int D, int K, int d_model, int ffn_dim,
+                                                int heads, int layers);
+EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
+                                 const float *text_param, int B, int T, int D, int K, float logit_scale,
+                                 int agg, int use_probs_loss, const ec_adapter_train_params *params,
+                                 const ec_adapter_train_params *grads, float *loss, float *grad_text,
+                                 float *agg_logits, void *workspace, size_t workspace_bytes,
+                                 ec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ Pinning (what anchors each restatement):
   the reference's ``datasets/imagenet.py:load_event`` (``tools/make_golden_ingest.py``).
 * ``oracle.pseudo_label`` -- PARITY UNPINNED: restates code that is inline in ``gen_data.py``'s
   ``main()`` (lines 132-164, 196-215), which cannot run without clip / nerv / datasets.
-* ``oracle.train`` -- pinned: loss and d loss / d text_feats of the `text-identity` few-shot step
+* ``oracle.train`` -- pinned: loss and gradients of the `text-identity` and `text-trans` few-shot steps
   against the reference's own ``FSCLIPClassifier`` under torch autograd
   (``tools/make_golden_train.py``); Adam against ``torch.optim.Adam``; the warm-up + cosine schedule is
   PARITY UNPINNED (it lives in the absent ``nerv``).

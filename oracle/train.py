@@ -80,3 +80,53 @@ def cosine_warmup_lr(step, total_steps, max_lr, min_lr, warmup_steps):
         return min_lr + (max_lr - min_lr) * step / max(warmup_steps, 1)
     frac = (step - warmup_steps) / max(total_steps - warmup_steps, 1)
     return min_lr + (max_lr - min_lr) * (1 + math.cos(math.pi * min(frac, 1.0))) / 2
+
+
+def fs_trans_loss_and_grads(sd, feats, valid, labels, text_param, logit_scale, heads, residual, agg='mean',
+                            probs_loss=False):
+    """'text-trans': loss and gradients of every adapter parameter and of text_feats, from torch
+    float64 autograd over the oracle's own explicit forward (oracle/adapter.py's math, not the
+    nn.Module).  sd: adapter state dict (reference names).  Pinned against the reference's
+    FSCLIPClassifier under autograd by tests/golden/train_text_trans.npz."""
+    import torch
+    import torch.nn.functional as F
+    p = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    t = torch.tensor(np.asarray(text_param), dtype=torch.float64, requires_grad=True)
+    x0 = torch.tensor(np.asarray(feats), dtype=torch.float64)
+    m = torch.tensor(np.asarray(valid), dtype=torch.bool)
+    y = torch.tensor(np.asarray(labels), dtype=torch.long)
+    B, T, _ = x0.shape
+    x = F.linear(x0, p['in_proj.weight'], p['in_proj.bias'])
+    dm = x.shape[-1]
+    hd = dm // heads
+    n_layers = len({k.split('.')[2] for k in sd if k.startswith('transformer_encoder.layers.')})
+    key_mask = torch.zeros(B, 1, 1, T, dtype=torch.float64).masked_fill(~m[:, None, None, :], float('-inf'))
+    for i in range(n_layers):
+        q = f'transformer_encoder.layers.{i}.'
+        h = F.layer_norm(x, (dm,), p[q + 'norm1.weight'], p[q + 'norm1.bias'], 1e-5)
+        qkv = F.linear(h, p[q + 'self_attn.in_proj_weight'], p[q + 'self_attn.in_proj_bias'])
+        qq, kk, vv = qkv.split(dm, dim=-1)
+        qq = qq.view(B, T, heads, hd).transpose(1, 2) * hd ** -0.5
+        kk = kk.view(B, T, heads, hd).transpose(1, 2)
+        vv = vv.view(B, T, heads, hd).transpose(1, 2)
+        att = (qq @ kk.transpose(-1, -2) + key_mask).softmax(-1)
+        o = (att @ vv).transpose(1, 2).reshape(B, T, dm)
+        x = x + F.linear(o, p[q + 'self_attn.out_proj.weight'], p[q + 'self_attn.out_proj.bias'])
+        h = F.layer_norm(x, (dm,), p[q + 'norm2.weight'], p[q + 'norm2.bias'], 1e-5)
+        h = F.relu(F.linear(h, p[q + 'linear1.weight'], p[q + 'linear1.bias']))
+        x = x + F.linear(h, p[q + 'linear2.weight'], p[q + 'linear2.bias'])
+    new = F.linear(x, p['out_proj.weight'], p['out_proj.bias'])
+    mixed = x0 * residual + new * (1. - residual)
+    fn = F.normalize(mixed, p=2, dim=-1) * m[..., None]
+    L = logit_scale * fn @ F.normalize(t, p=2, dim=-1).T
+    n = m.double().sum(1, keepdim=True)
+    logits = L.sum(1) if agg == 'sum' else L.sum(1) / n
+    if not probs_loss:
+        loss = F.cross_entropy(logits, y)
+    else:
+        probs = (L.softmax(-1) * m[..., None]).sum(1) / n
+        loss = F.nll_loss((probs + 1e-6).log(), y)
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in p.items()}
+    grads['text_feats'] = t.grad.numpy()
+    return float(loss.detach()), grads, logits.detach().numpy()

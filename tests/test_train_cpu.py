@@ -48,3 +48,24 @@ def test_cosine_warmup_shape():
     lr = [ot.cosine_warmup_lr(s, 100, 1e-3, 1e-5, 10) for s in range(101)]
     assert lr[0] == 1e-5 and abs(lr[10] - 1e-3) < 1e-12 and abs(lr[100] - 1e-5) < 1e-12
     assert all(a <= b + 1e-15 for a, b in zip(lr[:10], lr[1:11])) and all(a >= b - 1e-15 for a, b in zip(lr[10:100], lr[11:]))
+
+
+def trans_cases():
+    z = np.load(os.path.join(GOLDEN, 'train_text_trans.npz'))
+    return [(ci, agg, loss) for ci in range(len(z['cases'])) for agg, loss in (('sum', 'logits'), ('mean', 'probs'))]
+
+
+@pytest.mark.parametrize('ci,agg,loss', trans_cases())
+def test_text_trans_gradients_match_reference_autograd(ci, agg, loss):
+    z = np.load(os.path.join(GOLDEN, 'train_text_trans.npz'))
+    tag = f'c{ci}_{agg}_{loss}'
+    sd = {k[2:]: z[k] for k in z.files if k.startswith('w:')}
+    got_loss, grads, logits = ot.fs_trans_loss_and_grads(
+        sd, z[f'c{ci}_feats'], z[f'c{ci}_valid'], z[f'c{ci}_labels'], z[f'c{ci}_text_param'],
+        float(z[f'c{ci}_logit_scale']), int(z['adcfg_num_heads']), float(z['adcfg_residual']), agg, loss == 'probs')
+    assert abs(got_loss - float(z[tag + '_loss'])) < 1e-4 * max(1., abs(got_loss))
+    np.testing.assert_allclose(logits, z[tag + '_logits'], rtol=1e-4, atol=1e-4)
+    assert set(grads) == {k.split('_g:')[1] for k in z.files if k.startswith(tag + '_g:')}
+    for k, g in grads.items():
+        want = z[f'{tag}_g:{k}']
+        assert np.abs(g - want).max() < 2e-4 * max(np.abs(want).max(), 1e-3), k

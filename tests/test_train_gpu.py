@@ -108,3 +108,101 @@ def test_trainer_fits_a_few_shot_problem(hip):
     _, _, logits = __import__('eventclip_amd.train', fromlist=['x']).fs_text_loss_grad(
         sep, valid, labels, clf.text_feats.data, clf.logit_scale, clf.agg_func, clf.use_probs_loss, return_logits=True)
     assert float((logits.argmax(-1) == labels).float().mean()) == 1.0
+
+
+def _trans_adapter(z, dev='cuda'):
+    import torch
+    from eventclip_amd.adapter import TransformerAdapter
+    ad = TransformerAdapter(in_dim=int(z['C']), d_model=int(z['adcfg_d_model']), num_heads=int(z['adcfg_num_heads']),
+                            ffn_dim=int(z['adcfg_ffn_dim']), num_layers=int(z['adcfg_num_layers']),
+                            residual=float(z['adcfg_residual']))
+    ad.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w:')})
+    return ad.to(dev)
+
+
+@pytest.mark.parametrize('ci,agg,loss', [(ci, a, l) for ci in range(3) for a, l in (('sum', 'logits'), ('mean', 'probs'))])
+def test_text_trans_gradients_match_reference_autograd(ci, agg, loss, hip):
+    import torch
+    from eventclip_amd import train
+    z = np.load(os.path.join(GOLDEN, 'train_text_trans.npz'))
+    tag = f'c{ci}_{agg}_{loss}'
+    ad = _trans_adapter(z)
+    f = torch.from_numpy(z[f'c{ci}_feats']).cuda()
+    v = torch.from_numpy(z[f'c{ci}_valid']).cuda()
+    y = torch.from_numpy(z[f'c{ci}_labels']).cuda()
+    t = torch.from_numpy(z[f'c{ci}_text_param']).cuda()
+    got_loss, grads, logits = train.fs_trans_loss_grad(f, v, y, t, float(z[f'c{ci}_logit_scale']), ad, agg,
+                                                       loss == 'probs', return_logits=True)
+    want_loss = float(z[tag + '_loss'])
+    assert abs(float(got_loss) - want_loss) < 2e-4 * max(1., abs(want_loss))
+    np.testing.assert_allclose(logits.cpu().numpy(), z[tag + '_logits'], rtol=2e-4, atol=2e-3)
+    assert set(grads) == {k.split('_g:')[1] for k in z.files if k.startswith(tag + '_g:')}
+    for k, g in grads.items():
+        want = z[f'{tag}_g:{k}']
+        err = np.abs(g.cpu().numpy() - want).max()
+        assert err < 5e-4 * max(np.abs(want).max(), 1e-3), (k, err, np.abs(want).max())
+
+
+def test_text_trans_full_size_against_oracle(hip):
+    """The shipped adapter geometry (in 768, d_model 256, 4 heads, ffn 1024, 2 layers, r = 0.95), T = 10."""
+    import torch
+    from eventclip_amd import train
+    from eventclip_amd.adapter import TransformerAdapter
+    from oracle import train as ot
+    torch.manual_seed(3)
+    B, T, D, K = 24, 10, 768, 101
+    ad = TransformerAdapter(in_dim=D, residual=0.95)
+    with torch.no_grad():
+        for p in ad.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    valid = torch.rand(B, T) < 0.7
+    valid[:, 0] = True
+    labels = torch.randint(0, K, (B,))
+    text = torch.randn(K, D) * 0.5
+    feats = (torch.randn(B, T, D) + 2.0 * text[labels][:, None]) * valid[..., None]
+    want_loss, want, want_logits = ot.fs_trans_loss_and_grads(
+        {k: v.detach().numpy() for k, v in ad.state_dict().items()}, feats.numpy(), valid.numpy(), labels.numpy(),
+        text.numpy(), 100.0, 4, 0.95, 'mean', True)
+    got_loss, grads = train.fs_trans_loss_grad(feats.cuda(), valid.cuda(), labels.cuda(), text.cuda(), 100.0,
+                                               ad.cuda(), 'mean', True)
+    assert abs(float(got_loss) - want_loss) < 3e-4 * max(1., abs(want_loss))
+    for k, g in grads.items():
+        err = np.abs(g.cpu().numpy() - want[k]).max()
+        assert err < 1e-3 * max(np.abs(want[k]).max(), 1e-4), (k, err, np.abs(want[k]).max())
+
+
+def test_adapter_trainer_reduces_the_loss_and_updates_the_forward(hip):
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import FSCLIPClassifier
+    from eventclip_amd.train import AdapterTrainer
+    cfg = eclip.arch_config('ViT-B/32', layers=1, text_layers=1, vocab_size=49408)
+    m = eclip.CLIP(cfg, eclip.random_state_dict(cfg, seed=9)).cuda().eval()
+    K, B, T, D = 4, 16, 3, cfg['embed_dim']
+    clf = FSCLIPClassifier(adapter_dict=dict(adapter_type='text-trans', in_dim=D, d_model=64, num_heads=2, ffn_dim=128,
+                                             num_layers=2, residual=0.5),
+                           clip_dict=dict(clip_model=m, prompt='a {}', class_names=[f'c{i}' for i in range(K)],
+                                          agg_func='mean', class_tokens=eclip.synthetic_tokens(K, seed=4)),
+                           loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(2)
+    labels = torch.arange(B, device='cuda') % K
+    centres = torch.randn(K, D, device='cuda', generator=g)
+    valid = torch.ones(B, T, dtype=torch.bool, device='cuda')
+    valid[1::3, 2] = False
+    feats = (centres[labels][:, None] + 0.5 * torch.randn(B, T, D, device='cuda', generator=g)) * valid[..., None]
+    w0 = clf.adapter.in_proj.weight.data.clone()
+    trainer = AdapterTrainer(clf, lr=3e-3, total_steps=60)
+    losses = [float(trainer.step(feats, valid, labels)) for _ in range(60)]
+    assert losses[-1] < 0.2 * losses[0]
+    assert not torch.equal(w0, clf.adapter.in_proj.weight.data)
+    # the inference kernel sees the trained weights: same aggregated logits as the training forward
+    from eventclip_amd.train import fs_trans_loss_grad
+    _, _, logits = fs_trans_loss_grad(feats, valid, labels, clf.text_feats.data, clf.logit_scale, clf.adapter,
+                                      clf.agg_func, clf.use_probs_loss, return_logits=True)
+    idx = torch.where(valid, torch.arange(B * T, device='cuda').view(B, T), torch.full((B, T), -1, device='cuda')).int()
+    ad = clf.adapter.forward_rows(feats.reshape(B * T, D), idx)
+    fn = torch.nn.functional.normalize(ad, dim=-1) * valid[..., None]
+    tx = torch.nn.functional.normalize(clf.text_feats.data, dim=-1)
+    want = (clf.logit_scale * fn @ tx.T).sum(1) / valid.sum(1, keepdim=True)
+    torch.testing.assert_close(logits, want, rtol=1e-3, atol=1e-2)
+    assert float((logits.argmax(-1) == labels).float().mean()) == 1.0
