@@ -118,8 +118,10 @@ SIGNATURES = {
     'ec_fs_trans_train_workspace_bytes': (ctypes.c_size_t, [c_int] * 8),
     'ec_fs_trans_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       ctypes.c_float, c_int, c_int, ctypes.POINTER(EcAdapterTrainParams),
-                                      ctypes.POINTER(EcAdapterTrainParams), c_void_p, c_void_p, c_void_p,
-                                      c_void_p, ctypes.c_size_t, c_void_p]),
+                                      ctypes.POINTER(EcAdapterTrainParams), ctypes.c_float, ctypes.c_uint64,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    'ec_dropout_mask': (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, ctypes.c_float, c_void_p,
+                                c_void_p]),
     'ec_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     'ec_gemm': (c_int, [ctypes.POINTER(EcGemmArgs), c_void_p]),

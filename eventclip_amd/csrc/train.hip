@@ -345,11 +345,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *dy, const floa
     }
 }
 
+// Dropout (nn.TransformerEncoderLayer's p = 0.1 in train mode) without stored masks: element i of
+// tensor `id` is kept iff a stateless hash of (seed, id, i) clears p; the backward pass recomputes it.
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned id, unsigned long long i, float p)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)id + 1) + i * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.f / 16777216.f) >= p;     // 24 uniform bits
+}
+// out = base + dropout(x) (base may be null): the residual adds after self-attention and the MLP
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float *base, const float *x, long n, float p,
+                                                          unsigned long long seed, unsigned id, float *out)
+{
+    const float k = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = drop_keep(seed, id, i, p) ? x[i] * k : 0.f;
+        out[i] = base ? base[i] + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(long n, float p, unsigned long long seed, unsigned id,
+                                                           unsigned char *mask)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        mask[i] = drop_keep(seed, id, i, p) ? 1 : 0;
+}
+
 // nn.MultiheadAttention over the T <= 16 views of a sample with src_key_padding_mask = ~valid
 // (adapter.py:97-99): one 64-thread block per (sample, head).  qkv [B*T, 3d]; P [B, heads, T, T].
 constexpr int AD_MAXT = 16;
 __global__ __launch_bounds__(64) void adapter_attn_fwd_kernel(const float *qkv, const unsigned char *valid, int T,
-                                                              int d, int heads, float *P, float *O)
+                                                              int d, int heads, float *P, float *O, float drop_p,
+                                                              unsigned long long seed, unsigned drop_id)
 {
     __shared__ float sp[AD_MAXT][AD_MAXT];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads, hd = d / heads;
@@ -369,8 +397,10 @@ __global__ __launch_bounds__(64) void adapter_attn_fwd_kernel(const float *qkv, 
         for (int j = 0; j < T; j++) se += __expf(sp[t][j] - mx);
         for (int j = 0; j < T; j++) {
             const float p = __expf(sp[t][j] - mx) / se;
-            sp[t][j] = p;
-            P[(((long)b * heads + h) * T + t) * T + j] = p;
+            const long pi = (((long)b * heads + h) * T + t) * T + j;
+            P[pi] = p;                                   // the softmax output (its backward needs it undropped)
+            // MultiheadAttention's dropout on the attention weights
+            sp[t][j] = drop_p > 0.f ? (drop_keep(seed, drop_id, pi, drop_p) ? p / (1.f - drop_p) : 0.f) : p;
         }
     }
     __syncthreads();
@@ -383,9 +413,10 @@ __global__ __launch_bounds__(64) void adapter_attn_fwd_kernel(const float *qkv, 
 }
 
 __global__ __launch_bounds__(64) void adapter_attn_bwd_kernel(const float *qkv, const float *P, const float *dO,
-                                                              int T, int d, int heads, float *dqkv)
+                                                              int T, int d, int heads, float *dqkv, float drop_p,
+                                                              unsigned long long seed, unsigned drop_id)
 {
-    __shared__ float sp[AD_MAXT][AD_MAXT], ds[AD_MAXT][AD_MAXT];
+    __shared__ float sp[AD_MAXT][AD_MAXT], ds[AD_MAXT][AD_MAXT], sk[AD_MAXT][AD_MAXT];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads, hd = d / heads;
     const float scale = 1.f / __builtin_sqrtf((float)hd);
     const float *base = qkv + (long)b * T * 3 * d + h * hd;
@@ -393,10 +424,13 @@ __global__ __launch_bounds__(64) void adapter_attn_bwd_kernel(const float *qkv, 
     float *dq = dqkv + (long)b * T * 3 * d + h * hd;
     for (int i = threadIdx.x; i < T * T; i += 64) {
         const int t = i / T, j = i % T;
-        sp[t][j] = P[(((long)b * heads + h) * T + t) * T + j];
+        const long pi = (((long)b * heads + h) * T + t) * T + j;
+        sp[t][j] = P[pi];
+        // keep-scale of the attention-weight dropout: P_drop = P * sk
+        sk[t][j] = drop_p > 0.f ? (drop_keep(seed, drop_id, pi, drop_p) ? 1.f / (1.f - drop_p) : 0.f) : 1.f;
         float dp = 0.f;
         for (int c = 0; c < hd; c++) dp += dob[(long)t * d + c] * base[(long)j * 3 * d + 2 * d + c];
-        ds[t][j] = dp;                                   // dP for now
+        ds[t][j] = dp * sk[t][j];                        // dP (through the dropout) for now
     }
     __syncthreads();
     if (threadIdx.x < T) {
@@ -412,7 +446,7 @@ __global__ __launch_bounds__(64) void adapter_attn_bwd_kernel(const float *qkv, 
         for (int j = 0; j < T; j++) {
             gq += ds[t][j] * base[(long)j * 3 * d + d + c];        // dQ[t] = sum_j dS[t, j] K[j]
             gk += ds[j][t] * base[(long)j * 3 * d + c];            // dK[t] = sum_j dS[j, t] Q[j]
-            gv += sp[j][t] * dob[(long)j * d + c];                 // dV[t] = sum_j P[j, t] dO[j]
+            gv += sp[j][t] * sk[j][t] * dob[(long)j * d + c];      // dV[t] = sum_j P_drop[j, t] dO[j]
         }
         dq[(long)t * 3 * d + c] = gq;
         dq[(long)t * 3 * d + d + c] = gk;
@@ -426,11 +460,12 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float *x, const float 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
-// g[i] = f[i] > 0 ? g[i] : 0  (ReLU backward on the saved post-activation)
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float *f, long n, float *g)
+// g[i] = f[i] > 0 ? g[i] * scale : 0: backward of dropout(ReLU(.)) on the saved, already dropped
+// post-activation (a dropped or clamped element is 0 there; scale = 1 / (1 - p))
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float *f, long n, float scale, float *g)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        if (!(f[i] > 0.f)) g[i] = 0.f;
+        g[i] = f[i] > 0.f ? g[i] * scale : 0.f;
 }
 // through F.normalize + the validity mask (clip_cls.py:325-329): dm = valid ? (dfn - fn (fn . dfn)) / |m| : 0,
 // scaled by `scale` (the (1 - residual) of Adapter.residual_add on the way to out_proj)
@@ -615,11 +650,13 @@ extern "C" EC_API size_t ec_fs_trans_train_workspace_bytes(int B, int T, int D, 
 extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
                                             const float *text_param, int B, int T, int D, int K, float logit_scale,
                                             int agg, int use_probs_loss, const ec_adapter_train_params *w,
-                                            const ec_adapter_train_params *g, float *loss, float *grad_text,
+                                            const ec_adapter_train_params *g, float dropout_p,
+                                            uint64_t dropout_seed, float *loss, float *grad_text,
                                             float *agg_logits, void *workspace, size_t workspace_bytes,
                                             ec_stream_t stream)
 {
     EC_REQUIRE(B > 0 && T > 0 && D > 0 && K > 0, "ec_fs_trans_loss_grad: bad shape");
+    EC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "ec_fs_trans_loss_grad: dropout_p=%g", (double)dropout_p);
     EC_REQUIRE(w && g && w->blocks && g->blocks, "ec_fs_trans_loss_grad: null parameter / gradient structs");
     EC_REQUIRE(agg == EC_AGG_SUM || agg == EC_AGG_MEAN, "ec_fs_trans_loss_grad: agg must be sum or mean");
     const int d = w->d_model, ffn = w->ffn_dim, heads = w->heads, layers = w->layers;
@@ -644,6 +681,10 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
     const int R = B * T;
     const float r = w->residual;
     const unsigned ln_grid = (unsigned)((R + 3) / 4);
+    const float dp = dropout_p, keep_scale = 1.f / (1.f - dropout_p);
+    const unsigned long long seed = dropout_seed;
+    // dropout sites of layer l (nn.TransformerEncoderLayer, norm_first): 4 l + {0 attention weights,
+    // 1 dropout1 after out_proj, 2 dropout inside the MLP, 3 dropout2 after linear2}
 
     // ---------------- forward (adapter.py:82-105) ----------------
     linear_fwd(s, img_feats, w->in_w, w->in_b, R, D, d, t.h0);
@@ -653,26 +694,33 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
         LayerBufs &b = t.L[l];
         hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid), dim3(256), 0, s, h, p.ln1_g, p.ln1_b, R, d, b.a, b.xhat1, b.rstd1);
         linear_fwd(s, b.a, p.qkv_w, p.qkv_b, R, d, 3 * d, b.qkv);
-        hipLaunchKernelGGL(adapter_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, s, b.qkv, valid, T, d, heads, b.P, b.o);
-        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, h, (const float *)nullptr,
-                           (long)R * d, 1.f, 0.f, b.h1);
-        linear_fwd(s, b.o, p.o_w, p.o_b, R, d, d, b.h1, 1.f);                       // h1 = h + out_proj(o)
+        hipLaunchKernelGGL(adapter_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, s, b.qkv, valid, T, d, heads, b.P, b.o,
+                           dp, seed, (unsigned)(4 * l));
+        if (dp > 0.f) {
+            linear_fwd(s, b.o, p.o_w, p.o_b, R, d, d, t.dtmp_d);
+            hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, h, t.dtmp_d,
+                               (long)R * d, dp, seed, (unsigned)(4 * l + 1), b.h1);   // h1 = h + dropout1(out_proj(o))
+        } else {
+            hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, h, (const float *)nullptr,
+                               (long)R * d, 1.f, 0.f, b.h1);
+            linear_fwd(s, b.o, p.o_w, p.o_b, R, d, d, b.h1, 1.f);                   // h1 = h + out_proj(o)
+        }
         hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid), dim3(256), 0, s, b.h1, p.ln2_g, p.ln2_b, R, d, b.bn, b.xhat2,
                            b.rstd2);
         linear_fwd(s, b.bn, p.w1, p.b1, R, d, ffn, b.f, 0.f, true);                   // relu(linear1)
-        float *hn = (l + 1 < layers) ? t.L[l + 1].h1 : t.hfin;   // next layer's h1 buffer is free until its own turn
-        hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, b.h1, (const float *)nullptr,
-                           (long)R * d, 1.f, 0.f, hn);
-        linear_fwd(s, b.f, p.w2, p.b2, R, ffn, d, hn, 1.f);                           // h = h1 + linear2(f)
-        if (l + 1 < layers) {
-            // keep this layer's output where the next layer reads it, but its h1 slot must stay its own:
-            // copy into hfin as the running residual stream instead
-            hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, hn, (const float *)nullptr,
-                               (long)R * d, 1.f, 0.f, t.hfin);
-            h = t.hfin;
+        if (dp > 0.f)
+            hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for((long)R * ffn)), dim3(256), 0, s,
+                               (const float *)nullptr, b.f, (long)R * ffn, dp, seed, (unsigned)(4 * l + 2), b.f);
+        if (dp > 0.f) {
+            linear_fwd(s, b.f, p.w2, p.b2, R, ffn, d, t.dtmp_d);
+            hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, b.h1, t.dtmp_d,
+                               (long)R * d, dp, seed, (unsigned)(4 * l + 3), t.hfin);  // h = h1 + dropout2(linear2(f))
         } else {
-            h = t.hfin;
+            hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s, b.h1, (const float *)nullptr,
+                               (long)R * d, 1.f, 0.f, t.hfin);
+            linear_fwd(s, b.f, p.w2, p.b2, R, ffn, d, t.hfin, 1.f);                   // h = h1 + linear2(f)
         }
+        h = t.hfin;      // this layer's input is dead (ln_1 consumed it, h1 took its copy): reuse its slot
     }
     linear_fwd(s, h, w->out_w, w->out_b, R, d, D, t.y);
     hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((long)R * D)), dim3(256), 0, s, img_feats, t.y, (long)R * D, r,
@@ -696,9 +744,16 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
         const ec_adapter_train_layer &p = w->blocks[l];
         const ec_adapter_train_layer &q = g->blocks[l];
         LayerBufs &b = t.L[l];
-        // h = h1 + linear2(relu(linear1(ln2(h1))))
-        linear_bwd(s, b.f, p.w2, t.dh, R, ffn, d, t.df, 0.f, const_cast<float *>(q.w2), const_cast<float *>(q.b2));
-        hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for((long)R * ffn)), dim3(256), 0, s, b.f, (long)R * ffn, t.df);
+        // h = h1 + dropout2(linear2(dropout(relu(linear1(ln2(h1))))))
+        const float *dlin2 = t.dh;
+        if (dp > 0.f) {
+            hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s,
+                               (const float *)nullptr, t.dh, (long)R * d, dp, seed, (unsigned)(4 * l + 3), t.dtmp_d);
+            dlin2 = t.dtmp_d;
+        }
+        linear_bwd(s, b.f, p.w2, dlin2, R, ffn, d, t.df, 0.f, const_cast<float *>(q.w2), const_cast<float *>(q.b2));
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for((long)R * ffn)), dim3(256), 0, s, b.f, (long)R * ffn,
+                           keep_scale, t.df);
         linear_bwd(s, b.bn, p.w1, t.df, R, d, ffn, t.dtmp_d, 0.f, const_cast<float *>(q.w1), const_cast<float *>(q.b1));
         hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, b.xhat2, R, d,
                            const_cast<float *>(q.ln2_g));
@@ -708,10 +763,16 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
                            (long)R * d, 1.f, 0.f, t.dh1);
         hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, t.dtmp_d, b.xhat2, b.rstd2, p.ln2_g, R, d, t.dh1,
                            1);
-        // h1 = h + out_proj(attn(in_proj(ln1(h))))
-        linear_bwd(s, b.o, p.o_w, t.dh1, R, d, d, t.dtmp_d, 0.f, const_cast<float *>(q.o_w), const_cast<float *>(q.o_b));
+        // h1 = h + dropout1(out_proj(attn(in_proj(ln1(h)))))
+        const float *dlin_o = t.dh1;
+        if (dp > 0.f) {
+            hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for((long)R * d)), dim3(256), 0, s,
+                               (const float *)nullptr, t.dh1, (long)R * d, dp, seed, (unsigned)(4 * l + 1), t.dh);
+            dlin_o = t.dh;        // dh is rebuilt from dh1 below
+        }
+        linear_bwd(s, b.o, p.o_w, dlin_o, R, d, d, t.dtmp_d, 0.f, const_cast<float *>(q.o_w), const_cast<float *>(q.o_b));
         hipLaunchKernelGGL(adapter_attn_bwd_kernel, dim3(B * heads), dim3(64), 0, s, b.qkv, b.P, t.dtmp_d, T, d, heads,
-                           t.dqkv);
+                           t.dqkv, dp, seed, (unsigned)(4 * l));
         linear_bwd(s, b.a, p.qkv_w, t.dqkv, R, d, 3 * d, t.dtmp_d, 0.f, const_cast<float *>(q.qkv_w),
                    const_cast<float *>(q.qkv_b));
         hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, s, t.dtmp_d, b.xhat1, R, d,
@@ -723,6 +784,18 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
         hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, t.dtmp_d, b.xhat1, b.rstd1, p.ln1_g, R, d, t.dh, 1);
     }
     linear_bwd(s, img_feats, w->in_w, t.dh, R, D, d, nullptr, 0.f, g->in_w, g->in_b);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+extern "C" EC_API int ec_dropout_mask(uint64_t seed, uint32_t site, int64_t n, float p, uint8_t *mask,
+                                      ec_stream_t stream)
+{
+    EC_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, "ec_dropout_mask: n=%lld p=%g", (long long)n, (double)p);
+    if (n == 0) return EC_OK;
+    EC_REQUIRE(mask, "ec_dropout_mask: null buffer");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for((long)n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (long)n, p, (unsigned long long)seed, (unsigned)site, mask);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

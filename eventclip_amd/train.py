@@ -70,12 +70,23 @@ def _adapter_struct(adapter, tensors):
     return p, layers
 
 
+def dropout_mask(seed, site, n, p):
+    """Keep mask (uint8 CUDA [n]) of dropout site ``site`` = 4 * layer + {0 attention weights, 1 after
+    out_proj, 2 inside the MLP, 3 after linear2} as ``fs_trans_loss_grad`` draws it."""
+    dev = _lib.require_gpu()
+    m = torch.empty((int(n),), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().ec_dropout_mask(int(seed), int(site), int(n), float(p), _lib.ptr(m), _lib.stream_ptr()),
+               'ec_dropout_mask')
+    return m
+
+
 def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapter, agg='sum',
-                       use_probs_loss=False, return_logits=False):
+                       use_probs_loss=False, return_logits=False, dropout_p=0., seed=0):
     """The `text-trans` step: img_feats fp32 CUDA [B, T, D] with ZERO rows on invalid views
     (clip_cls.py:319-321), ``adapter`` an eventclip_amd.adapter.TransformerAdapter on the GPU.
     Returns (loss, grads) with grads = {adapter state-dict name: tensor, 'text_feats': [K, D]}
-    (the deterministic function: encoder-layer dropout is not applied)."""
+    dropout_p > 0: the train-mode dropouts of nn.TransformerEncoderLayer (p = 0.1 upstream), masks from a
+    stateless hash of (seed, site, element); 0: the deterministic eval-mode function."""
     import ctypes
     dev = _lib.require_gpu()
     if agg not in _AGG:
@@ -103,7 +114,7 @@ def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapte
     rc = _lib.lib().ec_fs_trans_loss_grad(
         _lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab),
         _lib.ptr(t), B, T, D, K, float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), ctypes.byref(ps),
-        ctypes.byref(gs), _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(logits), _lib.ptr(ws), ws.numel(),
+        ctypes.byref(gs), float(dropout_p), int(seed), _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(logits), _lib.ptr(ws), ws.numel(),
         _lib.stream_ptr())
     _lib.check(rc, 'ec_fs_trans_loss_grad')
     grads['text_feats'] = gtext
@@ -164,17 +175,18 @@ class TextFeatTrainer:
 
 class AdapterTrainer:
     """Trains the TransformerAdapter (+ ``text_feats`` for 'text-trans') of an FSCLIPClassifier on
-    cached encoder features: ``fs_trans_loss_grad`` + one ``adam_step`` per tensor.  Encoder-layer
-    dropout is not applied (see ``fs_trans_loss_grad``)."""
+    cached encoder features: ``fs_trans_loss_grad`` + one ``adam_step`` per tensor, with the
+    encoder layers' dropout (``dropout``, 0.1 like nn.TransformerEncoderLayer's default) reseeded per step."""
 
     def __init__(self, classifier, lr, total_steps, warmup_steps_pct=0.05, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.):
+                 weight_decay=0., dropout=0.1, seed=0):
         if getattr(classifier, 'adapter_type', None) != 'trans':
             raise NotImplementedError("AdapterTrainer handles adapter_type='trans' / 'text-trans'")
         self.clf = classifier
         self.lr, self.total_steps = float(lr), int(total_steps)
         self.warmup_steps = warmup_steps_pct * self.total_steps
         self.betas, self.eps, self.weight_decay = betas, float(eps), float(weight_decay)
+        self.dropout, self.seed = float(dropout), int(seed)
         self.tensors = {k: p.data for k, p in classifier.adapter.named_parameters()}
         if classifier.prompt_tuning:
             self.tensors['text_feats'] = classifier.text_feats.data
@@ -186,7 +198,8 @@ class AdapterTrainer:
         clf = self.clf
         text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
         loss, grads = fs_trans_loss_grad(img_feats, valid, labels, text, clf.logit_scale, clf.adapter,
-                                         clf.agg_func, clf.use_probs_loss)
+                                         clf.agg_func, clf.use_probs_loss, dropout_p=self.dropout,
+                                         seed=self.seed * 1000003 + self.steps)
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
         self.steps += 1

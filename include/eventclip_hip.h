@@ -388,8 +388,13 @@ EC_API int ec_adam_step(float *param, const float *grad, float *exp_avg, float *
  * out_proj -> residual mix) in front of the normalisation, differentiated with respect to every
  * adapter parameter and text_feats.  Parameter tensors are passed in torch's own layouts
  * ([out, in] weights, state-dict names in the comments), gradients come back in a second struct of the
- * same shape.  Dropout inside the encoder layers is not applied (the deterministic, eval-mode
- * function).  img_feats must hold ZERO rows for invalid views (clip_cls.py:319-321). */
+ * same shape.  img_feats must hold ZERO rows for invalid views (clip_cls.py:319-321).
+ * dropout_p > 0 applies the four dropouts of nn.TransformerEncoderLayer in train mode (attention
+ * weights, after out_proj, inside the MLP, after linear2; p = 0.1 upstream) with masks from a
+ * stateless hash of (dropout_seed, site, element) -- the same distribution as torch's, not its random
+ * stream; site = 4 * layer + {0, 1, 2, 3} in that order, element = flat index into [B, heads, T, T] /
+ * [B*T, d_model] / [B*T, ffn_dim] / [B*T, d_model].  ec_dropout_mask returns the keep mask of a site
+ * (tests replay it in the oracle).  dropout_p = 0: the deterministic, eval-mode function. */
 typedef struct {
     float *ln1_g, *ln1_b;   /* norm1.weight / .bias [d] */
     float *qkv_w, *qkv_b;   /* self_attn.in_proj_weight [3d, d] / in_proj_bias [3d] */
@@ -412,9 +417,12 @@ EC_API size_t ec_fs_trans_train_workspace_bytes(int B, int T, int D, int K, int 
 EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
                                  const float *text_param, int B, int T, int D, int K, float logit_scale,
                                  int agg, int use_probs_loss, const ec_adapter_train_params *params,
-                                 const ec_adapter_train_params *grads, float *loss, float *grad_text,
+                                 const ec_adapter_train_params *grads, float dropout_p,
+                                 uint64_t dropout_seed, float *loss, float *grad_text,
                                  float *agg_logits, void *workspace, size_t workspace_bytes,
                                  ec_stream_t stream);
+EC_API int ec_dropout_mask(uint64_t seed, uint32_t site, int64_t n, float p, uint8_t *mask,
+                           ec_stream_t stream);
 
 #ifdef __cplusplus
 }

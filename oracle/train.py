@@ -83,11 +83,14 @@ def cosine_warmup_lr(step, total_steps, max_lr, min_lr, warmup_steps):
 
 
 def fs_trans_loss_and_grads(sd, feats, valid, labels, text_param, logit_scale, heads, residual, agg='mean',
-                            probs_loss=False):
+                            probs_loss=False, dropout_p=0., masks=None):
     """'text-trans': loss and gradients of every adapter parameter and of text_feats, from torch
     float64 autograd over the oracle's own explicit forward (oracle/adapter.py's math, not the
     nn.Module).  sd: adapter state dict (reference names).  Pinned against the reference's
-    FSCLIPClassifier under autograd by tests/golden/train_text_trans.npz."""
+    FSCLIPClassifier under autograd by tests/golden/train_text_trans.npz.
+    masks (with dropout_p > 0): {(layer, site): keep mask} for the four train-mode dropouts of
+    nn.TransformerEncoderLayer, site 0 attention weights [B, heads, T, T], 1 after out_proj [B*T, d],
+    2 inside the MLP [B*T, ffn], 3 after linear2 [B*T, d]; applied as x * keep / (1 - p)."""
     import torch
     import torch.nn.functional as F
     p = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
@@ -101,6 +104,13 @@ def fs_trans_loss_and_grads(sd, feats, valid, labels, text_param, logit_scale, h
     hd = dm // heads
     n_layers = len({k.split('.')[2] for k in sd if k.startswith('transformer_encoder.layers.')})
     key_mask = torch.zeros(B, 1, 1, T, dtype=torch.float64).masked_fill(~m[:, None, None, :], float('-inf'))
+
+    def drop(v, layer, site):
+        if not dropout_p:
+            return v
+        keep = torch.tensor(np.asarray(masks[(layer, site)]), dtype=torch.float64).reshape(v.shape)
+        return v * keep / (1. - dropout_p)
+
     for i in range(n_layers):
         q = f'transformer_encoder.layers.{i}.'
         h = F.layer_norm(x, (dm,), p[q + 'norm1.weight'], p[q + 'norm1.bias'], 1e-5)
@@ -109,12 +119,15 @@ def fs_trans_loss_and_grads(sd, feats, valid, labels, text_param, logit_scale, h
         qq = qq.view(B, T, heads, hd).transpose(1, 2) * hd ** -0.5
         kk = kk.view(B, T, heads, hd).transpose(1, 2)
         vv = vv.view(B, T, heads, hd).transpose(1, 2)
-        att = (qq @ kk.transpose(-1, -2) + key_mask).softmax(-1)
+        att = drop((qq @ kk.transpose(-1, -2) + key_mask).softmax(-1), i, 0)
         o = (att @ vv).transpose(1, 2).reshape(B, T, dm)
-        x = x + F.linear(o, p[q + 'self_attn.out_proj.weight'], p[q + 'self_attn.out_proj.bias'])
+        sa = F.linear(o, p[q + 'self_attn.out_proj.weight'], p[q + 'self_attn.out_proj.bias'])
+        x = x + drop(sa.reshape(B * T, dm), i, 1).reshape(B, T, dm)
         h = F.layer_norm(x, (dm,), p[q + 'norm2.weight'], p[q + 'norm2.bias'], 1e-5)
         h = F.relu(F.linear(h, p[q + 'linear1.weight'], p[q + 'linear1.bias']))
-        x = x + F.linear(h, p[q + 'linear2.weight'], p[q + 'linear2.bias'])
+        h = drop(h.reshape(B * T, -1), i, 2).reshape(B, T, -1)
+        ff = F.linear(h, p[q + 'linear2.weight'], p[q + 'linear2.bias'])
+        x = x + drop(ff.reshape(B * T, dm), i, 3).reshape(B, T, dm)
     new = F.linear(x, p['out_proj.weight'], p['out_proj.bias'])
     mixed = x0 * residual + new * (1. - residual)
     fn = F.normalize(mixed, p=2, dim=-1) * m[..., None]

@@ -206,3 +206,41 @@ def test_adapter_trainer_reduces_the_loss_and_updates_the_forward(hip):
     want = (clf.logit_scale * fn @ tx.T).sum(1) / valid.sum(1, keepdim=True)
     torch.testing.assert_close(logits, want, rtol=1e-3, atol=1e-2)
     assert float((logits.argmax(-1) == labels).float().mean()) == 1.0
+
+
+def test_text_trans_dropout_replayed_in_the_oracle(hip):
+    """Train-mode dropout: the kernels' masks (ec_dropout_mask) replayed in the float64 oracle give the
+    same loss and gradients; the masks have the right rate and depend on seed and site."""
+    import torch
+    from eventclip_amd import train
+    from eventclip_amd.adapter import TransformerAdapter
+    from oracle import train as ot
+    torch.manual_seed(5)
+    B, T, D, K, d, ffn, heads, p_drop, seed = 12, 6, 96, 9, 64, 128, 4, 0.3, 987654321
+    ad = TransformerAdapter(in_dim=D, d_model=d, num_heads=heads, ffn_dim=ffn, num_layers=2, residual=0.6)
+    with torch.no_grad():
+        for q in ad.parameters():
+            q.add_(torch.randn_like(q) * 0.05)
+    valid = torch.rand(B, T) < 0.7
+    valid[:, 0] = True
+    labels = torch.randint(0, K, (B,))
+    text = torch.randn(K, D) * 0.5
+    feats = (torch.randn(B, T, D) + 0.15 * text[labels][:, None]) * valid[..., None]   # hard: the loss stays > 0
+    sizes = {0: B * heads * T * T, 1: B * T * d, 2: B * T * ffn, 3: B * T * d}
+    masks = {(l, s): train.dropout_mask(seed, 4 * l + s, n, p_drop).cpu().numpy() for l in range(2) for s, n in sizes.items()}
+    for (l, s_), mk in masks.items():
+        assert abs(mk.mean() - (1 - p_drop)) < 0.05, (l, s_, mk.mean())
+    assert not np.array_equal(masks[(0, 1)], masks[(0, 3)]) and not np.array_equal(masks[(0, 1)], masks[(1, 1)])
+    assert not np.array_equal(masks[(0, 1)], train.dropout_mask(seed + 1, 1, sizes[1], p_drop).cpu().numpy())
+    want_loss, want, _ = ot.fs_trans_loss_and_grads(
+        {k: v.detach().numpy() for k, v in ad.state_dict().items()}, feats.numpy(), valid.numpy(), labels.numpy(),
+        text.numpy(), 100.0, heads, 0.6, 'mean', False, dropout_p=p_drop, masks=masks)
+    got_loss, grads = train.fs_trans_loss_grad(feats.cuda(), valid.cuda(), labels.cuda(), text.cuda(), 100.0,
+                                               ad.cuda(), 'mean', False, dropout_p=p_drop, seed=seed)
+    assert abs(float(got_loss) - want_loss) < 3e-4 * max(1., abs(want_loss))
+    for k, g in grads.items():
+        err = np.abs(g.cpu().numpy() - want[k]).max()
+        assert err < 1e-3 * max(np.abs(want[k]).max(), 1e-4), (k, err, np.abs(want[k]).max())
+    # and it is not the deterministic function
+    det_loss, _ = train.fs_trans_loss_grad(feats.cuda(), valid.cuda(), labels.cuda(), text.cuda(), 100.0, ad, 'mean', False)
+    assert want_loss > 0.1 and abs(float(det_loss) - float(got_loss)) > 1e-3
