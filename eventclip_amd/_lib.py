@@ -105,6 +105,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_events_sort_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcEventsParams)]),
     'ec_center_events': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ec_augment_events': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'ec_pack_events': (c_int, [c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     'ec_events_to_frames_packed': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(EcEventsParams),
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -52,18 +52,22 @@ class Event2ImagePipeline:
         self.strict = True   # raise on events outside the sensor, as the reference does
 
     # ---- host bookkeeping: which event rows make which view ----
-    def plan(self, n_events, tflip=False):
+    def plan(self, n_events, tflip=False, starts=None):
         """n_events: per-sample event counts.  Returns (frame_range int64 [Fv, 2],
         row_idx int32 [B, T], valid_mask bool [B, T]) as CPU tensors; row_idx[b, t] is the
         compact frame number of view t of sample b, or -1 for a padded view.
         tflip: chunk the time-reversed stream (utils.py:26-35): chunk [a, b) of the reversed
-        order covers rows [n - b, n - a) of the stored order (a histogram ignores order)."""
+        order covers rows [n - b, n - a) of the stored order (a histogram ignores order).
+        starts: first event row of every sample when the samples are not back to back (after
+        eventclip_amd.augment.augment_events_device has dropped events)."""
         T = self.max_imgs
         B = len(n_events)
         ranges, row_idx = [], np.full((B, T), -1, dtype=np.int32)
         off = 0
         for b, n in enumerate(n_events):
             n = int(n)
+            if starts is not None:
+                off = int(starts[b])
             if n <= 0:
                 raise IndexError('sample with no events (the reference resamples these upstream, '
                                  'caltech.py:181-182)')
@@ -108,7 +112,7 @@ class Event2ImagePipeline:
             cat = np.concatenate([vis.parse_events(e) for e in host], axis=0)
         return torch.from_numpy(cat).to(dev), n_events
 
-    def __call__(self, events, n_events=None, hflip=False, tflip=False, center=False):
+    def __call__(self, events, n_events=None, hflip=False, tflip=False, center=False, starts=None):
         """events: list of per-sample float32 [n_i, 4] arrays/tensors (or packed uint64 [n_i],
         vis.pack_events), or one CUDA tensor [sum n_i, 4] (packed: int64 [sum n_i]) with
         ``n_events`` giving the per-sample counts.
@@ -125,10 +129,11 @@ class Event2ImagePipeline:
         assert events.is_cuda and n_events is not None
         assert vis.is_packed(events) or events.dtype == torch.float32
         if center:
-            offs = np.concatenate([[0], np.cumsum(n_events)])
-            sr = torch.tensor(np.stack([offs[:-1], offs[1:]], 1), dtype=torch.int64, device=dev)
+            o0 = np.asarray(starts if starts is not None else np.concatenate([[0], np.cumsum(n_events)[:-1]]))
+            offs = np.stack([o0, o0 + np.asarray(n_events)], 1)
+            sr = torch.tensor(offs, dtype=torch.int64, device=dev)
             vis.center_events_device(events, sr, self.resolution)
-        fr, ri, vm = self.plan(n_events, tflip=tflip)
+        fr, ri, vm = self.plan(n_events, tflip=tflip, starts=starts)
         fr_d = fr.to(dev)
         frames = self.frames(events, fr_d, hflip=hflip, tflip=tflip)
         out = dict(valid_mask=vm.to(dev), row_idx=ri.to(dev))

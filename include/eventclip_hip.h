@@ -112,6 +112,15 @@ EC_API int ec_events_to_frames(const float *events, const int64_t *frame_range, 
 EC_API int ec_center_events(float *events, const int64_t *sample_range, int B, int H, int W,
                             ec_stream_t stream);
 
+/* Training-time event augmentation (NCaltech101._augment_events, datasets/caltech.py:153-163 =
+ * datasets/utils.py random_time_flip_events, random_shift_events, random_flip_events_along_x in that
+ * order) applied with host-drawn parameters: params int32 [B, 4] = (x_shift, y_shift, flip_x, flip_t)
+ * per sample.  Events shifted off the sensor are dropped (utils.py:11-13) and the survivors compacted
+ * in order into events_out at the sample's original offset; counts_out int64 [B] receives how many. */
+EC_API int ec_augment_events(const float *events, const int64_t *sample_range, int B,
+                             const int32_t *params, int H, int W, float *events_out,
+                             int64_t *counts_out, ec_stream_t stream);
+
 /* ---- packed event ingest ------------------------------------------
  * The reference keeps events as float32 [n, 4] (x, y, t, p) (datasets/caltech.py:149-151; N-ImageNet's
  * structured x, y, t [us], p [0/1] is converted to that at datasets/imagenet.py:8-27) and only ever

@@ -66,3 +66,22 @@ def packed_fields(events):
     code = np.where(p == 0, 0, np.where(p > 0, 1, 2))
     t_us = np.clip(np.rint(ev[:, 2].astype(np.float64) * 1e6), 0, (1 << 30) - 1).astype(np.int64)
     return ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), code, t_us
+
+
+def augment_events(events, params, resolution):
+    """NCaltech101._augment_events (caltech.py:153-163) with the draws given: params =
+    (x_shift, y_shift, flip_x, flip_t).  utils.py:26-35, :4-15, :18-23 in that order."""
+    dx, dy, flip_x, flip_t = (int(v) for v in params)
+    H, W = resolution
+    ev = np.array(events, copy=True)
+    if flip_t:
+        ev = np.ascontiguousarray(np.flip(ev, axis=0))
+        ev[:, 2] = ev[0, 2] - ev[:, 2]
+        ev[:, 3] = -ev[:, 3]
+    ev[:, 0] += dx
+    ev[:, 1] += dy
+    keep = (ev[:, 0] >= 0) & (ev[:, 0] < W) & (ev[:, 1] >= 0) & (ev[:, 1] < H)
+    ev = ev[keep]
+    if flip_x:
+        ev[:, 0] = W - 1 - ev[:, 0]
+    return ev

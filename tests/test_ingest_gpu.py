@@ -114,3 +114,39 @@ def test_pipeline_accepts_packed_samples(hip):
     assert torch.equal(a['patches'], b['patches'])
     for va, vb in zip(pipe.tta(samples), pipe.tta([vis.pack_events(s) for s in samples])):
         assert torch.equal(va['patches'], vb['patches'])
+
+
+def test_event_augmentation_matches_reference_and_feeds_the_pipeline(hip):
+    """ec_augment_events == NCaltech101._augment_events' own output for replayed draws (bit for bit,
+    including the dropped events and the time flip), batched, and the pipeline accepts the result."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from eventclip_amd import augment, vis
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from oracle import event_utils as eu
+    z = np.load(os.path.join(GOLDEN, 'event_utils.npz'))
+    res = tuple(int(v) for v in z['resolution'])
+    ms = int(z['aug_max_shift'])
+    for i in range(int(z['n_cases'])):
+        for seed in (0, 1, 2, 3):
+            for ft in (0, 1):
+                np.random.seed(1000 * i + 10 * seed + ft)
+                got = augment.augment_events(z[f'in{i}'], res, ms, bool(ft))
+                np.testing.assert_array_equal(got, z[f'aug{i}_{seed}_{ft}'])
+    # a batch: per-sample parameters, survivors at the samples' original offsets
+    evs = [z[f'in{i}'].astype(np.float32) for i in range(int(z['n_cases']))]
+    prm = np.array([[5, -7, 1, 0], [-12, 12, 0, 1], [0, 0, 1, 1]], dtype=np.int32)
+    cat = torch.from_numpy(np.concatenate(evs)).cuda()
+    out, counts, starts = augment.augment_events_device(cat, [len(e) for e in evs], prm, res)
+    for b, e in enumerate(evs):
+        want = eu.augment_events(e, prm[b], res)
+        assert counts[b] == len(want)
+        np.testing.assert_array_equal(out[starts[b]:starts[b] + counts[b]].cpu().numpy(), want)
+    # frames of the augmented batch == frames of the separately augmented samples
+    qa = dict(split_method='event_count', convert_method='event_histogram', max_imgs=3, N=200,
+              grayscale=True, count_non_zero=False, background_mask=True)
+    pipe = Event2ImagePipeline(res, 600, qa, n_px=224, patch=32, kpad=3072)
+    a = pipe(out, counts, starts=starts)
+    b_ = pipe([eu.augment_events(e, prm[b], res) for b, e in enumerate(evs)])
+    assert torch.equal(a['valid_mask'], b_['valid_mask']) and torch.equal(a['patches'], b_['patches'])

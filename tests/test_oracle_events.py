@@ -71,3 +71,21 @@ def test_event_utils_oracle_matches_reference():
         np.testing.assert_array_equal(eu.tflip_events(ev.copy()), z[f'tflip{i}'])
         views = eu.tta_views(ev.copy(), res)
         np.testing.assert_array_equal(views[3], z[f'htflip{i}'])
+
+
+def test_event_augmentation_replays_the_reference_stream():
+    """Seeded numpy draws (eventclip_amd.augment.draw_event_augment makes the reference's calls in the
+    reference's order) + the oracle's restatement == NCaltech101._augment_events' own output."""
+    from conftest import GOLDEN
+    from eventclip_amd.augment import draw_event_augment
+    from oracle import event_utils as eu
+    z = np.load(os.path.join(GOLDEN, 'event_utils.npz'))
+    res = tuple(int(v) for v in z['resolution'])
+    ms = int(z['aug_max_shift'])
+    for i in range(int(z['n_cases'])):
+        for seed in (0, 1, 2, 3):
+            for ft in (0, 1):
+                np.random.seed(1000 * i + 10 * seed + ft)
+                prm = draw_event_augment(1, ms, bool(ft))[0]
+                got = eu.augment_events(z[f'in{i}'], prm, res)
+                np.testing.assert_array_equal(got, z[f'aug{i}_{seed}_{ft}'])

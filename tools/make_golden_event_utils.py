@@ -31,6 +31,18 @@ for i, (n, lo, hi) in enumerate([(700, (3, 2), (40, 30)), (500, (10, 0), (51, 35
     out[f'tflip{i}'] = ru.random_time_flip_events(ev.copy(), p=1.)
     h = ru.random_flip_events_along_x(ev.copy(), resolution=res, p=1.)
     out[f'htflip{i}'] = ru.random_time_flip_events(copy.deepcopy(h), p=1.)
+    # NCaltech101._augment_events (caltech.py:153-163): the reference's own functions in its order, with
+    # the global numpy stream seeded so the draws can be replayed
+    for seed in (0, 1, 2, 3):
+        for ft in (False, True):
+            np.random.seed(1000 * i + 10 * seed + int(ft))
+            a = ev.copy()
+            if ft:
+                a = ru.random_time_flip_events(a)
+            a = ru.random_shift_events(a, max_shift=12, resolution=res)
+            a = ru.random_flip_events_along_x(a, resolution=res)
+            out[f'aug{i}_{seed}_{int(ft)}'] = a
+out['aug_max_shift'] = np.array(12)
 out['resolution'] = np.array(res)
 out['n_cases'] = np.array(3)
 np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'event_utils.npz'), **out)
