@@ -27,8 +27,8 @@ namespace {
 
 using namespace ec;
 
-constexpr int AT_WAVES = 8;            // waves per workgroup (two workgroups fit a CU's LDS)
-constexpr int AT_THREADS = AT_WAVES * 64;
+// Waves per workgroup: 8 when two workgroups fit a CU's LDS (K + V <= 80 KiB: S <= 320), 16 when the
+// sequence's K and V leave room for one workgroup only (S = 577: 148 KiB) -- four waves per SIMD either way.
 
 struct AttnArgs {
     const void *qkv;  // [n_seq * S, 3W] 16-bit: q | k | v, heads are 64-wide column blocks
@@ -158,12 +158,13 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(const AttnArgs a)
+template <int DT, int AT_WAVES>
+__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
 
+    constexpr int AT_THREADS = AT_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = a.S, W = a.W;
     const int n32 = (S + 31) / 32;       // 32-key steps; keys padded to 32 * n32
@@ -253,17 +254,18 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const int lds = 32 * n32 * 128 * 2;
     if (lds > 160 * 1024)
         return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d > 640", a.S);
-    auto kern = attention_kernel<DT>;
-    static int attr_lds = 0;
-    if (lds > 64 * 1024 && lds > attr_lds) {
+    const bool wide = lds > 80 * 1024;       // one workgroup per CU: give it 16 waves
+    auto kern = wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>;
+    static int attr_lds[2] = {0, 0};
+    if (lds > 64 * 1024 && lds > attr_lds[wide]) {
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_lds = lds;
+        attr_lds[wide] = lds;
     }
     // algorithmic work: QK^T and PV, 2 * 2 * S^2 * 64 flops per head; bytes: read qkv, write out
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.q_rows * a.S * 64.0 * heads * n_seq,
                        (double)n_seq * a.W * 2.0 * (2.0 * a.S + 2.0 * a.q_rows));
-    hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(AT_THREADS), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)heads * (unsigned)n_seq), dim3(wide ? 1024 : 512), lds, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
