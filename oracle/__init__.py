@@ -31,6 +31,7 @@ Pinning (what anchors each restatement):
   ViT / text arithmetic lives in un-vendored ``openai/CLIP`` (``clip==1.0``,
   git HEAD) and no weights or golden vectors exist upstream.  The restatement
   follows the published architecture and is cross-checked against HF
-  ``transformers`` CLIP with seeded random weights
-  (``tools/make_golden_clip.py``).
+  ``transformers`` CLIP with seeded random weights: a tiny model for both towers
+  (``tools/make_golden_clip.py``) and the vision tower at the full ViT-L/14 / ViT-B/32 geometry and
+  depth (``tools/make_golden_vit.py``).
 """

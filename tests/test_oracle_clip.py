@@ -67,3 +67,16 @@ def test_patchify_layout_matches_conv():
     got = p @ wp.t()                                             # [2, 4, 8]
     want = F.conv2d(x, w, stride=14).reshape(2, 8, 4).permute(0, 2, 1)
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_oracle_outputs_agree_with_hf_transformers():
+    """tests/golden/towers_seeded.npz holds, for ViT-L/14 and ViT-B/32 at full depth (and L/14@336px at 4
+    layers), both the oracle's image features and HF transformers' for the same seeded weights and images."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'towers_seeded.npz'))
+    for name in ('vitl14', 'vitb32', 'vitl14_336'):
+        a, b = z[name], z[name + '_hf']
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() / np.abs(b).max() < 2e-5

@@ -143,6 +143,8 @@ def test_image_tower_matches_oracle_fixture(name, arch, ov, n, dt, tol, hip):
     assert rel_err(got, want) < tol
     if dt == 'float16':   # same 16-bit-rounded weights on both sides: arithmetic error only
         assert rel_err(got, torch.from_numpy(seeded(name + '_w16'))) < tol
+    # and against HF transformers' CLIP vision tower run on the same weights / images (tools/make_golden_vit.py)
+    assert rel_err(got, torch.from_numpy(seeded(name + '_hf'))) < tol
 
 
 @pytest.mark.parametrize('S,heads,causal,q_rows', [(257, 16, 0, 1), (257, 16, 0, 20), (50, 12, 0, 1),

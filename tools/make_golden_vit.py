@@ -14,6 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from eventclip_amd import clip as eclip  # noqa: E402
 from oracle import clip_ref  # noqa: E402
 
@@ -40,6 +41,17 @@ def main():
                                                    img).numpy()
         out[name + '_img_checksum'] = np.array(float(img.double().sum()))
         print(name, out[name].shape, float(np.abs(out[name]).max()))
+        # the same weights and images through HF transformers' CLIP vision tower at the full geometry
+        # (and depth, except the 336-px case): the restatement is not only checked on a toy model
+        import make_golden_clip as mgc
+        hf = mgc.hf_model(cfg, {**sd, 'logit_scale': torch.tensor(float(np.log(100.0)))})
+        with torch.no_grad():
+            hf_img = mgc.feats(hf.get_image_features(pixel_values=img))
+        rel = float((torch.from_numpy(out[name]) - hf_img).abs().max() / hf_img.abs().max())
+        print(f'  oracle vs HF transformers at {arch} {ov}: rel {rel:.2e}')
+        assert rel < 2e-5, rel
+        out[name + '_hf'] = hf_img.numpy()
+        del hf
     # text towers, full depth
     for name, arch in (('text_l14', 'ViT-L/14'), ('text_b32', 'ViT-B/32')):
         cfg = eclip.arch_config(arch, layers=1)
