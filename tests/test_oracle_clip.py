@@ -71,12 +71,13 @@ def test_patchify_layout_matches_conv():
 
 def test_full_size_oracle_outputs_agree_with_hf_transformers():
     """tests/golden/towers_seeded.npz holds, for ViT-L/14 and ViT-B/32 at full depth (and L/14@336px at 4
-    layers), both the oracle's image features and HF transformers' for the same seeded weights and images."""
+    layers) and the full-depth text towers, both the oracle's features and HF transformers' for the same seeded
+    weights and inputs."""
     import os
     import numpy as np
     from conftest import GOLDEN
     z = np.load(os.path.join(GOLDEN, 'towers_seeded.npz'))
-    for name in ('vitl14', 'vitb32', 'vitl14_336'):
+    for name in ('vitl14', 'vitb32', 'vitl14_336', 'text_l14', 'text_b32'):
         a, b = z[name], z[name + '_hf']
         assert a.shape == b.shape
         assert np.abs(a - b).max() / np.abs(b).max() < 2e-5

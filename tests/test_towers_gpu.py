@@ -208,6 +208,7 @@ def test_text_tower_matches_oracle_fixture(name, arch, precise, tol, hip):
     tok = eclip.synthetic_tokens(9, seed=3)
     got = model.encode_text(tok.cuda()).cpu()
     assert rel_err(got, torch.from_numpy(seeded(name))) < tol
+    assert rel_err(got, torch.from_numpy(seeded(name + '_hf'))) < tol      # HF transformers, same weights / tokens
 
 
 def test_precise_image_tower_reproduces_fp32_oracle(hip):

@@ -59,6 +59,15 @@ def main():
         tok = eclip.synthetic_tokens(9, seed=3)
         out[name] = clip_ref.encode_text(sd, cfg, tok).numpy()
         print(name, out[name].shape)
+        import make_golden_clip as mgc
+        hf = mgc.hf_model(cfg, {**sd, 'logit_scale': torch.tensor(float(np.log(100.0)))})
+        with torch.no_grad():
+            hf_txt = mgc.feats(hf.get_text_features(input_ids=tok.long()))
+        rel = float((torch.from_numpy(out[name]) - hf_txt).abs().max() / hf_txt.abs().max())
+        print(f'  oracle vs HF transformers text tower of {arch}: rel {rel:.2e}')
+        assert rel < 2e-5, rel
+        out[name + '_hf'] = hf_txt.numpy()
+        del hf
     np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'towers_seeded.npz'), **out)
 
 
