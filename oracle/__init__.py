@@ -18,8 +18,9 @@ Pinning (what anchors each restatement):
 * ``oracle.event_utils`` -- pinned: ``center_events`` / flips against the reference's
   ``datasets/utils.py`` (``tools/make_golden_event_utils.py``) and the N-ImageNet reader against
   the reference's ``datasets/imagenet.py:load_event`` (``tools/make_golden_ingest.py``).
-* ``oracle.pseudo_label`` -- PARITY UNPINNED: restates code that is inline in ``gen_data.py``'s
-  ``main()`` (lines 132-164, 196-215), which cannot run without clip / nerv / datasets.
+* ``oracle.pseudo_label`` -- pinned: ``gen_data.py``'s ``main()`` itself is run with stand-ins for clip /
+  nerv / models / datasets around the selection code (lines 132-164, 196-215) and the pseudo-labels it
+  writes are the fixture (``tools/make_golden_pseudo.py``).
 * ``oracle.train`` -- pinned: loss and gradients of the `text-identity` and `text-trans` few-shot steps
   against the reference's own ``FSCLIPClassifier`` under torch autograd
   (``tools/make_golden_train.py``); Adam against ``torch.optim.Adam``; the warm-up + cosine schedule is

@@ -1,9 +1,11 @@
 """Oracle for the pseudo-label filter (TEST INFRASTRUCTURE).
 
 Restates the per-batch tensor code of /root/reference/gen_data.py:132-164 and the --topk
-post-filter of :196-215 with torch on the CPU.  PARITY UNPINNED: that code is inline in
-gen_data.py's main(), which needs clip / nerv / the datasets to run, so no fixture can be produced
-from the reference itself; the restatement follows the cited lines operation by operation.
+post-filter of :196-215 with torch on the CPU.  Pinned by tests/golden/pseudo_label.npz: that code is
+inline in gen_data.py's main(), so tools/make_golden_pseudo.py runs main() itself end to end with
+in-memory stand-ins for what surrounds it (clip, nerv, build_model, build_dataset; a fake classifier returns
+prescribed probabilities) and reads the per-sample pseudo-labels off the symlink tree it writes, for 30
+combinations of --tta / --tta_consistent / --tta_min_prob / --conf_thresh / --topk.
 """
 import torch
 

@@ -28,3 +28,30 @@ def test_topk_keeps_most_confident_per_class():
     sel = torch.tensor([True, True, True, True, False, True])
     assert opl.topk_per_class(pred, prob, sel, 3, 2).tolist() == [True, False, True, True, False, True]
     assert opl.topk_per_class(pred, prob, sel, 3, 1).tolist() == [True, False, False, True, False, True]
+
+
+def _golden():
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, 'pseudo_label.npz'))
+
+
+def _parse(tag):
+    parts = tag.split('_')
+    return (parts[0] == 'tta1', parts[1] == 'c1', parts[2] == 'm1', float(parts[3][1:]), int(parts[4][1:]))
+
+
+def test_oracle_matches_the_references_gen_data_main():
+    """tests/golden/pseudo_label.npz: per-sample pseudo-labels written by the reference's own gen_data.main()
+    (tools/make_golden_pseudo.py drives it with stand-ins around the selection code) for 30 flag combinations."""
+    import numpy as np
+    z = _golden()
+    probs4, labels, K = torch.from_numpy(z['probs4']), torch.from_numpy(z['labels']), int(z['K'])
+    for tag in z['cases']:
+        tta, cons, minp, thr, topk = _parse(str(tag))
+        p = probs4.flatten(0, 1) if tta else probs4[:, 0]
+        r = opl.select(p, thr, tta, cons, minp)
+        keep = opl.topk_per_class(r['pred'], r['max_prob'], r['selected'], K, topk) if topk > 0 else r['selected']
+        got = torch.where(keep, r['pred'], torch.full_like(r['pred'], -1)).numpy()
+        np.testing.assert_array_equal(got, z['sel_' + str(tag)], err_msg=str(tag))

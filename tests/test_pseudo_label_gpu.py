@@ -99,3 +99,24 @@ def test_labeler_end_to_end_tiny(hip):
     want = opl.select(torch.stack(views, 1).flatten(0, 1).cpu(), 1.0 / K, True, True, False)
     assert torch.equal(got['pred'].cpu(), want['pred'])
     assert torch.equal(got['selected'].cpu(), want['selected'])
+
+
+def test_kernel_matches_the_references_gen_data_main(hip):
+    """ec_pseudo_label + topk_per_class against the per-sample pseudo-labels the reference's own
+    gen_data.main() wrote (tests/golden/pseudo_label.npz), all 30 flag combinations."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from eventclip_amd import pseudo_label as pl
+    z = np.load(os.path.join(GOLDEN, 'pseudo_label.npz'))
+    probs4, K = torch.from_numpy(z['probs4']).cuda(), int(z['K'])
+    for tag in z['cases']:
+        parts = str(tag).split('_')
+        tta, cons, minp = parts[0] == 'tta1', parts[1] == 'c1', parts[2] == 'm1'
+        thr, topk = float(parts[3][1:]), int(parts[4][1:])
+        p = probs4.flatten(0, 1) if tta else probs4[:, 0].contiguous()
+        r = pl.select(p, thr, tta, cons, minp)
+        keep = pl.topk_per_class(r['pred'], r['max_prob'], r['selected'], K, topk)
+        got = torch.where(keep, r['pred'], torch.full_like(r['pred'], -1)).cpu().numpy()
+        np.testing.assert_array_equal(got, z['sel_' + str(tag)], err_msg=str(tag))
