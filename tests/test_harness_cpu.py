@@ -187,3 +187,31 @@ def test_tokenize_with_synthetic_bpe_vocab(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError):
         eclip.tokenize('cat')
     eclip._tokenizer.cache_clear()
+
+
+def test_meters_match_the_references_test_py_main():
+    """tests/golden/eval_meters.npz: accuracies printed / returned by the reference's own test.py main()
+    (driven with stand-ins by tools/make_golden_eval.py) for uneven batches, top-1 and top-5."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from eventclip_amd.harness import AverageMeter, batch_accuracies
+    z = np.load(os.path.join(GOLDEN, 'eval_meters.npz'))
+    for name, top5 in (('ncaltech', False), ('nin', True)):
+        labels, logits, probs = (torch.from_numpy(z[f'{name}_{k}']) for k in ('labels', 'logits', 'probs'))
+        meters, i0 = {}, 0
+        for n in z[name + '_sizes']:
+            sl = slice(i0, i0 + int(n))
+            acc = batch_accuracies({'probs': probs[sl], 'logits': logits[sl]}, labels[sl], top5=top5)
+            for k, v in acc.items():
+                meters.setdefault(k, AverageMeter()).update(v, int(n))
+            i0 += int(n)
+        got = {k: m.avg for k, m in meters.items()}
+        assert abs(got['probs_acc'] - float(z[name + '_acc1'][0])) < 1e-12
+        assert abs(got['logits_acc'] - float(z[name + '_acc1'][1])) < 1e-12
+        printed = z[name + '_printed']
+        order = ['probs_acc', 'logits_acc'] + (['probs_acc5', 'logits_acc5'] if top5 else [])
+        assert len(printed) == len(order)
+        for k, want in zip(order, printed):
+            assert abs(round(got[k] * 100., 2) - float(want)) < 1e-9, (name, k)
