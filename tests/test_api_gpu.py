@@ -120,3 +120,42 @@ def test_evaluate_harness_with_pipeline(hip):
     assert abs(accs['logits_acc'] - 0.75) < 1e-6                       # (1.0 * 3 + 0.0 * 1) / 4
     assert set(accs) == {'probs_acc', 'logits_acc', 'probs_acc5', 'logits_acc5'}
     assert accs['logits_acc5'] >= accs['logits_acc']
+
+
+def test_views_match_the_references_event2image_dataset(hip):
+    """Frames, zero padding, masks, the random chunk subset (same torch RNG stream) and the four TTA views
+    in order, against the reference's own Event2ImageDataset run with an identity transform
+    (tests/golden/event2img.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from eventclip_amd.event2img import Event2ImagePipeline
+    z = np.load(os.path.join(GOLDEN, 'event2img.npz'))
+    qa = dict(max_imgs=int(z['qa_max_imgs']), split_method=str(z['qa_split_method']),
+              convert_method=str(z['qa_convert_method']), N=int(z['qa_N']), grayscale=bool(z['qa_grayscale']),
+              count_non_zero=bool(z['qa_count_non_zero']), background_mask=bool(z['qa_background_mask']))
+    res = tuple(int(v) for v in z['resolution'])
+    pipe = Event2ImagePipeline(res, int(z['max_n']), qa, n_px=224)
+    T = pipe.max_imgs
+
+    def views(ev_d, n, hflip, tflip):
+        fr, ri, vm = pipe.plan([n], tflip=tflip)
+        frames = pipe.frames(ev_d, fr.cuda(), hflip=hflip, tflip=tflip).cpu().numpy()
+        full = np.zeros((T, *res, 3), dtype=np.uint8)                      # padded views are all-zero tensors
+        for t in range(T):
+            if ri[0, t] >= 0:
+                full[t] = frames[int(ri[0, t])]
+        return full, vm[0].numpy()
+
+    for i, n in enumerate(z['counts']):
+        ev_d = torch.from_numpy(z[f'events{i}']).cuda()
+        torch.manual_seed(1000 + i)
+        got, vm = views(ev_d, int(n), False, False)
+        np.testing.assert_array_equal(vm, z[f'tta0_valid{i}'])
+        np.testing.assert_array_equal(got, z[f'tta0_img{i}'].transpose(0, 2, 3, 1))
+        torch.manual_seed(1000 + i)
+        for v, (h, t) in enumerate(((False, False), (True, False), (False, True), (True, True))):
+            got, vm = views(ev_d, int(n), h, t)                                # event2img.py:97-103 order
+            np.testing.assert_array_equal(vm, z[f'tta1_valid{i}'][v])
+            np.testing.assert_array_equal(got, z[f'tta1_img{i}'][v].transpose(0, 2, 3, 1), err_msg=f'sample {i} view {v}')

@@ -215,3 +215,29 @@ def test_meters_match_the_references_test_py_main():
         assert len(printed) == len(order)
         for k, want in zip(order, printed):
             assert abs(round(got[k] * 100., 2) - float(want)) < 1e-9, (name, k)
+
+
+def _e2i():
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'event2img.npz'))
+    qa = dict(max_imgs=int(z['qa_max_imgs']), split_method=str(z['qa_split_method']),
+              convert_method=str(z['qa_convert_method']), N=int(z['qa_N']), grayscale=bool(z['qa_grayscale']),
+              count_non_zero=bool(z['qa_count_non_zero']), background_mask=bool(z['qa_background_mask']))
+    return z, qa
+
+
+def test_view_planning_matches_the_references_event2image_dataset():
+    """max_imgs, valid masks and view counts of the reference's own Event2ImageDataset
+    (tests/golden/event2img.npz, tools/make_golden_event2img.py) from Event2ImagePipeline.plan (host only)."""
+    import torch
+    from eventclip_amd.event2img import Event2ImagePipeline
+    z, qa = _e2i()
+    pipe = Event2ImagePipeline(tuple(int(v) for v in z['resolution']), int(z['max_n']), qa, n_px=224)
+    assert pipe.max_imgs == int(z['max_imgs'])
+    for i, n in enumerate(z['counts']):
+        torch.manual_seed(1000 + i)
+        fr, ri, vm = pipe.plan([int(n)])
+        assert vm[0].tolist() == z[f'tta0_valid{i}'].tolist()
+        assert fr.shape[0] == int(z[f'tta0_valid{i}'].sum())
