@@ -244,3 +244,24 @@ def test_text_trans_dropout_replayed_in_the_oracle(hip):
     # and it is not the deterministic function
     det_loss, _ = train.fs_trans_loss_grad(feats.cuda(), valid.cuda(), labels.cuda(), text.cuda(), 100.0, ad, 'mean', False)
     assert want_loss > 0.1 and abs(float(det_loss) - float(got_loss)) > 1e-3
+
+
+def test_two_rank_training_equals_one_rank_full_batch(hip, tmp_path):
+    """DDP semantics of AdapterTrainer: two ranks (gloo, sharing the one GPU) on half batches with the
+    gradient all-reduce reach the same parameters as one rank on the full batch (mean losses, equal shards)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, 'tests', 'ddp_train_worker.py')
+    one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    r = subprocess.run([sys.executable, worker, one], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29544', worker, two], cwd=root,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert set(a.files) == set(b.files) and len(a.files) == 29
+    for k in a.files:
+        np.testing.assert_allclose(b[k], a[k], rtol=2e-4, atol=2e-6, err_msg=k)
