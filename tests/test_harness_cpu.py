@@ -241,3 +241,39 @@ def test_view_planning_matches_the_references_event2image_dataset():
         fr, ri, vm = pipe.plan([int(n)])
         assert vm[0].tolist() == z[f'tta0_valid{i}'].tolist()
         assert fr.shape[0] == int(z[f'tta0_valid{i}'].sum())
+
+
+def test_lora_fold_matches_the_references_effective_weights():
+    """eventclip_amd.lora.merge_lora_visual against the reference's own LoRA modules (tests/golden/lora.npz,
+    tools/make_golden_lora.py): int rank (q, k, v), 'qv-3' (no k factors) and 'qkvo-2' (out_proj too)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from eventclip_amd.lora import load_finetuned_visual, merge_lora_visual
+    z = np.load(os.path.join(GOLDEN, 'lora.npz'))
+    for tag in ('r4', 'qv', 'qkvo'):
+        sd = {k.split('sd:')[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + '/sd:')}
+        base = {k.split('base:')[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + '/base:')}
+        merged = merge_lora_visual(sd)
+        assert sorted(merged) == sorted(base)                         # plain nn.MultiheadAttention keys again
+        x = torch.from_numpy(z[tag + '/x'])
+        for i in range(2):
+            pre = f'transformer.resblocks.{i}.attn.'
+            for name in ('in_proj_weight', 'out_proj.weight'):
+                want = z[f'{tag}/eff:{pre}{name}']
+                np.testing.assert_allclose(merged[pre + name].numpy(), want, rtol=1e-6, atol=1e-7)
+            assert torch.equal(merged[pre + 'in_proj_bias'], base[pre + 'in_proj_bias'])
+            # a plain MHA with the folded weights reproduces the LoRA module's output
+            mha = torch.nn.MultiheadAttention(x.shape[-1], 2).eval()
+            mha.load_state_dict({k[len(pre):]: v for k, v in merged.items() if k.startswith(pre)})
+            with torch.no_grad():
+                y = mha(x, x, x, need_weights=False)[0]
+            np.testing.assert_allclose(y.numpy(), z[f'{tag}/y{i}'], rtol=1e-5, atol=1e-6)
+        if tag == 'qv':       # no k factors: the k block is the frozen weight
+            w = merged['transformer.resblocks.0.attn.in_proj_weight']
+            assert torch.equal(w[16:32], sd['transformer.resblocks.0.attn.in_proj_weight.merged_proj'][16:32])
+    ck = {'state_dict': {'model.visual.' + k: v for k, v in sd.items()} | {'text_feats': torch.zeros(2, 4)}}
+    full = load_finetuned_visual({'visual.conv1.weight': torch.ones(1), 'token_embedding.weight': torch.ones(1)}, ck)
+    assert 'token_embedding.weight' in full and 'visual.conv1.weight' not in full
+    assert 'visual.transformer.resblocks.1.attn.out_proj.weight' in full and not any('lora' in k for k in full)
