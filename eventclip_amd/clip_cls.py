@@ -6,8 +6,9 @@ Mirror of /root/reference/models/clip_cls.py: ``ZSCLIPClassifier`` (:14-219) and
 ``get_img_feats``, ``get_text_feats``, ``state_dict`` / ``load_state_dict`` that
 leave the frozen CLIP weights out, and ``load_weight``.  The arithmetic (image tower,
 text tower, adapter, logits, aggregation) is done by libeventclip_hip.so; torch is
-used for tensors and the nn.Module plumbing only.  Inference only: the training
-losses of the reference (calc_train_loss, :164-175) are outside the accelerated path.
+used for tensors and the nn.Module plumbing only.  ``forward`` is the inference path; the
+training losses of the reference (calc_train_loss, :164-175) and their gradients live in
+``eventclip_amd.train`` (cached-feature few-shot training).
 
 ``forward`` accepts the reference's batch (``img`` [B, T, 3, R, R] + ``valid_mask``)
 or the fused batch of ``Event2ImagePipeline`` (``patches`` + ``row_idx`` +
@@ -30,51 +31,48 @@ def _l2_normalize(x):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
 
 
+# constructor defaults of the reference (clip_cls.py:17-30, :225-243)
+ZS_CLIP_DEFAULTS = dict(clip_model=None, prompt='a point cloud image of a {}', class_names=None, agg_func='sum')
+ZS_LOSS_DEFAULTS = dict(use_logits_loss=True, use_probs_loss=False)
+FS_ADAPTER_DEFAULTS = dict(adapter_type='trans', residual=True)
+FS_LOSS_DEFAULTS = dict(use_logits_loss=False, use_probs_loss=True)
+_ADAPTERS = {'identity': IdentityAdapter, 'trans': TransformerAdapter}
+
+
 class ZSCLIPClassifier(nn.Module):
     """CLIP model for **zero-shot** classification (clip_cls.py:14-219)."""
 
-    def __init__(
-            self,
-            clip_dict=dict(
-                clip_model=None,
-                prompt='a point cloud image of a {}',
-                class_names=None,
-                agg_func='sum',
-            ),
-            loss_dict=dict(
-                use_logits_loss=True,
-                use_probs_loss=False,
-            ),
-    ):
+    def __init__(self, clip_dict=None, loss_dict=None):
         super().__init__()
-        self.clip_dict = clip_dict
-        self.loss_dict = loss_dict
+        self.clip_dict = dict(ZS_CLIP_DEFAULTS) if clip_dict is None else clip_dict
+        self.loss_dict = dict(ZS_LOSS_DEFAULTS) if loss_dict is None else loss_dict
         self._build_clip()
         self._build_loss()
 
     def _build_clip(self):
-        model = self.clip_dict['clip_model']
-        for p in model.parameters():                                     # clip_cls.py:41-42
-            p.requires_grad = False
-        self.model = model.eval()
-        self.logit_scale = model.logit_scale.exp().item()                # clip_cls.py:44
-        self.prompt = self.clip_dict['prompt']
-        self.class_names = self.clip_dict['class_names']
+        cd = self.clip_dict
+        clip_model = cd['clip_model']
+        for w in clip_model.parameters():                                # frozen encoder, clip_cls.py:41-42
+            w.requires_grad_(False)
+        self.model = clip_model.eval()
+        self.logit_scale = float(clip_model.logit_scale.exp())           # clip_cls.py:44
+        self.prompt, self.class_names, self.agg_func = cd['prompt'], cd['class_names'], cd['agg_func']
+        if self.agg_func not in _AGG:                                    # clip_cls.py:53
+            raise AssertionError(f'agg_func {self.agg_func!r} not in {sorted(_AGG)}')
         # token ids [K, 77] for the class prompts, for when the BPE vocabulary file is not
         # available to clip.tokenize (it does not ship with this repo)
-        self.class_tokens = self.clip_dict.get('class_tokens', None)
-        self.text_feats = None
-        self._text_t = None
-        self.agg_func = self.clip_dict['agg_func']
-        assert self.agg_func in ['sum', 'mean', 'max']                   # clip_cls.py:53
+        self.class_tokens = cd.get('class_tokens', None)
+        self.text_feats, self._text_t = None, None
 
     def _build_loss(self):
-        self.use_logits_loss = self.loss_dict['use_logits_loss']
-        self.use_probs_loss = self.loss_dict['use_probs_loss']
-        assert int(self.use_logits_loss) + int(self.use_probs_loss) == 1
+        ld = self.loss_dict
+        self.use_logits_loss, self.use_probs_loss = ld['use_logits_loss'], ld['use_probs_loss']
+        if bool(self.use_logits_loss) == bool(self.use_probs_loss):      # exactly one of them, clip_cls.py:58-61
+            raise AssertionError('set exactly one of use_logits_loss / use_probs_loss')
 
     def _same_class_names(self, class_names):
-        return all([c1 == c2 for c1, c2 in zip(class_names, self.class_names)])
+        """Pairwise comparison over the shorter of the two lists, as clip_cls.py:62."""
+        return all(a == b for a, b in zip(class_names, self.class_names))
 
     def _tokenize(self, class_names):
         if self.class_tokens is not None and (class_names is self.class_names or
@@ -110,21 +108,17 @@ class ZSCLIPClassifier(nn.Module):
         """imgs [N, 3, R, R] -> [N, C] (clip_cls.py:95-102)."""
         return self.model.encode_image(imgs)
 
-    # torch restatements kept for API parity (the HIP path aggregates in ec_classify)
+    # torch versions of the two aggregations, kept for API parity (the HIP path does them in ec_classify)
     def _aggregate_logits(self, logits, valid_masks):
-        if self.agg_func == 'sum':
-            return logits.sum(1)
-        if self.agg_func == 'mean':
-            return logits.sum(1) / valid_masks.float().sum(1, keepdim=True)
-        if self.agg_func == 'max':
-            logits = logits - (1. - valid_masks.float())[..., None] * 1e6
-            return logits.max(1)[0]
-        raise NotImplementedError
+        m = valid_masks.float()
+        if self.agg_func == 'max':                       # the evident intent of clip_cls.py:116-118
+            return (logits - (1. - m).unsqueeze(-1) * 1e6).amax(1)
+        total = logits.sum(1)
+        return total / m.sum(1, keepdim=True) if self.agg_func == 'mean' else total
 
     def _aggregate_probs(self, logits, valid_masks):
-        valid_masks = valid_masks.detach().float()
-        probs = logits.softmax(dim=-1) * valid_masks[..., None]
-        return probs.sum(1) / valid_masks.sum(1, keepdim=True)
+        m = valid_masks.detach().float()
+        return (logits.softmax(-1) * m.unsqueeze(-1)).sum(1) / m.sum(1, keepdim=True)
 
     # ---- shared pieces of forward ----
     def _view_feats(self, data_dict):
@@ -164,33 +158,21 @@ class ZSCLIPClassifier(nn.Module):
         feats, row_idx, valid_masks = self._view_feats(data_dict)
         # logits = logit_scale * img_feats @ text_feats.T with UN-normalised image feats (:148)
         full_logits, logits, probs = self._classify(feats, row_idx, normalize=False)
-        return {
-            'full_logits': full_logits,  # [B, T, n_classes]
-            'valid_masks': valid_masks,  # [B, T]
-            'logits': logits,  # [B, n_classes]
-            'probs': probs,  # [B, n_classes]
-        }
+        return dict(full_logits=full_logits, valid_masks=valid_masks, logits=logits, probs=probs)
 
     @torch.no_grad()
     def calc_eval_loss(self, data_dict, out_dict):
         """Accuracies of clip_cls.py:177-192 (the CE terms belong to training)."""
-        labels = data_dict['label']
-        return {
-            'probs_acc': (out_dict['probs'].argmax(dim=-1) == labels).float().mean(),
-            'logits_acc': (out_dict['logits'].argmax(dim=-1) == labels).float().mean(),
-        }
+        y = data_dict['label']
+        hit = lambda scores: (scores.argmax(-1) == y).float().mean()     # noqa: E731
+        return dict(probs_acc=hit(out_dict['probs']), logits_acc=hit(out_dict['logits']))
 
-    @property
-    def dtype(self):
-        return self.model.logit_scale.dtype
-
-    @property
-    def device(self):
-        return self.model.logit_scale.device
+    dtype = property(lambda self: self.model.logit_scale.dtype)          # clip_cls.py:194-200
+    device = property(lambda self: self.model.logit_scale.device)
 
     def train(self, mode=True):
-        nn.Module.train(self, mode)
-        self.model.eval()                                                # clip_cls.py:202-206
+        super().train(mode)
+        self.model.eval()                 # the encoder never leaves eval mode (clip_cls.py:202-206)
         return self
 
     def state_dict(self, *args, **kwargs):
@@ -199,9 +181,9 @@ class ZSCLIPClassifier(nn.Module):
         return {k: v for k, v in w.items() if not k.startswith('model.')}
 
     def load_state_dict(self, state_dict, strict=True):
-        clip_w = {f'model.{k}': v for k, v in self.model.state_dict().items()}   # :214-219
-        state_dict = {**clip_w, **state_dict}
-        out = super().load_state_dict(state_dict, strict=strict)
+        merged = {'model.' + k: v for k, v in self.model.state_dict().items()}    # :214-219
+        merged.update(state_dict)
+        out = super().load_state_dict(merged, strict=strict)
         self._text_t = None
         return out
 
@@ -215,61 +197,37 @@ class ZSCLIPClassifier(nn.Module):
 class FSCLIPClassifier(ZSCLIPClassifier):
     """CLIP model for **few-shot** classification (clip_cls.py:222-354)."""
 
-    def __init__(
-            self,
-            adapter_dict=dict(
-                adapter_type='trans',
-                residual=True,
-            ),
-            clip_dict=dict(
-                clip_model=None,
-                prompt='a point cloud image of a {}',
-                class_names=None,
-                agg_func='sum',
-            ),
-            loss_dict=dict(
-                use_logits_loss=False,
-                use_probs_loss=True,
-            ),
-    ):
-        super().__init__(clip_dict=clip_dict, loss_dict=loss_dict)
-        self.adapter_dict = copy.deepcopy(adapter_dict)
+    def __init__(self, adapter_dict=None, clip_dict=None, loss_dict=None):
+        super().__init__(clip_dict=clip_dict, loss_dict=dict(FS_LOSS_DEFAULTS) if loss_dict is None else loss_dict)
+        self.adapter_dict = copy.deepcopy(FS_ADAPTER_DEFAULTS if adapter_dict is None else adapter_dict)
         self._build_adapter()
 
     def _build_prompts(self, adapter_type):
+        """'text-xxx': the class prompts' features become a trainable parameter (clip_cls.py:253-259)."""
         with torch.no_grad():
-            text_feats = ZSCLIPClassifier.get_text_feats(self).float()   # [n_classes, C]
-        self.text_feats = nn.Parameter(text_feats.clone(), requires_grad=True)
-        return adapter_type[5:]
+            init = ZSCLIPClassifier.get_text_feats(self).float().clone()  # [n_classes, C]
+        self.text_feats = nn.Parameter(init, requires_grad=True)
+        return adapter_type[len('text-'):]
 
     def _build_adapter(self):
-        adapter_type = self.adapter_dict.pop('adapter_type').lower()
-        if adapter_type.startswith('text-'):                             # clip_cls.py:263-266
-            self.prompt_tuning = True
-            adapter_type = self._build_prompts(adapter_type)
-        else:
-            self.prompt_tuning = False
-        self.adapter_type = adapter_type
-        if adapter_type == 'identity':
-            model = IdentityAdapter
-        elif adapter_type == 'trans':
-            model = TransformerAdapter
-        else:
-            raise NotImplementedError(f'adapter {adapter_type} not supported!')
-        self.adapter = model(**self.adapter_dict)
+        kind = self.adapter_dict.pop('adapter_type').lower()
+        self.prompt_tuning = kind.startswith('text-')                    # clip_cls.py:263-266
+        if self.prompt_tuning:
+            kind = self._build_prompts(kind)
+        if kind not in _ADAPTERS:
+            raise NotImplementedError(f'adapter {kind} not supported!')
+        self.adapter_type = kind
+        self.adapter = _ADAPTERS[kind](**self.adapter_dict)
 
     def _adjust_dtype(self, x):
-        if self.training:
-            return x
-        return x.type(self.dtype)
+        """fp16 encoder outputs are widened to the adapter's dtype outside training (clip_cls.py:281-288)."""
+        return x if self.training else x.to(self.dtype)
 
     def get_text_feats(self, class_names=None):
         if self.prompt_tuning:                                           # clip_cls.py:292-295
-            text_feats = _l2_normalize(self.text_feats)
-        else:
-            with torch.no_grad():
-                text_feats = super().get_text_feats(class_names)
-        return self._adjust_dtype(text_feats)
+            return self._adjust_dtype(_l2_normalize(self.text_feats))
+        with torch.no_grad():
+            return self._adjust_dtype(super().get_text_feats(class_names))
 
     def _text_transposed(self):
         # learned text features can change under load_state_dict: rebuild when asked
@@ -277,10 +235,9 @@ class FSCLIPClassifier(ZSCLIPClassifier):
             return self.get_text_feats().detach().float().t().contiguous()
         return super()._text_transposed()
 
+    @torch.no_grad()
     def get_img_feats(self, imgs):
-        with torch.no_grad():
-            img_feats = super().get_img_feats(imgs)
-        return self._adjust_dtype(img_feats)
+        return self._adjust_dtype(super().get_img_feats(imgs))
 
     @torch.no_grad()
     def forward(self, data_dict):
@@ -295,12 +252,7 @@ class FSCLIPClassifier(ZSCLIPClassifier):
                           torch.full((B, T), -1, device=feats.device)).to(torch.int32)
         full_logits, logits, probs = self._classify(full_img_feats.reshape(B * T, C).contiguous(),
                                                     idx.contiguous(), normalize=True)
-        return {
-            'full_logits': full_logits,
-            'valid_masks': valid_masks,
-            'logits': logits,
-            'probs': probs,
-        }
+        return dict(full_logits=full_logits, valid_masks=valid_masks, logits=logits, probs=probs)
 
     @torch.no_grad()
     def cache_feats(self, data_dict):
@@ -311,16 +263,14 @@ class FSCLIPClassifier(ZSCLIPClassifier):
         full = IdentityAdapter.forward_rows(None, feats.float(), row_idx)
         return full.reshape(B, T, feats.shape[-1]), valid_masks
 
-    @property
-    def dtype(self):
-        return self.adapter.dtype
+    dtype = property(lambda self: self.adapter.dtype)
 
 
 def build_model(params):
     """models/__init__.py:5-21 (FTCLIP = fine-tuning of CLIP itself, is out of scope)."""
-    if params.model == 'ZSCLIP':
+    kind = params.model
+    if kind == 'ZSCLIP':
         return ZSCLIPClassifier(clip_dict=params.clip_dict)
-    elif params.model == 'FSCLIP':
-        return FSCLIPClassifier(adapter_dict=params.adapter_dict, clip_dict=params.clip_dict,
-                                loss_dict=params.loss_dict)
-    raise NotImplementedError(f'{params.model} is not implemented.')
+    if kind == 'FSCLIP':
+        return FSCLIPClassifier(params.adapter_dict, params.clip_dict, params.loss_dict)
+    raise NotImplementedError(f'{kind} is not implemented.')
