@@ -33,7 +33,9 @@ namespace {
 constexpr int EV_THREADS = 1024;
 constexpr int EV_WAVES = EV_THREADS / 64;
 constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
-constexpr int EV_SCRATCH_BYTES = 8 * EV_WAVES * 2; // block-reduction scratch (u64 per wave, 2 slots)
+constexpr int EV_LUT_N = 16;                       // colour look-up table over counts 0..15 x 0..15
+constexpr int EV_REDUCE_BYTES = 8 * EV_WAVES * 2;  // block-reduction scratch (u64 per wave, 2 slots)
+constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4;   // + the LUT
 
 struct EvArgs {
     const void *events;      // float4 (x, y, t, p) or packed 8-byte events
@@ -375,6 +377,17 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         }
     }
 
+    // The comparison `count > thr` (vis.py:24) in integers: for a non-negative integer h and a finite
+    // thr >= 0, h > thr <=> h > floor(thr); a NaN or infinite thr removes nothing.  The one count whose
+    // comparison could depend on numpy's summation order (|h - thr| <= 1e-9 |thr|) is rint(thr).
+    unsigned thr_hi = 0xFFFFFFFFu;
+    long long amb_h = -1;
+    if (use_thr && thr == thr && thr < 4294967295.) {
+        thr_hi = (unsigned)__builtin_floor(thr);
+        const double hr = __builtin_rint(thr);
+        if (spread && __builtin_fabs(hr - thr) <= 1e-9 * __builtin_fabs(thr)) amb_h = (long long)hr;
+    }
+
     // ---- pass 2: max of the counts that survive (vis.py:24,27) ----
     unsigned mx = 0, amb = 0;
     for (int b = 0; b < bands; b++) {
@@ -391,11 +404,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         const int nb = (y1 - y0) * W * 2;
         for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
             unsigned h = bins[i];
-            if (use_thr) {
-                const double dh = (double)h;
-                if (dh > thr) h = 0;
-                if (spread && __builtin_fabs(dh - thr) <= 1e-9 * __builtin_fabs(thr)) amb++;
-            }
+            amb += (long long)h == amb_h;
+            if (h > thr_hi) h = 0;
             mx = h > mx ? h : mx;
             if (bands == 1) bins[i] = h;  // single band: keep the thresholded counts for pass 3
             if (a.kept) a.kept[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
@@ -416,6 +426,26 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         st.thr = use_thr ? thr : __builtin_nan("");
         a.stats[f] = st;
     }
+
+    // Event frames are mostly 0 .. few counts per pixel: the float64 colour stage is evaluated once per
+    // frame for every pair of counts below 16 and looked up (same function, same bytes)
+    unsigned *lut = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES);
+    if (threadIdx.x < EV_LUT_N * EV_LUT_N) {
+        uint8_t px[4] = {0, 0, 0, 0};
+        colour_pixel(threadIdx.x / EV_LUT_N, threadIdx.x % EV_LUT_N, dmx, a, px);
+        lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+    }
+    __syncthreads();
+    auto colour = [&](unsigned h0, unsigned h1, uint8_t *px) {
+        if (h0 > thr_hi) h0 = 0;                       // bands > 1: the counts were re-binned, threshold again
+        if (h1 > thr_hi) h1 = 0;
+        if (h0 < EV_LUT_N && h1 < EV_LUT_N) {
+            const unsigned v = lut[h0 * EV_LUT_N + h1];
+            px[0] = (uint8_t)v, px[1] = (uint8_t)(v >> 8), px[2] = (uint8_t)(v >> 16);
+        } else {
+            colour_pixel(h0, h1, dmx, a, px);
+        }
+    };
 
     // ---- pass 3: normalise, colour, blend, round -> uint8 (vis.py:27-39) ----
     uint8_t *out = a.frames + (long long)f * H * W * 3;
@@ -443,12 +473,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
                 unsigned c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    unsigned h0 = c[2 * k], h1 = c[2 * k + 1];
-                    if (use_thr && bands > 1) {
-                        if ((double)h0 > thr) h0 = 0;
-                        if ((double)h1 > thr) h1 = 0;
-                    }
-                    colour_pixel(h0, h1, dmx, a, bytes + 3 * k);
+                    colour(c[2 * k], c[2 * k + 1], bytes + 3 * k);
                 }
                 unsigned *dst = reinterpret_cast<unsigned *>(o + (long long)g * 12);
                 dst[0] = words[0];
@@ -457,13 +482,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
             }
         } else {
             for (int q = threadIdx.x; q < npix; q += EV_THREADS) {
-                unsigned h0 = bins[2 * q], h1 = bins[2 * q + 1];
-                if (use_thr && bands > 1) {
-                    if ((double)h0 > thr) h0 = 0;
-                    if ((double)h1 > thr) h1 = 0;
-                }
                 uint8_t px[3];
-                colour_pixel(h0, h1, dmx, a, px);
+                colour(bins[2 * q], bins[2 * q + 1], px);
                 o[3 * q] = px[0];
                 o[3 * q + 1] = px[1];
                 o[3 * q + 2] = px[2];
