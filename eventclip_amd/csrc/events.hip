@@ -167,19 +167,26 @@ template <typename EV>
 __device__ void fill_cache(const EV *ev, long long n, int H, int W, int flip_x, int negate_p,
                            unsigned *cache, unsigned &dropped)
 {
-    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
-        const EV e = ev[i];
+    auto encode = [&](const EV e) {
         int x, y, p;
         parse(e, W, flip_x, negate_p, x, y, p);
-        unsigned c = EV_SKIP;
-        if (p != 0) {
-            if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H)
-                dropped++;
-            else
-                c = ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+        if (p == 0) return EV_SKIP;
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
+            dropped++;
+            return EV_SKIP;
         }
-        cache[i] = c;
+        return ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+    };
+    // eight loads in flight per thread: this phase is the frame's only HBM read and nothing overlaps it
+    long long i = threadIdx.x;
+    for (; i + 7 * EV_THREADS < n; i += 8 * EV_THREADS) {
+        EV e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = ev[i + k * EV_THREADS];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cache[i + k * EV_THREADS] = encode(e[k]);
     }
+    for (; i < n; i += EV_THREADS) cache[i] = encode(ev[i]);
 }
 
 __device__ void bin_band_cached(const unsigned *cache, int n, int y0, int y1, int W, unsigned *bins)
