@@ -18,6 +18,8 @@ around its own launches during the timed steps, `cpu_baseline` is the CPU oracle
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,12 +54,37 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames):
-    """The CPU oracle chain on a bounded sample of the same workload (rank 0, N=1 only)."""
+def _cpu_event2img(args):
+    """One sample through the CPU event2img stage (what a DataLoader worker of the reference does,
+    datasets/event2img.py:114-128): events -> frames -> CLIP preprocess.  Returns the frame count."""
+    ev, qa, n_px = args
+    from oracle import events as oe
+    from oracle import preprocess as op
+    frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
+    op.preprocess(frames, n_px)
+    return frames.shape[0]
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, workers=16):
+    """The CPU oracle chain on a bounded sample of the same workload (rank 0, N=1 only), plus the
+    event2img stage alone in one process and in a pool of `workers` processes, the way the
+    reference's DataLoader runs it (num_workers=16, configs/zsclip/zsclip_nin_params.py:15)."""
+    import multiprocessing as mp
     from oracle import classify as oc
     from oracle import clip_ref
     from oracle import events as oe
     from oracle import preprocess as op
+    oe.build()
     threads = min(os.cpu_count() or 1, 64)   # more threads than this slow torch's CPU GEMMs down
     torch.set_num_threads(threads)
     qa = {k: v for k, v in quantize_args.items()
@@ -74,33 +101,86 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames):
         oc.zs_forward(feats, valid, text, 100.0, 'mean')
         n_frames += frames.shape[0]
     dt = time.perf_counter() - t0
-    return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_samples} sample(s) cut to {n_frames} frames of the same workload through the '
-                      f'CPU oracle (C events2frames + numpy Pillow-bicubic + torch fp32 '
-                      f'{threads}-thread ViT), {dt:.1f} s'}
+    res = {'value': n_frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+           'cpu_model': cpu_model(), 'host_cores': os.cpu_count(),
+           'sample': f'{n_samples} sample(s) cut to {n_frames} frames of the same workload through the '
+                     f'CPU oracle (C events2frames + numpy Pillow-bicubic + torch fp32 '
+                     f'{threads}-thread ViT), {dt:.1f} s'}
+    # event2img stage alone: one process, then a worker pool (fork: the parent holds a GPU context
+    # the children never touch; they only run numpy / the C oracle)
+    jobs = [(np.ascontiguousarray(ev[:max_frames * qa['N']]), qa, cfg['image_size'])
+            for ev in events[:max(n_samples, 2)]]
+    t0 = time.perf_counter()
+    single = sum(_cpu_event2img(j) for j in jobs)
+    res['event2img_frames_per_s_1proc'] = single / (time.perf_counter() - t0)
+    try:
+        workers = min(workers, os.cpu_count() or 1)
+        pool_jobs = [jobs[i % len(jobs)] for i in range(2 * workers)]
+        with mp.get_context('fork').Pool(workers) as pool:
+            pool.map(_cpu_event2img, pool_jobs[:workers])           # start the workers, build caches
+            t0 = time.perf_counter()
+            done = sum(pool.map(_cpu_event2img, pool_jobs))
+            res[f'event2img_frames_per_s_pool{workers}'] = done / (time.perf_counter() - t0)
+    except Exception as e:   # noqa: BLE001 -- a baseline must never take the bench line down
+        res['event2img_pool_error'] = repr(e)
+    return res
+
+
+def _amdgpu_sysfs():
+    """(pp_dpm_sclk path, power1_average path) of the first amdgpu card, or None."""
+    import glob
+    for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+        sclk = os.path.join(card, 'pp_dpm_sclk')
+        pw = glob.glob(os.path.join(card, 'hwmon', 'hwmon*', 'power1_average')) + \
+            glob.glob(os.path.join(card, 'hwmon', 'hwmon*', 'power1_input'))
+        if os.path.exists(sclk) and pw:
+            return sclk, pw[0]
+    return None
+
+
+def _under_profiler():
+    return any(k == 'LD_PRELOAD' or k.startswith(('ROCP_', 'ROCPROFILER_', 'ROCPROF')) for k in os.environ)
 
 
 def sample_dvfs(step, fence, n_steps=6):
     """Shader clock and socket power while the step runs (untimed extra steps, after the timed
-    region): `rocm-smi` is polled from a thread that never touches the HIP context.  The MFMA peak
-    in `roofline` is quoted at the 2.4 GHz boost clock; under its 1400 W cap the chip sustains less
-    on this workload, and `peak_at_sclk` restates the peak at the clock that was actually observed."""
+    region), polled from a thread that never touches the HIP context.  Source: the amdgpu sysfs
+    files (pp_dpm_sclk, hwmon power1_average) -- no child process; only when they are unreadable and
+    no profiler is preloaded does it fall back to the rocm-smi script (run by this interpreter
+    directly, with a clean environment: under rocprofv3 a child inherits the profiler's preload, and
+    an `env`-shebang hop after the GPU is initialised is exactly what the GPU pool forbids).
+    The MFMA peak in `roofline` is quoted at the 2.4 GHz boost clock; under its 1400 W cap the chip
+    sustains less on this workload, and `peak_at_sclk` restates the peak at the observed clock."""
     import re
-    import subprocess
     import threading
+    sysfs = _amdgpu_sysfs()
+    smi = '/opt/rocm/libexec/rocm_smi/rocm_smi.py'
+    use_smi = sysfs is None and not _under_profiler() and os.path.exists(smi)
+    if sysfs is None and not use_smi:
+        return None
     samples, stop = [], threading.Event()
 
     def poll():
+        clean = {k: v for k, v in os.environ.items()
+                 if k != 'LD_PRELOAD' and not k.startswith(('ROCP_', 'ROCPROFILER_', 'ROCPROF'))}
         while not stop.is_set():
             try:
-                out = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True,
-                                     text=True, timeout=20).stdout
-            except Exception:
+                if sysfs:
+                    cur = [ln for ln in open(sysfs[0]).read().splitlines() if ln.rstrip().endswith('*')]
+                    clk = re.search(r'(\d+)\s*Mhz', cur[0], re.I) if cur else None
+                    pw = float(open(sysfs[1]).read()) * 1e-6
+                    if clk:
+                        samples.append((int(clk.group(1)), pw))
+                    time.sleep(0.05)
+                else:
+                    out = subprocess.run([sys.executable, smi, '--showclocks', '--showpower'],
+                                         capture_output=True, text=True, timeout=20, env=clean).stdout
+                    clk = re.search(r'GPU\[0\].*sclk clock level.*\((\d+)Mhz\)', out)
+                    pw = re.search(r'GPU\[0\].*Power \(W\): ([\d.]+)', out)
+                    if clk and pw:
+                        samples.append((int(clk.group(1)), float(pw.group(1))))
+            except Exception:   # noqa: BLE001
                 return
-            clk = re.search(r'GPU\[0\].*sclk clock level.*\((\d+)Mhz\)', out)
-            pw = re.search(r'GPU\[0\].*Power \(W\): ([\d.]+)', out)
-            if clk and pw:
-                samples.append((int(clk.group(1)), float(pw.group(1))))
 
     th = threading.Thread(target=poll, daemon=True)
     th.start()
@@ -114,12 +194,28 @@ def sample_dvfs(step, fence, n_steps=6):
         return None
     sclk = sum(s[0] for s in busy) / len(busy)
     return {'sclk_mhz': sclk, 'socket_power_w': sum(s[1] for s in busy) / len(busy),
-            'samples': len(busy), 'boost_mhz': 2400,
+            'samples': len(busy), 'boost_mhz': 2400, 'source': 'sysfs' if sysfs else 'rocm-smi',
             'peak_at_sclk': PEAK_MFMA_TFLOPS * sclk / 2400.}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU through
+    torch.distributed.run (the reference's own launch line, scripts/sbatch_run.sh:48-51) as a CHILD
+    and exit with its code.  This parent has not touched the GPU (importing torch does not) and
+    never re-execs."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -137,6 +233,13 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    # proof that the collective library saw every rank: world size after init and each rank's device
+    ranks_seen, devices = 1, [local]
+    if world > 1:
+        ranks_seen = dist.get_world_size()
+        devs = [None] * world
+        dist.all_gather_object(devs, f'{socket.gethostname()}:cuda{local}')
+        devices = devs
 
     from eventclip_amd import _lib
     from eventclip_amd import clip as eclip
@@ -164,11 +267,12 @@ def main():
     model.get_text_feats()
 
     # ---- data: per-rank batch of event streams, resident in HBM ----
-    uniq = min(a.batch, 32)
+    # every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
+    # then not flattered by an 8x reuse pattern)
     evs = [make_events(T * N, geo['resolution'], seed=2 * 100003 + rank * 1000 + i)
-           for i in range(uniq)]
+           for i in range(a.batch)]
     n_events = [T * N] * a.batch
-    events = torch.from_numpy(np.concatenate([evs[i % uniq] for i in range(a.batch)])).cuda()
+    events = torch.from_numpy(np.concatenate(evs)).cuda()
     if a.packed_events:
         from eventclip_amd.vis import pack_events_device
         events = pack_events_device(events)
@@ -222,11 +326,26 @@ def main():
                     'frac': achieved / PEAK_HBM_GBS}
         roof.update(kernel=dom['name'], launches_per_step=dom['launches'] / a.steps,
                     avg_launch_ms=avg_ms, traffic=None)
+        # HBM-side bytes per launch come from the committed PMC passes (separate rocprofv3 --pmc runs
+        # of this command, tools/profile_round.sh), not from this run: say which file and which commit
         traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(traffic_file):
-            tr = json.load(open(traffic_file))
-            if tr.get('kernel') == dom['name']:
-                roof['traffic'] = tr.get('hbm_bytes_per_launch')
+        tr = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        per_kernel = tr.get('all_kernels', {})
+        if dom['name'] in per_kernel:
+            roof['traffic'] = per_kernel[dom['name']].get('hbm_bytes_per_launch')
+            roof['traffic_source'] = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit " \
+                                     f"{tr.get('commit', 'unrecorded')})"
+        # north_star asks for the achieved HBM rate of event2img next to the MFMA number
+        ev_rec = next((e for e in prof if e['name'] == 'events_to_frames_kernel'), None)
+        roof_events = None
+        if ev_rec:
+            ev_ms = ev_rec['total_ms'] / ev_rec['launches']
+            ev_bytes = ev_rec['bytes'] / ev_rec['launches']
+            roof_events = {'bound': 'hbm', 'kernel': 'events_to_frames_kernel',
+                           'algorithmic_bytes_per_launch': ev_bytes, 'avg_launch_ms': ev_ms,
+                           'achieved_GBps': ev_bytes / (ev_ms * 1e-3) / 1e9, 'peak_GBps': PEAK_HBM_GBS,
+                           'frac': ev_bytes / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           'traffic': per_kernel.get('events_to_frames_kernel', {}).get('hbm_bytes_per_launch')}
         gpu_ms = sum(e['total_ms'] for e in prof) / a.steps
         breakdown = {e['name']: round(e['total_ms'] / a.steps, 3) for e in prof}
         res = {
@@ -240,12 +359,18 @@ def main():
                        'frames_per_step_per_gpu': frames_per_step, 'classes': a.classes,
                        'events_per_frame': N, 'resolution': list(geo['resolution']),
                        'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
+                       'unique_samples': a.batch,
                        'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
+                       'precision': ('16-bit MFMA operands, fp32 accumulate / residual stream / LayerNorm / '
+                                     'softmax; patch embedding and ln_post @ proj with hi + lo operands; '
+                                     'text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else
                                       'keys/values for every token; query, out_proj, MLP for the class '
                                       'token only (bit-identical encode_image output)'),
-                       'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU'},
-            'roofline': roof,
+                       'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU',
+                       'collective_backend': (backend if world > 1 else None),
+                       'collective_ranks': ranks_seen, 'rank_devices': devices},
+            'roofline': roof, 'roofline_events': roof_events,
             'kernel_ms_per_step': breakdown, 'kernel_ms_per_step_total': gpu_ms,
             'kernel_launches_per_step': {e['name']: e['launches'] / a.steps for e in prof},
             'kernel_algorithmic_bytes_per_launch': {e['name']: e['bytes'] / e['launches'] for e in prof},

@@ -7,7 +7,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeventclip_hip.so')
+# EVENTCLIP_HIP_LIB: tools/ point it at libeventclip_hip_diag.so (python -m eventclip_amd.build --diag),
+# the build whose ec_gemm also has the stamp / timeline / timing-experiment variants
+LIB_PATH = os.environ.get('EVENTCLIP_HIP_LIB') or os.path.join(_HERE, 'libeventclip_hip.so')
+DIAG_LIB_PATH = os.path.join(_HERE, 'libeventclip_hip_diag.so')
 
 EC_F16, EC_BF16 = 0, 1
 
@@ -26,7 +29,8 @@ class EcEventsParams(ctypes.Structure):
                 ('background_mask', c_int), ('red', ctypes.c_uint8 * 3),
                 ('blue', ctypes.c_uint8 * 3), ('max_frame_events', c_int), ('flip_x', c_int),
                 ('negate_p', c_int), ('sort_workspace', c_void_p),
-                ('sort_workspace_bytes', ctypes.c_size_t)]
+                ('sort_workspace_bytes', ctypes.c_size_t), ('float32_stage', c_int),
+                ('total_events', ctypes.c_int64)]
 
 
 class EcAdapterLayer(ctypes.Structure):
@@ -49,7 +53,7 @@ class EcProfileEntry(ctypes.Structure):
 class EcGemmArgs(ctypes.Structure):
     _fields_ = [('M', c_int), ('N', c_int), ('K', c_int), ('dtype', c_int), ('epilogue', c_int),
                 ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
-                ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long)]
+                ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3

@@ -1,10 +1,12 @@
 """Build libeventclip_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m eventclip_amd.build [--force] [--jobs N]
+    python -m eventclip_amd.build [--force] [--jobs N] [--diag]
 
 Every ``csrc/*.hip`` is compiled to an object next to it (cached by mtime) and
 linked into ``eventclip_amd/libeventclip_hip.so``.  The .so is git-ignored but
-travels with the tree to the GPU box.
+travels with the tree to the GPU box.  ``--diag`` builds ``libeventclip_hip_diag.so`` with
+-DEC_GEMM_DIAG instead: the same library plus ec_gemm's timing / stamp / timeline variants, for
+tools/ only (the product never loads it).
 """
 import argparse
 import glob
@@ -28,12 +30,12 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, force):
-    obj = src[:-4] + '.o'
+def _compile(src, force, diag=False):
+    obj = src[:-4] + ('.diag.o' if diag else '.o')
     stamp = max(os.path.getmtime(src), _newest_header())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+    cmd = [HIPCC] + FLAGS + (['-DEC_GEMM_DIAG'] if diag else []) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}')
@@ -42,29 +44,31 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force=False, jobs=None, verbose=False):
+def build(force=False, jobs=None, verbose=False, diag=False):
+    lib = LIB.replace('.so', '_diag.so') if diag else LIB
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     if not srcs:
         raise RuntimeError('no HIP sources found')
     jobs = jobs or min(len(srcs), os.cpu_count() or 4)
     with ThreadPoolExecutor(jobs) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force, diag), srcs))
     objs = [o for o, _ in res]
     rebuilt = any(c for _, c in res)
-    if rebuilt or force or not os.path.exists(LIB) or \
-            os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if rebuilt or force or not os.path.exists(lib) or \
+            os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
         if verbose:
-            print('linked', LIB)
-    return LIB
+            print('linked', lib)
+    return lib
 
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--force', action='store_true')
     ap.add_argument('--jobs', type=int, default=None)
+    ap.add_argument('--diag', action='store_true', help='libeventclip_hip_diag.so (-DEC_GEMM_DIAG)')
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs, verbose=True))
+    print(build(force=a.force, jobs=a.jobs, verbose=True, diag=a.diag))

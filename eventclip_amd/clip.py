@@ -244,10 +244,17 @@ class CLIP(nn.Module):
 
         c = self.cfg
         P, W = c['patch'], c['width']
+        # a patch row carries every pixel value as hi + lo 16-bit parts, [hi | lo | 0] (kpad wide);
+        # conv1.weight is packed as [w_hi | w_hi | 0] and [w_lo | 0] (ec_vit_encode, patch_embed)
         k = 3 * P * P
-        kpad = ((k + 63) // 64) * 64
+        kpad = ((2 * k + 63) // 64) * 64
+        klo = ((k + 63) // 64) * 64
+        cw = sd['visual.conv1.weight'].reshape(W, k).float().cpu()
         conv = torch.zeros(W, kpad)
-        conv[:, :k] = sd['visual.conv1.weight'].reshape(W, k).float().cpu()
+        conv[:, :k] = cw
+        conv[:, k:2 * k] = cw
+        conv_lo = torch.zeros(W, klo)
+        conv_lo[:, :k] = cw
         v = _lib.EcVitWeights()
         v.dtype, v.image_size, v.patch, v.width = code, c['image_size'], P, W
         v.layers, v.heads, v.out_dim, v.kpad = c['layers'], W // 64, c['embed_dim'], kpad
@@ -259,8 +266,7 @@ class CLIP(nn.Module):
         v.proj_w = dev16(sd['visual.proj'].t())
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
-        if self.image_precise:
-            v.conv_w_lo, v.proj_w_lo = dev16_lo(conv), dev16_lo(sd['visual.proj'].t())
+        v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
         vb = blocks('visual.transformer', c['layers'], self.image_precise)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
         t = _lib.EcTextWeights()

@@ -41,6 +41,12 @@ struct ProfScope {
     hipStream_t stream;
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kern` on the CURRENT device, set once per
+// (kernel, device) and safe to call from several threads; returns EC_OK or EC_ERR_HIP.
+int ensure_dynamic_lds(const void *kern, int bytes);
+// compute units of the current device (cached per device); 0 on error
+int cu_count();
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

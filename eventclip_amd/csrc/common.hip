@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace ec {
@@ -20,6 +21,35 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(err_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+namespace {
+std::mutex g_attr_mu;
+std::vector<std::pair<const void *, int>> g_attr_done;   // (kernel, device) pairs already raised
+int g_cus[64] = {0};
+}  // namespace
+
+int ensure_dynamic_lds(const void *kern, int bytes)
+{
+    int dev = 0;
+    EC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    for (const auto &d : g_attr_done)
+        if (d.first == kern && d.second == dev) return EC_OK;
+    EC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_attr_done.emplace_back(kern, dev);
+    return EC_OK;
+}
+
+int cu_count()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (!g_cus[dev] &&
+        hipDeviceGetAttribute(&g_cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        g_cus[dev] = 0;
+    return g_cus[dev];
 }
 
 namespace {

@@ -50,6 +50,7 @@ struct EvArgs {
     ec_frame_stats *stats;
     int rows_per_band, bands;
     int flip_x, negate_p; // test-time-augmentation views (utils.py:18-35)
+    int float32_stage;    // vis.py:27-39 in float32 (numpy 1.x value-based casting) instead of float64
     int bin_bytes;       // LDS bytes of the histogram band (scratch and the event cache follow)
     int cache_events;    // capacity of the LDS event cache, 0 = none
     int F;               // frames; a workgroup takes frames blockIdx.x, + gridDim.x, ...
@@ -276,10 +277,40 @@ __device__ void bin_band_sorted(const unsigned *ws, unsigned begin, unsigned end
     __syncthreads();
 }
 
+// vis.py:27-39 for one pixel in float32: what the reference's pinned numpy 1.25 computes (value-based
+// casting keeps `float32 array / int64 scalar` and everything after it in float32; sgemm's K = 2
+// inner product is fmaf(q, blue, p * red), every ufunc after it rounds once).  FP contraction is off.
+__device__ __forceinline__ void colour_pixel_f32(unsigned c0, unsigned c1, float fmx, const EvArgs &a,
+                                                 uint8_t out[3])
+{
+    const float p = (float)c0 / fmx;
+    const float q = (float)c1 / fmx;
+    float w = 0.f;
+    if (a.background_mask) {
+        w = p + q;
+        if (w < 0.f) w = 0.f;
+        if (w > 1.f) w = 1.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = p * (float)a.red[c];
+        float v = __builtin_fmaf(q, (float)a.blue[c], t);
+        if (a.background_mask) {
+            const float t1 = v * w;
+            const float om = 1.f - w;
+            const float t2 = 255.f * om;
+            v = t1 + t2;
+        }
+        const float r = __builtin_rintf(v);
+        out[c] = (r != r) ? (uint8_t)0 : (uint8_t)(int)r;
+    }
+}
+
 // vis.py:27-39 for one pixel, float64, numpy's operation order.
 __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dmx, const EvArgs &a,
                                              uint8_t out[3])
 {
+    if (a.float32_stage) return colour_pixel_f32(c0, c1, (float)dmx, a, out);
     const double p = (double)(float)c0 / dmx;  // vis.py:27 (astype(float32) then / int64 max)
     const double q = (double)(float)c1 / dmx;
     double w = 0.;
@@ -659,6 +690,7 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     a.thresh = prm->thresh;
     a.count_non_zero = prm->count_non_zero;
     a.flip_x = prm->flip_x, a.negate_p = prm->negate_p;
+    a.float32_stage = prm->float32_stage;
     a.background_mask = prm->background_mask;
     for (int c = 0; c < 3; c++) {
         a.red[c] = (double)(float)prm->red[c];    // cmap.astype(float32), vis.py:30
@@ -716,18 +748,15 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     a.F = F;
     a.band_magic = (unsigned)((0x100000000ull + (unsigned)a.rows_per_band - 1) / (unsigned)a.rows_per_band);
 
-    static bool attr_set = false;
     const int lds = LDS_TOTAL;   // always the full carve: one attribute call, one workgroup per CU
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(events_to_frames_kernel<EV>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    // algorithmic bytes: 16 B (packed: 8 B) per event in + 3*H*W out; the
-    // event count is only known on the device, so the call site reports the output part and
-    // the caller adds the event bytes
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_to_frames_kernel<EV>), lds))
+        return rc;
+    // algorithmic bytes: 16 B (packed: 8 B) per event in + 3*H*W out.  The frame
+    // ranges live on the device; the caller states their total length in prm->total_events (0 =
+    // unknown: only the output part is reported then)
     ec::ProfScope prof(ec::PROF_EVENTS, static_cast<hipStream_t>(stream), 0,
-                       (double)F * prm->H * prm->W * 3.0);
+                       (double)F * prm->H * prm->W * 3.0 +
+                           (double)(prm->total_events > 0 ? prm->total_events : 0) * sizeof(EV));
     hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(grid), dim3(EV_THREADS), lds,
                        static_cast<hipStream_t>(stream), a);
     EC_CHECK_HIP(hipGetLastError());

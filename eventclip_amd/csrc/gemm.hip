@@ -41,6 +41,7 @@ struct GemmArgs {
     void *C;
     long ldc;
     int tiles_m, tiles_n;
+    unsigned long long *diag;   // EC_GEMM_DIAG builds: stamp / timeline records (ec_gemm_args.diag)
 };
 
 __device__ __forceinline__ int swz_key(int row) { return (row & 7) ^ ((row >> 3) & 6); }
@@ -389,12 +390,7 @@ int launch(const GemmArgs &g0, hipStream_t stream)
     g.tiles_n = ec::ceil_div(g.N, BN);
     constexpr int lds = 2 * (BM + BN) * 128;
     auto kern = gemm_kernel<DT, BM, BN, WM, WN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -408,6 +404,9 @@ int launch(const GemmArgs &g0, hipStream_t stream)
 }
 
 
+#define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+#ifdef EC_GEMM_DIAG
 // ---------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves, four phases per K tile, LDS-DMA kept in flight across raw
 // barriers, the two wave groups staggered by one barrier interval.
@@ -430,8 +429,6 @@ int launch(const GemmArgs &g0, hipStream_t stream)
 // (interval 2q); it is overwritten again 8 phases after it was staged, 5 phases after its
 // last read.
 // ---------------------------------------------------------------------------------------
-#define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
 template <int DT, int EPI>
 __global__ __launch_bounds__(512) void gemm4p_kernel(const GemmArgs g)
 {
@@ -602,12 +599,7 @@ template <int DT, int EPI> int launch4p(const GemmArgs &g0, hipStream_t stream)
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 2 * 4 * 128 * 128;
     auto kern = gemm4p_kernel<DT, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -619,6 +611,8 @@ template <int DT, int EPI> int launch4p(const GemmArgs &g0, hipStream_t stream)
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
+
+#endif  // EC_GEMM_DIAG
 
 template <int DT, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
@@ -748,10 +742,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
     // whole tile ahead: load segment B(t) stages {Am0, Bn0, Bn1} of tile t+2 into the
     // regions phase A(t) has just drained, load segment A(t) stages Am1 of tile t+1.
     // DBG == 5 (diagnostic build only): s_memtime stamps of waves 0 and 4 of workgroup 300 go to
-    // the buffer passed as `bias` (which is then not applied); layout [wave>>2][t][8 stamps]
+    // g.diag; layout [wave>>2][t][8 stamps]
     unsigned long long *stamps = nullptr;
     if (DBG == 5 && blockIdx.x == 300 && (wave & 3) == 0 && lane == 0)
-        stamps = (unsigned long long *)g.bias + (wave >> 2) * 64 * 8;
+        stamps = g.diag + (wave >> 2) * 64 * 8;
     auto stamp = [&](int t, int i) {
         if (DBG == 5) {
             unsigned long long now;
@@ -761,9 +755,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
             if (stamps && t < 64) stamps[t * 8 + i] = now;
         }
     };
-    // DBG == 9 (diagnostic build only): one record per workgroup in the buffer passed as `bias`
-    // (not applied): {HW_ID, start, prologue landed, loop done, epilogue issued, stores
-    // acknowledged, XCC_ID}, for the per-CU timeline of tools/timeline_gemm.py
+    // DBG == 9 (diagnostic build only): one record per workgroup in g.diag: {HW_ID, start,
+    // prologue landed, loop done, epilogue issued, stores acknowledged, XCC_ID}, for the per-CU
+    // timeline of tools/timeline_gemm.py
     unsigned long long *tl = nullptr;
     auto tstamp = [&](int i) {
         if (DBG == 9) {
@@ -775,7 +769,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
         }
     };
     if (DBG == 9 && threadIdx.x == 0) {
-        tl = (unsigned long long *)g.bias + (long)blockIdx.x * 8;
+        tl = g.diag + (long)blockIdx.x * 8;
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -854,16 +848,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
     if (wm == 0) bar();   // balance the stagger barrier
 
     if (DBG == 5 || DBG == 9) {
-        GemmArgs g2 = g;
-        g2.bias = nullptr;
         tstamp(3);
         if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32)
-            epilogue32_lds<EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane,
+            epilogue32_lds<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane,
                                    reinterpret_cast<float *>(smem) + wave * (2 * 16 * 68));
         else if constexpr (DBG == 9)
-            epilogue16_lds<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
+            epilogue16_lds<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
         else
-            epilogue<DT, EPI, 8>(g2, acc, m0 + wm * 128, n0 + wn * 64, lane);
+            epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
         tstamp(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tstamp(5);
@@ -885,12 +877,7 @@ template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStre
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 2 * 4 * 128 * 128;
     auto kern = gemm2p_kernel<DT, EPI, DBG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -1033,7 +1020,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     };
     auto tl_open = [&](int id) {
         if (TL && threadIdx.x == 0) {
-            tl = (unsigned long long *)g.bias + (long)id * 8;
+            tl = g.diag + (long)id * 8;
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1041,8 +1028,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             tl[6] = xcc;
         }
     };
-    GemmArgs ge = g;
-    if (TL) ge.bias = nullptr;
+    const GemmArgs &ge = g;
 
     int id = blockIdx.x;
     tl_open(id);
@@ -1148,16 +1134,9 @@ template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hi
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 2 * 4 * 128 * 128;
     auto kern = gemm2pp_kernel<DT, EPI, TL>;
-    static bool attr_set = false;
-    static int cus = 0;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int dev = 0;
-        EC_CHECK_HIP(hipGetDevice(&dev));
-        EC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+    const int cus = ec::cu_count();
+    EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -1172,6 +1151,7 @@ template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hi
 }
 
 
+#ifdef EC_GEMM_DIAG
 // ---------------------------------------------------------------------------------------
 // Two workgroups per CU: 128 x 256 x 32 tiles, 4 waves (one per SIMD), each wave 128 x 64.
 // A 3-stage LDS-DMA ring of 24-KiB K tiles (72 KiB per workgroup, so two workgroups share a
@@ -1290,12 +1270,7 @@ template <int DT, int EPI> int launch_b2(const GemmArgs &g0, hipStream_t stream)
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 3 * (128 + 256) * 64;
     auto kern = gemm_b2_kernel<DT, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -1439,12 +1414,7 @@ template <int DT, int EPI> int launch_b2p(const GemmArgs &g0, hipStream_t stream
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 3 * (128 + 256) * 64;
     auto kern = gemm_b2p_kernel<DT, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
                         : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
@@ -1457,29 +1427,39 @@ template <int DT, int EPI> int launch_b2p(const GemmArgs &g0, hipStream_t stream
     return EC_OK;
 }
 
+#endif  // EC_GEMM_DIAG
+
+// Variants that ship: the default and three independent tilings (kept as cross-checks of each
+// other in the GPU tests).  Everything else -- timing experiments that compute wrong results on
+// purpose, stamp / timeline builds that write s_memtime records through args.diag, retired A/B
+// schedules -- only exists in a -DEC_GEMM_DIAG build (python -m eventclip_amd.build --diag), which
+// tools/ load explicitly; the product library rejects those variant numbers.
 template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, hipStream_t s)
 {
     switch (variant) {
     case 0: return launch2pp<DT, EPI>(g, s);                     // default: persistent staggered 2-phase
-    case 1: return launch<DT, 256, 256, 2, 4, EPI>(g, s);
+    case 1: return launch<DT, 256, 256, 2, 4, EPI>(g, s);        // plain two-barrier loop, 256 x 256
     case 2: return launch<DT, 128, 128, 2, 2, EPI>(g, s);
     case 3: return launch<DT, 128, 256, 1, 4, EPI>(g, s);
+    case 5: return launch2p<DT, EPI>(g, s);                      // staggered 2-phase, one tile per workgroup
+#ifdef EC_GEMM_DIAG
     case 4: return launch4p<DT, EPI>(g, s);
-    case 5: return launch2p<DT, EPI>(g, s);                      // one tile per workgroup
     case 6: return launch2p<DT, EPI, 1>(g, s);   // timing experiment: no DMA in the loop (wrong results)
     case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)
     case 8: return launch2p<DT, EPI, 3>(g, s);   // no s_setprio
     case 9: return launch2p<DT, EPI, 4>(g, s);   // priority on the load segments
-    case 10: return launch2p<DT, EPI, 5>(g, s);
+    case 10: return launch2p<DT, EPI, 5>(g, s);  // s_memtime stamps of one workgroup -> args.diag
     case 11: return launch2p<DT, EPI, 6>(g, s);
     case 12: return launch_b2<DT, EPI>(g, s);     // two 4-wave workgroups per CU, 128x256x32
     case 13: return launch_b2p<DT, EPI>(g, s);    // same with register-prefetched fragments
     case 14: return launch2p<DT, EPI, 7>(g, s);   // first-round start times spread over a tile period
     case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
-    case 16: return launch2p<DT, EPI, 9>(g, s);   // diagnostic: per-workgroup timeline into the bias buffer
-    case 17: return launch2pp<DT, EPI>(g, s);        // persistent, next tile's first K tile prefetched
-    case 18: return launch2pp<DT, EPI, true>(g, s);  // ... with timeline records
-    default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d", variant);
+    case 16: return launch2p<DT, EPI, 9>(g, s);   // per-workgroup timeline -> args.diag
+    case 18: return launch2pp<DT, EPI, true>(g, s);  // persistent, with timeline records -> args.diag
+#endif
+    default:
+        return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d (diagnostic variants need an "
+                        "EC_GEMM_DIAG build)", variant);
     }
 }
 
@@ -1512,6 +1492,13 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.M = a->M, g.N = a->N, g.K = a->K;
     g.A = a->A, g.lda = lda, g.W = a->W, g.bias = a->bias, g.C = a->C, g.ldc = ldc;
     g.tiles_m = g.tiles_n = 0;
+    g.diag = static_cast<unsigned long long *>(a->diag);
+#ifdef EC_GEMM_DIAG
+    {
+        const int v = a->variant;
+        EC_REQUIRE(!(v == 10 || v == 16 || v == 18) || a->diag, "ec_gemm: variant %d needs args.diag", v);
+    }
+#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a->dtype == EC_F16) return dispatch_epi<EC_F16>(g, a->epilogue, a->variant, s);
     if (a->dtype == EC_BF16) return dispatch_epi<EC_BF16>(g, a->epilogue, a->variant, s);

@@ -172,27 +172,32 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a)
             o[0] = (uint8_t)u0, o[1] = (uint8_t)u1, o[2] = (uint8_t)u2;
         } else {
             const int py = oy / p, i = oy - py * p, px = ox / p, j = ox - px * p;
+            // a patch row carries every value as hi + lo 16-bit parts: [hi (c,i,j) | lo (c,i,j) | 0]
             elem *o = (elem *)a.out + ((long)f * a.grid_w * a.grid_w + py * a.grid_w + px) * a.kpad +
                       i * p + j;
-            o[0] = to16(v0, elem());
-            o[pp] = to16(v1, elem());
-            o[2 * pp] = to16(v2, elem());
+            const elem h0 = to16(v0, elem()), h1 = to16(v1, elem()), h2 = to16(v2, elem());
+            o[0] = h0;
+            o[pp] = h1;
+            o[2 * pp] = h2;
+            o[3 * pp] = to16(v0 - (float)h0, elem());
+            o[4 * pp] = to16(v1 - (float)h1, elem());
+            o[5 * pp] = to16(v2 - (float)h2, elem());
         }
     }
     if (a.mode == EC_PRE_PATCHES16) {
         // zero the K padding of the patches this band owns
-        const int pad = a.kpad - 3 * pp;
+        const int pad = a.kpad - 6 * pp;
         const int py0 = oy0 / p, npatch = ((oy1 - oy0) / p) * a.grid_w;
         for (int it = threadIdx.x; it < npatch * pad; it += 256) {
             const int q = it / pad, e = it - q * pad;
             elem *o = (elem *)a.out + ((long)f * a.grid_w * a.grid_w + py0 * a.grid_w + q) * a.kpad +
-                      3 * pp + e;
+                      6 * pp + e;
             *o = to16(0.f, elem());
         }
     }
 }
 
-// fp32 [N, 3, R, R] -> 16-bit im2col rows [N, G, kpad], (c, i, j) order, zero padded
+// fp32 [N, 3, R, R] -> 16-bit im2col rows [N, G, kpad]: [hi (c, i, j) | lo (c, i, j) | 0]
 template <int DT>
 __global__ __launch_bounds__(256) void patchify_kernel(const float *img, void *out, int n_img, int R,
                                                        int p, int kpad)
@@ -205,12 +210,15 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *img, void *o
         const long q = it / kpad;
         const int px = (int)(q % g), py = (int)((q / g) % g);
         const long n = q / ((long)g * g);
-        float v = 0.f;
-        if (e < 3 * pp) {
-            const int c = e / pp, r = e - c * pp, i = r / p, j = r - i * p;
-            v = img[((n * 3 + c) * R + (py * p + i)) * R + px * p + j];
+        elem o = to16(0.f, elem());
+        if (e < 6 * pp) {
+            const int e3 = e < 3 * pp ? e : e - 3 * pp;
+            const int c = e3 / pp, r = e3 - c * pp, i = r / p, j = r - i * p;
+            const float v = img[((n * 3 + c) * R + (py * p + i)) * R + px * p + j];
+            const elem hi = to16(v, elem());
+            o = e < 3 * pp ? hi : to16(v - (float)hi, elem());
         }
-        ((elem *)out)[it] = to16(v, elem());
+        ((elem *)out)[it] = o;
     }
 }
 
@@ -287,7 +295,7 @@ EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, co
     if (mode == EC_PRE_PATCHES16) {
         EC_REQUIRE(patch > 0 && R % patch == 0, "ec_preprocess: n_px %d not a multiple of patch %d", R,
                    patch);
-        EC_REQUIRE(kpad >= 3 * patch * patch, "ec_preprocess: kpad %d < %d", kpad, 3 * patch * patch);
+        EC_REQUIRE(kpad >= 6 * patch * patch, "ec_preprocess: kpad %d < %d", kpad, 6 * patch * patch);
         a.patch = patch, a.kpad = kpad, a.grid_w = R / patch;
         a.band_rows = patch * (patch >= 32 ? 1 : (32 / patch));
     } else {
@@ -324,7 +332,7 @@ EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, co
 EC_API int ec_patchify(const float *img, int n_img, int n_px, int patch, int kpad, void *out16,
                        int dtype, ec_stream_t stream)
 {
-    EC_REQUIRE(n_img >= 0 && patch > 0 && n_px % patch == 0 && kpad >= 3 * patch * patch,
+    EC_REQUIRE(n_img >= 0 && patch > 0 && n_px % patch == 0 && kpad >= 6 * patch * patch,
                "ec_patchify: bad geometry");
     if (n_img == 0) return EC_OK;
     EC_REQUIRE(img && out16, "ec_patchify: null buffer");

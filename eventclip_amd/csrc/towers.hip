@@ -35,11 +35,11 @@ struct BlockBufs {
 };
 
 int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
-         void *C, ec_stream_t s, long ldc = 0)
+         void *C, ec_stream_t s, long ldc = 0, long lda = 0)
 {
     ec_gemm_args g;
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
-    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
+    g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
     return ec_gemm(&g, s);
 }
 
@@ -99,6 +99,20 @@ int gemm3(int M, int N, int K, int dtype, bool accumulate, const void *a_hi, con
     return gemm(M, N, K, dtype, EC_EPI_RESID32, a_lo, w_hi, nullptr, C, s);
 }
 
+// conv1 (kernel = stride = patch, no bias) as a GEMM over im2col rows, to fp32 accuracy: a patch
+// row is [hi | lo | 0] (kpad wide) and conv_w = [w_hi | w_hi | 0], so the first launch gives
+// x_hi.w_hi + x_lo.w_hi; the second adds x_hi.w_lo over the row's first klo columns (conv_w_lo =
+// [w_lo | 0]: the lo values the row holds beyond 3 p^2 meet zeros).  0.6 % of the tower's flops; the
+// rounding of pixels and conv1.weight to 16 bits would otherwise be ~8 % of the logit error budget
+// (tools/rounding_budget.py).
+int patch_embed(const ec_vit_weights *w, const void *patches, int rows, float *out, ec_stream_t s)
+{
+    const int klo = ((3 * w->patch * w->patch + 63) / 64) * 64;
+    EC_TRY(gemm(rows, w->width, w->kpad, w->dtype, EC_EPI_STORE32, patches, w->conv_w, nullptr, out, s));
+    return gemm(rows, w->width, klo, w->dtype, EC_EPI_RESID32, patches, w->conv_w_lo, nullptr, out, s, 0,
+                w->kpad);
+}
+
 int run_blocks_precise(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
                        int causal, int dtype, const PreciseBufs &b, ec_stream_t s)
 {
@@ -143,7 +157,7 @@ size_t carve_precise(Scratch &sc, int chunk, int S, int W, PreciseBufs &b, void 
 // carve the scratch for `chunk` sequences of length S; patch_rows > 0 adds the fp32
 // patch-GEMM output (aliased onto the mlp buffer: both are dead at the same time)
 size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs &b, void **small16,
-             int **idx)
+             int **idx, void **small16_lo = nullptr)
 {
     const size_t rows = (size_t)chunk * S;
     b.x = (float *)sc.take(rows * W * 4);
@@ -151,6 +165,8 @@ size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs
     b.qkv = sc.take(rows * 3 * W * 2);
     b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
     *small16 = sc.take((size_t)chunk * W * 2);
+    void *lo = sc.take((size_t)chunk * W * 2);
+    if (small16_lo) *small16_lo = lo;
     *idx = (int *)sc.take((size_t)chunk * 4 + (size_t)out_rows_extra);
     return sc.off;
 }
@@ -209,15 +225,16 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     EC_REQUIRE(w->image_size % w->patch == 0, "ec_vit_encode: image %d not a multiple of patch %d",
                w->image_size, w->patch);
     EC_REQUIRE(w->width == w->heads * 64, "ec_vit_encode: head dim must be 64");
-    EC_REQUIRE(w->kpad % 64 == 0 && w->kpad >= 3 * w->patch * w->patch, "ec_vit_encode: bad kpad %d",
+    EC_REQUIRE(w->kpad % 64 == 0 && w->kpad >= 6 * w->patch * w->patch, "ec_vit_encode: bad kpad %d",
                w->kpad);
+    EC_REQUIRE(w->conv_w && w->conv_w_lo && w->proj_w && w->proj_w_lo,
+               "ec_vit_encode: conv / proj weights need their hi and lo parts");
     EC_REQUIRE(w->out_dim % 16 == 0, "ec_vit_encode: out_dim %d", w->out_dim);
     const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype;
     if (chunk > n_img) chunk = n_img;
     Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
     const size_t esz = 2;
     if (w->precise) {
-        EC_REQUIRE(w->conv_w_lo && w->proj_w_lo, "ec_vit_encode: precise tower without lo weights");
         PreciseBufs pb;
         void *c_hi, *c_lo;
         int *pidx;
@@ -228,10 +245,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         for (int i0 = 0; i0 < n_img; i0 += chunk) {
             const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
             const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
-            // the 16-bit patch values are exact inputs: x.w = x.wh + x.wl
-            EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_STORE32, p, w->conv_w, nullptr, pb.wide, stream));
-            EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_RESID32, p, w->conv_w_lo, nullptr, pb.wide,
-                        stream));
+            EC_TRY(patch_embed(w, p, n * G, pb.wide, stream));
             EC_TRY(ec_vit_embed(pb.wide, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS,
                                 pb.x, stream));
             EC_TRY(run_blocks_precise(w->blocks, w->layers, n, S, W, w->heads, 0, dt, pb, stream));
@@ -243,9 +257,9 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         return EC_OK;
     }
     BlockBufs b;
-    void *cls16;
+    void *cls16, *cls16_lo;
     int *idx;
-    const size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx);
+    const size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes", workspace_bytes,
                         need);
@@ -253,17 +267,19 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
         const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
         float *patch_out = (float *)b.mlp;
-        // conv1 (kernel = stride = patch, no bias) as a GEMM over im2col rows
-        EC_TRY(gemm(n * G, W, w->kpad, dt, EC_EPI_STORE32, p, w->conv_w, nullptr, patch_out, stream));
+        EC_TRY(patch_embed(w, p, n * G, patch_out, stream));
         EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, b.x,
                             stream));
         EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream,
                           w->full_last_block == 0));
-        // ln_post on the CLS rows (row stride S*W), then @ proj
-        EC_TRY(ec_layernorm(b.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16,
-                            W, dt, stream));
-        EC_TRY(gemm(n, w->out_dim, W, dt, EC_EPI_STORE32, cls16, w->proj_w, nullptr,
-                    feats + (size_t)i0 * w->out_dim, stream));
+        // ln_post on the CLS rows (row stride S*W), then @ proj.  These n rows are the features
+        // themselves: their 16-bit rounding is not averaged over anything downstream and was 45 % of the
+        // logit error budget (tools/rounding_budget.py), so both operands keep their lo parts here
+        // (three launches over n rows: free).
+        EC_TRY(ec_layernorm_split(b.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS,
+                                  cls16, cls16_lo, W, dt, stream));
+        EC_TRY(gemm3(n, w->out_dim, W, dt, false, cls16, cls16_lo, w->proj_w, w->proj_w_lo, nullptr,
+                     feats + (size_t)i0 * w->out_dim, stream));
     }
     return EC_OK;
 }

@@ -47,6 +47,8 @@ class Event2ImagePipeline:
         self.thresh = float(qa.get('thresh', 10.))
         self.count_non_zero = bool(qa.get('count_non_zero', False))
         self.background_mask = bool(qa.get('background_mask', True))
+        # not a key of the reference's configs: which numpy the frames should agree with (vis.py:27)
+        self.float_stage = qa.get('float_stage', 'float64')
         self.n_px, self.patch, self.kpad, self.dtype = int(n_px), patch, kpad, dtype
         self.generator = generator
         self.strict = True   # raise on events outside the sensor, as the reference does
@@ -86,12 +88,13 @@ class Event2ImagePipeline:
         ri = torch.from_numpy(row_idx)
         return fr, ri, ri >= 0
 
-    def frames(self, events, frame_range, hflip=False, tflip=False):
+    def frames(self, events, frame_range, hflip=False, tflip=False, total_events=0):
         """uint8 [Fv, H, W, 3] for the planned views (vis.events2frames, batched)."""
         out = vis.events_to_frames_device(
             events, frame_range, self.resolution, grayscale=self.grayscale, thresh=self.thresh,
             count_non_zero=self.count_non_zero, background_mask=self.background_mask,
-            return_stats=self.strict, max_frame_events=self.N, flip_x=hflip, negate_p=tflip)
+            return_stats=self.strict, max_frame_events=self.N, flip_x=hflip, negate_p=tflip,
+            float_stage=self.float_stage, total_events=total_events)
         if self.strict:
             frames, stats = out
             if int(stats['dropped'].sum()) > 0:
@@ -135,7 +138,8 @@ class Event2ImagePipeline:
             vis.center_events_device(events, sr, self.resolution)
         fr, ri, vm = self.plan(n_events, tflip=tflip, starts=starts)
         fr_d = fr.to(dev)
-        frames = self.frames(events, fr_d, hflip=hflip, tflip=tflip)
+        frames = self.frames(events, fr_d, hflip=hflip, tflip=tflip,
+                             total_events=int((fr[:, 1] - fr[:, 0]).sum()))
         out = dict(valid_mask=vm.to(dev), row_idx=ri.to(dev))
         if self.patch:
             out['patches'] = preprocess_frames(frames, self.n_px, mode='patches', patch=self.patch,

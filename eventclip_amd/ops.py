@@ -17,7 +17,7 @@ def dtype_code(t):
     raise TypeError(f'16-bit dtype expected, got {t}')
 
 
-def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0):
+def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32.
     resid32 accumulates into ``out`` (fp32) in place."""
     import torch
@@ -41,5 +41,6 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0):
     a.W = W.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
     a.C, a.ldc = out.data_ptr(), out.stride(0)
+    a.diag = diag.data_ptr() if diag is not None else None    # EC_GEMM_DIAG builds only
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
     return out

@@ -65,7 +65,8 @@ def colour_map(grayscale=True):
 
 
 def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, background_mask=True,
-                max_frame_events=0, flip_x=False, negate_p=False):
+                max_frame_events=0, flip_x=False, negate_p=False, float_stage='float64',
+                total_events=0):
     H, W = shape
     red, blue = colour_map(grayscale)
     p = _lib.EcEventsParams()
@@ -75,6 +76,10 @@ def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, backgro
     p.background_mask = int(bool(background_mask))
     p.max_frame_events = int(max_frame_events)
     p.flip_x, p.negate_p = int(bool(flip_x)), int(bool(negate_p))
+    if float_stage not in ('float64', 'float32'):
+        raise ValueError(f'float_stage {float_stage!r}: float64 (numpy >= 2) or float32 (numpy 1.x)')
+    p.float32_stage = int(float_stage == 'float32')
+    p.total_events = int(total_events)
     for c in range(3):
         p.red[c] = int(red[c])
         p.blue[c] = int(blue[c])
@@ -167,12 +172,16 @@ def pack_events_device(events, return_bad=False):
 def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=10.,
                             count_non_zero=False, background_mask=True, return_counts=False,
                             return_stats=False, out=None, max_frame_events=0, flip_x=False,
-                            negate_p=False, sort_workspace=True):
+                            negate_p=False, sort_workspace=True, float_stage='float64',
+                            total_events=0):
     """Batched device entry.
 
     events:      float32 CUDA tensor [n_total, 4], or packed events: int64 CUDA tensor [n_total]
                  (pack_events / pack_events_device, layout in include/eventclip_hip.h).
     frame_range: int64 CUDA tensor [F, 2] of (begin, end) rows per frame.
+    float_stage: 'float64' runs vis.py:27-39 as numpy >= 2 does (the default, and what the
+                 fixtures of this image record), 'float32' as the reference's pinned numpy 1.25 did.
+    total_events: sum of the frame lengths when known (profiling: the launch's algorithmic bytes).
     Returns uint8 CUDA tensor [F, H, W, 3] (+ raw, kept int32 [F, H, W, 2] and a
     stats structured array when asked).
     """
@@ -192,7 +201,7 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
     if return_stats:
         stats = torch.zeros((F, ctypes.sizeof(_lib.EcFrameStats)), dtype=torch.uint8, device=dev)
     prm = make_params(shape, grayscale, thresh, count_non_zero, background_mask, max_frame_events,
-                      flip_x, negate_p)
+                      flip_x, negate_p, float_stage, total_events)
     ws = attach_sort_workspace(prm, events.device, sort_workspace)   # noqa: F841 (kept alive over the call)
     entry = _lib.lib().ec_events_to_frames_packed if packed else _lib.lib().ec_events_to_frames
     rc = entry(_lib.ptr(events), _lib.ptr(frame_range), F, ctypes.byref(prm), _lib.ptr(frames),
@@ -227,7 +236,9 @@ def events2frames(events, split_method, convert_method, shape=(180, 240), **kwar
         ev_d, rng, shape, grayscale=grayscale, thresh=float(kwargs.get('thresh', 10.)),
         count_non_zero=kwargs.get('count_non_zero', False),
         background_mask=kwargs.get('background_mask', True), return_stats=True,
-        max_frame_events=max(b - a for a, b in zip(idx0, idx1)))
+        max_frame_events=max(b - a for a, b in zip(idx0, idx1)),
+        float_stage=kwargs.get('float_stage', 'float64'),
+        total_events=sum(b - a for a, b in zip(idx0, idx1)))
     if int(stats['dropped'].sum()) > 0:
         # the reference's bincount/reshape raises on such input (vis.py:11)
         raise ValueError('events2frames: events outside the sensor '

@@ -89,6 +89,12 @@ typedef struct {
                                  more events than the on-chip cache holds (N-ImageNet) are bucketed by row
                                  band there once instead of being re-read for every band pass */
     size_t sort_workspace_bytes;
+    int float32_stage;        /* 0: the float stage of vis.py:27-39 in float64, as numpy >= 2 runs the
+                                 reference (NEP 50); != 0: in float32, as the reference's pinned numpy
+                                 1.25.2 ran it (environment.yml:49).  The two differ by 1 LSB at exact
+                                 .5 ties only (e.g. 127 * 3/6); counts are identical. */
+    int64_t total_events;     /* sum of (end - begin) over frame_range if the caller knows it, else 0:
+                                 only states the launch's algorithmic bytes to ec_profile_end */
 } ec_events_params;
 
 /* bytes of sort_workspace that pay off for this geometry / max_frame_events (0: not needed) */
@@ -162,7 +168,9 @@ EC_API int ec_center_events_packed(uint64_t *events, const int64_t *sample_range
  * ------------------------------------------------------------------------ */
 enum {
     EC_PRE_CHW_F32 = 0,   /* float32 [F, 3, n_px, n_px]: the reference's tensor */
-    EC_PRE_PATCHES16 = 1, /* 16-bit [F, G, kpad] im2col rows for ec_vit_encode */
+    EC_PRE_PATCHES16 = 1, /* 16-bit [F, G, kpad] im2col rows for ec_vit_encode: every value v of the
+                           * (c, i, j)-ordered patch as hi = round16(v) and lo = round16(v - hi),
+                           * row = [hi (3 p^2) | lo (3 p^2) | 0 ...], kpad >= 6 p^2 */
     EC_PRE_HWC_U8 = 2,    /* uint8 [F, n_px, n_px, 3]: resized + cropped, before ToTensor */
 };
 
@@ -172,7 +180,7 @@ EC_API int ec_preprocess_plan(int in_h, int in_w, int n_px, void *host_plan, siz
 EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, const void *plan_dev,
                          void *out, int mode, int patch, int kpad, int dtype, ec_stream_t stream);
 /* float32 [N, 3, n_px, n_px] (what the reference feeds encode_image) -> 16-bit
- * im2col rows [N, G, kpad] in conv1.weight's (c, i, j) order, zero padded. */
+ * im2col rows [N, G, kpad] in the EC_PRE_PATCHES16 layout ([hi | lo | 0], (c, i, j) order). */
 EC_API int ec_patchify(const float *img, int n_img, int n_px, int patch, int kpad, void *out16,
                        int dtype, ec_stream_t stream);
 
@@ -195,13 +203,16 @@ typedef struct {
     int M, N, K;       /* K % 64 == 0, N % 16 == 0 */
     int dtype;         /* EC_F16 / EC_BF16: A, W and 16-bit outputs */
     int epilogue;      /* EC_EPI_* */
-    int variant;       /* 0 = default tiling; others select tilings for A/B runs */
+    int variant;       /* 0 = default tiling; 1, 2, 3, 5 = other tilings with the same results (A/B
+                          runs and cross-checks); anything else is EC_ERR_INVALID */
     const void *A;     /* [M, K] 16-bit, row stride lda elements (0 = K) */
     long lda;
     const void *W;     /* [N, K] 16-bit, dense (nn.Linear weight layout) */
     const float *bias; /* [N] fp32 or NULL */
     void *C;           /* [M, N] 16-bit or fp32 by epilogue, row stride ldc (0 = N) */
     long ldc;
+    void *diag;        /* NULL.  (Only a -DEC_GEMM_DIAG build of the library reads it: device buffer
+                          for the s_memtime records of its stamp / timeline variants.) */
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -272,14 +283,20 @@ typedef struct {
 typedef struct {
     int dtype;                  /* EC_F16 / EC_BF16 */
     int image_size, patch, width, layers, heads, out_dim;
-    int kpad;                   /* 3 * patch * patch rounded up to a multiple of 64 */
-    const void *conv_w;         /* visual.conv1.weight as [W, kpad] 16-bit, (c, i, j) order, zero padded */
+    int kpad;                   /* patch-row width: 6 * patch * patch rounded up to a multiple of 64
+                                   (EC_PRE_PATCHES16: [hi | lo | 0]) */
+    const void *conv_w;         /* visual.conv1.weight [W, 3 p^2] in (c, i, j) order, rounded to 16 bits
+                                   and laid out against the patch row: [W, kpad] = [w_hi | w_hi | 0] */
     const float *cls, *pos;     /* class_embedding [W], positional_embedding [S, W] */
     const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
     const void *proj_w;         /* visual.proj transposed: [out_dim, W] 16-bit */
     const ec_block_weights *blocks; /* host array [layers] */
-    int precise;                /* != 0: split-precision arithmetic (3x the GEMM work, ~fp32 results) */
-    const void *conv_w_lo, *proj_w_lo;
+    int precise;                /* != 0: split-precision arithmetic in the blocks too (3x the GEMM work,
+                                   ~fp32 results).  The patch embedding and ln_post @ proj always run
+                                   split (hi + lo operands): they are 0.6 % of the flops and would be
+                                   half of the logit error otherwise */
+    const void *conv_w_lo;      /* [W, roundup64(3 p^2)] = [w - w_hi rounded to 16 bits | 0] */
+    const void *proj_w_lo;      /* [out_dim, W] lo part of proj_w */
     int full_last_block;        /* encode_image returns ln_post(x[:, 0]) @ proj (openai/CLIP model.py), so
                                    of the last block's output only the class-token rows are ever read.
                                    0 (default): that block computes keys / values for every token but the

@@ -28,6 +28,8 @@ def lib():
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
+        _lib.ec_oracle_set_float32_stage.restype = None
+        _lib.ec_oracle_set_float32_stage.argtypes = [ctypes.c_int]
         _lib.ec_oracle_np_sum.restype = ctypes.c_double
         _lib.ec_oracle_np_sum.argtypes = [ctypes.c_void_p, ctypes.c_long]
         _lib.ec_oracle_split_event_count.restype = ctypes.c_long
@@ -82,6 +84,9 @@ def events2frames(events, split_method='event_count', convert_method='event_hist
         raise NotImplementedError(f'{convert_method} not implemented!')
     N = int(kwargs['N'])
     thresh = float(kwargs.get('thresh', 10.))
+    # float_stage='float32': the reference's pinned numpy 1.25 semantics of vis.py:27-39 (value-based
+    # casting keeps the stage in float32); default 'float64' = numpy >= 2, what the fixtures record
+    f32 = kwargs.get('float_stage', 'float64') == 'float32'
     cnz = bool(kwargs.get('count_non_zero', False))
     bgm = bool(kwargs.get('background_mask', True))
     red, blue = colour_map(grayscale)
@@ -95,10 +100,12 @@ def events2frames(events, split_method='event_count', convert_method='event_hist
     frames = np.zeros((max_frames, H, W, 3), dtype=np.uint8)
     raw = np.zeros((max_frames, H, W, 2), dtype=np.int64) if return_counts else None
     kept = np.zeros((max_frames, H, W, 2), dtype=np.int64) if return_counts else None
+    lib().ec_oracle_set_float32_stage(int(f32))
     F = lib().ec_oracle_events2frames(
         ev.ctypes.data, n_ev, N, H, W, thresh, int(cnz), int(bgm), red.ctypes.data,
         blue.ctypes.data, max_frames, frames.ctypes.data,
         raw.ctypes.data if return_counts else None, kept.ctypes.data if return_counts else None)
+    lib().ec_oracle_set_float32_stage(0)
     if F == -1:
         raise ValueError('event outside the sensor (the reference fails at vis.py:11)')
     assert F > 0

@@ -93,6 +93,13 @@ static void np_mean_std(const int64_t *v, long n, double *mean, double *std, dou
  * (one rounding each).  np.round is round-half-to-even.  All-zero frames give
  * 0/0 = NaN, which astype(uint8) turns into 0 on x86.
  */
+/* Float stage of vis.py:27-39: 0 = float64 (numpy >= 2, NEP 50: this image, and what the committed
+ * fixtures were generated under), 1 = float32 (the reference's pinned numpy 1.25.2,
+ * environment.yml:49: `float32 array / np.int64 scalar` stays float32 under value-based casting, the
+ * matmul is sgemm, and every later ufunc runs in float32 because python floats do not upcast). */
+static int g_float32_stage = 0;
+EXPORT void ec_oracle_set_float32_stage(int on) { g_float32_stage = on; }
+
 EXPORT int ec_oracle_event_histogram(const int32_t *x, const int32_t *y, const int32_t *p, long n,
                                      int H, int W, double thresh, int count_non_zero,
                                      int background_mask, const uint8_t *red, const uint8_t *blue,
@@ -132,6 +139,30 @@ EXPORT int ec_oracle_event_histogram(const int32_t *x, const int32_t *y, const i
     for (long i = 0; i < M; i++) if (hist[i] > mx) mx = hist[i];
     const double dmx = (double)mx;
 
+    if (g_float32_stage) {
+        const float fmx = (float)mx;                 /* the int64 scalar is cast to the array's float32 */
+        for (long q = 0; q < (long)H * W; q++) {
+            float a = (float)hist[2 * q] / fmx;
+            float b = (float)hist[2 * q + 1] / fmx;
+            float w = 0.f;
+            if (background_mask) {
+                w = a + b;
+                if (w < 0.f) w = 0.f;
+                if (w > 1.f) w = 1.f;
+            }
+            for (int c = 0; c < 3; c++) {
+                float v = fmaf(b, (float)blue[c], a * (float)red[c]);   /* sgemm, K = 2 */
+                if (background_mask) {
+                    float t1 = v * w;
+                    float t2 = 255.f * (1.f - w);
+                    v = t1 + t2;
+                }
+                float r = nearbyintf(v);
+                img[3 * q + c] = isnan(r) ? 0 : (uint8_t)r;
+            }
+        }
+        goto done;
+    }
     for (long q = 0; q < (long)H * W; q++) {
         double a = (double)(float)hist[2 * q] / dmx;     /* astype(float32) is exact below 2^24 */
         double b = (double)(float)hist[2 * q + 1] / dmx;

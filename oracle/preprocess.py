@@ -154,3 +154,17 @@ def patchify(img, patch, kpad=None):
     out = np.zeros((N, g * g, kpad), dtype=img.dtype)
     out[:, :, :k] = x
     return out
+
+
+def patchify_split(img, patch, kpad, dtype):
+    """The EC_PRE_PATCHES16 layout of include/eventclip_hip.h as a torch tensor of `dtype`
+    (torch.float16 / torch.bfloat16): row = [hi | lo | 0], hi = round16(v), lo = round16(v - hi)."""
+    import torch
+    k = 3 * patch * patch
+    x = torch.from_numpy(patchify(np.asarray(img, dtype=np.float32), patch, k))
+    hi = x.to(dtype)
+    lo = (x - hi.float()).to(dtype)
+    out = torch.zeros(x.shape[0], x.shape[1], kpad, dtype=dtype)
+    out[:, :, :k] = hi
+    out[:, :, k:2 * k] = lo
+    return out

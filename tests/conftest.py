@@ -41,6 +41,11 @@ def load_event_fixture(path):
     if 'frames' in z.files:
         exp['frames'] = z['frames']
         exp['raw'] = z['raw']
+    # the reference's float32 stage (numpy 1.x casting; tools/make_golden_events.py)
+    exp['frames_f32_sha256'] = str(z['frames_f32_sha256'])
+    exp['f32_differs'] = int(z['f32_differs'])
+    if exp['f32_differs']:
+        exp['f32_diff_index'], exp['f32_diff_value'] = z['f32_diff_index'], z['f32_diff_value']
     return ev, shape, kw, exp
 
 

@@ -34,6 +34,14 @@ def test_single_rank_line(hip):
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['unit'] == 'frames/s'
+    assert cb['cpu_model'] and cb['event2img_frames_per_s_1proc'] > 0
+    assert any(k.startswith('event2img_frames_per_s_pool') for k in cb), cb
+    # the events kernel's HBM roofline, with the 16 B per event it reads counted
+    re_ = d['roofline_events']
+    frames = 4 * 10
+    assert re_['algorithmic_bytes_per_launch'] == frames * (16 * 20000 + 3 * 180 * 240)
+    assert abs(re_['frac'] - re_['achieved_GBps'] / re_['peak_GBps']) < 1e-9
+    assert d['config']['unique_samples'] == 4
 
 
 def test_two_ranks_share_the_gpu_over_gloo(hip):
@@ -46,3 +54,20 @@ def test_two_ranks_share_the_gpu_over_gloo(hip):
     assert d['n_gpus'] == 2 and 'cpu_baseline' not in d
     assert abs(d['value'] - 2 * 4 * 10 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']   # whole-job aggregate
     assert d['config']['parallelism'].startswith('dp2')
+    assert d['config']['collective_ranks'] == 2 and len(d['config']['rank_devices']) == 2
+
+
+def test_gpus_2_launches_itself(hip):
+    """`python bench.py --gpus 2` the way the driver runs `--gpus 1`: no launcher around it.  The parent
+    starts the ranks as a child torch.distributed.run and relays its exit code."""
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2'] + SMALL, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['config']['collective_ranks'] == 2
+    # a failing child is reported, not swallowed
+    bad = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--arch', 'no-such-arch'] + SMALL[:4],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert bad.returncode != 0

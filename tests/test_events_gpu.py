@@ -14,7 +14,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def run_hip(ev, shape, kw, max_frame_events=0):
+def run_hip(ev, shape, kw, max_frame_events=0, float_stage='float64'):
     import torch
     from eventclip_amd import vis
     idx0, idx1 = vis.chunk_bounds(ev.shape[0], kw['N'])
@@ -23,7 +23,7 @@ def run_hip(ev, shape, kw, max_frame_events=0):
     frames, raw, kept, stats = vis.events_to_frames_device(
         ev_d, rng, shape, grayscale=kw['grayscale'], count_non_zero=kw['count_non_zero'],
         background_mask=kw['background_mask'], return_counts=True, return_stats=True,
-        max_frame_events=max_frame_events)
+        max_frame_events=max_frame_events, float_stage=float_stage)
     torch.cuda.synchronize()
     return frames.cpu().numpy(), raw.cpu().numpy(), kept.cpu().numpy(), stats
 
@@ -51,6 +51,12 @@ def test_hip_matches_reference_fixture(path, hip):
     assert sha(frames) == exp['frames_sha256']
     assert int(stats['dropped'].sum()) == 0
     np.testing.assert_array_equal(stats['sum'], o_raw.reshape(o_raw.shape[0], -1).sum(1))
+    # float32 stage (the reference under its pinned numpy 1.25): same counts, frames as recorded
+    f_frames, f_raw, f_kept, _ = run_hip(ev, shape, kw, max_frame_events=nmax, float_stage='float32')
+    np.testing.assert_array_equal(f_raw, raw)
+    np.testing.assert_array_equal(f_kept, kept)
+    assert sha(f_frames) == exp['frames_f32_sha256']
+    assert int((f_frames != frames).sum()) == exp['f32_differs']
 
 
 def test_numpy_api_drop_in(hip):

@@ -16,7 +16,7 @@ def ref_gemm(A, W, bias, epilogue, resid=None):
     return y
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 12, 13])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 5])
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 3072, 1024), (513, 1024, 4096),
                                    (77, 768, 640), (5, 512, 64), (256, 256, 128), (300, 48, 64)])

@@ -106,7 +106,7 @@ def test_pipeline_accepts_packed_samples(hip):
     res = (180, 240)
     qa = dict(split_method='event_count', convert_method='event_histogram', max_imgs=4, N=20000,
               grayscale=False, count_non_zero=False, background_mask=True)
-    pipe = Event2ImagePipeline(res, 225000, qa, n_px=224, patch=14, kpad=640, dtype=torch.float16)
+    pipe = Event2ImagePipeline(res, 225000, qa, n_px=224, patch=14, kpad=1216, dtype=torch.float16)
     samples = [make_events(n, res, seed=5 + i) for i, n in enumerate((45000, 20000, 9000))]
     a = pipe(samples, center=True)
     b = pipe([vis.pack_events(s) for s in samples], center=True)
@@ -146,7 +146,7 @@ def test_event_augmentation_matches_reference_and_feeds_the_pipeline(hip):
     # frames of the augmented batch == frames of the separately augmented samples
     qa = dict(split_method='event_count', convert_method='event_histogram', max_imgs=3, N=200,
               grayscale=True, count_non_zero=False, background_mask=True)
-    pipe = Event2ImagePipeline(res, 600, qa, n_px=224, patch=32, kpad=3072)
+    pipe = Event2ImagePipeline(res, 600, qa, n_px=224, patch=32, kpad=6144)
     a = pipe(out, counts, starts=starts)
     b_ = pipe([eu.augment_events(e, prm[b], res) for b, e in enumerate(evs)])
     assert torch.equal(a['valid_mask'], b_['valid_mask']) and torch.equal(a['patches'], b_['patches'])

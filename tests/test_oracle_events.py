@@ -26,10 +26,22 @@ def test_oracle_matches_reference_fixture(path):
         np.testing.assert_array_equal(frames, exp['frames'])
         np.testing.assert_array_equal(raw, exp['raw'])
     assert (kept <= raw).all()
+    # float32 stage: what the reference computes under its pinned numpy 1.25 (value-based casting)
+    f32 = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape, float_stage='float32', **kw)
+    assert sha(f32) == exp['frames_f32_sha256']
+    d = np.flatnonzero(f32.ravel() != frames.ravel())
+    assert len(d) == exp['f32_differs']
+    if len(d):                                   # 1 LSB apart, at exact .5 ties only
+        np.testing.assert_array_equal(d, exp['f32_diff_index'])
+        np.testing.assert_array_equal(f32.ravel()[d], exp['f32_diff_value'])
+        assert np.abs(f32.ravel()[d].astype(int) - frames.ravel()[d].astype(int)).max() == 1
 
 
 def test_fixture_count():
-    assert len(event_fixture_paths()) >= 30
+    paths = event_fixture_paths()
+    assert len(paths) >= 35
+    # some fixtures must actually separate the two float stages
+    assert sum(load_event_fixture(p)[3]['f32_differs'] > 0 for p in paths) >= 3
 
 
 @pytest.mark.parametrize('tot,N,exp0,exp1', [

@@ -42,12 +42,17 @@ def test_patch_rows_equal_rounded_transform(patch, n_px, dt, hip):
     rng = np.random.default_rng(patch)
     frames = rng.integers(0, 256, size=(2, 100, 120, 3), dtype=np.uint8)
     k = 3 * patch * patch
-    kpad = ((k + 63) // 64) * 64
+    kpad = ((2 * k + 63) // 64) * 64              # [hi | lo | 0] rows
     out = torch.full((2, (n_px // patch) ** 2, kpad), 7., dtype=dtype, device='cuda')
     got = pp.preprocess_frames(torch.from_numpy(frames).cuda(), n_px, mode='patches', patch=patch,
                                kpad=kpad, dtype=dtype, out=out)
-    want = torch.from_numpy(op.patchify(op.preprocess(frames, n_px), patch, kpad)).to(dtype)
+    ref = op.preprocess(frames, n_px)
+    want = op.patchify_split(ref, patch, kpad, dtype)
     assert torch.equal(got.cpu(), want)           # incl. zeroed K padding
+    # hi + lo carries the fp32 pixel value to 2^-22 (f16) / 2^-16 (bf16) relative
+    full = torch.from_numpy(op.patchify(ref, patch, k))
+    back = got[:, :, :k].float().cpu() + got[:, :, k:2 * k].float().cpu()
+    assert float((back - full).abs().max()) < (2e-6 if dt == 'float16' else 1e-4)
 
 
 def test_patchify_matches_oracle(hip):
@@ -56,10 +61,10 @@ def test_patchify_matches_oracle(hip):
     from eventclip_amd import _lib
     from oracle import preprocess as op
     x = torch.randn(3, 3, 224, 224, device='cuda')
-    out = torch.empty(3, 256, 640, dtype=torch.float16, device='cuda')
-    _lib.check(_lib.lib().ec_patchify(_lib.ptr(x), 3, 224, 14, 640, _lib.ptr(out), _lib.EC_F16,
+    out = torch.empty(3, 256, 1216, dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_patchify(_lib.ptr(x), 3, 224, 14, 1216, _lib.ptr(out), _lib.EC_F16,
                                       _lib.stream_ptr()))
-    want = torch.from_numpy(op.patchify(x.cpu().numpy(), 14, 640)).half()
+    want = op.patchify_split(x.cpu().numpy(), 14, 1216, torch.float16)
     assert torch.equal(out.cpu(), want)
 
 

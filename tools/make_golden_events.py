@@ -25,6 +25,35 @@ vis = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(vis)
 
 
+# ---- the float32 stage of the reference's pinned numpy 1.25 (environment.yml:49) ----
+# Under numpy < 2 `hist.astype(np.float32) / hist.max()` (vis.py:27) stays float32 (value-based
+# casting: an int64 SCALAR does not upcast a float32 array) and so does everything after it; under
+# numpy >= 2 (this image) the np.int64 scalar promotes the stage to float64.  numpy 2.2 has no
+# legacy-promotion switch, so the SAME reference code is run a second time on a module copy whose
+# `np.stack` hands back integer arrays with a `.max()` that returns a python int -- a weak scalar,
+# which NEP 50 treats exactly as numpy 1.x treated the int64 scalar.  Nothing else differs.
+class _WeakMax(np.ndarray):
+    def max(self, *a, **k):
+        r = np.ndarray.max(self.view(np.ndarray), *a, **k)
+        return int(r) if np.ndim(r) == 0 else r
+
+
+class _LegacyNumpy:
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+    @staticmethod
+    def stack(arrays, axis=0, **kw):
+        out = np.stack(arrays, axis=axis, **kw)
+        return out.view(_WeakMax) if out.dtype.kind == 'i' else out
+
+
+spec32 = importlib.util.spec_from_file_location('refvis_f32', '/root/reference/datasets/vis.py')
+vis32 = importlib.util.module_from_spec(spec32)
+spec32.loader.exec_module(vis32)
+vis32.np = _LegacyNumpy()
+
+
 def ref_counts(ev, N, shape):
     """Raw per-chunk counts through the reference's own parse/split + bincount lines."""
     x, y, t, p = vis.parse_events(ev)
@@ -49,6 +78,9 @@ def case(name, ev, shape, N, grayscale=True, count_non_zero=False, background_ma
               background_mask=background_mask)
     frames = vis.events2frames(ev.copy(), 'event_count', 'event_histogram', shape=shape,
                                max_imgs=10, **dict(kw))
+    frames32 = np.asarray(vis32.events2frames(ev.copy(), 'event_count', 'event_histogram', shape=shape,
+                                              max_imgs=10, **dict(kw)))
+    assert frames32.dtype == np.uint8 and frames32.shape == frames.shape
     raw = ref_counts(ev.copy(), N, shape)
     d = dict(
         name=name, shape=np.array(shape), N=N,
@@ -58,6 +90,8 @@ def case(name, ev, shape, N, grayscale=True, count_non_zero=False, background_ma
         ev_x=ev[:, 0].copy(), ev_y=ev[:, 1].copy(), ev_t=ev[:, 2].copy(), ev_p=ev[:, 3].copy(),
         frames_sha256=sha(frames), raw_sha256=sha(raw), n_frames=frames.shape[0],
         numpy_version=np.__version__, float_stage='float64',
+        frames_f32_sha256=sha(frames32),
+        f32_differs=int((frames32 != frames).sum()),
     )
     # integer-valued coordinates compress to int16
     if np.all(ev[:, 0] == np.floor(ev[:, 0])) and np.all(ev[:, 1] == np.floor(ev[:, 1])):
@@ -68,6 +102,10 @@ def case(name, ev, shape, N, grayscale=True, count_non_zero=False, background_ma
     if store_full:
         d['frames'] = frames
         d['raw'] = raw
+    if d['f32_differs']:
+        idx = np.flatnonzero(frames32.ravel() != frames.ravel())
+        d['f32_diff_index'] = idx.astype(np.int64)          # where the float32 stage rounds differently
+        d['f32_diff_value'] = frames32.ravel()[idx]
     return d
 
 
@@ -123,11 +161,29 @@ def main():
     cases.append(case('rem_exactly_half', make_events(900 * 3 + 450, tiny, 46), tiny, 900))
     cases.append(case('rem_half_plus1', make_events(900 * 3 + 451, tiny, 47), tiny, 900))
 
+    # every (positive, negative) count pair up to a maximum of 6 / 10 / 12: the .5 ties where the
+    # float32 stage (numpy 1.25) and the float64 stage (numpy >= 2) round differently
+    for mx, gray, bg in ((6, True, False), (12, True, False), (6, False, True), (10, False, True),
+                         (12, False, True)):
+        rows = []
+        pix = 0
+        for c0 in range(mx + 1):
+            for c1 in range(mx + 1):
+                x, y = pix % tiny[1], pix // tiny[1]
+                rows += [[x, y, 0., 1.]] * c0 + [[x, y, 0., -1.]] * c1
+                pix += 1
+        ev = np.array(rows, dtype=np.float32)
+        ev = ev[np.random.default_rng(mx).permutation(len(ev))]
+        ev[:, 2] = np.linspace(0, 0.1, len(ev))
+        cases.append(case(f'ties_max{mx}_{"gray" if gray else "rgb"}_bg{int(bg)}', ev, tiny, len(ev) + 7,
+                          grayscale=gray, background_mask=bg))
+
     for i, d in enumerate(cases):
         np.savez_compressed(os.path.join(out_dir, f'events_{i:02d}_{d["name"]}.npz'), **d)
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir)
               if f.startswith('events_'))
-    print(f'wrote {len(cases)} fixtures, {tot / 1024:.0f} KiB')
+    print(f'wrote {len(cases)} fixtures, {tot / 1024:.0f} KiB; float32 stage differs from float64 in '
+          f'{sum(int(d["f32_differs"]) for d in cases)} bytes over {sum(1 for d in cases if d["f32_differs"])} fixtures')
 
 
 if __name__ == '__main__':

@@ -1,10 +1,21 @@
+# One measurement round on the GPU box: bench line, kernel trace, the two PMC passes.
+#   gpurun -- 'bash tools/profile_round.sh r2_a <commit>'
+# Every profiled run passes --no-dvfs: bench.py's clock / power sampling must not start anything
+# while rocprofv3's preload is in the environment.
 set -x
+TAG=${1:-r2_a}
+COMMIT=${2:-unrecorded}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python bench.py --steps 3 --warmup 1 > gpurun_out/bench_r1_f.json 2> gpurun_out/bench_r1_f.err
-tail -c 600 gpurun_out/bench_r1_f.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_r1_f.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch_f.json 2> gpurun_out/pmc_fetch_f.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write_f.log 2>&1
-find gpurun_out/prof_r1_f gpurun_out/pmc_fetch_f gpurun_out/pmc_write_f -name "*.csv" | head -20
+python bench.py --steps 5 --warmup 2 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+tail -c 1500 gpurun_out/bench_$TAG.json
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dvfs > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dvfs > gpurun_out/pmc_fetch_$TAG.json 2> gpurun_out/pmc_fetch_$TAG.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dvfs > gpurun_out/pmc_write_$TAG.log 2>&1
+F=$(find gpurun_out/pmc_fetch_$TAG -name "*counter_collection.csv" | head -1)
+W=$(find gpurun_out/pmc_write_$TAG -name "*counter_collection.csv" | head -1)
+S=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
+python tools/traffic_summary.py $F $W gpurun_out/pmc_fetch_$TAG.json $COMMIT > gpurun_out/traffic_$TAG.json
+cp $S gpurun_out/${TAG}_kernel_stats.csv
+ls -la gpurun_out/*$TAG*

@@ -1,14 +1,17 @@
 """Diagnostic: per-segment s_memtime stamps of the 2-phase GEMM (variant 10)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the stamp / timeline variants only exist in the diagnostic build (python -m eventclip_amd.build --diag)
+os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', 'libeventclip_hip_diag.so'))
 from eventclip_amd import ops
 M, N, K = 65792, 1024, 4096
 A = torch.randn(M, K, device='cuda').half(); W = (torch.randn(N, K, device='cuda') / 64).half()
 out = torch.zeros(M, N, device='cuda')
 dbg = torch.zeros(2 * 64 * 8 * 2, device='cuda', dtype=torch.float32)   # 2 waves x 64 tiles x 8 stamps (u64)
 for _ in range(3):
-    ops.gemm(A, W, dbg, 'store32', out=out, variant=10)
+    ops.gemm(A, W, None, 'store32', out=out, variant=10, diag=dbg)
 torch.cuda.synchronize()
 st = dbg.cpu().numpy().view(np.uint64).reshape(2, 64, 8).astype(np.int64)
 names = ['L_A start', 'reads issued', 'dma+vmcnt', 'barrier1', 'mma done', 'L_B start(bar2)', 'L_B done', 'mma2 done']

@@ -9,7 +9,10 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the stamp / timeline variants only exist in the diagnostic build (python -m eventclip_amd.build --diag)
+os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', 'libeventclip_hip_diag.so'))
 from eventclip_amd import ops  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
@@ -22,7 +25,7 @@ out = torch.zeros(M, N, device='cuda', dtype=torch.float32 if epi.endswith('32')
 tiles = ((M + 255) // 256) * ((N + 255) // 256)
 dbg = torch.zeros(tiles * 8 * 2, device='cuda', dtype=torch.float32)
 for _ in range(2):
-    ops.gemm(A, W, dbg, epi, out=out, variant=int(os.environ.get('TL_VARIANT', '16')))
+    ops.gemm(A, W, None, epi, out=out, variant=int(os.environ.get('TL_VARIANT', '16')), diag=dbg)
 torch.cuda.synchronize()
 r = dbg.cpu().numpy().view(np.uint64).reshape(tiles, 8).astype(np.int64)
 hw, xcc = r[:, 0], r[:, 6]

@@ -1,6 +1,6 @@
 """Fold the rocprofv3 FETCH_SIZE / WRITE_SIZE passes over bench.py into profiles/traffic.json.
 
-    python tools/traffic_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv bench.json > profiles/traffic.json
+    python tools/traffic_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv bench.json [commit] > profiles/traffic.json
 
 Units per MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KiB; on gfx950
 FETCH_SIZE counts the 128-byte requests of 16-B/lane streams at 64 B, so it is doubled.
@@ -46,10 +46,7 @@ def collect(path, counter):
 def main():
     fetch_csv, write_csv, bench_json = sys.argv[1:4]
     bench = json.loads([ln for ln in open(bench_json) if ln.startswith('{')][-1])
-    alg = dict(bench['kernel_algorithmic_bytes_per_launch'])
-    # the events kernel's call site only knows the output bytes: add 16 B per event
-    cfg = bench['config']
-    alg['events_to_frames_kernel'] += 16.0 * cfg['events_per_frame'] * cfg['frames_per_step_per_gpu']
+    alg = dict(bench['kernel_algorithmic_bytes_per_launch'])   # the events kernel's figure includes its 16 B / event
     ft, fc = collect(fetch_csv, 'FETCH_SIZE')
     wt, wc = collect(write_csv, 'WRITE_SIZE')
     kernels = {}
@@ -63,6 +60,7 @@ def main():
                       'algorithmic_bytes_per_launch': alg[k], 'ratio': hbm / alg[k]}
     dom = bench['roofline']['kernel']
     out = {'kernel': dom,
+           'commit': sys.argv[4] if len(sys.argv) > 4 else 'unrecorded',   # tree the counters were taken on
            'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over '
                    '`bench.py --steps 1 --warmup 1 --no-cpu-baseline`, averaged over the full-size launches '
                    'of each kernel class. Units KiB; '
