@@ -108,18 +108,6 @@ class ZSCLIPClassifier(nn.Module):
         """imgs [N, 3, R, R] -> [N, C] (clip_cls.py:95-102)."""
         return self.model.encode_image(imgs)
 
-    # torch versions of the two aggregations, kept for API parity (the HIP path does them in ec_classify)
-    def _aggregate_logits(self, logits, valid_masks):
-        m = valid_masks.float()
-        if self.agg_func == 'max':                       # the evident intent of clip_cls.py:116-118
-            return (logits - (1. - m).unsqueeze(-1) * 1e6).amax(1)
-        total = logits.sum(1)
-        return total / m.sum(1, keepdim=True) if self.agg_func == 'mean' else total
-
-    def _aggregate_probs(self, logits, valid_masks):
-        m = valid_masks.detach().float()
-        return (logits.softmax(-1) * m.unsqueeze(-1)).sum(1) / m.sum(1, keepdim=True)
-
     # ---- shared pieces of forward ----
     def _view_feats(self, data_dict):
         """Features of the valid views [Nv, C] fp32 plus row_idx [B, T] int32 (CUDA)."""

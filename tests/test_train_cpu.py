@@ -50,6 +50,56 @@ def test_cosine_warmup_shape():
     assert all(a <= b + 1e-15 for a, b in zip(lr[:10], lr[1:11])) and all(a >= b - 1e-15 for a, b in zip(lr[10:100], lr[11:]))
 
 
+def test_lr_schedule_equals_the_published_scheduler_driven_by_torch():
+    """The reference's schedule (method.py:82-98) is nerv's CosineAnnealingWarmupRestarts, un-vendored;
+    it is the widely published scheduler of that name (one cycle here: first_cycle_steps = total steps,
+    cycle_mult = 1, gamma = 1, lr initialised to min_lr, stepped once per optimiser step).  Its
+    published rule, stated here independently as a torch LRScheduler and driven by a real optimiser
+    the way nerv drives it (scheduler.step() after every optimizer.step()), must give the learning
+    rate every training step of eventclip_amd.train uses -- fractional warm-up lengths included, as
+    `warmup_steps_pct * total_steps` produces them."""
+    import math
+    import torch
+    from eventclip_amd.train import cosine_warmup_lr
+
+    class Published(torch.optim.lr_scheduler.LRScheduler):
+        def __init__(self, optimizer, first_cycle_steps, max_lr, min_lr, warmup_steps):
+            self.first_cycle_steps, self.max_lr, self.min_lr = first_cycle_steps, max_lr, min_lr
+            self.warmup_steps, self.step_in_cycle = warmup_steps, -1
+            for g in optimizer.param_groups:              # init_lr(): every group starts at min_lr
+                g['lr'] = min_lr
+            self.base = [min_lr for _ in optimizer.param_groups]
+            super().__init__(optimizer)                    # steps once: step_in_cycle = 0
+
+        def get_lr(self):
+            if self.step_in_cycle == -1:
+                return self.base
+            if self.step_in_cycle < self.warmup_steps:
+                return [(self.max_lr - b) * self.step_in_cycle / self.warmup_steps + b for b in self.base]
+            return [b + (self.max_lr - b) * (1 + math.cos(math.pi * (self.step_in_cycle - self.warmup_steps) /
+                                                          (self.first_cycle_steps - self.warmup_steps))) / 2
+                    for b in self.base]
+
+        def step(self, epoch=None):
+            self.step_in_cycle += 1
+            if self.step_in_cycle >= self.first_cycle_steps:
+                self.step_in_cycle -= self.first_cycle_steps
+            for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+                g['lr'] = lr
+
+    for total, pct, lr in ((100, 0.05, 1e-3), (37, 0.05, 5e-4), (250, 0.1, 2e-2), (12, 0.0, 1e-3)):
+        p = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.Adam([p], lr=lr)
+        sched = Published(opt, total, lr, lr / 100., pct * total)
+        for step in range(total):
+            used = opt.param_groups[0]['lr']               # what optimizer.step() number `step` runs at
+            mine = cosine_warmup_lr(step, total, lr, lr / 100., pct * total)
+            assert abs(used - mine) <= 1e-12 * lr, (total, pct, step, used, mine)
+            p.grad = torch.ones(3)
+            opt.step()
+            sched.step()
+
+
 def trans_cases():
     z = np.load(os.path.join(GOLDEN, 'train_text_trans.npz'))
     return [(ci, agg, loss) for ci in range(len(z['cases'])) for agg, loss in (('sum', 'logits'), ('mean', 'probs'))]
