@@ -131,16 +131,10 @@ class TransformerAdapter(Adapter):
 
     @torch.no_grad()
     def forward_rows(self, feats, row_idx):
-        pk = self._pack()
-        B, T = row_idx.shape
-        feats = feats.float().contiguous()
-        out = torch.empty((B, T, self.in_dim), dtype=torch.float32, device=feats.device)
-        row_idx = row_idx.contiguous()
-        rc = _lib.lib().ec_adapter_forward(ctypes.byref(pk['w']), _lib.ptr(feats),
-                                           _lib.ptr(row_idx), B, T, _lib.ptr(out),
-                                           _lib.stream_ptr())
-        _lib.check(rc, 'ec_adapter_forward')
-        return out
+        from . import torch_ops
+        self._pack()
+        return torch.ops.eventclip_hip.adapter_fwd(feats.float().contiguous(), row_idx.contiguous(),
+                                                    torch_ops.handle_of(self))
 
     @torch.no_grad()
     def forward(self, feats, valid_masks):

@@ -301,21 +301,12 @@ class CLIP(nn.Module):
     @torch.no_grad()
     def encode_patches(self, patches, n_img=None):
         """patches: 16-bit CUDA tensor [N, G, kpad] (ec_preprocess / ec_patchify layout)."""
-        pk = self._pack()
-        n = int(patches.shape[0]) if n_img is None else int(n_img)
-        feats = torch.empty((n, self.cfg['embed_dim']), dtype=torch.float32, device=pk['dev'])
-        chunk = max(1, min(self.chunk, n))
-        need = _lib.lib().ec_vit_workspace_bytes(ctypes.byref(pk['vit']), chunk)
-        if need > self.workspace_budget:     # keep the scratch bounded (e.g. 336-px inputs)
-            chunk = max(1, int(chunk * self.workspace_budget / need))
-            need = _lib.lib().ec_vit_workspace_bytes(ctypes.byref(pk['vit']), chunk)
-        ws = self._workspace(need, pk['dev'])
+        from . import torch_ops
+        self._pack()
+        if n_img is not None and int(n_img) != int(patches.shape[0]):
+            patches = patches[:int(n_img)]
         assert patches.dtype == self.compute_dtype and patches.is_contiguous()
-        rc = _lib.lib().ec_vit_encode(ctypes.byref(pk['vit']), _lib.ptr(patches), n,
-                                      _lib.ptr(feats), _lib.ptr(ws), ws.numel(), chunk,
-                                      _lib.stream_ptr())
-        _lib.check(rc, 'ec_vit_encode')
-        return feats
+        return torch.ops.eventclip_hip.vit_encode(patches, torch_ops.handle_of(self))
 
     @torch.no_grad()
     def encode_image(self, image):
@@ -341,16 +332,9 @@ class CLIP(nn.Module):
         c = self.cfg
         if text.dim() != 2 or text.shape[1] != c['context_length']:
             raise ValueError(f'encode_text expects [K, {c["context_length"]}]')
+        from . import torch_ops
         tok = text.to(pk['dev'], torch.int32).contiguous()
-        n = tok.shape[0]
-        feats = torch.empty((n, c['embed_dim']), dtype=torch.float32, device=pk['dev'])
-        chunk = max(1, min(512, n))
-        need = _lib.lib().ec_text_workspace_bytes(ctypes.byref(pk['text']), chunk)
-        ws = self._workspace(need, pk['dev'])
-        rc = _lib.lib().ec_text_encode(ctypes.byref(pk['text']), _lib.ptr(tok), n, _lib.ptr(feats),
-                                       _lib.ptr(ws), ws.numel(), chunk, _lib.stream_ptr())
-        _lib.check(rc, 'ec_text_encode')
-        return feats
+        return torch.ops.eventclip_hip.text_encode(tok, torch_ops.handle_of(self))
 
     def forward(self, image, text):
         """Cosine-similarity logits, as OpenAI's CLIP.forward."""

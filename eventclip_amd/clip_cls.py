@@ -126,19 +126,10 @@ class ZSCLIPClassifier(nn.Module):
         return feats.float().contiguous(), row_idx.contiguous(), valid_masks
 
     def _classify(self, feats, row_idx, normalize):
-        B, T = row_idx.shape
-        text_t = self._text_transposed()
-        C, K = text_t.shape
-        dev = feats.device
-        full = torch.empty((B, T, K), dtype=torch.float32, device=dev)
-        logits = torch.empty((B, K), dtype=torch.float32, device=dev)
-        probs = torch.empty((B, K), dtype=torch.float32, device=dev)
-        rc = _lib.lib().ec_classify(_lib.ptr(feats), _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C, K,
-                                    float(self.logit_scale), _AGG[self.agg_func], int(normalize),
-                                    _lib.ptr(full), _lib.ptr(logits), _lib.ptr(probs),
-                                    _lib.stream_ptr())
-        _lib.check(rc, 'ec_classify')
-        return full, logits, probs
+        from . import torch_ops  # noqa: F401  (registers eventclip_hip::classify)
+        return torch.ops.eventclip_hip.classify(feats, row_idx, self._text_transposed(),
+                                                float(self.logit_scale), _AGG[self.agg_func],
+                                                bool(normalize))
 
     @torch.no_grad()
     def forward(self, data_dict):

@@ -66,9 +66,9 @@ def preprocess_frames(frames, n_px=224, mode='chw', patch=None, kpad=None, dtype
     else:
         raise ValueError(mode)
     if out is None:
-        out = torch.empty(shape, dtype=odt, device=dev)
-    else:
-        assert out.dtype == odt and out.is_contiguous() and out.numel() >= int(np.prod(shape))
+        from . import torch_ops  # noqa: F401  (registers eventclip_hip::preprocess)
+        return torch.ops.eventclip_hip.preprocess(frames, int(n_px), m, int(patch), int(kpad), code)
+    assert out.dtype == odt and out.is_contiguous() and out.numel() >= int(np.prod(shape))
     rc = _lib.lib().ec_preprocess(_lib.ptr(frames), F, host.ctypes.data, _lib.ptr(plan),
                                   _lib.ptr(out), m, patch, kpad, code, _lib.stream_ptr())
     _lib.check(rc, 'ec_preprocess')

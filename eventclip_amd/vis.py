@@ -193,6 +193,17 @@ def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=1
     assert packed or (events.dtype == torch.float32 and events.dim() == 2 and events.shape[1] == 4)
     assert frame_range.is_cuda and frame_range.dtype == torch.int64 and frame_range.is_contiguous()
     F = int(frame_range.shape[0])
+    if out is None and not return_counts and not return_stats and sort_workspace:
+        # the production form: the registered custom op (eventclip_hip::events_to_frames)
+        from . import torch_ops  # noqa: F401  (registers the namespace)
+        red, blue = colour_map(grayscale)
+        if float_stage not in ('float64', 'float32'):
+            raise ValueError(f'float_stage {float_stage!r}: float64 (numpy >= 2) or float32 (numpy 1.x)')
+        return torch.ops.eventclip_hip.events_to_frames(
+            events, frame_range, int(H), int(W), float(thresh), [int(v) for v in red],
+            [int(v) for v in blue], bool(count_non_zero), bool(background_mask), int(max_frame_events),
+            bool(flip_x), bool(negate_p), float_stage == 'float32', int(total_events))
+    # debug form (raw / kept counts, per-frame statistics, caller-owned output): straight to the C ABI
     frames = out if out is not None else torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
     raw = kept = stats = None
     if return_counts:

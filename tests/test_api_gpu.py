@@ -159,3 +159,52 @@ def test_views_match_the_references_event2image_dataset(hip):
             got, vm = views(ev_d, int(n), h, t)                                # event2img.py:97-103 order
             np.testing.assert_array_equal(vm, z[f'tta1_valid{i}'][v])
             np.testing.assert_array_equal(got, z[f'tta1_img{i}'][v].transpose(0, 2, 3, 1), err_msg=f'sample {i} view {v}')
+
+
+def test_classifier_forward_runs_through_the_registered_custom_ops(hip):
+    """The drop-in classes reach the kernels through torch.ops.eventclip_hip.* (north_star's boundary):
+    chaining the ops by hand gives the classifier's out_dict bit for bit, and every op is seen by a
+    torch dispatch trace of model.forward."""
+    import torch
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from eventclip_amd import _lib, torch_ops, vis
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import make_batch
+    qa = dict(max_imgs=3, N=20000, split_method='event_count', convert_method='event_histogram',
+              grayscale=False, count_non_zero=False, background_mask=True)
+    cfg = eclip.arch_config('ViT-B/32', layers=2, text_layers=1)
+    m = eclip.CLIP(cfg, eclip.random_state_dict(cfg, seed=3)).cuda().eval()
+    tokens = eclip.synthetic_tokens(7, seed=1)
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a {}', class_names=list('abcdefg'),
+                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
+    pipe = Event2ImagePipeline((180, 240), 225000, qa, n_px=224, patch=32, kpad=m.kpad)
+    pipe.strict = False
+    evs = make_batch(2, [50000, 21000], (180, 240), seed=4)
+
+    seen = []
+
+    class Trace(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if 'eventclip_hip' in str(func):
+                seen.append(str(func).split('.')[1])
+            return func(*args, **(kwargs or {}))
+
+    with Trace():
+        out = model(pipe(evs))
+    assert {'events_to_frames', 'preprocess', 'vit_encode', 'text_encode', 'classify'} <= set(seen), seen
+
+    # the same chain by hand
+    ev, n_ev = pipe._concat(evs, torch.device('cuda'))
+    fr, ri, vm = pipe.plan(n_ev)
+    ops = torch.ops.eventclip_hip
+    frames = ops.events_to_frames(ev, fr.cuda(), 180, 240, 10., [255, 0, 0], [0, 0, 255], False, True, 20000,
+                                  False, False, False, 0)
+    patches = ops.preprocess(frames, 224, _lib.EC_PRE_PATCHES16, 32, m.kpad, _lib.EC_F16)
+    feats = ops.vit_encode(patches, torch_ops.handle_of(m))
+    from eventclip_amd.clip_cls import _l2_normalize
+    text = _l2_normalize(ops.text_encode(tokens.cuda().int(), torch_ops.handle_of(m)))
+    full, logits, probs = ops.classify(feats, ri.cuda(), text.t().contiguous(), 100.0, 1, False)
+    assert torch.equal(full, out['full_logits']) and torch.equal(logits, out['logits'])
+    assert torch.equal(probs, out['probs'])

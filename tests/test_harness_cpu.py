@@ -277,3 +277,30 @@ def test_lora_fold_matches_the_references_effective_weights():
     full = load_finetuned_visual({'visual.conv1.weight': torch.ones(1), 'token_embedding.weight': torch.ones(1)}, ck)
     assert 'token_embedding.weight' in full and 'visual.conv1.weight' not in full
     assert 'visual.transformer.resblocks.1.attn.out_proj.weight' in full and not any('lora' in k for k in full)
+
+
+def test_custom_ops_are_registered_and_have_no_cpu_kernel():
+    """north_star's boundary: `eventclip_hip::` PyTorch custom ops over the C ABI.  Registered for
+    CUDA (HIP) tensors only: shapes come from the fake kernels, CPU tensors are refused."""
+    import pytest
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from eventclip_amd import torch_ops
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.eventclip_hip, name), name
+    with FakeTensorMode():
+        f = torch.empty(12, 768, device='cuda')
+        ri = torch.zeros(4, 3, dtype=torch.int32, device='cuda')
+        full, logits, probs = torch.ops.eventclip_hip.classify(f, ri, torch.empty(768, 101, device='cuda'),
+                                                               100.0, 1, False)
+        assert full.shape == (4, 3, 101) and logits.shape == (4, 101) and probs.shape == (4, 101)
+        ev = torch.empty(1000, 4, device='cuda')
+        fr = torch.zeros(5, 2, dtype=torch.int64, device='cuda')
+        frames = torch.ops.eventclip_hip.events_to_frames(ev, fr, 180, 240, 10., [255, 0, 0], [0, 0, 255], False,
+                                                          True, 0, False, False, False, 0)
+        assert frames.shape == (5, 180, 240, 3) and frames.dtype == torch.uint8
+        pt = torch.ops.eventclip_hip.preprocess(frames, 224, 1, 14, 1216, 0)
+        assert pt.shape == (5, 256, 1216) and pt.dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        torch.ops.eventclip_hip.classify(torch.zeros(2, 4), torch.zeros(1, 2, dtype=torch.int32),
+                                         torch.zeros(4, 3), 1.0, 1, False)
