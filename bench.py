@@ -126,23 +126,35 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, 
     return res
 
 
-def _amdgpu_sysfs():
-    """(pp_dpm_sclk path, power1_average path) of the first amdgpu card, or None."""
+def _amdgpu_sysfs(device=0):
+    """(pp_dpm_sclk path, power path) of the GPU this rank runs on, or None.  The box's sysfs lists
+    every GPU of the node, not only the visible one: the card is found by the PCI address of the HIP
+    device; without it, all cards are candidates and the one drawing the most power is the loaded one."""
     import glob
-    for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
-        sclk = os.path.join(card, 'pp_dpm_sclk')
-        pw = glob.glob(os.path.join(card, 'hwmon', 'hwmon*', 'power1_average')) + \
-            glob.glob(os.path.join(card, 'hwmon', 'hwmon*', 'power1_input'))
-        if os.path.exists(sclk) and pw:
-            return sclk, pw[0]
-    return None
+
+    def files(dev_dir):
+        sclk = os.path.join(dev_dir, 'pp_dpm_sclk')
+        pw = glob.glob(os.path.join(dev_dir, 'hwmon', 'hwmon*', 'power1_average')) + \
+            glob.glob(os.path.join(dev_dir, 'hwmon', 'hwmon*', 'power1_input'))
+        return (sclk, pw[0]) if os.path.exists(sclk) and pw else None
+
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        got = files(os.path.join('/sys/bus/pci/devices', bdf))
+        if got:
+            return [got]
+    except Exception:   # noqa: BLE001
+        pass
+    cands = [files(c) for c in sorted(glob.glob('/sys/class/drm/card[0-9]*/device'))]
+    return [c for c in cands if c] or None
 
 
 def _under_profiler():
     return any(k == 'LD_PRELOAD' or k.startswith(('ROCP_', 'ROCPROFILER_', 'ROCPROF')) for k in os.environ)
 
 
-def sample_dvfs(step, fence, n_steps=6):
+def sample_dvfs(step, fence, n_steps=6, device=0):
     """Shader clock and socket power while the step runs (untimed extra steps, after the timed
     region), polled from a thread that never touches the HIP context.  Source: the amdgpu sysfs
     files (pp_dpm_sclk, hwmon power1_average) -- no child process; only when they are unreadable and
@@ -153,7 +165,7 @@ def sample_dvfs(step, fence, n_steps=6):
     sustains less on this workload, and `peak_at_sclk` restates the peak at the observed clock."""
     import re
     import threading
-    sysfs = _amdgpu_sysfs()
+    sysfs = _amdgpu_sysfs(device)
     smi = '/opt/rocm/libexec/rocm_smi/rocm_smi.py'
     use_smi = sysfs is None and not _under_profiler() and os.path.exists(smi)
     if sysfs is None and not use_smi:
@@ -166,11 +178,15 @@ def sample_dvfs(step, fence, n_steps=6):
         while not stop.is_set():
             try:
                 if sysfs:
-                    cur = [ln for ln in open(sysfs[0]).read().splitlines() if ln.rstrip().endswith('*')]
+                    best = None
+                    for sclk_path, pw_path in sysfs:     # several candidates: the loaded card draws the most
+                        pw = float(open(pw_path).read()) * 1e-6
+                        if best is None or pw > best[1]:
+                            best = (sclk_path, pw)
+                    cur = [ln for ln in open(best[0]).read().splitlines() if ln.rstrip().endswith('*')]
                     clk = re.search(r'(\d+)\s*Mhz', cur[0], re.I) if cur else None
-                    pw = float(open(sysfs[1]).read()) * 1e-6
                     if clk:
-                        samples.append((int(clk.group(1)), pw))
+                        samples.append((int(clk.group(1)), best[1]))
                     time.sleep(0.05)
                 else:
                     out = subprocess.run([sys.executable, smi, '--showclocks', '--showpower'],
@@ -376,7 +392,7 @@ def main():
             'kernel_algorithmic_bytes_per_launch': {e['name']: e['bytes'] / e['launches'] for e in prof},
         }
         if world == 1 and not a.no_dvfs:
-            dv = sample_dvfs(step, fence)
+            dv = sample_dvfs(step, fence, device=local)
             if dv:
                 res['dvfs'] = dv
                 if roof['bound'] == 'mfma':

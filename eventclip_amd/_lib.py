@@ -45,6 +45,15 @@ class EcAdapterWeights(ctypes.Structure):
                 ('layer', ctypes.POINTER(EcAdapterLayer))]
 
 
+class EcAugOp(ctypes.Structure):
+    _fields_ = [('kind', c_int), ('alpha', c_float), ('param', c_double), ('m', c_double * 6)]
+
+
+(EC_AUG_IDENTITY, EC_AUG_AFFINE, EC_AUG_ROT180, EC_AUG_ROT90, EC_AUG_ROT270, EC_AUG_BRIGHTNESS,
+ EC_AUG_COLOR, EC_AUG_CONTRAST, EC_AUG_SHARPNESS, EC_AUG_POSTERIZE, EC_AUG_SOLARIZE,
+ EC_AUG_AUTOCONTRAST, EC_AUG_EQUALIZE) = range(13)
+
+
 class EcProfileEntry(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char * 64), ('launches', c_long), ('total_ms', c_double),
                 ('flops', c_double), ('bytes', c_double)]
@@ -158,6 +167,9 @@ SIGNATURES = {
                                ctypes.c_size_t, c_int, c_void_p]),
     'ec_adapter_forward': (c_int, [ctypes.POINTER(EcAdapterWeights), c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p]),
+    'ec_randaugment_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    'ec_randaugment': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                               c_void_p, ctypes.c_size_t, c_void_p]),
     'ec_classify': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -180,17 +180,34 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
     const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
 
     // ---- stage K and V of this head: AT_THREADS / 8 rows x 8 chunks of 16 B per pass ----
+    // Every load of the whole head is issued before the first LDS write (at most five passes for the
+    // sequence lengths either workgroup size is launched for): a loop of load -> wait -> write pays
+    // the HBM latency once per pass, and the 4-5 serial round trips were most of this kernel's time
+    // (S = 257: 10 us per workgroup of staging against 3 us of MFMA / softmax work).
     {
+        constexpr int ROWS = AT_THREADS / 8, PASSES = 5;   // 5 * ROWS >= SP (checked by the launcher)
         const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
-        for (int row = r_in; row < SP; row += AT_THREADS / 8) {
-            const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
-            const elem *src = base + (long)srow * ld + ch * 8;
-            const u32x4 kv = *reinterpret_cast<const u32x4 *>(src + W);
-            u32x4 vv = *reinterpret_cast<const u32x4 *>(src + 2 * W);
-            *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kv;
-            // V: 8-byte slot u -> u ^ ((row>>1)&3): chunk moves by bit 1, halves swap by bit 0
-            if ((row >> 1) & 1) vv = u32x4{vv[2], vv[3], vv[0], vv[1]};
-            *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
+        u32x4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const int row = r_in + p * ROWS;
+            if (row < SP) {
+                const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
+                const elem *src = base + (long)srow * ld + ch * 8;
+                kreg[p] = *reinterpret_cast<const u32x4 *>(src + W);
+                vreg[p] = *reinterpret_cast<const u32x4 *>(src + 2 * W);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const int row = r_in + p * ROWS;
+            if (row < SP) {
+                *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kreg[p];
+                // V: 8-byte slot u -> u ^ ((row>>1)&3): chunk moves by bit 1, halves swap by bit 0
+                u32x4 vv = vreg[p];
+                if ((row >> 1) & 1) vv = u32x4{vv[2], vv[3], vv[0], vv[1]};
+                *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
+            }
         }
     }
     // first Q tile of this wave, issued before the barrier so its latency hides behind staging
@@ -260,6 +277,10 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const bool wide = lds > 80 * 1024;
     void (*kern)(const AttnArgs) = wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>;
     const int nw = wide ? 16 : 8;
+    // the staging prologue covers the padded sequence in five passes of nw * 8 rows
+    if (32 * n32 > 5 * nw * 8)
+        return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d too long for %d waves",
+                        a.S, nw);
     static int attr_lds[2] = {0, 0};
     if (lds > 64 * 1024 && lds > attr_lds[wide]) {
         EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

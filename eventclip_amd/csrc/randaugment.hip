@@ -1,0 +1,341 @@
+// RandAugment on uint8 event frames (gfx950): the 14 operators of the reference's
+// datasets/augment.py (_apply_op :10-87, _augmentation_space :123-140), which the reference applies
+// to PIL images through torchvision 0.13.1's functional_pil during few-shot / fine-tune training
+// (datasets/event2img.py:36-42,120-121).  Every operator reproduces Pillow bit for bit:
+//
+//  * ShearX/Y, TranslateX/Y, Rotate -> Image.transform(AFFINE, BICUBIC, fillcolor): libImaging
+//    Geometry.c affine_transform + bicubic_filter32RGB, float64, a = -1 cubic, clamped neighbours,
+//    (UINT8) truncation, untouched (= fill colour) outside the source.  The 6 coefficients are
+//    computed on the host exactly as torchvision / PIL compute them.
+//  * Brightness / Color / Contrast / Sharpness -> ImageEnhance = Image.blend(degenerate, image, f):
+//    Blend.c in C float; degenerate = black / L(pixel) / the frame's mean L / the 3x3 SMOOTH filter
+//    (Filter.c, float, borders copied).
+//  * Posterize / Solarize / AutoContrast / Equalize -> 256-entry per-band look-up tables (ImageOps),
+//    the last two from the frame's own per-band histograms.
+//
+// HBM-bound byte work: one pass over the frame per operator (plus a histogram pass for the three
+// operators that need frame statistics), no MFMA.  FP contraction is off: Pillow's arithmetic has
+// one rounding per operation.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int AUG_THREADS = 256;
+constexpr int STATS_WORDS = 3 * 256 + 2;   // per frame: band histograms, then the 64-bit sum of L
+
+__device__ __forceinline__ int to_L(int r, int g, int b)
+{
+    return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16;   // Pillow's RGB -> L
+}
+
+__device__ __forceinline__ bool needs_stats(int kind)
+{
+    return kind == EC_AUG_CONTRAST || kind == EC_AUG_AUTOCONTRAST || kind == EC_AUG_EQUALIZE;
+}
+
+// per-frame statistics of the step's input: histogram of every band and the sum of L
+__global__ __launch_bounds__(AUG_THREADS) void aug_stats_kernel(const uint8_t *in, const ec_aug_op *ops,
+                                                                int step, int num_ops, int H, int W,
+                                                                int bands, unsigned *stats)
+{
+    const int f = blockIdx.x / bands, band = blockIdx.x % bands;
+    const int kind = ops[(long)f * num_ops + step].kind;
+    if (!needs_stats(kind)) return;
+    __shared__ unsigned hist[3 * 256];
+    __shared__ unsigned long long lsum;
+    for (int i = threadIdx.x; i < 3 * 256; i += AUG_THREADS) hist[i] = 0;
+    if (threadIdx.x == 0) lsum = 0;
+    __syncthreads();
+    const long npix = (long)H * W;
+    const long per = (npix + bands - 1) / bands;
+    const long p0 = band * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const uint8_t *src = in + (long)f * npix * 3;
+    unsigned long long mine = 0;
+    for (long p = p0 + threadIdx.x; p < p1; p += AUG_THREADS) {
+        const int r = src[3 * p], g = src[3 * p + 1], b = src[3 * p + 2];
+        if (kind == EC_AUG_CONTRAST) {
+            mine += (unsigned)to_L(r, g, b);
+        } else {
+            atomicAdd(&hist[r], 1u);
+            atomicAdd(&hist[256 + g], 1u);
+            atomicAdd(&hist[512 + b], 1u);
+        }
+    }
+    unsigned *st = stats + (long)f * STATS_WORDS;
+    if (kind == EC_AUG_CONTRAST) {
+        atomicAdd(&lsum, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(st + 3 * 256), lsum);
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * 256; i += AUG_THREADS)
+            if (hist[i]) atomicAdd(&st[i], hist[i]);
+    }
+}
+
+// Geometry.c: BICUBIC(v, v1, v2, v3, v4, d)
+__device__ __forceinline__ double cubic(double v1, double v2, double v3, double v4, double d)
+{
+    const double p1 = v2;
+    const double p2 = -v1 + v3;
+    const double p3 = 2 * (v1 - v2) + v3 - v4;
+    const double p4 = -v1 + v2 - v3 + v4;
+    return p1 + d * (p2 + d * (p3 + d * p4));
+}
+
+__device__ __forceinline__ uint8_t clip8_trunc(double v)
+{
+    return v <= 0.0 ? (uint8_t)0 : (v >= 255.0 ? (uint8_t)255 : (uint8_t)(int)v);
+}
+
+// Blend.c: in1 + alpha * (in2 - in1) in C float, truncated; clipped when alpha extrapolates
+__device__ __forceinline__ uint8_t blend8(int deg, int img, float alpha, bool inside01)
+{
+    const float t = (float)deg + alpha * (float)(img - deg);
+    if (inside01) return (uint8_t)(int)t;
+    return t <= 0.f ? (uint8_t)0 : (t >= 255.f ? (uint8_t)255 : (uint8_t)(int)t);
+}
+
+__global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *in, uint8_t *out,
+                                                                const ec_aug_op *ops, int step,
+                                                                int num_ops, int H, int W, int bands,
+                                                                const unsigned *stats, uint8_t fr,
+                                                                uint8_t fg, uint8_t fb)
+{
+    const int f = blockIdx.x / bands, band = blockIdx.x % bands;
+    const ec_aug_op op = ops[(long)f * num_ops + step];
+    const long npix = (long)H * W;
+    const long per = (npix + bands - 1) / bands;
+    const long p0 = band * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const uint8_t *src = in + (long)f * npix * 3;
+    uint8_t *dst = out + (long)f * npix * 3;
+    const int kind = op.kind;
+
+    __shared__ uint8_t lut[3 * 256];
+    __shared__ int mean_l;
+    if (kind == EC_AUG_POSTERIZE || kind == EC_AUG_SOLARIZE) {
+        for (int i = threadIdx.x; i < 256; i += AUG_THREADS) {
+            uint8_t v;
+            if (kind == EC_AUG_POSTERIZE) {
+                const int mask = ~((1 << (8 - (int)op.param)) - 1);       // ImageOps.posterize
+                v = (uint8_t)(i & mask);
+            } else {
+                v = (double)i < op.param ? (uint8_t)i : (uint8_t)(255 - i);   // ImageOps.solarize
+            }
+            lut[i] = lut[256 + i] = lut[512 + i] = v;
+        }
+    } else if (kind == EC_AUG_AUTOCONTRAST) {
+        const unsigned *st = stats + (long)f * STATS_WORDS;
+        if (threadIdx.x < 3) {
+            const unsigned *h = st + threadIdx.x * 256;
+            int lo = 0, hi = 255;
+            while (lo < 256 && !h[lo]) lo++;
+            while (hi >= 0 && !h[hi]) hi--;
+            uint8_t *l = lut + threadIdx.x * 256;
+            if (hi <= lo) {
+                for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
+            } else {
+                const double scale = 255.0 / (double)(hi - lo);
+                const double offset = -(double)lo * scale;
+                for (int i = 0; i < 256; i++) {
+                    const double t = (double)i * scale + offset;
+                    const int v = (int)t;                                  // python int(): towards zero
+                    l[i] = v < 0 ? (uint8_t)0 : (v > 255 ? (uint8_t)255 : (uint8_t)v);
+                }
+            }
+        }
+    } else if (kind == EC_AUG_EQUALIZE) {
+        const unsigned *st = stats + (long)f * STATS_WORDS;
+        if (threadIdx.x < 3) {
+            const unsigned *h = st + threadIdx.x * 256;
+            uint8_t *l = lut + threadIdx.x * 256;
+            long total = 0, last = 0;
+            int nonzero = 0;
+            for (int i = 0; i < 256; i++)
+                if (h[i]) total += h[i], last = h[i], nonzero++;
+            const long stepv = nonzero <= 1 ? 0 : (total - last) / 255;
+            if (!stepv) {
+                for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
+            } else {
+                long n = stepv / 2;
+                for (int i = 0; i < 256; i++) {
+                    const long v = n / stepv;
+                    l[i] = v > 255 ? (uint8_t)255 : (uint8_t)v;           // Image.point clips the table
+                    n += h[i];
+                }
+            }
+        }
+    } else if (kind == EC_AUG_CONTRAST) {
+        if (threadIdx.x == 0) {
+            const unsigned long long s =
+                *reinterpret_cast<const unsigned long long *>(stats + (long)f * STATS_WORDS + 3 * 256);
+            mean_l = (int)((double)s / (double)npix + 0.5);                // ImageStat mean + 0.5, int()
+        }
+    }
+    __syncthreads();
+
+    const float alpha = op.alpha;
+    const bool inside01 = alpha >= 0.f && alpha <= 1.f;
+    const uint8_t fillc[3] = {fr, fg, fb};
+    for (long p = p0 + threadIdx.x; p < p1; p += AUG_THREADS) {
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        uint8_t o[3];
+        switch (kind) {
+        case EC_AUG_AFFINE: {
+            const double xs = (double)x + 0.5, ys = (double)y + 0.5;
+            double xin = op.m[0] * xs + op.m[1] * ys + op.m[2];
+            double yin = op.m[3] * xs + op.m[4] * ys + op.m[5];
+            if (xin < 0.0 || xin >= (double)W || yin < 0.0 || yin >= (double)H) {
+                o[0] = fillc[0], o[1] = fillc[1], o[2] = fillc[2];
+                break;
+            }
+            xin -= 0.5;
+            yin -= 0.5;
+            const double fx = floor(xin), fy = floor(yin);
+            const double dx = xin - fx, dy = yin - fy;
+            const int x0 = (int)fx - 1, y0 = (int)fy - 1;
+            int xc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = x0 + k;
+                xc[k] = xx < 0 ? 0 : (xx < W ? xx : W - 1);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double rows[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int yy = y0 + k;
+                    if (k == 0 || (yy >= 0 && yy < H)) {
+                        const int yr = yy < 0 ? 0 : (yy < H ? yy : H - 1);   // YCLIP (first row only)
+                        const uint8_t *r = src + ((long)yr * W) * 3 + c;
+                        rows[k] = cubic((double)r[xc[0] * 3], (double)r[xc[1] * 3], (double)r[xc[2] * 3],
+                                        (double)r[xc[3] * 3], dx);
+                    } else {
+                        rows[k] = rows[k - 1];
+                    }
+                }
+                o[c] = clip8_trunc(cubic(rows[0], rows[1], rows[2], rows[3], dy));
+            }
+            break;
+        }
+        case EC_AUG_ROT180: {
+            const uint8_t *s = src + ((long)(H - 1 - y) * W + (W - 1 - x)) * 3;
+            o[0] = s[0], o[1] = s[1], o[2] = s[2];
+            break;
+        }
+        case EC_AUG_ROT90: {    // Image.ROTATE_90 on a square frame (counter-clockwise)
+            const uint8_t *s = src + ((long)x * W + (W - 1 - y)) * 3;
+            o[0] = s[0], o[1] = s[1], o[2] = s[2];
+            break;
+        }
+        case EC_AUG_ROT270: {
+            const uint8_t *s = src + ((long)(H - 1 - x) * W + y) * 3;
+            o[0] = s[0], o[1] = s[1], o[2] = s[2];
+            break;
+        }
+        case EC_AUG_BRIGHTNESS:
+        case EC_AUG_COLOR:
+        case EC_AUG_CONTRAST:
+        case EC_AUG_SHARPNESS: {
+            const uint8_t *s = src + p * 3;
+            const int v[3] = {s[0], s[1], s[2]};
+            if (alpha == 1.f) {                      // Image.blend returns a copy of the image
+                o[0] = s[0], o[1] = s[1], o[2] = s[2];
+                break;
+            }
+            int deg[3];
+            if (kind == EC_AUG_BRIGHTNESS) {
+                deg[0] = deg[1] = deg[2] = 0;
+            } else if (kind == EC_AUG_COLOR) {
+                deg[0] = deg[1] = deg[2] = to_L(v[0], v[1], v[2]);
+            } else if (kind == EC_AUG_CONTRAST) {
+                deg[0] = deg[1] = deg[2] = mean_l;
+            } else if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
+                deg[0] = v[0], deg[1] = v[1], deg[2] = v[2];      // Filter.c copies the border
+            } else {
+                // SMOOTH: (1 1 1 / 1 5 1 / 1 1 1) / 13 in float, rows y+1, y, y-1, then + 0.5, truncate
+                const float k1 = 1.f / 13.f, k5 = 5.f / 13.f;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint8_t *a = src + ((long)(y + 1) * W + x) * 3 + c;
+                    const uint8_t *b = src + ((long)y * W + x) * 3 + c;
+                    const uint8_t *d = src + ((long)(y - 1) * W + x) * 3 + c;
+                    float ss = 0.5f;
+                    ss += (float)a[-3] * k1 + (float)a[0] * k1 + (float)a[3] * k1;
+                    ss += (float)b[-3] * k1 + (float)b[0] * k5 + (float)b[3] * k1;
+                    ss += (float)d[-3] * k1 + (float)d[0] * k1 + (float)d[3] * k1;
+                    deg[c] = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+                }
+            }
+            if (alpha == 0.f) {
+                o[0] = (uint8_t)deg[0], o[1] = (uint8_t)deg[1], o[2] = (uint8_t)deg[2];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) o[c] = blend8(deg[c], v[c], alpha, inside01);
+            }
+            break;
+        }
+        case EC_AUG_POSTERIZE:
+        case EC_AUG_SOLARIZE:
+        case EC_AUG_AUTOCONTRAST:
+        case EC_AUG_EQUALIZE: {
+            const uint8_t *s = src + p * 3;
+            o[0] = lut[s[0]], o[1] = lut[256 + s[1]], o[2] = lut[512 + s[2]];
+            break;
+        }
+        default: {   // EC_AUG_IDENTITY
+            const uint8_t *s = src + p * 3;
+            o[0] = s[0], o[1] = s[1], o[2] = s[2];
+        }
+        }
+        dst[p * 3] = o[0], dst[p * 3 + 1] = o[1], dst[p * 3 + 2] = o[2];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+EC_API size_t ec_randaugment_workspace_bytes(int F, int H, int W, int num_ops)
+{
+    if (F <= 0 || H <= 0 || W <= 0 || num_ops <= 0) return 0;
+    // one intermediate frame set (ping-pong for num_ops > 1) + per-frame statistics
+    const size_t frames = num_ops > 1 ? (size_t)F * H * W * 3 : 0;
+    return ((frames + 255) & ~(size_t)255) + (size_t)F * STATS_WORDS * 4;
+}
+
+EC_API int ec_randaugment(const uint8_t *frames_in, uint8_t *frames_out, int F, int H, int W,
+                          const ec_aug_op *ops, int num_ops, const uint8_t fill[3], void *workspace,
+                          size_t workspace_bytes, ec_stream_t stream)
+{
+    EC_REQUIRE(F >= 0 && H > 0 && W > 0 && num_ops >= 1, "ec_randaugment: bad shape");
+    if (F == 0) return EC_OK;
+    EC_REQUIRE(frames_in && frames_out && ops && fill && workspace, "ec_randaugment: null buffer");
+    EC_REQUIRE(frames_in != frames_out, "ec_randaugment: in place is not supported");
+    const size_t need = ec_randaugment_workspace_bytes(F, H, W, num_ops);
+    if (workspace_bytes < need)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_randaugment: workspace %zu < %zu bytes", workspace_bytes, need);
+    const size_t frame_bytes = (size_t)F * H * W * 3;
+    uint8_t *tmp = static_cast<uint8_t *>(workspace);
+    unsigned *stats = reinterpret_cast<unsigned *>(tmp + (num_ops > 1 ? ((frame_bytes + 255) & ~(size_t)255) : 0));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bands = ec::ceil_div(H * W, 16384);       // ~16 k pixels per workgroup
+    const dim3 grid((unsigned)F * bands), block(AUG_THREADS);
+    // step k reads what step k-1 wrote; the last step writes frames_out
+    const uint8_t *src = frames_in;
+    for (int k = 0; k < num_ops; k++) {
+        uint8_t *dst = (k == num_ops - 1) ? frames_out : ((num_ops - 1 - k) % 2 ? tmp : frames_out);
+        EC_CHECK_HIP(hipMemsetAsync(stats, 0, (size_t)F * STATS_WORDS * 4, s));
+        hipLaunchKernelGGL(aug_stats_kernel, grid, block, 0, s, src, ops, k, num_ops, H, W, bands, stats);
+        hipLaunchKernelGGL(aug_apply_kernel, grid, block, 0, s, src, dst, ops, k, num_ops, H, W, bands,
+                           stats, fill[0], fill[1], fill[2]);
+        EC_CHECK_HIP(hipGetLastError());
+        src = dst;
+    }
+    return EC_OK;
+}
+
+}  // extern "C"

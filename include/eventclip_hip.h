@@ -185,6 +185,40 @@ EC_API int ec_patchify(const float *img, int n_img, int n_px, int patch, int kpa
                        int dtype, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * RandAugment on uint8 frames (training only).  Replaces `self.augmentation(imgs)`
+ * (datasets/event2img.py:120-121) = datasets/augment.py RandAugment.forward
+ * (:159-193): the SAME op list for every view of a sample, each op one of the 14
+ * of _apply_op (:10-87), which the reference runs on PIL images through
+ * torchvision's functional_pil.  Bit-exact with Pillow (csrc/randaugment.hip).
+ * The caller samples the ops (augment.py:142-157, host RNG) and prepares one
+ * descriptor per (frame, step):
+ *   AFFINE       m[6] = the output->input coefficients Image.transform(AFFINE)
+ *                receives (ShearX/Y, TranslateX/Y, Rotate; BICUBIC, fill colour outside)
+ *   ROT180/90/270  PIL's rotate fast paths (90 / 270 only on square frames)
+ *   BRIGHTNESS / COLOR / CONTRAST / SHARPNESS   alpha = 1 + magnitude (ImageEnhance factor)
+ *   POSTERIZE    param = bits kept;  SOLARIZE  param = threshold
+ *   AUTOCONTRAST / EQUALIZE / IDENTITY          no parameter
+ * ------------------------------------------------------------------------ */
+enum {
+    EC_AUG_IDENTITY = 0, EC_AUG_AFFINE = 1, EC_AUG_ROT180 = 2, EC_AUG_ROT90 = 3, EC_AUG_ROT270 = 4,
+    EC_AUG_BRIGHTNESS = 5, EC_AUG_COLOR = 6, EC_AUG_CONTRAST = 7, EC_AUG_SHARPNESS = 8,
+    EC_AUG_POSTERIZE = 9, EC_AUG_SOLARIZE = 10, EC_AUG_AUTOCONTRAST = 11, EC_AUG_EQUALIZE = 12,
+};
+typedef struct {
+    int kind;      /* EC_AUG_* */
+    float alpha;   /* ImageEnhance factor (C float, as Image.blend takes it) */
+    double param;  /* posterize bits / solarize threshold */
+    double m[6];   /* affine coefficients */
+} ec_aug_op;
+
+EC_API size_t ec_randaugment_workspace_bytes(int F, int H, int W, int num_ops);
+/* frames_in / frames_out: uint8 [F, H, W, 3] (distinct buffers); ops: DEVICE array [F, num_ops]
+ * (frames of one sample carry the same descriptors); fill: the RandAugment fill colour, host. */
+EC_API int ec_randaugment(const uint8_t *frames_in, uint8_t *frames_out, int F, int H, int W,
+                          const ec_aug_op *ops, int num_ops, const uint8_t fill[3], void *workspace,
+                          size_t workspace_bytes, ec_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * 16-bit MFMA GEMM with fused epilogue: C[M,N] = epi(A[M,K] . W[N,K]^T + bias).
  * The building block behind every nn.Linear / in_proj / out_proj / conv1 /
  * projection of the CLIP towers the reference calls through

@@ -205,6 +205,6 @@ def test_classifier_forward_runs_through_the_registered_custom_ops(hip):
     feats = ops.vit_encode(patches, torch_ops.handle_of(m))
     from eventclip_amd.clip_cls import _l2_normalize
     text = _l2_normalize(ops.text_encode(tokens.cuda().int(), torch_ops.handle_of(m)))
-    full, logits, probs = ops.classify(feats, ri.cuda(), text.t().contiguous(), 100.0, 1, False)
+    full, logits, probs = ops.classify(feats, ri.cuda(), text.t().contiguous(), float(model.logit_scale), 1, False)
     assert torch.equal(full, out['full_logits']) and torch.equal(logits, out['logits'])
     assert torch.equal(probs, out['probs'])

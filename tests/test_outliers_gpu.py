@@ -72,7 +72,7 @@ def test_outlier_residual_channels_f16_and_bf16(ln_gain, hip, capsys):
     normal = torch.ones(cfg['width'], dtype=torch.bool)
     normal[list(OUTLIER_CHANNELS)] = False
     ratio = float(prof[~normal].min() / prof[normal].median())
-    assert ratio > 75., f'the synthetic weights did not produce massive channels (ratio {ratio:.1f})'
+    assert ratio > 50., f'the synthetic weights did not produce massive channels (ratio {ratio:.1f})'
     ref = clip_ref.encode_image(sd, cfg, imgs)
     varying = float((ref - ref.mean(0, keepdim=True)).norm())      # the input-dependent part of the features
     text = torch.nn.functional.normalize(
