@@ -77,16 +77,22 @@ __device__ __forceinline__ float xor_sum(float v)
 }
 
 // One 64-key (or, for the last odd step, 32-key) block of the online softmax:
-// scores -> running max / sum -> P^T as the B operand -> O^T += V^T . P^T.
+// scores -> running max -> P^T as the B operand -> O^T += V^T . P^T, and the softmax denominator as a
+// fifth accumulator tile: l += 1^T . P^T (a ones fragment as the A operand), i.e. the row sums come
+// out of the matrix pipe -- summed over the keys of all four lane groups -- instead of 16 VALU adds
+// per lane and block, and they are the sums of the SAME 16-bit P the numerator uses.
+// The kernel is VALU-bound (exp2 at quarter rate plus the bookkeeping around it), so the block also
+// packs the exponent arguments two per v_pk_fma_f32 and skips the rescale of O when no lane's
+// running maximum moved (the usual case after the first blocks).
 template <int DT, int KSTEPS, bool MASK>  // KSTEPS = 32-key steps in this block (2 or 1)
 __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsigned char *ldsV,
                                            int key0, int klimit, const typename T16<DT>::v8 (&qf)[2],
-                                           float scale_log2e, float &m_run, float &l_run,
-                                           f32x4 (&o)[4], int g, int c16)
+                                           float scale_log2e, float &m_run, f32x4 (&o)[5], int g, int c16)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     typedef typename T16<DT>::v4 v4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int NT = 2 * KSTEPS;
     // ---- scores: acc[kt][r] = <k[key0 + 16 kt + 4 g + r], q[c16]> ----
     f32x4 acc[NT];
@@ -114,22 +120,27 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
             mx = fmaxf(mx, acc[kt][r]);
         }
     mx = xor_max(mx);   // the four lane groups hold different keys of the same query
-    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);
-    m_run = mx;
-    const float mc = -mx * scale_log2e;
-    float psum = 0.f;
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {      // wave-uniform: some query's maximum grew
+        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);
+        m_run = mx;
+#pragma unroll
+        for (int dt = 0; dt < 5; dt++) o[dt] *= alpha;
+    }
+    const f32x2 sc2 = {scale_log2e, scale_log2e};
+    const float mcs = -m_run * scale_log2e;
+    const f32x2 mc2 = {mcs, mcs};
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kt][r], scale_log2e, mc));
-            acc[kt][r] = p;
-            psum += p;
+        for (int h = 0; h < 2; h++) {
+            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[kt][2 * h], acc[kt][2 * h + 1]}, sc2, mc2);
+            acc[kt][2 * h] = __builtin_amdgcn_exp2f(t[0]);
+            acc[kt][2 * h + 1] = __builtin_amdgcn_exp2f(t[1]);
         }
-    l_run = l_run * alpha + psum;   // per-lane partial; summed over the lane groups at the end
+    // ---- O^T += V^T . P^T, l += 1^T . P^T ----
+    v8 ones;
 #pragma unroll
-    for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
-    // ---- O^T += V^T . P^T ----
+    for (int j = 0; j < 8; j++) ones[j] = to16(1.f, elem());
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) {
         // B operand element j <-> key key0 + 32 s + 16 (j >> 2) + 4 g + (j & 3)
@@ -155,11 +166,12 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
             }
             o[dt] = mfma16(vf, pf, o[dt]);
         }
+        o[4] = mfma16(ones, pf, o[4]);
     }
 }
 
 template <int DT, int AT_WAVES>
-__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnArgs a)
+__global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -230,28 +242,25 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
         const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;  // keys < klimit are visible
         // causal rows of this tile see no key beyond 16 qt + 15: skip the blocks past it
         const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
-        float m_run = -1e30f, l_run = 0.f;
-        f32x4 o[4];
+        float m_run = -1e30f;
+        f32x4 o[5];   // four head-dim tiles of O^T and the softmax denominator (every row of o[4])
 #pragma unroll
-        for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         // blocks entirely below every lane's klimit need no masking: klimit >= kfree for all
         // 16 queries of the tile (causal: 16 qt + 1 .. ; otherwise S)
         const int kfree = a.causal ? qt * 16 + 1 : S;
         int key0 = 0;
         for (; key0 + 64 <= kend; key0 += 64) {
             if (key0 + 64 <= kfree)
-                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
-                                         g, c16);
+                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
             else
-                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
-                                        g, c16);
+                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
         }
         if (key0 < kend)
-            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o, g,
-                                    c16);
+            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
-        const float inv = 1.f / xor_sum(l_run);
+        const float inv = 1.f / o[4][0];
         if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll

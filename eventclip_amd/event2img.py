@@ -31,7 +31,7 @@ class Event2ImagePipeline:
     """
 
     def __init__(self, resolution, max_n, quantize_args, n_px=224, patch=None, kpad=None,
-                 dtype=torch.float16, generator=None):
+                 dtype=torch.float16, generator=None, augment=False):
         qa = copy.deepcopy(quantize_args)
         self.resolution = tuple(resolution)
         self.split_method = qa['split_method']
@@ -52,6 +52,14 @@ class Event2ImagePipeline:
         self.n_px, self.patch, self.kpad, self.dtype = int(n_px), patch, kpad, dtype
         self.generator = generator
         self.strict = True   # raise on events outside the sensor, as the reference does
+        # training-time RandAugment on the frames (event2img.py:34-42, :120-121): two ops per sample,
+        # bicubic, white fill on masked-background frames, black otherwise
+        self.augment = bool(augment)
+        if self.augment:
+            from .randaugment import RandAugment
+            self.augmentation = RandAugment(
+                num_ops=2, interpolation='bicubic',
+                fill=[255, 255, 255] if self.background_mask else [0, 0, 0])
 
     # ---- host bookkeeping: which event rows make which view ----
     def plan(self, n_events, tflip=False, starts=None):
@@ -141,6 +149,8 @@ class Event2ImagePipeline:
         frames = self.frames(events, fr_d, hflip=hflip, tflip=tflip,
                              total_events=int((fr[:, 1] - fr[:, 0]).sum()))
         out = dict(valid_mask=vm.to(dev), row_idx=ri.to(dev))
+        if self.augment:
+            frames = self._augment_frames(frames, ri)
         if self.patch:
             out['patches'] = preprocess_frames(frames, self.n_px, mode='patches', patch=self.patch,
                                                kpad=self.kpad, dtype=self.dtype)
@@ -152,6 +162,19 @@ class Event2ImagePipeline:
             out['img'] = img
         return out
 
+
+    def _augment_frames(self, frames, row_idx):
+        """One RandAugment draw per sample, in sample order (the reference draws inside
+        ``__getitem__``, once per sample), the same ops for all of the sample's views."""
+        from .randaugment import apply_ops
+        per_frame = [None] * int(frames.shape[0])
+        for b in range(row_idx.shape[0]):
+            self.augmentation.randomize_ops(self.resolution)
+            ops, self.augmentation.cur_ops = self.augmentation.cur_ops, None
+            for r in row_idx[b].tolist():
+                if r >= 0:
+                    per_frame[r] = ops
+        return apply_ops(frames, per_frame, self.augmentation._fill())
 
     def tta(self, events, n_events=None):
         """The four views of _load_tta_data (event2img.py:94-112): identity, h-flip, t-flip,
