@@ -23,9 +23,28 @@
 #include "common.h"
 #include "mfma.h"
 
+#ifdef EC_GEMM_DIAG
+// diagnostic build only (python -m eventclip_amd.build --diag, tools/timeline_attn.py): s_memtime at
+// workgroup start / K and V staged / done, and the CU the workgroup ran on
+__device__ unsigned long long ec_attn_stamps[4 * 65536];
+#endif
+
 namespace {
 
 using namespace ec;
+
+#ifdef EC_GEMM_DIAG
+__device__ __forceinline__ void attn_stamp(int i)
+{
+    unsigned long long now;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && blockIdx.x < 65536) ec_attn_stamps[blockIdx.x * 4 + i] = now;
+}
+#else
+__device__ __forceinline__ void attn_stamp(int) {}
+#endif
 
 // Waves per workgroup: 8 when two workgroups fit a CU's LDS (K + V <= 80 KiB: S <= 320), 16 when the
 // sequence's K and V leave room for one workgroup only (S = 577: 148 KiB) -- four waves per SIMD either way.
@@ -77,22 +96,16 @@ __device__ __forceinline__ float xor_sum(float v)
 }
 
 // One 64-key (or, for the last odd step, 32-key) block of the online softmax:
-// scores -> running max -> P^T as the B operand -> O^T += V^T . P^T, and the softmax denominator as a
-// fifth accumulator tile: l += 1^T . P^T (a ones fragment as the A operand), i.e. the row sums come
-// out of the matrix pipe -- summed over the keys of all four lane groups -- instead of 16 VALU adds
-// per lane and block, and they are the sums of the SAME 16-bit P the numerator uses.
-// The kernel is VALU-bound (exp2 at quarter rate plus the bookkeeping around it), so the block also
-// packs the exponent arguments two per v_pk_fma_f32 and skips the rescale of O when no lane's
-// running maximum moved (the usual case after the first blocks).
+// scores -> running max / sum -> P^T as the B operand -> O^T += V^T . P^T.
 template <int DT, int KSTEPS, bool MASK>  // KSTEPS = 32-key steps in this block (2 or 1)
 __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsigned char *ldsV,
                                            int key0, int klimit, const typename T16<DT>::v8 (&qf)[2],
-                                           float scale_log2e, float &m_run, f32x4 (&o)[5], int g, int c16)
+                                           float scale_log2e, float &m_run, float &l_run,
+                                           f32x4 (&o)[4], int g, int c16)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     typedef typename T16<DT>::v4 v4;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int NT = 2 * KSTEPS;
     // ---- scores: acc[kt][r] = <k[key0 + 16 kt + 4 g + r], q[c16]> ----
     f32x4 acc[NT];
@@ -120,27 +133,22 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
             mx = fmaxf(mx, acc[kt][r]);
         }
     mx = xor_max(mx);   // the four lane groups hold different keys of the same query
-    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {      // wave-uniform: some query's maximum grew
-        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);
-        m_run = mx;
-#pragma unroll
-        for (int dt = 0; dt < 5; dt++) o[dt] *= alpha;
-    }
-    const f32x2 sc2 = {scale_log2e, scale_log2e};
-    const float mcs = -m_run * scale_log2e;
-    const f32x2 mc2 = {mcs, mcs};
+    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);
+    m_run = mx;
+    const float mc = -mx * scale_log2e;
+    float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[kt][2 * h], acc[kt][2 * h + 1]}, sc2, mc2);
-            acc[kt][2 * h] = __builtin_amdgcn_exp2f(t[0]);
-            acc[kt][2 * h + 1] = __builtin_amdgcn_exp2f(t[1]);
+        for (int r = 0; r < 4; r++) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kt][r], scale_log2e, mc));
+            acc[kt][r] = p;
+            psum += p;
         }
-    // ---- O^T += V^T . P^T, l += 1^T . P^T ----
-    v8 ones;
+    l_run = l_run * alpha + psum;   // per-lane partial; summed over the lane groups at the end
 #pragma unroll
-    for (int j = 0; j < 8; j++) ones[j] = to16(1.f, elem());
+    for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
+    // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) {
         // B operand element j <-> key key0 + 32 s + 16 (j >> 2) + 4 g + (j & 3)
@@ -166,12 +174,11 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
             }
             o[dt] = mfma16(vf, pf, o[dt]);
         }
-        o[4] = mfma16(ones, pf, o[4]);
     }
 }
 
 template <int DT, int AT_WAVES>
-__global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnArgs a)
+__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -190,36 +197,20 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
     const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
     const long ld = 3L * W;
     const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
+    attn_stamp(0);
 
     // ---- stage K and V of this head: AT_THREADS / 8 rows x 8 chunks of 16 B per pass ----
-    // Every load of the whole head is issued before the first LDS write (at most five passes for the
-    // sequence lengths either workgroup size is launched for): a loop of load -> wait -> write pays
-    // the HBM latency once per pass, and the 4-5 serial round trips were most of this kernel's time
-    // (S = 257: 10 us per workgroup of staging against 3 us of MFMA / softmax work).
     {
-        constexpr int ROWS = AT_THREADS / 8, PASSES = 5;   // 5 * ROWS >= SP (checked by the launcher)
         const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
-        u32x4 kreg[PASSES], vreg[PASSES];
-#pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const int row = r_in + p * ROWS;
-            if (row < SP) {
-                const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
-                const elem *src = base + (long)srow * ld + ch * 8;
-                kreg[p] = *reinterpret_cast<const u32x4 *>(src + W);
-                vreg[p] = *reinterpret_cast<const u32x4 *>(src + 2 * W);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const int row = r_in + p * ROWS;
-            if (row < SP) {
-                *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kreg[p];
-                // V: 8-byte slot u -> u ^ ((row>>1)&3): chunk moves by bit 1, halves swap by bit 0
-                u32x4 vv = vreg[p];
-                if ((row >> 1) & 1) vv = u32x4{vv[2], vv[3], vv[0], vv[1]};
-                *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
-            }
+        for (int row = r_in; row < SP; row += AT_THREADS / 8) {
+            const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
+            const elem *src = base + (long)srow * ld + ch * 8;
+            const u32x4 kv = *reinterpret_cast<const u32x4 *>(src + W);
+            u32x4 vv = *reinterpret_cast<const u32x4 *>(src + 2 * W);
+            *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kv;
+            // V: 8-byte slot u -> u ^ ((row>>1)&3): chunk moves by bit 1, halves swap by bit 0
+            if ((row >> 1) & 1) vv = u32x4{vv[2], vv[3], vv[0], vv[1]};
+            *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
         }
     }
     // first Q tile of this wave, issued before the barrier so its latency hides behind staging
@@ -234,6 +225,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
     };
     if (wave < n_qt) load_q(wave, qn);
     __syncthreads();
+    attn_stamp(1);
 
     for (int qt = wave; qt < n_qt; qt += AT_WAVES) {
         qf[0] = qn[0], qf[1] = qn[1];
@@ -242,25 +234,28 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
         const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;  // keys < klimit are visible
         // causal rows of this tile see no key beyond 16 qt + 15: skip the blocks past it
         const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
-        float m_run = -1e30f;
-        f32x4 o[5];   // four head-dim tiles of O^T and the softmax denominator (every row of o[4])
+        float m_run = -1e30f, l_run = 0.f;
+        f32x4 o[4];
 #pragma unroll
-        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         // blocks entirely below every lane's klimit need no masking: klimit >= kfree for all
         // 16 queries of the tile (causal: 16 qt + 1 .. ; otherwise S)
         const int kfree = a.causal ? qt * 16 + 1 : S;
         int key0 = 0;
         for (; key0 + 64 <= kend; key0 += 64) {
             if (key0 + 64 <= kfree)
-                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
+                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
+                                         g, c16);
             else
-                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
+                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
+                                        g, c16);
         }
         if (key0 < kend)
-            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, o, g, c16);
+            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o, g,
+                                    c16);
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
-        const float inv = 1.f / o[4][0];
+        const float inv = 1.f / xor_sum(l_run);
         if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll
@@ -272,6 +267,15 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
             *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
         }
     }
+    attn_stamp(2);
+#ifdef EC_GEMM_DIAG
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ec_attn_stamps[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
@@ -286,16 +290,8 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const bool wide = lds > 80 * 1024;
     void (*kern)(const AttnArgs) = wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>;
     const int nw = wide ? 16 : 8;
-    // the staging prologue covers the padded sequence in five passes of nw * 8 rows
-    if (32 * n32 > 5 * nw * 8)
-        return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d too long for %d waves",
-                        a.S, nw);
-    static int attr_lds[2] = {0, 0};
-    if (lds > 64 * 1024 && lds > attr_lds[wide]) {
-        EC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_lds[wide] = lds;
-    }
+    // always the full carve (one attribute call per kernel and device, thread-safe)
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     // algorithmic work: QK^T and PV, 2 * 2 * S^2 * 64 flops per head; bytes: read qkv, write out
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * a.q_rows * a.S * 64.0 * heads * n_seq,
                        (double)n_seq * a.W * 2.0 * (2.0 * a.S + 2.0 * a.q_rows));
@@ -383,6 +379,14 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, vo
 }
 
 }  // namespace
+
+#ifdef EC_GEMM_DIAG
+// diagnostic build only (not part of the public header): copy the stamp records to the host
+extern "C" __attribute__((visibility("default"))) int ec_attn_stamps_read(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ec_attn_stamps), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
                                    int heads, int causal, int dtype, ec_stream_t stream)
