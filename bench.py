@@ -381,8 +381,8 @@ def main():
                                      'softmax; patch embedding and ln_post @ proj with hi + lo operands; '
                                      'text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else
-                                      'keys/values for every token; query, out_proj, MLP for the class '
-                                      'token only (bit-identical encode_image output)'),
+                                      'keys/values for every token; query projection, attention, out_proj, '
+                                      'MLP for the class token only (bit-identical encode_image output)'),
                        'parallelism': f'dp{world}, all-gather of logits' if world > 1 else 'single GPU',
                        'collective_backend': (backend if world > 1 else None),
                        'collective_ranks': ranks_seen, 'rank_devices': devices},

@@ -51,7 +51,7 @@ int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, 
 
 // first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
 // tower: ln_post(x[:, 0]) @ proj).  That block still needs every token's keys and values, but its
-// attention query, out_proj, ln_2 and MLP only for row 0: n_seq rows instead of n_seq * S, through the
+// query projection, attention, out_proj, ln_2 and MLP only for row 0: n_seq rows instead of n_seq * S, through the
 // same kernels with the residual stream addressed at row stride S * W.  Each output row of these
 // kernels depends on its own input row only, so the class-token features are bit-identical.
 int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
@@ -63,7 +63,14 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
         if (first_only && l == layers - 1) {
             const long ldx = (long)S * W;
             EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, W, dtype, s));
-            EC_TRY(gemm(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s));
+            // keys and values of every token (the k | v rows of in_proj: N = 2W into columns W .. 3W of
+            // the qkv buffer), the query of the class-token rows only (N = W, one row per sequence)
+            const size_t esz = 2;
+            const unsigned char *wqkv = static_cast<const unsigned char *>(w.qkv_w);
+            EC_TRY(gemm(rows, 2 * W, W, dtype, EC_EPI_STORE16, b.h, wqkv + (size_t)W * W * esz, w.qkv_b + W,
+                        static_cast<unsigned char *>(b.qkv) + (size_t)W * esz, s, 3L * W));
+            EC_TRY(gemm(n_seq, W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s, 3L * W * S,
+                        (long)S * W));
             EC_TRY(ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, causal, 1, dtype, s));
             EC_TRY(gemm(n_seq, W, W, dtype, EC_EPI_RESID32, b.h, w.out_w, w.out_b, b.x, s, ldx));
             EC_TRY(ec_layernorm(b.x, ldx, nullptr, w.ln2_g, w.ln2_b, n_seq, W, LN_EPS, b.h, W, dtype, s));
