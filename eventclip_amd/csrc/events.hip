@@ -22,6 +22,8 @@
 // The float stage is the float64 sequence numpy >= 2 executes for
 // vis.py:27-39, including the fused multiply-add of the dgemm behind
 // `hist @ cmap`, with FP contraction disabled everywhere else.
+#include <cstdlib>
+
 #include "common.h"
 
 // numpy evaluates every ufunc with one rounding per operation: no FMA contraction anywhere in
@@ -35,7 +37,7 @@ constexpr int EV_WAVES = EV_THREADS / 64;
 constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
 constexpr int EV_LUT_N = 16;                       // colour look-up table over counts 0..15 x 0..15
 constexpr int EV_REDUCE_BYTES = 8 * EV_WAVES * 2;  // block-reduction scratch (u64 per wave, 2 slots)
-constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4;   // + the LUT
+constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4 + 16;   // + the LUT + a flag word
 
 struct EvArgs {
     const void *events;      // float4 (x, y, t, p) or packed 8-byte events
@@ -57,6 +59,7 @@ struct EvArgs {
     unsigned *sort_ws;   // band-sorted bin indices, sort_cap per workgroup (long frames), or null
     int sort_cap;
     unsigned band_magic; // ceil(2^32 / rows_per_band): y / rows_per_band == (y * magic) >> 32 for y < 2^16
+    int pack10;          // whole-frame histogram in LDS as three 10-bit counts per word (see frame_pack10)
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -334,6 +337,64 @@ __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dm
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole frame in LDS: three 10-bit counts per 32-bit word.
+//
+// A sensor of up to ~59 000 pixels (N-Caltech: 180 x 240 x 2 bins -> 115 KiB) then holds its complete
+// histogram on chip: the events are read from HBM ONCE, binned ONCE (no event cache, no bands), and
+// the three frame-wide passes the reference needs (sum / sum of squares, max of what survives the
+// hot-pixel threshold, colour) walk 28 800 words of LDS instead of re-binning 20 000 events for
+// each of 3 passes x 5 bands.  A field that would pass 1023 (a pixel with more than 5 % of a
+// 20 000-event frame on one polarity) is detected by the value the atomic returns; the frame is
+// then redone by the banded 32-bit path below, so the result never depends on the packing.
+// Returns false on overflow (nothing was written).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned P10_MASK = 1023u;
+
+__device__ __forceinline__ unsigned p10_get(const unsigned *bins, unsigned bin)
+{
+    const unsigned w = bin / 3u;
+    return (bins[w] >> (10u * (bin - 3u * w))) & P10_MASK;
+}
+
+// bins the whole frame; returns false when a field overflowed (the caller re-does the frame)
+template <typename EV>
+__device__ bool bin_pack10(const EvArgs &a, const EV *ev, long long n, unsigned *bins, unsigned *flag,
+                           unsigned &dropped)
+{
+    const int H = a.H, W = a.W;
+    const int words = (H * W * 2 + 2) / 3;
+    for (int i = threadIdx.x; i < words; i += EV_THREADS) bins[i] = 0;
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    unsigned over = 0;
+    auto bin_one10 = [&](const EV e) {
+        int x, y, p;
+        parse(e, W, a.flip_x, a.negate_p, x, y, p);
+        if (p == 0) return;
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
+            dropped++;
+            return;
+        }
+        const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
+        const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
+        const unsigned old = atomicAdd(&bins[w], 1u << sh);
+        over |= ((old >> sh) & P10_MASK) == P10_MASK;     // this add carried out of its field
+    };
+    long long i = threadIdx.x;
+    for (; i + 7 * EV_THREADS < n; i += 8 * EV_THREADS) {  // eight loads in flight: the only HBM read
+        EV e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = ev[i + k * EV_THREADS];
+#pragma unroll
+        for (int k = 0; k < 8; k++) bin_one10(e[k]);
+    }
+    for (; i < n; i += EV_THREADS) bin_one10(ev[i]);
+    if (over) atomicOr(flag, 1u);
+    __syncthreads();
+    return *flag == 0;
+}
+
 template <typename EV>
 __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvArgs a)
 {
@@ -359,7 +420,30 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     const bool sorted = !cached && ws != nullptr && bands > 1 && n <= (long long)a.sort_cap;
     unsigned long long s1 = 0, s2 = 0;
     unsigned nnz = 0, dropped = 0;
-    if (cached) {
+    // whole frame on chip as 10-bit counts (no cache, no bands) unless a count passes 1023
+    unsigned *p10_flag = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4);
+    bool p10 = false;
+    if (a.pack10) {
+        p10 = bin_pack10(a, ev, n, bins, p10_flag, dropped);
+        if (!p10) dropped = 0;            // redo the frame with 32-bit bins (streamed from L2)
+    }
+    const int words10 = (int)((M2 + 2) / 3);
+    const int nbands = p10 ? 1 : bands;
+    // visits every (bin index within the band, count) of the band's histogram
+    auto for_counts = [&](int nb, auto &&fn) {
+        if (p10) {
+            for (int w = threadIdx.x; w < words10; w += EV_THREADS) {
+                const unsigned v = bins[w];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (3 * w + k < nb) fn(3 * w + k, (v >> (10 * k)) & P10_MASK);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nb; i += EV_THREADS) fn(i, bins[i]);
+        }
+    };
+    if (p10) {
+    } else if (cached) {
         fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
         __syncthreads();
     } else if (sorted) {
@@ -367,24 +451,24 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
                      dropped);
     }
     // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
-    for (int b = 0; b < bands; b++) {
-        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
+    for (int b = 0; b < nbands; b++) {
+        const int y0 = p10 ? 0 : b * rpb, y1 = p10 ? H : min(H, y0 + rpb);
         unsigned dr = 0;
-        if (cached)
+        if (p10) {
+        } else if (cached)
             bin_band_cached(cache, (int)n, y0, y1, W, bins);
         else if (sorted)
             bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
         else
             bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
-        if (b == 0 && !cached && !sorted) dropped = dr;
+        if (b == 0 && !p10 && !cached && !sorted) dropped = dr;
         const int nb = (y1 - y0) * W * 2;
-        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
-            const unsigned h = bins[i];
+        for_counts(nb, [&](int i, unsigned h) {
             s1 += h;
             s2 += (unsigned long long)h * h;
             nnz += h > 0;
             if (a.raw) a.raw[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
-        }
+        });
     }
     s1 = block_sum_u64(s1, scratch);
     s2 = block_sum_u64(s2, scratch);
@@ -428,10 +512,10 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     // ---- pass 2: max of the counts that survive (vis.py:24,27) ----
     unsigned mx = 0, amb = 0;
-    for (int b = 0; b < bands; b++) {
-        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
+    for (int b = 0; b < nbands; b++) {
+        const int y0 = p10 ? 0 : b * rpb, y1 = p10 ? H : min(H, y0 + rpb);
         unsigned dr = 0;
-        if (bands > 1) {
+        if (nbands > 1) {
             if (cached)
                 bin_band_cached(cache, (int)n, y0, y1, W, bins);
             else if (sorted)
@@ -440,14 +524,13 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
                 bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
         }
         const int nb = (y1 - y0) * W * 2;
-        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
-            unsigned h = bins[i];
+        for_counts(nb, [&](int i, unsigned h) {
             amb += (long long)h == amb_h;
             if (h > thr_hi) h = 0;
             mx = h > mx ? h : mx;
-            if (bands == 1) bins[i] = h;  // single band: keep the thresholded counts for pass 3
+            if (nbands == 1 && !p10) bins[i] = h;  // single band: keep the thresholded counts for pass 3
             if (a.kept) a.kept[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
-        }
+        });
     }
     mx = block_max_u32(mx, scratch);
     amb = (unsigned)block_sum_u64(amb, scratch);
@@ -487,7 +570,37 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     // ---- pass 3: normalise, colour, blend, round -> uint8 (vis.py:27-39) ----
     uint8_t *out = a.frames + (long long)f * H * W * 3;
-    for (int b = 0; b < bands; b++) {
+    if (p10) {
+        // 12 pixels = 24 counts = 8 words in, 36 bytes = 9 dwords out per step
+        const int npix = H * W;
+        const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 12 : 0;   // dword stores need aligned frames
+        for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
+            const uint4 wa = *reinterpret_cast<const uint4 *>(&bins[g * 8]);
+            const uint4 wb = *reinterpret_cast<const uint4 *>(&bins[g * 8 + 4]);
+            const unsigned w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            unsigned c[24];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                c[3 * k] = w8[k] & P10_MASK;
+                c[3 * k + 1] = (w8[k] >> 10) & P10_MASK;
+                c[3 * k + 2] = (w8[k] >> 20) & P10_MASK;
+            }
+            unsigned words[9];
+            uint8_t *bytes = reinterpret_cast<uint8_t *>(words);
+#pragma unroll
+            for (int k = 0; k < 12; k++) colour(c[2 * k], c[2 * k + 1], bytes + 3 * k);
+            unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
+#pragma unroll
+            for (int k = 0; k < 9; k++) dst[k] = words[k];
+        }
+        for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) {
+            uint8_t px[3];
+            colour(p10_get(bins, 2u * q), p10_get(bins, 2u * q + 1u), px);
+            out[3 * q] = px[0], out[3 * q + 1] = px[1], out[3 * q + 2] = px[2];
+        }
+        __syncthreads();
+    }
+    for (int b = 0; b < (p10 ? 0 : bands); b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
         if (bands > 1) {
@@ -740,10 +853,24 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
             if ((size_t)grid > slots) grid = (int)slots;
         }
     }
+    // Sensors whose whole histogram fits LDS as three 10-bit counts per word (and does not as 32-bit
+    // counts) are binned once, with no cache and no bands; a frame with a count above 1023 falls back
+    // to 32-bit bands streamed from L2 (frame_pack10 above).
+    const long pack_bytes = (((long)prm->H * prm->W * 2 + 2) / 3 * 4 + 15) / 16 * 16;
+    a.pack10 = 0;
+    if ((long)row_bytes * prm->H > EV_BIN_BYTES && pack_bytes <= EV_BIN_BYTES && !getenv("EC_EVENTS_NO_PACK10")) {
+        a.pack10 = 1;
+        cache_events = 0;
+        bin_budget = EV_BIN_BYTES;
+        a.sort_ws = nullptr;
+        a.sort_cap = 0;
+        grid = F;
+    }
     const int max_rows = bin_budget / row_bytes;
     a.bands = ec::ceil_div(prm->H, max_rows);
     a.rows_per_band = ec::ceil_div(prm->H, a.bands);
     a.bin_bytes = (a.rows_per_band * row_bytes + 15) / 16 * 16;
+    if (a.pack10 && a.bin_bytes < pack_bytes) a.bin_bytes = (int)pack_bytes;
     a.cache_events = cache_events;
     a.F = F;
     a.band_magic = (unsigned)((0x100000000ull + (unsigned)a.rows_per_band - 1) / (unsigned)a.rows_per_band);

@@ -230,6 +230,23 @@ def test_precise_image_tower_reproduces_fp32_oracle(hip):
     assert rel_err(m3.encode_image(img.cuda()).cpu(), clip_ref.encode_image(sd3, small, img)) < 2e-5
 
 
+def test_bf16_operands_reach_1e3_only_in_split_mode(hip):
+    """north_star names bf16 MFMA operands and 1e-3: bf16 has 8 significant bits, so the plain path is
+    ~4e-3 off the fp32 oracle; carried as hi + lo parts (the split-precision tower: three MFMA launches
+    per GEMM on the same bf16 instruction) it is inside 1e-3 with two orders to spare."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-B/32', layers=3, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=3)
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    want = clip_ref.encode_image(sd, cfg, img)
+    plain = eclip.CLIP(cfg, sd, dtype='bfloat16').cuda().eval().encode_image(img.cuda()).cpu()
+    split = eclip.CLIP(cfg, sd, dtype='bfloat16', image_precise=True).cuda().eval().encode_image(img.cuda()).cpu()
+    assert 1e-3 < rel_err(plain, want) < 1e-2
+    assert rel_err(split, want) < 1e-4
+
+
 def test_chunked_encode_is_batch_invariant(hip):
     import torch
     from eventclip_amd import clip as eclip
