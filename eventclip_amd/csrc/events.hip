@@ -37,7 +37,7 @@ constexpr int EV_WAVES = EV_THREADS / 64;
 constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
 constexpr int EV_LUT_N = 16;                       // colour look-up table over counts 0..15 x 0..15
 constexpr int EV_REDUCE_BYTES = 8 * EV_WAVES * 2;  // block-reduction scratch (u64 per wave, 2 slots)
-constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4 + 16;   // + the LUT + a flag word
+constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4;   // + the LUT
 
 struct EvArgs {
     const void *events;      // float4 (x, y, t, p) or packed 8-byte events
@@ -59,7 +59,8 @@ struct EvArgs {
     unsigned *sort_ws;   // band-sorted bin indices, sort_cap per workgroup (long frames), or null
     int sort_cap;
     unsigned band_magic; // ceil(2^32 / rows_per_band): y / rows_per_band == (y * magic) >> 32 for y < 2^16
-    int pack10;          // whole-frame histogram in LDS as three 10-bit counts per word (see frame_pack10)
+    uint8_t *redo;       // per-frame flags shared with events_pack10_kernel: that kernel sets redo[f] for
+                         // a frame it could not finish, this one then processes ONLY those frames
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -337,62 +338,49 @@ __device__ __forceinline__ void colour_pixel(unsigned c0, unsigned c1, double dm
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Whole frame in LDS: three 10-bit counts per 32-bit word.
-//
-// A sensor of up to ~59 000 pixels (N-Caltech: 180 x 240 x 2 bins -> 115 KiB) then holds its complete
-// histogram on chip: the events are read from HBM ONCE, binned ONCE (no event cache, no bands), and
-// the three frame-wide passes the reference needs (sum / sum of squares, max of what survives the
-// hot-pixel threshold, colour) walk 28 800 words of LDS instead of re-binning 20 000 events for
-// each of 3 passes x 5 bands.  A field that would pass 1023 (a pixel with more than 5 % of a
-// 20 000-event frame on one polarity) is detected by the value the atomic returns; the frame is
-// then redone by the banded 32-bit path below, so the result never depends on the packing.
-// Returns false on overflow (nothing was written).
-// ---------------------------------------------------------------------------------------------
-constexpr unsigned P10_MASK = 1023u;
+// ---- hot-pixel threshold, vis.py:17-24 ----
+// mean = S1/cnt; sum of squared deviations = S2 - S1^2/cnt = (cnt*S2 - S1^2)/cnt, exact in 128-bit
+// integers, then numpy's own sequence: /cnt, sqrt, thresh*std + mean.
+// The comparison `count > thr` (vis.py:24) in integers: for a non-negative integer h and a finite
+// thr >= 0, h > thr <=> h > floor(thr); a NaN or infinite thr removes nothing.  The one count whose
+// comparison could depend on numpy's summation order (|h - thr| <= 1e-9 |thr|) is rint(thr).
+struct HotPixel {
+    double thr;
+    bool use_thr;
+    unsigned thr_hi;     // counts above this are removed
+    long long amb_h;     // the ambiguous count, or -1
+};
 
-__device__ __forceinline__ unsigned p10_get(const unsigned *bins, unsigned bin)
+__device__ __forceinline__ HotPixel hot_pixel_threshold(const EvArgs &a, unsigned long long s1,
+                                                        unsigned long long s2, unsigned nnz, long long M2)
 {
-    const unsigned w = bin / 3u;
-    return (bins[w] >> (10u * (bin - 3u * w))) & P10_MASK;
-}
-
-// bins the whole frame; returns false when a field overflowed (the caller re-does the frame)
-template <typename EV>
-__device__ bool bin_pack10(const EvArgs &a, const EV *ev, long long n, unsigned *bins, unsigned *flag,
-                           unsigned &dropped)
-{
-    const int H = a.H, W = a.W;
-    const int words = (H * W * 2 + 2) / 3;
-    for (int i = threadIdx.x; i < words; i += EV_THREADS) bins[i] = 0;
-    if (threadIdx.x == 0) *flag = 0;
-    __syncthreads();
-    unsigned over = 0;
-    auto bin_one10 = [&](const EV e) {
-        int x, y, p;
-        parse(e, W, a.flip_x, a.negate_p, x, y, p);
-        if (p == 0) return;
-        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
-            dropped++;
-            return;
+    HotPixel r;
+    r.thr = __builtin_inf();
+    r.use_thr = a.thresh > 0.;
+    r.thr_hi = 0xFFFFFFFFu;
+    r.amb_h = -1;
+    bool spread = false;  // population not constant: numpy's summation order can matter
+    if (r.use_thr) {
+        const unsigned long long cnt = a.count_non_zero ? (unsigned long long)nnz : (unsigned long long)M2;
+        if (cnt == 0) {
+            r.thr = __builtin_nan("");  // empty population: comparisons are all false
+        } else {
+            const unsigned __int128 num = (unsigned __int128)cnt * s2 - (unsigned __int128)s1 * s1;
+            spread = num != 0;
+            const double mean = (double)s1 / (double)cnt;
+            const double ss = (double)num / (double)cnt;
+            const double var = ss / (double)cnt;
+            const double sd = __builtin_sqrt(var);
+            const double tsd = a.thresh * sd;
+            r.thr = tsd + mean;
         }
-        const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
-        const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
-        const unsigned old = atomicAdd(&bins[w], 1u << sh);
-        over |= ((old >> sh) & P10_MASK) == P10_MASK;     // this add carried out of its field
-    };
-    long long i = threadIdx.x;
-    for (; i + 7 * EV_THREADS < n; i += 8 * EV_THREADS) {  // eight loads in flight: the only HBM read
-        EV e[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) e[k] = ev[i + k * EV_THREADS];
-#pragma unroll
-        for (int k = 0; k < 8; k++) bin_one10(e[k]);
     }
-    for (; i < n; i += EV_THREADS) bin_one10(ev[i]);
-    if (over) atomicOr(flag, 1u);
-    __syncthreads();
-    return *flag == 0;
+    if (r.use_thr && r.thr == r.thr && r.thr < 4294967295.) {
+        r.thr_hi = (unsigned)__builtin_floor(r.thr);
+        const double hr = __builtin_rint(r.thr);
+        if (spread && __builtin_fabs(hr - r.thr) <= 1e-9 * __builtin_fabs(r.thr)) r.amb_h = (long long)hr;
+    }
+    return r;
 }
 
 template <typename EV>
@@ -407,6 +395,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     unsigned *ws = a.sort_ws ? a.sort_ws + (size_t)blockIdx.x * a.sort_cap : nullptr;
 
   for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
+    if (a.redo && !a.redo[f]) continue;   // finished by events_pack10_kernel (workgroup-uniform)
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
     const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
     const long long n = e1 - e0;
@@ -420,30 +409,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     const bool sorted = !cached && ws != nullptr && bands > 1 && n <= (long long)a.sort_cap;
     unsigned long long s1 = 0, s2 = 0;
     unsigned nnz = 0, dropped = 0;
-    // whole frame on chip as 10-bit counts (no cache, no bands) unless a count passes 1023
-    unsigned *p10_flag = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4);
-    bool p10 = false;
-    if (a.pack10) {
-        p10 = bin_pack10(a, ev, n, bins, p10_flag, dropped);
-        if (!p10) dropped = 0;            // redo the frame with 32-bit bins (streamed from L2)
-    }
-    const int words10 = (int)((M2 + 2) / 3);
-    const int nbands = p10 ? 1 : bands;
-    // visits every (bin index within the band, count) of the band's histogram
-    auto for_counts = [&](int nb, auto &&fn) {
-        if (p10) {
-            for (int w = threadIdx.x; w < words10; w += EV_THREADS) {
-                const unsigned v = bins[w];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    if (3 * w + k < nb) fn(3 * w + k, (v >> (10 * k)) & P10_MASK);
-            }
-        } else {
-            for (int i = threadIdx.x; i < nb; i += EV_THREADS) fn(i, bins[i]);
-        }
-    };
-    if (p10) {
-    } else if (cached) {
+    if (cached) {
         fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
         __syncthreads();
     } else if (sorted) {
@@ -451,71 +417,42 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
                      dropped);
     }
     // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
-    for (int b = 0; b < nbands; b++) {
-        const int y0 = p10 ? 0 : b * rpb, y1 = p10 ? H : min(H, y0 + rpb);
+    for (int b = 0; b < bands; b++) {
+        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
-        if (p10) {
-        } else if (cached)
+        if (cached)
             bin_band_cached(cache, (int)n, y0, y1, W, bins);
         else if (sorted)
             bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
         else
             bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
-        if (b == 0 && !p10 && !cached && !sorted) dropped = dr;
+        if (b == 0 && !cached && !sorted) dropped = dr;
         const int nb = (y1 - y0) * W * 2;
-        for_counts(nb, [&](int i, unsigned h) {
+        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
+            const unsigned h = bins[i];
             s1 += h;
             s2 += (unsigned long long)h * h;
             nnz += h > 0;
             if (a.raw) a.raw[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
-        });
+        }
     }
     s1 = block_sum_u64(s1, scratch);
     s2 = block_sum_u64(s2, scratch);
     nnz = (unsigned)block_sum_u64(nnz, scratch);
     dropped = (unsigned)block_sum_u64(dropped, scratch);
 
-    // ---- hot-pixel threshold, vis.py:17-24 ----
-    // mean = S1/cnt; sum of squared deviations = S2 - S1^2/cnt = (cnt*S2 - S1^2)/cnt, exact
-    // in 128-bit integers, then numpy's own sequence: /cnt, sqrt, thresh*std + mean.
-    double thr = __builtin_inf();
-    bool use_thr = a.thresh > 0.;
-    bool spread = false;  // population not constant: numpy's summation order can matter
-    if (use_thr) {
-        const unsigned long long cnt = a.count_non_zero ? (unsigned long long)nnz
-                                                        : (unsigned long long)M2;
-        if (cnt == 0) {
-            thr = __builtin_nan("");  // empty population: comparisons are all false
-        } else {
-            const unsigned __int128 num =
-                (unsigned __int128)cnt * s2 - (unsigned __int128)s1 * s1;
-            spread = num != 0;
-            const double mean = (double)s1 / (double)cnt;
-            const double ss = (double)num / (double)cnt;
-            const double var = ss / (double)cnt;
-            const double sd = __builtin_sqrt(var);
-            const double tsd = a.thresh * sd;
-            thr = tsd + mean;
-        }
-    }
-
-    // The comparison `count > thr` (vis.py:24) in integers: for a non-negative integer h and a finite
-    // thr >= 0, h > thr <=> h > floor(thr); a NaN or infinite thr removes nothing.  The one count whose
-    // comparison could depend on numpy's summation order (|h - thr| <= 1e-9 |thr|) is rint(thr).
-    unsigned thr_hi = 0xFFFFFFFFu;
-    long long amb_h = -1;
-    if (use_thr && thr == thr && thr < 4294967295.) {
-        thr_hi = (unsigned)__builtin_floor(thr);
-        const double hr = __builtin_rint(thr);
-        if (spread && __builtin_fabs(hr - thr) <= 1e-9 * __builtin_fabs(thr)) amb_h = (long long)hr;
-    }
+    const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
+    const double thr = hp.thr;
+    const bool use_thr = hp.use_thr;
+    const unsigned thr_hi = hp.thr_hi;
+    const long long amb_h = hp.amb_h;
 
     // ---- pass 2: max of the counts that survive (vis.py:24,27) ----
     unsigned mx = 0, amb = 0;
-    for (int b = 0; b < nbands; b++) {
-        const int y0 = p10 ? 0 : b * rpb, y1 = p10 ? H : min(H, y0 + rpb);
+    for (int b = 0; b < bands; b++) {
+        const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
-        if (nbands > 1) {
+        if (bands > 1) {
             if (cached)
                 bin_band_cached(cache, (int)n, y0, y1, W, bins);
             else if (sorted)
@@ -524,13 +461,14 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
                 bin_band(ev, n, y0, y1, H, W, a.flip_x, a.negate_p, bins, dr);
         }
         const int nb = (y1 - y0) * W * 2;
-        for_counts(nb, [&](int i, unsigned h) {
+        for (int i = threadIdx.x; i < nb; i += EV_THREADS) {
+            unsigned h = bins[i];
             amb += (long long)h == amb_h;
             if (h > thr_hi) h = 0;
             mx = h > mx ? h : mx;
-            if (nbands == 1 && !p10) bins[i] = h;  // single band: keep the thresholded counts for pass 3
+            if (bands == 1) bins[i] = h;  // single band: keep the thresholded counts for pass 3
             if (a.kept) a.kept[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
-        });
+        }
     }
     mx = block_max_u32(mx, scratch);
     amb = (unsigned)block_sum_u64(amb, scratch);
@@ -570,37 +508,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     // ---- pass 3: normalise, colour, blend, round -> uint8 (vis.py:27-39) ----
     uint8_t *out = a.frames + (long long)f * H * W * 3;
-    if (p10) {
-        // 12 pixels = 24 counts = 8 words in, 36 bytes = 9 dwords out per step
-        const int npix = H * W;
-        const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 12 : 0;   // dword stores need aligned frames
-        for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
-            const uint4 wa = *reinterpret_cast<const uint4 *>(&bins[g * 8]);
-            const uint4 wb = *reinterpret_cast<const uint4 *>(&bins[g * 8 + 4]);
-            const unsigned w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-            unsigned c[24];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                c[3 * k] = w8[k] & P10_MASK;
-                c[3 * k + 1] = (w8[k] >> 10) & P10_MASK;
-                c[3 * k + 2] = (w8[k] >> 20) & P10_MASK;
-            }
-            unsigned words[9];
-            uint8_t *bytes = reinterpret_cast<uint8_t *>(words);
-#pragma unroll
-            for (int k = 0; k < 12; k++) colour(c[2 * k], c[2 * k + 1], bytes + 3 * k);
-            unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
-#pragma unroll
-            for (int k = 0; k < 9; k++) dst[k] = words[k];
-        }
-        for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) {
-            uint8_t px[3];
-            colour(p10_get(bins, 2u * q), p10_get(bins, 2u * q + 1u), px);
-            out[3 * q] = px[0], out[3 * q + 1] = px[1], out[3 * q + 2] = px[2];
-        }
-        __syncthreads();
-    }
-    for (int b = 0; b < (p10 ? 0 : bands); b++) {
+    for (int b = 0; b < bands; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
         if (bands > 1) {
@@ -643,6 +551,171 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         __syncthreads();
     }
   }   // frames of this workgroup
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole frame in LDS: three 10-bit counts per 32-bit word.
+//
+// A sensor of up to ~59 000 pixels (N-Caltech: 180 x 240 x 2 bins -> 113 KiB) holds its complete
+// histogram on chip in this form: the events are read from HBM ONCE and binned ONCE with
+// fire-and-forget LDS atomics (no event cache, no bands), and the three frame-wide passes the
+// reference needs (sum / sum of squares, max of what survives the hot-pixel threshold, colour) walk
+// 28 800 words of LDS instead of re-binning 20 000 events for each of 3 passes x 5 bands.
+// An overflow of a 10-bit field (a pixel with more than 1023 events of one polarity) carries into its
+// neighbour and lowers the sum of all fields by 1022 or 1023, never raises it, so `sum of the fields ==
+// events binned` -- the first pass computes that sum anyway -- holds exactly when no count passed
+// 1023.  A frame that fails the check writes nothing and sets redo[f]; events_to_frames_kernel,
+// launched behind this kernel over the same frames, processes exactly those with 32-bit bins.
+// Its own kernel rather than a mode of the one above so that its registers are its own (as a mode it
+// pushed both paths into scratch spills).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned P10_MASK = 1023u;
+
+template <typename EV>
+__global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *bins = reinterpret_cast<unsigned *>(smem);
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + a.bin_bytes);
+    unsigned *lut = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES);
+    const int f = blockIdx.x;
+    const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
+    const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
+    const long long n = e1 - e0;
+    const int H = a.H, W = a.W;
+    const int M2 = H * W * 2;
+    const int words = (M2 + 2) / 3;
+
+    for (int i = threadIdx.x; i < words; i += EV_THREADS) bins[i] = 0;
+    __syncthreads();
+    unsigned dropped = 0, binned = 0;
+    auto bin_one = [&](const EV e) {
+        int x, y, p;
+        parse(e, W, a.flip_x, a.negate_p, x, y, p);
+        if (p == 0) return;
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
+            dropped++;
+            return;
+        }
+        const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
+        const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
+        atomicAdd(&bins[w], 1u << sh);
+        binned++;
+    };
+    {   // the frame's only HBM read: eight 16-byte loads in flight per thread
+        long long i = threadIdx.x;
+        for (; i + 7 * EV_THREADS < n; i += 8 * EV_THREADS) {
+            EV e[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = ev[i + k * EV_THREADS];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bin_one(e[k]);
+        }
+        for (; i < n; i += EV_THREADS) bin_one(ev[i]);
+    }
+    __syncthreads();
+
+    // ---- pass 1: sum, sum of squares, non-zero bins (fields past M2 in the last word are zero) ----
+    // per-thread partial sums stay in 32 bits: at most ceil(58 000 / 1024) words x 3 counts <= 1023
+    unsigned s1t = 0, s2t = 0, nnz = 0;
+    for (int w = threadIdx.x; w < words; w += EV_THREADS) {
+        const unsigned v = bins[w];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const unsigned h = (v >> (10 * k)) & P10_MASK;
+            s1t += h;
+            s2t += h * h;
+            nnz += h > 0;
+        }
+    }
+    unsigned long long s1 = block_sum_u64(s1t, scratch), s2 = s2t;
+    const unsigned long long total = block_sum_u64(binned, scratch);
+    if (s1 != total) {                               // a field overflowed: leave the frame to the 32-bit kernel
+        if (threadIdx.x == 0) a.redo[f] = 1;
+        return;
+    }
+    s2 = block_sum_u64(s2, scratch);
+    nnz = (unsigned)block_sum_u64(nnz, scratch);
+    dropped = (unsigned)block_sum_u64(dropped, scratch);
+    const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
+    const unsigned thr_hi = hp.thr_hi;
+
+    // ---- pass 2: max of the counts that survive; debug outputs ----
+    unsigned mx = 0, amb = 0;
+    for (int w = threadIdx.x; w < words; w += EV_THREADS) {
+        const unsigned v = bins[w];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int idx = 3 * w + k;
+            unsigned h = (v >> (10 * k)) & P10_MASK;
+            if (a.raw && idx < M2) a.raw[(long long)f * M2 + idx] = (int)h;
+            amb += (long long)h == hp.amb_h;
+            if (h > thr_hi) h = 0;
+            mx = h > mx ? h : mx;
+            if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
+        }
+    }
+    mx = block_max_u32(mx, scratch);
+    amb = (unsigned)block_sum_u64(amb, scratch);
+    const double dmx = (double)mx;
+    if (a.stats && threadIdx.x == 0) {
+        ec_frame_stats st;
+        st.sum = s1;
+        st.sumsq = s2;
+        st.nnz = nnz;
+        st.max_kept = mx;
+        st.dropped = dropped;
+        st.ambiguous = amb;
+        st.thr = hp.use_thr ? hp.thr : __builtin_nan("");
+        a.stats[f] = st;
+    }
+
+    // ---- pass 3: colour through the per-frame look-up table for small counts ----
+    if (threadIdx.x < EV_LUT_N * EV_LUT_N) {
+        uint8_t px[4] = {0, 0, 0, 0};
+        colour_pixel(threadIdx.x / EV_LUT_N, threadIdx.x % EV_LUT_N, dmx, a, px);
+        lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+    }
+    __syncthreads();
+    auto colour = [&](unsigned h0, unsigned h1) -> unsigned {      // 0x00BBGGRR
+        if (h0 > thr_hi) h0 = 0;
+        if (h1 > thr_hi) h1 = 0;
+        if (h0 < EV_LUT_N && h1 < EV_LUT_N) return lut[h0 * EV_LUT_N + h1];
+        uint8_t px[3];
+        colour_pixel(h0, h1, dmx, a, px);
+        return (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+    };
+    uint8_t *out = a.frames + (long long)f * H * W * 3;
+    const int npix = H * W;
+    // 4 pixels = 8 counts out of up to 4 consecutive words (the group's first count is field (8 g) % 3
+    // of word (8 g) / 3), 12 bytes = three dwords out; frames whose byte size is not a multiple of 4 take
+    // the byte path
+    const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 4 : 0;
+    for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
+        const unsigned first = 8u * g, w0 = first / 3u, k0 = first - 3u * w0;
+        // fields k0 .. k0 + 7 of the 12 in words w0 .. w0 + 3 (120 bits; k0 <= 2)
+        unsigned __int128 bits = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const unsigned v = w0 + j < (unsigned)words ? (bins[w0 + j] & 0x3FFFFFFFu) : 0u;
+            bits = (bits << 30) | v;
+        }
+        bits >>= 10 * k0;
+        unsigned c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            c[k] = colour((unsigned)(bits >> (20 * k)) & P10_MASK, (unsigned)(bits >> (20 * k + 10)) & P10_MASK);
+        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 12);
+        dst[0] = c[0] | (c[1] << 24);
+        dst[1] = (c[1] >> 8) | (c[2] << 16);
+        dst[2] = (c[2] >> 16) | (c[3] << 8);
+    }
+    for (int q = groups * 4 + threadIdx.x; q < npix; q += EV_THREADS) {
+        const unsigned b0 = 2u * q, wa = b0 / 3u, wb = (b0 + 1u) / 3u;
+        const unsigned v = colour((bins[wa] >> (10u * (b0 - 3u * wa))) & P10_MASK,
+                                  (bins[wb] >> (10u * (b0 + 1u - 3u * wb))) & P10_MASK);
+        out[3 * q] = (uint8_t)v, out[3 * q + 1] = (uint8_t)(v >> 8), out[3 * q + 2] = (uint8_t)(v >> 16);
+    }
 }
 
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
@@ -779,6 +852,14 @@ extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_rang
 
 namespace {
 
+// LDS bytes of the whole-frame 10-bit histogram, and whether that path applies: the frame does not fit
+// one band of 32-bit bins but does as packed counts (next to the reduction scratch and the LUT)
+inline long pack10_bytes(int H, int W) { return (((long)H * W * 2 + 2) / 3 * 4 + 15) / 16 * 16; }
+inline bool pack10_fits(int H, int W)
+{
+    return (long)W * 2 * 4 * H > EV_BIN_BYTES && pack10_bytes(H, W) + EV_SCRATCH_BYTES <= 160 * 1024;
+}
+
 template <typename EV>
 int launch_events(const void *events, const int64_t *frame_range, int F, const ec_events_params *prm,
                   uint8_t *frames, int32_t *raw_counts, int32_t *kept_counts, ec_frame_stats *stats,
@@ -853,24 +934,10 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
             if ((size_t)grid > slots) grid = (int)slots;
         }
     }
-    // Sensors whose whole histogram fits LDS as three 10-bit counts per word (and does not as 32-bit
-    // counts) are binned once, with no cache and no bands; a frame with a count above 1023 falls back
-    // to 32-bit bands streamed from L2 (frame_pack10 above).
-    const long pack_bytes = (((long)prm->H * prm->W * 2 + 2) / 3 * 4 + 15) / 16 * 16;
-    a.pack10 = 0;
-    if ((long)row_bytes * prm->H > EV_BIN_BYTES && pack_bytes <= EV_BIN_BYTES && !getenv("EC_EVENTS_NO_PACK10")) {
-        a.pack10 = 1;
-        cache_events = 0;
-        bin_budget = EV_BIN_BYTES;
-        a.sort_ws = nullptr;
-        a.sort_cap = 0;
-        grid = F;
-    }
     const int max_rows = bin_budget / row_bytes;
     a.bands = ec::ceil_div(prm->H, max_rows);
     a.rows_per_band = ec::ceil_div(prm->H, a.bands);
     a.bin_bytes = (a.rows_per_band * row_bytes + 15) / 16 * 16;
-    if (a.pack10 && a.bin_bytes < pack_bytes) a.bin_bytes = (int)pack_bytes;
     a.cache_events = cache_events;
     a.F = F;
     a.band_magic = (unsigned)((0x100000000ull + (unsigned)a.rows_per_band - 1) / (unsigned)a.rows_per_band);
@@ -878,14 +945,48 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     const int lds = LDS_TOTAL;   // always the full carve: one attribute call, one workgroup per CU
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_to_frames_kernel<EV>), lds))
         return rc;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
     // algorithmic bytes: 16 B (packed: 8 B) per event in + 3*H*W out.  The frame
     // ranges live on the device; the caller states their total length in prm->total_events (0 =
     // unknown: only the output part is reported then)
-    ec::ProfScope prof(ec::PROF_EVENTS, static_cast<hipStream_t>(stream), 0,
+    ec::ProfScope prof(ec::PROF_EVENTS, hs, 0,
                        (double)F * prm->H * prm->W * 3.0 +
                            (double)(prm->total_events > 0 ? prm->total_events : 0) * sizeof(EV));
-    hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(grid), dim3(EV_THREADS), lds,
-                       static_cast<hipStream_t>(stream), a);
+    a.redo = nullptr;
+    if (pack10_fits(prm->H, prm->W) && prm->sort_workspace && prm->sort_workspace_bytes >= 256 &&
+        !getenv("EC_EVENTS_NO_PACK10")) {
+        // whole-frame 10-bit path first, then the 32-bit kernel for the frames it flagged (none, for
+        // ordinary data: its workgroups return at once).  The caller's workspace holds the flags.
+        if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_pack10_kernel<EV>), lds))
+            return rc;
+        uint8_t *flags = static_cast<uint8_t *>(prm->sort_workspace);
+        const long cap = (long)prm->sort_workspace_bytes;
+        const long M2 = (long)prm->H * prm->W * 2;
+        if (a.sort_ws) {            // the workspace is the flag array here, not sort slots
+            a.sort_ws = nullptr;
+            a.sort_cap = 0;
+            grid = F;
+        }
+        for (long f0 = 0; f0 < F; f0 += cap) {
+            const int fc = (int)(F - f0 < cap ? F - f0 : cap);
+            EvArgs g = a;
+            g.range = a.range + 2 * f0;
+            g.frames = a.frames + f0 * prm->H * prm->W * 3;
+            g.raw = a.raw ? a.raw + f0 * M2 : nullptr;
+            g.kept = a.kept ? a.kept + f0 * M2 : nullptr;
+            g.stats = a.stats ? a.stats + f0 : nullptr;
+            g.F = fc;
+            g.redo = flags;
+            EvArgs p = g;
+            p.bin_bytes = (int)pack10_bytes(prm->H, prm->W);
+            EC_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)fc, hs));
+            hipLaunchKernelGGL(events_pack10_kernel<EV>, dim3(fc), dim3(EV_THREADS), lds, hs, p);
+            hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(fc < grid ? fc : grid), dim3(EV_THREADS), lds, hs, g);
+            EC_CHECK_HIP(hipGetLastError());
+        }
+        return EC_OK;
+    }
+    hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(grid), dim3(EV_THREADS), lds, hs, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
@@ -894,7 +995,9 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
 
 extern "C" EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *prm)
 {
-    if (!prm || prm->max_frame_events <= 0 || prm->H <= 0 || prm->W <= 0) return 0;
+    if (!prm || prm->H <= 0 || prm->W <= 0) return 0;
+    if (pack10_fits(prm->H, prm->W)) return 65536;    // per-frame redo flags of the 10-bit path
+    if (prm->max_frame_events <= 0) return 0;
     const long row_bytes = (long)prm->W * 2 * 4;
     const long cache_bytes = ((long)prm->max_frame_events * 4 + 15) / 16 * 16;
     const long left = (long)EV_BIN_BYTES - cache_bytes;
