@@ -246,10 +246,14 @@ class FSCLIPClassifier(ZSCLIPClassifier):
 
 
 def build_model(params):
-    """models/__init__.py:5-21 (FTCLIP = fine-tuning of CLIP itself, is out of scope)."""
+    """models/__init__.py:5-21.  'FTCLIP' gives the serving form of FTCLIPClassifier (forward and
+    checkpoints; fine-tuning of CLIP itself is out of scope)."""
     kind = params.model
     if kind == 'ZSCLIP':
         return ZSCLIPClassifier(clip_dict=params.clip_dict)
     if kind == 'FSCLIP':
         return FSCLIPClassifier(params.adapter_dict, params.clip_dict, params.loss_dict)
+    if kind == 'FTCLIP':
+        from .clip_cls_ft import FTCLIPClassifier
+        return FTCLIPClassifier(params.adapter_dict, params.clip_dict, params.loss_dict)
     raise NotImplementedError(f'{kind} is not implemented.')

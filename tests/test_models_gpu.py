@@ -180,3 +180,118 @@ def test_end_to_end_events_to_logits_matches_oracle(hip):
         assert float((o['probs'].cpu() - want['probs']).abs().max()) < 5e-2
         assert torch.equal(o['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
     torch.testing.assert_close(o1['logits'], o2['logits'], rtol=0, atol=0)  # same kernels, same bits
+
+
+def _ft_fake_clip(C, z):
+    """The stand-in of tools/make_golden_ft.py with PLAIN attention blocks (what a served model has)."""
+    import torch
+    import torch.nn as nn
+
+    class Block(nn.Module):
+        def __init__(self, d, heads):
+            super().__init__()
+            self.attn = nn.MultiheadAttention(d, heads)
+            self.ln_1 = nn.LayerNorm(d)
+
+    class Visual(nn.Module):
+        def __init__(self, d=16, heads=2, layers=2, out=8):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, d, 2, 2, bias=False)
+            self.class_embedding = nn.Parameter(torch.zeros(d))
+            self.transformer = nn.Module()
+            self.transformer.resblocks = nn.Sequential(*[Block(d, heads) for _ in range(layers)])
+            self.ln_post = nn.LayerNorm(d)
+            self.proj = nn.Parameter(torch.zeros(d, out))
+            self.output_dim = out
+
+        def forward(self, x):
+            for blk in self.transformer.resblocks:
+                h = blk.ln_1(x)
+                x = x + blk.attn(h, h, h, need_weights=False)[0]
+            return self.ln_post(x[0]) @ self.proj
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logit_scale = nn.Parameter(torch.tensor(float(np.log(100.))))
+            self.table = nn.Parameter(torch.from_numpy(z['table']))
+            self.visual = Visual(out=C)
+
+        def encode_image(self, imgs):
+            return imgs.flatten(1)[:, :C] * 1.5
+
+        def encode_text(self, tokens):
+            return self.table[tokens[:, 0].long()]
+
+    m = Fake()
+    m.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('base:')})
+    return m
+
+
+@pytest.mark.parametrize('tag', ['full', 'lora'])
+def test_finetuned_classifier_serves_reference_checkpoints(tag, hip):
+    """FTCLIPClassifier (models/clip_cls_ft.py) for serving: a checkpoint exactly as the reference's class
+    writes it -- fully fine-tuned, or with LoRA factors in every attention block -- loads key for key,
+    the LoRA factors fold into plain weights that reproduce the reference's injected tower on a probe,
+    and the forward (normalised features against the tuned text features) matches the reference's."""
+    import torch
+    from eventclip_amd.clip_cls import build_model
+    from eventclip_amd.clip_cls_ft import FTCLIPClassifier
+    z = load('classify_ft.npz')
+    C, K = int(z['C']), int(z['K'])
+    names = [f'class_{i}' for i in range(K)]
+    imgs, valid = torch.from_numpy(z['imgs']).cuda(), torch.from_numpy(z['valid']).cuda()
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + '/sd:')}
+    assert any('lora_' in k for k in sd) == (tag == 'lora')
+    for agg in ('sum', 'mean'):
+        params = types.SimpleNamespace(
+            model='FTCLIP', adapter_dict=dict(adapter_type='text-identity', residual=True),
+            clip_dict=dict(clip_model=_ft_fake_clip(C, z), prompt='a point cloud image of a {}',
+                           class_names=names, agg_func=agg, class_tokens=torch.from_numpy(z['tokens']),
+                           lora=-1 if tag == 'full' else 'qkvo-2', only_conv1=False, only_bias=False,
+                           only_ln=False),
+            loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
+        model = build_model(params)
+        assert isinstance(model, FTCLIPClassifier)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        o = model({'img': imgs, 'valid_mask': valid})
+        for k in ('full_logits', 'logits', 'probs'):
+            torch.testing.assert_close(o[k].cpu(), torch.from_numpy(z[f'{tag}/{agg}_{k}']), rtol=1e-4, atol=2e-4)
+        # the tower the checkpoint describes: plain weights after the fold == the reference's (injected) one
+        with torch.no_grad():
+            got = model.model.visual.cpu()(torch.from_numpy(z['probe']))
+        torch.testing.assert_close(got, torch.from_numpy(z[f'{tag}/visual_out']), rtol=1e-5, atol=1e-5)
+        # what it writes back is a plain fine-tuned checkpoint: model.visual.* + text_feats + adapter.dummy
+        keys = set(model.state_dict())
+        assert 'text_feats' in keys and 'adapter.dummy' in keys
+        assert {k for k in keys if k.startswith('model.')} == {'model.visual.' + k for k in model.model.visual.state_dict()}
+        with pytest.raises(NotImplementedError):
+            model.train()
+
+
+def test_finetuned_checkpoint_through_the_real_tower(hip):
+    """A fine-tuned `model.visual.*` checkpoint swaps the HIP tower's weights: after load_state_dict the
+    features are those of a CLIP built from the fine-tuned weights directly."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls_ft import FTCLIPClassifier
+    cfg = eclip.arch_config('ViT-B/32', layers=2, text_layers=1, vocab_size=1024)
+    sd0, sd1 = eclip.random_state_dict(cfg, seed=1), eclip.random_state_dict(cfg, seed=2)
+    tuned = dict(sd0)
+    tuned.update({k: v for k, v in sd1.items() if k.startswith('visual.')})     # "fine-tuned" tower
+    tokens = eclip.synthetic_tokens(5, seed=0)
+    clf = FTCLIPClassifier(clip_dict=dict(clip_model=eclip.CLIP(cfg, sd0).cuda().eval(), prompt='a {}',
+                                          class_names=list('abcde'), agg_func='mean', class_tokens=tokens))
+    ckpt = {'model.visual.' + k[len('visual.'):]: v for k, v in sd1.items() if k.startswith('visual.')}
+    ckpt['text_feats'] = torch.randn(5, cfg['embed_dim'])
+    ckpt['adapter.dummy'] = torch.zeros(1)
+    clf.load_state_dict(ckpt)
+    clf = clf.cuda().eval()
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(4)).cuda()
+    want = eclip.CLIP(cfg, tuned).cuda().eval().encode_image(img)
+    assert torch.equal(clf.model.encode_image(img), want)
+    out = clf({'img': img[None], 'valid_mask': torch.ones(1, 3, dtype=torch.bool).cuda()})
+    t = torch.nn.functional.normalize(ckpt['text_feats'], dim=-1).cuda()
+    f = torch.nn.functional.normalize(want, dim=-1)
+    torch.testing.assert_close(out['full_logits'][0], clf.logit_scale * f @ t.T, rtol=1e-4, atol=1e-3)
