@@ -62,10 +62,13 @@ class EcProfileEntry(ctypes.Structure):
 class EcGemmArgs(ctypes.Structure):
     _fields_ = [('M', c_int), ('N', c_int), ('K', c_int), ('dtype', c_int), ('epilogue', c_int),
                 ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
-                ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p)]
+                ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p),
+                ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
+                ('split_stride', c_long)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
+EC_EPI_GELU16_SAVE, EC_EPI_GELU_BWD16 = 4, 5
 EC_PRE_CHW_F32, EC_PRE_PATCHES16, EC_PRE_HWC_U8 = 0, 1, 2
 EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
 
@@ -104,6 +107,27 @@ class EcTextWeights(ctypes.Structure):
                 ('ln_final_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('proj_w_lo', c_void_p)]
+
+
+class EcBlockWeightsT(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('qkv_wt', 'out_wt', 'fc1_wt', 'fc2_wt')]
+
+
+class EcVitTrainWeights(ctypes.Structure):
+    _fields_ = [('blocks', ctypes.POINTER(EcBlockWeightsT)), ('proj', c_void_p)]
+
+
+BLOCK_GRAD_FIELDS = ('ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
+                     'fc2_w', 'fc2_b')
+
+
+class EcBlockGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in BLOCK_GRAD_FIELDS]
+
+
+class EcVitGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('conv_w', 'cls', 'pos', 'ln_pre_g', 'ln_pre_b', 'ln_post_g', 'ln_post_b',
+                                        'proj')] + [('blocks', ctypes.POINTER(EcBlockGrads))]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every
@@ -172,6 +196,27 @@ SIGNATURES = {
                                c_void_p, ctypes.c_size_t, c_void_p]),
     'ec_classify': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_attention_train': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ec_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p]),
+    'ec_vit_embed_train': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_float, c_void_p, c_void_p, c_void_p]),
+    'ec_sgemm': (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_int, c_int, c_int, c_float,
+                         c_float, c_void_p, c_long, c_void_p]),
+    'ec_vit_train_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcVitWeights), c_int]),
+    'ec_vit_train_forward': (c_int, [ctypes.POINTER(EcVitWeights), c_void_p, c_int, c_void_p, c_void_p,
+                                     ctypes.c_size_t, c_void_p]),
+    'ec_vit_train_backward': (c_int, [ctypes.POINTER(EcVitWeights), ctypes.POINTER(EcVitTrainWeights), c_void_p,
+                                      c_int, c_void_p, ctypes.POINTER(EcVitGrads), c_void_p, ctypes.c_size_t,
+                                      c_void_p]),
+    'ec_pack_weight16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'ec_layernorm_backward_partials': (ctypes.c_size_t, [c_int, c_int]),
+    'ec_layernorm_backward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float,
+                                      c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_ft_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                ctypes.c_size_t, c_void_p]),
+    'ec_grad_unscale_check': (c_int, [c_void_p, ctypes.c_int64, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,4 +1,5 @@
-"""``FTCLIPClassifier`` of the reference (models/clip_cls_ft.py) for SERVING fine-tuned checkpoints.
+"""``FTCLIPClassifier`` of the reference (models/clip_cls_ft.py): serving fine-tuned checkpoints, and the model
+side of fine-tuning (the optimisation step itself is ``eventclip_amd.ft.FTTrainer``).
 
 The reference fine-tunes CLIP's vision tower (all of it, sub-sets, or LoRA factors injected into
 every attention block, clip_cls_ft.py:44-80, lora.py:384-403) and saves ``model.visual.*`` next to
@@ -7,8 +8,9 @@ with the identity adapter: encode the valid views, L2-normalise, logits against 
 features, aggregate.  This class is that forward on the HIP path plus the checkpoint format:
 ``load_state_dict`` takes a reference checkpoint as it is -- LoRA-injected keys included, folded into
 plain weights once (eventclip_amd.lora) -- and repacks the tower; ``state_dict`` emits the reference's
-key set.  TRAINING through the towers (``calc_train_loss`` + backward) is not built (out
-of scope): ``train(True)`` raises.
+key set.  With an ``FTTrainer`` attached the classifier is in the middle of a fine-tuning run: ``forward``
+then encodes through the trainer's (LoRA-merged) operand copies and ``state_dict`` writes the trainer's
+``model.visual.*`` entries, LoRA factors under the reference's key names included.
 """
 import torch
 
@@ -20,7 +22,7 @@ FT_LOSS_DEFAULTS = dict(use_logits_loss=True, use_probs_loss=False)
 
 
 class FTCLIPClassifier(FSCLIPClassifier):
-    """Fine-tuned CLIP for few-shot classification, inference only (clip_cls_ft.py:15-333)."""
+    """Fine-tuned CLIP for few-shot classification (clip_cls_ft.py:15-333)."""
 
     def __init__(self, adapter_dict=None, clip_dict=None, loss_dict=None):
         ad = dict(FT_ADAPTER_DEFAULTS if adapter_dict is None else adapter_dict)
@@ -32,11 +34,33 @@ class FTCLIPClassifier(FSCLIPClassifier):
         # which parts of the tower were trained (lora / only_conv1 / only_bias / ..., clip_cls_ft.py:50-80)
         # is a property of the checkpoint being served; kept for API parity
         self.lora = self.clip_dict.get('lora', -1)
+        self._tower = None        # eventclip_amd.ft.VisualTower while an FTTrainer is attached
+        self._trainer = None
+
+    def _view_feats(self, data_dict):
+        if self._tower is None or 'patches' not in data_dict:
+            return super()._view_feats(data_dict)
+        feats = self._tower.encode_patches(data_dict['patches'])
+        return feats.float().contiguous(), data_dict['row_idx'].contiguous(), data_dict['valid_mask']
+
+    def get_img_feats(self, imgs):
+        if self._tower is None:
+            return super().get_img_feats(imgs)
+        from . import _lib
+        t = self._tower
+        x = imgs.to(t.dev, torch.float32).contiguous()
+        patches = torch.empty((x.shape[0], t.G, t.kpad), dtype=t.cd, device=t.dev)
+        _lib.check(_lib.lib().ec_patchify(_lib.ptr(x), x.shape[0], t.cfg['image_size'], t.P, t.kpad, _lib.ptr(patches),
+                                          t.code, _lib.stream_ptr()), 'ec_patchify')
+        return self._adjust_dtype(t.encode_patches(patches))
 
     # ---- checkpoints: model.visual.* travels with the classifier (clip_cls_ft.py:313-333) ----
     def state_dict(self, *args, **kwargs):
         w = super(FSCLIPClassifier, self).state_dict(*args, **kwargs)    # the ZS filter drops model.*
-        vis = {'model.visual.' + k: v for k, v in self.model.visual.state_dict().items()}
+        if self._trainer is not None:
+            vis = {k: v.detach() for k, v in self._trainer.visual_state_dict().items()}
+        else:
+            vis = {'model.visual.' + k: v for k, v in self.model.visual.state_dict().items()}
         return {**vis, **w}
 
     def load_state_dict(self, state_dict, strict=True):
@@ -59,8 +83,6 @@ class FTCLIPClassifier(FSCLIPClassifier):
         return super().load_state_dict(rest, strict=strict)
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError(
-                'fine-tuning through the CLIP towers is not built on the MI355X path (DESIGN.md, out of '
-                'scope); train with the reference and serve the checkpoint here')
-        return super().train(False)
+        """clip_cls_ft.py:300-306: CLIP stays in eval mode except for its vision tower -- which has no
+        train-mode behaviour of its own (no dropout, no batch statistics)."""
+        return super().train(mode)

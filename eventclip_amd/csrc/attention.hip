@@ -56,44 +56,9 @@ struct AttnArgs {
     int q_rows;       // only the first q_rows query rows of every sequence are computed; out is
                       // [n_seq * q_rows, W] (q_rows = S: the whole sequence)
     float scale_log2e;
+    float *lse;       // LSE kernels only: [n_seq, heads, S] fp32, log2 of the softmax denominator in the
+                      // scaled-score domain (m * scale_log2e + log2 l), kept for ec_attention_backward
 };
-
-// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the
-// gfx950 row-swap VALU ops instead of ds_bpermute round trips through LDS:
-// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
-// second, v_permlane32_swap the upper half of the first with the lower half of the second.
-// (Written as inline asm: hipcc folds max / add over the two results of the swap builtins
-// to one operand.  s_nop 1 covers the VALU-write -> v_permlane-read hazard.)
-__device__ __forceinline__ float xor_max(float v)
-{
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_f32 %0, %0, %1\n\t"
-                 "v_mov_b32 %1, %0\n\t"
-                 "s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_f32 %0, %0, %1"
-                 : "+v"(a), "+v"(b));
-    return a;
-}
-__device__ __forceinline__ float xor_sum(float v)
-{
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_add_f32 %0, %0, %1\n\t"
-                 "v_mov_b32 %1, %0\n\t"
-                 "s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_add_f32 %0, %0, %1"
-                 : "+v"(a), "+v"(b));
-    return a;
-}
 
 // One 64-key (or, for the last odd step, 32-key) block of the online softmax:
 // scores -> running max / sum -> P^T as the B operand -> O^T += V^T . P^T.
@@ -177,7 +142,7 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
     }
 }
 
-template <int DT, int AT_WAVES>
+template <int DT, int AT_WAVES, bool LSE = false>
 __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
@@ -255,7 +220,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
                                     c16);
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
-        const float inv = 1.f / xor_sum(l_run);
+        const float lsum = xor_sum(l_run);
+        const float inv = 1.f / lsum;
+        if (LSE && qrow < a.q_rows && g == 0)
+            a.lse[((long)seq * a.heads + head) * S + qrow] = m_run * a.scale_log2e + __builtin_amdgcn_logf(lsum);
         if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll
@@ -288,7 +256,8 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     // which would spread the 17 query tiles of S = 257 over two even passes, measure 0.22 ms against
     // 0.17 ms for 8: the second workgroup no longer co-resides.)
     const bool wide = lds > 80 * 1024;
-    void (*kern)(const AttnArgs) = wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>;
+    void (*kern)(const AttnArgs) = a.lse ? (wide ? attention_kernel<DT, 16, true> : attention_kernel<DT, 8, true>)
+                                         : (wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>);
     const int nw = wide ? 16 : 8;
     // always the full carve (one attribute call per kernel and device, thread-safe)
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
@@ -407,11 +376,30 @@ extern "C" EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, i
     AttnArgs a;
     a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = causal;
     a.q_rows = q_rows;
+    a.lse = nullptr;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
     if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);
     return ec::fail(EC_ERR_INVALID, "ec_attention: unknown dtype %d", dtype);
+}
+
+extern "C" EC_API int ec_attention_train(const void *qkv, void *out, float *lse, int n_seq, int S, int width,
+                                         int heads, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention_train: bad shape");
+    EC_REQUIRE(width == heads * 64, "ec_attention_train: head dim must be 64 (width %d, heads %d)", width, heads);
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv && out && lse, "ec_attention_train: null buffer");
+    AttnArgs a;
+    a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = 0;
+    a.q_rows = S;
+    a.lse = lse;
+    a.scale_log2e = 0.125f * 1.4426950408889634f;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
+    if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);
+    return ec::fail(EC_ERR_INVALID, "ec_attention_train: unknown dtype %d", dtype);
 }
 
 extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_seq, int S,

@@ -42,6 +42,12 @@ struct GemmArgs {
     long ldc;
     int tiles_m, tiles_n;
     unsigned long long *diag;   // EC_GEMM_DIAG builds: stamp / timeline records (ec_gemm_args.diag)
+    // training extensions (persistent kernel only; see ec_gemm_args)
+    long ldw;                   // row stride of W in elements
+    const float *resid;         // RESID32: residual source (same ldc); null = C (in place)
+    void *aux;                  // GELU16_SAVE: pre-activation out; GELU_BWD16: pre-activation in (ldc)
+    int splits;                 // K-batches: batch s reads columns s*K .. of A and W, writes C + s * split_stride
+    long split_stride;          // elements of C between batches
 };
 
 __device__ __forceinline__ int swz_key(int row) { return (row & 7) ^ ((row >> 3) & 6); }
@@ -51,6 +57,16 @@ __device__ __forceinline__ float quick_gelu(float x)
     // QuickGELU of openai/CLIP: x * sigmoid(1.702 x); v_exp_f32 + v_rcp_f32 (1 ulp each),
     // far inside the 16-bit rounding of the output
     return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+}
+// d QuickGELU / dx = s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu_grad(float x)
+{
+    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+    return sg * (1.f + 1.702f * x * (1.f - sg));
+}
+constexpr bool epi_is16(int e)
+{
+    return e == EC_EPI_STORE16 || e == EC_EPI_GELU16 || e == EC_EPI_GELU16_SAVE || e == EC_EPI_GELU_BWD16;
 }
 
 // bijective XCD remap (blocks b and b+8 share an XCD): XCD x gets a contiguous id range
@@ -176,7 +192,7 @@ __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[T
             for (int p = 0; p < 4; p++) {
                 int m = m_base + i * 16 + q + 4 * p;
                 m = m < g.M ? m : g.M - 1;
-                const float *src = (const float *)g.C + (long)m * g.ldc + (col_ok ? col : 0);
+                const float *src = (g.resid ? g.resid : (const float *)g.C) + (long)m * g.ldc + (col_ok ? col : 0);
                 x[i % DEPTH][p] = *reinterpret_cast<const f32x4 *>(src);
             }
         }
@@ -217,7 +233,8 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
                                                int n_base, int lane, unsigned char *scratch)
 {
     typedef typename T16<DT>::elem elem;
-    static_assert(EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16, "16-bit outputs only");
+    typedef typename T16<DT>::v8 v8;
+    static_assert(epi_is16(EPI), "16-bit outputs only");
     constexpr int PITCH = 144;
     const int q = lane >> 4, lr = lane & 15;
     f32x4 bias[4];
@@ -240,17 +257,50 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float y = v[r];
-                if constexpr (EPI == EC_EPI_GELU16) y = quick_gelu(y);
+                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE) y = quick_gelu(y);
                 o[4 * j + r] = to16(y, elem());
             }
         }
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
+        if constexpr (EPI == EC_EPI_GELU16_SAVE) {
+            // the pre-activation goes out next to the activation (training keeps it for the backward pass):
+            // second scratch buffer, same transpose
+            unsigned char *buf2 = scratch + ((i & 1) ^ 1) * 16 * PITCH;
+            elem u[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 v = acc[i][j] + bias[j];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u[4 * j + r] = to16(v[r], elem());
+            }
+            *reinterpret_cast<u32x4 *>(buf2 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&u[0]);
+            *reinterpret_cast<u32x4 *>(buf2 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&u[8]);
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int row = (lane >> 3) + 8 * p;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(buf2 + row * PITCH + (lane & 7) * 16);
+                const int m = m_base + i * 16 + row;
+                if (m < g.M && col_ok)
+                    *reinterpret_cast<u32x4 *>((elem *)g.aux + (long)m * g.ldc + col) = v;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int row = (lane >> 3) + 8 * p;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(buf + row * PITCH + (lane & 7) * 16);
+            u32x4 v = *reinterpret_cast<const u32x4 *>(buf + row * PITCH + (lane & 7) * 16);
             const int m = m_base + i * 16 + row;
+            if constexpr (EPI == EC_EPI_GELU_BWD16) {
+                // out = dg * QuickGELU'(u), u = the saved pre-activation at the same [m, n]
+                if (m < g.M && col_ok) {
+                    const v8 uu = *reinterpret_cast<const v8 *>((const elem *)g.aux + (long)m * g.ldc + col);
+                    v8 dg = __builtin_bit_cast(v8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        dg[e] = to16((float)dg[e] * quick_gelu_grad((float)uu[e]), elem());
+                    v = __builtin_bit_cast(u32x4, dg);
+                }
+            }
             if (m < g.M && col_ok)
                 *reinterpret_cast<u32x4 *>((elem *)g.C + (long)m * g.ldc + col) = v;
         }
@@ -913,16 +963,24 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = g.tiles_m * g.tiles_n;
+    const int ntiles_mn = g.tiles_m * g.tiles_n;
+    const int ntiles = ntiles_mn * g.splits;   // K-batches are further tiles of the same launch
     const int nk = g.K / BK;
 
     auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
 
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, sp0 = 0;
     const unsigned char *src[4][2];
     auto setup = [&](int id) {
         int tm, tn;
-        raster(xcd_remap(id, ntiles), g.tiles_m, g.tiles_n, tm, tn);
+        int rid = xcd_remap(id, ntiles);
+        sp0 = 0;
+        if (g.splits > 1) {
+            sp0 = rid / ntiles_mn;
+            rid -= sp0 * ntiles_mn;
+        }
+        const long koff = (long)sp0 * g.K;       // this batch's first column of A and W
+        raster(rid, g.tiles_m, g.tiles_n, tm, tn);
         m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -933,12 +991,12 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 if (r < 2) {
                     int m = m0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
                     m = m < g.M ? m : g.M - 1;
-                    src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
+                    src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + koff + chunk * 8) * 2;
                 } else {
                     const int p = rr & 31;
                     int n = n0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
                     n = n < g.N ? n : g.N - 1;
-                    src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
+                    src[r][i] = (const unsigned char *)g.W + ((long)n * g.ldw + koff + chunk * 8) * 2;
                 }
             }
     };
@@ -1028,7 +1086,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             tl[6] = xcc;
         }
     };
-    const GemmArgs &ge = g;
+    GemmArgs ge = g;
 
     int id = blockIdx.x;
     tl_open(id);
@@ -1088,6 +1146,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         if (wm == 0) bar();   // balance the stagger barrier: every wave is out of the staging buffers
 
         const int cm0 = m0, cn0 = n0;
+        if (g.splits > 1)
+            ge.C = static_cast<unsigned char *>(g.C) + (long)sp0 * g.split_stride * (epi_is16(EPI) ? 2 : 4);
         const int next = id + gridDim.x;
         const bool more = next < ntiles;
         tstamp(3);
@@ -1098,7 +1158,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             issue(3, 0);
             issue(1, 0);
         }
-        if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32)
+        if constexpr (!epi_is16(EPI))
             epilogue32_lds<EPI, 8, 1>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
                                       reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
         else
@@ -1137,14 +1197,15 @@ template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hi
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
     EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
+    constexpr int cls = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU_BWD16) ? ec::PROF_GEMM_STORE16
+                        : (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE) ? ec::PROF_GEMM_GELU16
                         : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
+    constexpr double out_b = EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 ? 2.0
+                             : (EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU_BWD16) ? 4.0
                              : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    const int tiles = g.tiles_m * g.tiles_n;
+    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K * g.splits,
+                       (2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N) * g.splits);
+    const int tiles = g.tiles_m * g.tiles_n * g.splits;
     hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), lds, stream, g);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
@@ -1470,6 +1531,13 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_GELU16: return dispatch_variant<DT, EC_EPI_GELU16>(g, variant, s);
     case EC_EPI_RESID32: return dispatch_variant<DT, EC_EPI_RESID32>(g, variant, s);
     case EC_EPI_STORE32: return dispatch_variant<DT, EC_EPI_STORE32>(g, variant, s);
+    // the training epilogues only exist in the default kernel
+    case EC_EPI_GELU16_SAVE:
+        EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_GELU16_SAVE needs variant 0 and args.aux");
+        return launch2pp<DT, EC_EPI_GELU16_SAVE>(g, s);
+    case EC_EPI_GELU_BWD16:
+        EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_GELU_BWD16 needs variant 0 and args.aux");
+        return launch2pp<DT, EC_EPI_GELU_BWD16>(g, s);
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown epilogue %d", epi);
     }
 }
@@ -1493,6 +1561,17 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.A = a->A, g.lda = lda, g.W = a->W, g.bias = a->bias, g.C = a->C, g.ldc = ldc;
     g.tiles_m = g.tiles_n = 0;
     g.diag = static_cast<unsigned long long *>(a->diag);
+    g.ldw = a->ldw ? a->ldw : a->K, g.resid = a->resid, g.aux = a->aux;
+    g.splits = a->splits > 1 ? a->splits : 1, g.split_stride = a->split_stride;
+    EC_REQUIRE(g.ldw % 8 == 0 && g.ldw >= (long)g.K * g.splits && lda >= (long)g.K * g.splits,
+               "ec_gemm: lda / ldw must cover splits * K columns and be multiples of 8 elements");
+    EC_REQUIRE((((uintptr_t)a->resid | (uintptr_t)a->aux) & 15) == 0, "ec_gemm: resid / aux must be 16-byte aligned");
+    EC_REQUIRE(!a->resid || a->epilogue == EC_EPI_RESID32, "ec_gemm: args.resid goes with EC_EPI_RESID32");
+    if (g.ldw != g.K || g.splits > 1 || g.resid) {
+        EC_REQUIRE(a->variant == 0, "ec_gemm: ldw / splits / resid need variant 0");
+        EC_REQUIRE(g.splits == 1 || (g.split_stride >= (long)(g.M - 1) * ldc + g.N && g.split_stride % 8 == 0),
+                   "ec_gemm: split_stride %ld too small for an %d x %d output", g.split_stride, g.M, g.N);
+    }
 #ifdef EC_GEMM_DIAG
     {
         const int v = a->variant;

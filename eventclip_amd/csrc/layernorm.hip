@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, in
 __global__ __launch_bounds__(256) void vit_embed_kernel(const float *patch, const float *cls,
                                                         const float *pos, const float *gamma,
                                                         const float *beta, int n_img, int seq,
-                                                        int width, float eps, float *x)
+                                                        int width, float eps, float *x, float *pre)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const float *patch, cons
             const float4 a = *reinterpret_cast<const float4 *>(src + c);
             const float4 p = *reinterpret_cast<const float4 *>(pr + c);
             v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            // training keeps the un-normalised embedding: ln_pre's backward pass needs it
+            if (pre) *reinterpret_cast<float4 *>(pre + row * width + c) = v[i];
         }
     ln_row(v, nv, width, lane, gamma, beta, eps);
     float *o = x + row * width;
@@ -228,13 +230,20 @@ EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, 
                         const float *beta, int n_img, int seq, int width, float eps, float *x,
                         ec_stream_t stream)
 {
+    return ec_vit_embed_train(patch, cls, pos, gamma, beta, n_img, seq, width, eps, x, nullptr, stream);
+}
+
+EC_API int ec_vit_embed_train(const float *patch, const float *cls, const float *pos, const float *gamma,
+                              const float *beta, int n_img, int seq, int width, float eps, float *x,
+                              float *pre, ec_stream_t stream)
+{
     EC_REQUIRE(width % 4 == 0 && width <= LN_MAXV * 256 && seq >= 2, "ec_vit_embed: bad shape");
     if (n_img == 0) return EC_OK;
     const long rows = (long)n_img * seq;
     ec::ProfScope prof(ec::PROF_EMBED, static_cast<hipStream_t>(stream), 0, (double)rows * width * 8.0);
     hipLaunchKernelGGL(vit_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), patch, cls, pos, gamma, beta, n_img, seq,
-                       width, eps, x);
+                       width, eps, x, pre);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

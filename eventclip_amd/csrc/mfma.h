@@ -50,4 +50,41 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
         (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the
+// gfx950 row-swap VALU ops instead of ds_bpermute round trips through LDS:
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
+// second, v_permlane32_swap the upper half of the first with the lower half of the second.
+// (Written as inline asm: hipcc folds max / add over the two results of the swap builtins
+// to one operand.  s_nop 1 covers the VALU-write -> v_permlane-read hazard.)
+__device__ __forceinline__ float xor_max(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32 %0, %0, %1\n\t"
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32 %0, %0, %1"
+                 : "+v"(a), "+v"(b));
+    return a;
+}
+__device__ __forceinline__ float xor_sum(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %1\n\t"
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %1"
+                 : "+v"(a), "+v"(b));
+    return a;
+}
+
 }  // namespace ec

@@ -9,23 +9,11 @@
 // Residual stream fp32; every GEMM operand 16-bit; seven launches per block:
 //   LN -> GEMM(qkv) -> attention -> GEMM(out, +=x) -> LN -> GEMM(fc1, QuickGELU) -> GEMM(fc2, +=x)
 #include "common.h"
+#include "tower_ops.h"
 
 namespace {
 
-constexpr float LN_EPS = 1e-5f;
-
-inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
-
-struct Scratch {
-    unsigned char *base;
-    size_t off, cap;
-    void *take(size_t bytes)
-    {
-        void *p = base ? base + off : nullptr;
-        off += align_up(bytes);
-        return p;
-    }
-};
+using namespace ec_tower;
 
 struct BlockBufs {
     float *x;     // [rows, W] fp32 residual stream
@@ -33,21 +21,6 @@ struct BlockBufs {
     void *qkv;    // [rows, 3W] 16-bit
     void *mlp;    // [rows, 4W] 16-bit
 };
-
-int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
-         void *C, ec_stream_t s, long ldc = 0, long lda = 0)
-{
-    ec_gemm_args g;
-    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
-    g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
-    return ec_gemm(&g, s);
-}
-
-#define EC_TRY(expr)                  \
-    do {                              \
-        int _rc = (expr);             \
-        if (_rc != EC_OK) return _rc; \
-    } while (0)
 
 // first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
 // tower: ln_post(x[:, 0]) @ proj).  That block still needs every token's keys and values, but its
@@ -97,28 +70,6 @@ struct PreciseBufs {
     float *wide;        // [rows, 4W] fp32: qkv (3W) or the c_fc output (4W)
     void *m_hi, *m_lo;  // [rows, 4W] QuickGELU output, split
 };
-
-int gemm3(int M, int N, int K, int dtype, bool accumulate, const void *a_hi, const void *a_lo,
-          const void *w_hi, const void *w_lo, const float *bias, float *C, ec_stream_t s)
-{
-    EC_TRY(gemm(M, N, K, dtype, accumulate ? EC_EPI_RESID32 : EC_EPI_STORE32, a_hi, w_hi, bias, C, s));
-    EC_TRY(gemm(M, N, K, dtype, EC_EPI_RESID32, a_hi, w_lo, nullptr, C, s));
-    return gemm(M, N, K, dtype, EC_EPI_RESID32, a_lo, w_hi, nullptr, C, s);
-}
-
-// conv1 (kernel = stride = patch, no bias) as a GEMM over im2col rows, to fp32 accuracy: a patch
-// row is [hi | lo | 0] (kpad wide) and conv_w = [w_hi | w_hi | 0], so the first launch gives
-// x_hi.w_hi + x_lo.w_hi; the second adds x_hi.w_lo over the row's first klo columns (conv_w_lo =
-// [w_lo | 0]: the lo values the row holds beyond 3 p^2 meet zeros).  0.6 % of the tower's flops; the
-// rounding of pixels and conv1.weight to 16 bits would otherwise be ~8 % of the logit error budget
-// (tools/rounding_budget.py).
-int patch_embed(const ec_vit_weights *w, const void *patches, int rows, float *out, ec_stream_t s)
-{
-    const int klo = ((3 * w->patch * w->patch + 63) / 64) * 64;
-    EC_TRY(gemm(rows, w->width, w->kpad, w->dtype, EC_EPI_STORE32, patches, w->conv_w, nullptr, out, s));
-    return gemm(rows, w->width, klo, w->dtype, EC_EPI_RESID32, patches, w->conv_w_lo, nullptr, out, s, 0,
-                w->kpad);
-}
 
 int run_blocks_precise(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
                        int causal, int dtype, const PreciseBufs &b, ec_stream_t s)

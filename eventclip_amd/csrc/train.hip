@@ -788,6 +788,19 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
     return EC_OK;
 }
 
+extern "C" EC_API int ec_sgemm(const float *A, long sam, long sak, const float *B, long sbk, long sbn, int M, int N,
+                               int K, float alpha, float beta, float *C, long ldc, ec_stream_t stream)
+{
+    EC_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "ec_sgemm: bad shape %d x %d x %d (ldc %ld)", M, N, K, ldc);
+    if (M == 0 || N == 0) return EC_OK;
+    EC_REQUIRE(A && B && C, "ec_sgemm: null buffer");
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, sam, sak, B, sbk,
+                       sbn, M, N, K, alpha, beta, (const float *)nullptr, C, ldc);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 extern "C" EC_API int ec_dropout_mask(uint64_t seed, uint32_t site, int64_t n, float p, uint8_t *mask,
                                       ec_stream_t stream)
 {

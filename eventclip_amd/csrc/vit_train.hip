@@ -1,0 +1,763 @@
+// Fine-tuning the CLIP vision tower on the MI355X: forward with a tape, backward, weight packing.
+//
+// Replaces what torch autograd does for the reference's FTCLIPClassifier (models/clip_cls_ft.py:
+// _build_clip :44-80 marks model.visual -- or sub-sets, or LoRA factors acting through merged weights,
+// models/lora.py:138-150 -- trainable; forward :196-243 calls encode_image :180-183; loss :245-256) around
+// un-vendored openai/CLIP's VisionTransformer (conv1 -> class token + positions -> ln_pre -> L x
+// {x += MHA(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))} -> ln_post(CLS) @ proj).
+//
+// Layout of a step (M = n_img * S token rows, W = width):
+//   forward   the inference kernels, keeping per block both residual-stream inputs (fp32), q | k | v, the
+//             attention output with its log-sum-exp and the MLP pre-activation (16-bit): 24 M W bytes;
+//   backward  the residual-stream gradient dx stays fp32.  Every nn.Linear is two 16-bit MFMA GEMMs:
+//               dX = dY W        ec_gemm with the weight's transposed copy as the [N, K] operand;
+//               dW = dY^T X      ec_gemm over TRANSPOSED copies [features, rows] of both activations, the
+//                                row dimension cut into K-batches (`splits`) so that the few 256 x 256
+//                                output tiles of a weight gradient still fill 256 CUs; the partial
+//                                sums are reduced in fp32 in a fixed order (no atomics: reproducible);
+//             the QuickGELU derivative is fused into the GEMM that produces it (EC_EPI_GELU_BWD16), LayerNorm
+//             backward recomputes its statistics from the saved input, attention backward recomputes the
+//             probabilities from the saved log-sum-exp (attention_bwd.hip);
+//   gradients come out fp32 in the state dict's layouts; a NULL pointer skips the work behind it
+//   (LoRA on q k v o needs the attention weight gradients only: none of the MLP's dW GEMMs run).
+#include "common.h"
+#include "mfma.h"
+#include "tower_ops.h"
+
+namespace {
+
+using namespace ec;
+using namespace ec_tower;
+
+constexpr int LN_MAXV = 8;   // float4 per lane: width <= 2048
+constexpr int SIZING_CUS = 256;
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int units(int width, int lane)
+{
+    const int total = width / 4;
+    return (total - lane + 63) / 64;
+}
+__device__ __forceinline__ float quick_gelu_f(float x)
+{
+    return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));   // as the GEMM epilogue computes it
+}
+
+// ------------------------------------------------------------------------------------------
+// Transposed 16-bit copies: dst_t[n][m] = f(src[row(m)][n]) for m < M, 0 for M <= m < Mp.
+// MODE 0: 16-bit source; 1: QuickGELU of a 16-bit source (u -> g: the c_proj input is recomputed, not
+// stored); 2: fp32 source, optionally also written row-major as 16 bit (the dX GEMM's operand).
+// Logical row m reads source row (m / seq_out) * seq_in + seq_off + m % seq_out (seq_out = 0: row m):
+// the patch rows of the embedding gradient skip every sequence's class-token row.
+// ------------------------------------------------------------------------------------------
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void transpose_kernel(const void *src, long ld, int M, int N, int Mp, int seq_out,
+                                                        int seq_in, int seq_off, void *dst_t, void *dst_rm)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int PITCH = 72;   // elements: 144-B rows, 16-B aligned
+    __shared__ __attribute__((aligned(16))) elem tile[64 * PITCH];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int ch = threadIdx.x & 7;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int ml = (threadIdx.x >> 3) + 32 * it;
+        const int m = m0 + ml, n = n0 + ch * 8;
+        v8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (elem)0.f;
+        if (m < M && n < N) {
+            const long row = seq_out ? (long)(m / seq_out) * seq_in + seq_off + m % seq_out : m;
+            if (MODE == 2) {
+                const float *p = (const float *)src + row * ld + n;
+                const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+                v[0] = to16(a.x, elem()), v[1] = to16(a.y, elem()), v[2] = to16(a.z, elem()), v[3] = to16(a.w, elem());
+                v[4] = to16(b.x, elem()), v[5] = to16(b.y, elem()), v[6] = to16(b.z, elem()), v[7] = to16(b.w, elem());
+                if (dst_rm) *reinterpret_cast<v8 *>((elem *)dst_rm + (long)m * N + n) = v;
+            } else {
+                v = *reinterpret_cast<const v8 *>((const elem *)src + row * ld + n);
+                if (MODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = to16(quick_gelu_f((float)v[j]), elem());
+                }
+            }
+        }
+        if (dst_t) *reinterpret_cast<v8 *>(&tile[ml * PITCH + ch * 8]) = v;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int nl = (threadIdx.x >> 3) + 32 * it;
+        if (n0 + nl >= N) continue;
+        v8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = tile[(ch * 8 + j) * PITCH + nl];
+        *reinterpret_cast<v8 *>((elem *)dst_t + (long)(n0 + nl) * Mp + m0 + ch * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row, statistics recomputed from the saved input:
+//   xh = (x - mean) rstd, g = dy gamma, dx = rstd (g - mean(g) - xh mean(g xh)).
+// d_gamma / d_beta: per-lane column sums over the rows a workgroup walks, reduced over its 4 waves in
+// LDS, one partial row pair per workgroup (summed by reduce_kernel in a fixed order).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *x, long ldx, const float *dy, long ldy,
+                                                     const float *gamma, int rows, int width, float eps, float *dx,
+                                                     long ldo, int accumulate, float *partials)
+{
+    __shared__ float red[3][2 * LN_MAXV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = units(width, lane);
+    float4 sg[LN_MAXV], sb[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        sg[i] = sb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nv) gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+    }
+    const float inv_w = 1.f / (float)width;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        float4 v[LN_MAXV], d[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                v[i] = *reinterpret_cast<const float4 *>(x + row * ldx + (i * 64 + lane) * 4);
+                d[i] = *reinterpret_cast<const float4 *>(dy + row * ldy + (i * 64 + lane) * 4);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        const float mean = wave_sum(s) * inv_w;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                v[i].x -= mean, v[i].y -= mean, v[i].z -= mean, v[i].w -= mean;
+                q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        const float rstd = 1.f / __builtin_sqrtf(wave_sum(q) * inv_w + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                v[i].x *= rstd, v[i].y *= rstd, v[i].z *= rstd, v[i].w *= rstd;      // x hat
+                sg[i].x += d[i].x * v[i].x, sg[i].y += d[i].y * v[i].y;
+                sg[i].z += d[i].z * v[i].z, sg[i].w += d[i].w * v[i].w;
+                sb[i].x += d[i].x, sb[i].y += d[i].y, sb[i].z += d[i].z, sb[i].w += d[i].w;
+                d[i].x *= gm[i].x, d[i].y *= gm[i].y, d[i].z *= gm[i].z, d[i].w *= gm[i].w;   // g
+                s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                s2 += (d[i].x * v[i].x + d[i].y * v[i].y) + (d[i].z * v[i].z + d[i].w * v[i].w);
+            }
+        s1 = wave_sum(s1) * inv_w, s2 = wave_sum(s2) * inv_w;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                float *o = dx + row * ldo + (i * 64 + lane) * 4;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (accumulate) r = *reinterpret_cast<const float4 *>(o);
+                r.x += rstd * (d[i].x - s1 - v[i].x * s2);
+                r.y += rstd * (d[i].y - s1 - v[i].y * s2);
+                r.z += rstd * (d[i].z - s1 - v[i].z * s2);
+                r.w += rstd * (d[i].w - s1 - v[i].w * s2);
+                *reinterpret_cast<float4 *>(o) = r;
+            }
+    }
+    if (!partials) return;
+    // waves 1..3 hand their sums to wave 0 through LDS
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                *reinterpret_cast<float4 *>(&red[wave - 1][(i * 64 + lane) * 4]) = sg[i];
+                *reinterpret_cast<float4 *>(&red[wave - 1][LN_MAXV * 256 + (i * 64 + lane) * 4]) = sb[i];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *pg = partials + (long)blockIdx.x * 2 * width, *pb = pg + width;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                float4 a = sg[i], b = sb[i];
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    const float4 ra = *reinterpret_cast<const float4 *>(&red[w][(i * 64 + lane) * 4]);
+                    const float4 rb = *reinterpret_cast<const float4 *>(&red[w][LN_MAXV * 256 + (i * 64 + lane) * 4]);
+                    a.x += ra.x, a.y += ra.y, a.z += ra.z, a.w += ra.w;
+                    b.x += rb.x, b.y += rb.y, b.z += rb.z, b.w += rb.w;
+                }
+                *reinterpret_cast<float4 *>(pg + (i * 64 + lane) * 4) = a;
+                *reinterpret_cast<float4 *>(pb + (i * 64 + lane) * 4) = b;
+            }
+    }
+}
+
+// fp32 LayerNorm of a few rows (ln_post on the class rows: the projection gradient needs its fp32 output)
+__global__ __launch_bounds__(256) void ln_f32_kernel(const float *x, long ldx, const float *gamma, const float *beta,
+                                                     int rows, int width, float eps, float *out, long ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = units(width, lane);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            v[i] = *reinterpret_cast<const float4 *>(x + row * ldx + (i * 64 + lane) * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    const float rstd = 1.f / __builtin_sqrtf(wave_sum(q) / (float)width + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+            *reinterpret_cast<float4 *>(out + row * ldo + c) =
+                make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                            (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+        }
+}
+
+// column sums of a [M, N] matrix over row slabs: partial[slab][n] (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *src, long ld, int M, int N, int slab_rows, float *partial)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * slab_rows, r1 = r0 + slab_rows < M ? r0 + slab_rows : M;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        a0 += (float)src[(long)r * ld + n], a1 += (float)src[(long)(r + 1) * ld + n];
+        a2 += (float)src[(long)(r + 2) * ld + n], a3 += (float)src[(long)(r + 3) * ld + n];
+    }
+    for (; r < r1; r++) a0 += (float)src[(long)r * ld + n];
+    partial[(long)blockIdx.y * N + n] = (a0 + a1) + (a2 + a3);
+}
+
+// out[i] = sum_p part[p * stride + i], p ascending
+__global__ __launch_bounds__(256) void reduce_kernel(const float *part, long stride, int P, long n, float *out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int p = 0; p < P; p++) s += part[p * stride + i];
+        out[i] = s;
+    }
+}
+// conv1: the patch row is [hi | lo | 0], so d conv1.weight[w][c] = sum_p (part[w][c] + part[w][k + c])
+__global__ __launch_bounds__(256) void reduce_conv_kernel(const float *part, long stride, int P, int W, int k, int kpad,
+                                                          float *out)
+{
+    const long n = (long)W * k;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long w = i / k, c = i - w * k;
+        float s = 0.f;
+        for (int p = 0; p < P; p++) s += part[p * stride + w * kpad + c] + part[p * stride + w * kpad + k + c];
+        out[i] = s;
+    }
+}
+
+// d positional_embedding[s] = sum over images of de[n, s]; d class_embedding = the s = 0 row
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float *de, int n_img, int S, int W, float *dpos, float *dcls)
+{
+    const int s = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < W; c += 1024) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < n_img; n++) {
+            const float4 v = *reinterpret_cast<const float4 *>(de + ((long)n * S + s) * W + c);
+            a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+        }
+        if (dpos) *reinterpret_cast<float4 *>(dpos + (long)s * W + c) = a;
+        if (dcls && s == 0) *reinterpret_cast<float4 *>(dcls + c) = a;
+    }
+}
+
+// fp32 [rows, cols] -> hi (rounded), lo (rounded remainder), hi transposed
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, int rows, int cols, void *hi, void *lo,
+                                                          void *hi_t)
+{
+    typedef typename T16<DT>::elem elem;
+    __shared__ elem tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rl = i >> 6, cl = i & 63;
+        const int r = r0 + rl, c = c0 + cl;
+        elem h = (elem)0.f;
+        if (r < rows && c < cols) {
+            const float v = w[(long)r * cols + c];
+            h = to16(v, elem());
+            if (hi) ((elem *)hi)[(long)r * cols + c] = h;
+            if (lo) ((elem *)lo)[(long)r * cols + c] = to16(v - (float)h, elem());
+        }
+        tile[rl][cl] = h;
+    }
+    if (!hi_t) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cl = i >> 6, rl = i & 63;
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < rows && c < cols) ((elem *)hi_t)[(long)c * rows + r] = tile[rl][cl];
+    }
+}
+
+__global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, float inv_scale, int *found_inf)
+{
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = g[i] * inv_scale;
+        g[i] = v;
+        bad |= !__builtin_isfinite(v);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+
+// through F.normalize + the validity mask (clip_cls_ft.py:214-217): d f = valid ? (dfn - fn (fn . dfn)) / |f| : 0
+__global__ __launch_bounds__(256) void feat_grad_kernel(const float *feats, const float *fn, const float *dfn,
+                                                        const unsigned char *valid, int R, int D, float scale,
+                                                        float *dfeats)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float s = 0.f, dot = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const float m = feats[(long)r * D + j];
+        s += m * m, dot += fn[(long)r * D + j] * dfn[(long)r * D + j];
+    }
+    const float inv = valid[r] ? scale / fmaxf(__builtin_sqrtf(wave_sum(s)), 1e-12f) : 0.f;
+    dot = wave_sum(dot);
+    for (int j = lane; j < D; j += 64)
+        dfeats[(long)r * D + j] = (dfn[(long)r * D + j] - fn[(long)r * D + j] * dot) * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+inline int padded_rows(int M)
+{
+    const int mp = (M + 63) / 64 * 64;
+    return M >= 2048 ? (M + 1023) / 1024 * 1024 : mp;
+}
+// K-batches for a weight-gradient GEMM with an [n_out, n_in] output over mp reduction rows: enough
+// that the launch has about one tile per CU, each batch at least 256 rows long
+inline int pick_splits(int n_out, int n_in, int mp, int cus)
+{
+    const int tiles = ((n_out + 255) / 256) * ((n_in + 255) / 256);
+    int s = 1;
+    while (s < 16 && tiles * s * 2 <= cus && (mp / 64) % (s * 2) == 0 && mp / (s * 2) >= 256) s *= 2;
+    return s;
+}
+
+struct TrainBufs {
+    // tape
+    float *pre;                 // [M, W] un-normalised embedding
+    float *x[65];               // x[l]: input of block l; x[L]: the tower's last residual stream
+    float *xm[64];              // after the attention branch
+    void *qkv[64], *att[64], *u[64];
+    float *lse[64];
+    // scratch shared by both passes
+    void *h16, *g16;            // LayerNorm output [M, W]; QuickGELU output [M, 4W] (forward) / du, dqkv (backward)
+    void *cls_hi, *cls_lo;
+    // backward scratch
+    float *dx, *dh32, *delta, *clsln, *dclsln, *part, *lnpart, *colpart;
+    void *dx16, *da16, *ta, *tb;
+    int Mp, ln_wgs, col_slabs;
+    size_t part_floats;
+};
+
+size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
+{
+    const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, L = w->layers;
+    const size_t M = (size_t)n * S;
+    const int Mp = padded_rows((int)M);
+    b.Mp = Mp;
+    b.pre = (float *)sc.take(M * W * 4);
+    for (int l = 0; l <= L; l++) b.x[l] = (float *)sc.take(M * W * 4);
+    for (int l = 0; l < L; l++) {
+        b.xm[l] = (float *)sc.take(M * W * 4);
+        b.qkv[l] = sc.take(M * 3 * W * 2);
+        b.att[l] = sc.take(M * W * 2);
+        b.u[l] = sc.take(M * 4 * W * 2);
+        b.lse[l] = (float *)sc.take((size_t)n * w->heads * S * 4);
+    }
+    b.h16 = sc.take(M * W * 2);
+    b.g16 = sc.take(M * 4 * W * 2);          // >= n G W 4 bytes: also the patch GEMM's fp32 output
+    b.cls_hi = sc.take((size_t)n * W * 2);
+    b.cls_lo = sc.take((size_t)n * W * 2);
+    b.dx = (float *)sc.take(M * W * 4);
+    b.dh32 = (float *)sc.take(M * W * 4);
+    b.delta = (float *)sc.take((size_t)n * w->heads * S * 4);
+    b.clsln = (float *)sc.take((size_t)n * W * 4);
+    b.dclsln = (float *)sc.take((size_t)n * W * 4);
+    b.dx16 = sc.take(M * W * 2);
+    b.da16 = sc.take(M * W * 2);
+    const size_t wide = (size_t)(4 * W > w->kpad ? 4 * W : w->kpad);
+    b.ta = sc.take(wide * Mp * 2);
+    b.tb = sc.take(wide * Mp * 2);
+    size_t pf = 0;
+    const int shapes[5][2] = {{3 * W, W}, {W, W}, {4 * W, W}, {W, 4 * W}, {W, w->kpad}};
+    for (int i = 0; i < 5; i++) {
+        const size_t f = (size_t)pick_splits(shapes[i][0], shapes[i][1], Mp, SIZING_CUS) * shapes[i][0] * shapes[i][1];
+        pf = f > pf ? f : pf;
+    }
+    b.part_floats = pf;
+    b.part = (float *)sc.take(pf * 4);
+    b.ln_wgs = (int)((M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024);
+    b.lnpart = (float *)sc.take((size_t)b.ln_wgs * 2 * W * 4);
+    b.col_slabs = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
+    b.colpart = (float *)sc.take((size_t)b.col_slabs * 4 * W * 4);
+    return sc.off;
+}
+
+int check_geometry(const ec_vit_weights *w, const char *who)
+{
+    EC_REQUIRE(w && w->blocks, "%s: weights are null", who);
+    EC_REQUIRE(w->image_size % w->patch == 0, "%s: image %d not a multiple of patch %d", who, w->image_size, w->patch);
+    EC_REQUIRE(w->width == w->heads * 64 && w->width % 64 == 0 && w->width <= LN_MAXV * 256,
+               "%s: width %d (heads %d): head dim must be 64", who, w->width, w->heads);
+    EC_REQUIRE(w->layers >= 1 && w->layers <= 64, "%s: %d layers", who, w->layers);
+    EC_REQUIRE(w->kpad % 64 == 0 && w->kpad >= 6 * w->patch * w->patch, "%s: bad kpad %d", who, w->kpad);
+    EC_REQUIRE(w->conv_w && w->conv_w_lo && w->proj_w && w->proj_w_lo, "%s: conv / proj weights need hi and lo parts", who);
+    EC_REQUIRE(w->out_dim % 16 == 0, "%s: out_dim %d", who, w->out_dim);
+    EC_REQUIRE(!w->precise, "%s: the split-precision tower has no training form", who);
+    return EC_OK;
+}
+
+template <int MODE>
+int transpose(int dtype, const void *src, long ld, int M, int N, int Mp, int seq_out, int seq_in, int seq_off,
+              void *dst_t, void *dst_rm, hipStream_t s)
+{
+    const dim3 grid((unsigned)(Mp / 64), (unsigned)((N + 63) / 64));
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL((transpose_kernel<EC_F16, MODE>), grid, dim3(256), 0, s, src, ld, M, N, Mp, seq_out, seq_in,
+                           seq_off, dst_t, dst_rm);
+    else
+        hipLaunchKernelGGL((transpose_kernel<EC_BF16, MODE>), grid, dim3(256), 0, s, src, ld, M, N, Mp, seq_out, seq_in,
+                           seq_off, dst_t, dst_rm);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int reduce(const float *part, long stride, int P, long n, float *out, hipStream_t s)
+{
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, part, stride, P, n,
+                       out);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// db[N] = column sums of a [M, N] 16-bit or fp32 matrix
+template <typename T> int bias_grad(const T *src, long ld, int M, int N, const TrainBufs &b, float *out, hipStream_t s)
+{
+    const int slab = (M + b.col_slabs - 1) / b.col_slabs;
+    const int slabs = (M + slab - 1) / slab;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)((N + 255) / 256), (unsigned)slabs), dim3(256), 0, s, src, ld, M, N,
+                       slab, b.colpart);
+    return reduce(b.colpart, N, slabs, N, out, s);
+}
+
+// dW[n_out, n_in] = A_t[n_out, Mp] . B_t[n_in, Mp]^T in K-batches, reduced into `out` (or, conv: folded)
+int weight_grad(int dtype, const void *a_t, const void *b_t, int n_out, int n_in, const TrainBufs &b, float *out,
+                int conv_k, ec_stream_t stream)
+{
+    const int cus = ec::cu_count();
+    EC_REQUIRE(cus > 0, "ec_vit_train_backward: cannot read the device's compute-unit count");
+    int splits = pick_splits(n_out, n_in, b.Mp, cus);
+    while ((size_t)splits * n_out * n_in > b.part_floats) splits /= 2;   // a device with more CUs than sized for
+    ec_gemm_args g = {};
+    g.M = n_out, g.N = n_in, g.K = b.Mp / splits, g.dtype = dtype, g.epilogue = EC_EPI_STORE32, g.variant = 0;
+    g.A = a_t, g.lda = b.Mp, g.W = b_t, g.ldw = b.Mp, g.C = b.part, g.ldc = n_in;
+    g.splits = splits, g.split_stride = (long)n_out * n_in;
+    EC_TRY(ec_gemm(&g, stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_k) {
+        const long n = (long)n_out * conv_k;
+        hipLaunchKernelGGL(reduce_conv_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)),
+                           dim3(256), 0, s, b.part, (long)n_out * n_in, splits, n_out, conv_k, n_in, out);
+        EC_CHECK_HIP(hipGetLastError());
+        return EC_OK;
+    }
+    return reduce(b.part, (long)n_out * n_in, splits, (long)n_out * n_in, out, s);
+}
+
+int ln_backward(const float *x, long ldx, const float *dy, long ldy, const float *gamma, int rows, int W, float *dx,
+                long ldo, int accumulate, float *dg, float *db, float *partials, int max_wgs, hipStream_t s)
+{
+    int wgs = (rows + 3) / 4;
+    if (wgs > max_wgs) wgs = max_wgs;
+    const bool want = dg || db;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W, LN_EPS, dx, ldo,
+                       accumulate, want ? partials : (float *)nullptr);
+    EC_CHECK_HIP(hipGetLastError());
+    if (dg) EC_TRY(reduce(partials, 2L * W, wgs, W, dg, s));
+    if (db) EC_TRY(reduce(partials + W, 2L * W, wgs, W, db, s));
+    return EC_OK;
+}
+
+int gemm_x(int M, int N, int K, int dtype, int epi, const void *A, const void *W, void *C, const float *resid, void *aux,
+           const float *bias, ec_stream_t s)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.ldw = K, g.bias = bias, g.C = C, g.ldc = N, g.resid = resid, g.aux = aux;
+    return ec_gemm(&g, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+EC_API size_t ec_vit_train_workspace_bytes(const ec_vit_weights *w, int n_img)
+{
+    if (!w || n_img <= 0 || w->patch <= 0 || w->layers < 1 || w->layers > 64) return 0;
+    Scratch sc{nullptr, 0, 0};
+    TrainBufs b;
+    return carve_train(sc, w, n_img, b);
+}
+
+EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, int n_img, float *feats, void *workspace,
+                                size_t workspace_bytes, ec_stream_t stream)
+{
+    EC_TRY(check_geometry(w, "ec_vit_train_forward"));
+    EC_REQUIRE(n_img > 0, "ec_vit_train_forward: n_img=%d", n_img);
+    EC_REQUIRE(patches && feats && workspace, "ec_vit_train_forward: null buffer");
+    const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype, L = w->layers;
+    const int M = n_img * S;
+    Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    TrainBufs b;
+    const size_t need = carve_train(sc, w, n_img, b);
+    if (need > workspace_bytes)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_vit_train_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    float *patch_out = (float *)b.g16;
+    EC_TRY(patch_embed(w, patches, n_img * G, patch_out, stream));
+    EC_TRY(ec_vit_embed_train(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n_img, S, W, LN_EPS, b.x[0], b.pre,
+                              stream));
+    for (int l = 0; l < L; l++) {
+        const ec_block_weights &p = w->blocks[l];
+        EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
+        EC_TRY(gemm_x(M, 3 * W, W, dt, EC_EPI_STORE16, b.h16, p.qkv_w, b.qkv[l], nullptr, nullptr, p.qkv_b, stream));
+        EC_TRY(ec_attention_train(b.qkv[l], b.att[l], b.lse[l], n_img, S, W, w->heads, dt, stream));
+        EC_TRY(gemm_x(M, W, W, dt, EC_EPI_RESID32, b.att[l], p.out_w, b.xm[l], b.x[l], nullptr, p.out_b, stream));
+        EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h16, W, dt, stream));
+        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h16, p.fc1_w, b.g16, nullptr, b.u[l], p.fc1_b, stream));
+        EC_TRY(gemm_x(M, W, 4 * W, dt, EC_EPI_RESID32, b.g16, p.fc2_w, b.x[l + 1], b.xm[l], nullptr, p.fc2_b, stream));
+    }
+    EC_TRY(ec_layernorm_split(b.x[L], (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n_img, W, LN_EPS, b.cls_hi,
+                              b.cls_lo, W, dt, stream));
+    return gemm3(n_img, w->out_dim, W, dt, false, b.cls_hi, b.cls_lo, w->proj_w, w->proj_w_lo, nullptr, feats, stream);
+}
+
+EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches, int n_img,
+                                 const float *d_feats, const ec_vit_grads *gr, void *workspace, size_t workspace_bytes,
+                                 ec_stream_t stream)
+{
+    EC_TRY(check_geometry(w, "ec_vit_train_backward"));
+    EC_REQUIRE(n_img > 0, "ec_vit_train_backward: n_img=%d", n_img);
+    EC_REQUIRE(wt && wt->blocks && wt->proj && gr && gr->blocks, "ec_vit_train_backward: null weight / gradient structs");
+    EC_REQUIRE(patches && d_feats && workspace, "ec_vit_train_backward: null buffer");
+    const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype, L = w->layers;
+    const int M = n_img * S, D = w->out_dim;
+    Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
+    TrainBufs b;
+    const size_t need = carve_train(sc, w, n_img, b);
+    if (need > workspace_bytes)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_vit_train_backward: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Mp = b.Mp;
+
+    // how far down the gradient has to travel: the lowest block with a gradient asked for, or the
+    // embedding (-1); nothing below that is computed
+    int lowest = L;
+    if (gr->conv_w || gr->cls || gr->pos || gr->ln_pre_g || gr->ln_pre_b) lowest = -1;
+    else
+        for (int l = 0; l < L; l++) {
+            const ec_block_grads &q = gr->blocks[l];
+            if (q.ln1_g || q.ln1_b || q.qkv_w || q.qkv_b || q.out_w || q.out_b || q.ln2_g || q.ln2_b || q.fc1_w ||
+                q.fc1_b || q.fc2_w || q.fc2_b) {
+                lowest = l;
+                break;
+            }
+        }
+
+    // ---- head: feats = ln_post(x[:, 0]) @ proj ----
+    const long ldc = (long)S * W;
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, s, b.x[L], ldc, w->ln_post_g,
+                       w->ln_post_b, n_img, W, LN_EPS, b.clsln, (long)W);
+    EC_CHECK_HIP(hipGetLastError());
+    if (gr->proj)   // d proj[W, D] = cls_ln^T . d_feats
+        EC_TRY(ec_sgemm(b.clsln, 1, W, d_feats, D, 1, W, D, n_img, 1.f, 0.f, gr->proj, D, stream));
+    if (lowest == L && !gr->ln_post_g && !gr->ln_post_b) return EC_OK;
+    // d cls_ln[n, W] = d_feats . proj^T
+    EC_TRY(ec_sgemm(d_feats, D, 1, wt->proj, 1, D, n_img, W, D, 1.f, 0.f, b.dclsln, W, stream));
+    EC_CHECK_HIP(hipMemsetAsync(b.dx, 0, (size_t)M * W * 4, s));
+    EC_TRY(ln_backward(b.x[L], ldc, b.dclsln, W, w->ln_post_g, n_img, W, b.dx, ldc, 0, gr->ln_post_g, gr->ln_post_b,
+                       b.lnpart, b.ln_wgs, s));
+
+    // ---- blocks, last to first; b.dx = d loss / d x[l + 1] on entry ----
+    for (int l = L - 1; l >= 0 && l >= lowest; l--) {
+        const ec_block_weights &p = w->blocks[l];
+        const ec_block_weights_t &pt = wt->blocks[l];
+        const ec_block_grads &q = gr->blocks[l];
+        EC_REQUIRE(pt.qkv_wt && pt.out_wt && pt.fc1_wt && pt.fc2_wt, "ec_vit_train_backward: block %d lacks transposed weights", l);
+        // x[l + 1] = xm + c_proj(QuickGELU(c_fc(ln_2(xm))))
+        EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, q.fc2_w ? b.ta : nullptr, b.dx16, s));
+        if (q.fc2_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.fc2_b, s));
+        if (q.fc2_w) {
+            EC_TRY(transpose<1>(dt, b.u[l], 4L * W, M, 4 * W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(weight_grad(dt, b.ta, b.tb, W, 4 * W, b, q.fc2_w, 0, stream));
+        }
+        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU_BWD16, b.dx16, pt.fc2_wt, b.g16, nullptr, b.u[l], nullptr, stream));
+        if (q.fc1_b) {
+            if (dt == EC_F16) EC_TRY(bias_grad<_Float16>((const _Float16 *)b.g16, 4L * W, M, 4 * W, b, q.fc1_b, s));
+            else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 4L * W, M, 4 * W, b, q.fc1_b, s));
+        }
+        if (q.fc1_w) {
+            EC_TRY(transpose<0>(dt, b.g16, 4L * W, M, 4 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
+            EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h16, W, dt, stream));
+            EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(weight_grad(dt, b.ta, b.tb, 4 * W, W, b, q.fc1_w, 0, stream));
+        }
+        EC_TRY(gemm_x(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, nullptr, stream));
+        EC_TRY(ln_backward(b.xm[l], W, b.dh32, W, p.ln2_g, M, W, b.dx, W, 1, q.ln2_g, q.ln2_b, b.lnpart, b.ln_wgs, s));
+        // xm = x[l] + out_proj(attention(in_proj(ln_1(x[l]))))
+        EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, q.out_w ? b.ta : nullptr, b.dx16, s));
+        if (q.out_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.out_b, s));
+        if (q.out_w) {
+            EC_TRY(transpose<0>(dt, b.att[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(weight_grad(dt, b.ta, b.tb, W, W, b, q.out_w, 0, stream));
+        }
+        EC_TRY(gemm_x(M, W, W, dt, EC_EPI_STORE16, b.dx16, pt.out_wt, b.da16, nullptr, nullptr, nullptr, stream));
+        EC_TRY(ec_attention_backward(b.qkv[l], b.att[l], b.lse[l], b.da16, b.g16, b.delta, n_img, S, W, w->heads, dt,
+                                     stream));
+        if (q.qkv_b) {
+            if (dt == EC_F16) EC_TRY(bias_grad<_Float16>((const _Float16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
+            else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
+        }
+        if (q.qkv_w) {
+            EC_TRY(transpose<0>(dt, b.g16, 3L * W, M, 3 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
+            EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
+            EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(weight_grad(dt, b.ta, b.tb, 3 * W, W, b, q.qkv_w, 0, stream));
+        }
+        if (l == lowest && !q.ln1_g && !q.ln1_b) break;   // nothing below needs d x[l]
+        EC_TRY(gemm_x(M, W, 3 * W, dt, EC_EPI_STORE32, b.g16, pt.qkv_wt, b.dh32, nullptr, nullptr, nullptr, stream));
+        EC_TRY(ln_backward(b.x[l], W, b.dh32, W, p.ln1_g, M, W, b.dx, W, 1, q.ln1_g, q.ln1_b, b.lnpart, b.ln_wgs, s));
+    }
+    if (lowest >= 0) return EC_OK;
+
+    // ---- embedding: x[0] = ln_pre([cls; patches . conv1^T] + pos) ----
+    EC_TRY(ln_backward(b.pre, W, b.dx, W, w->ln_pre_g, M, W, b.dh32, W, 0, gr->ln_pre_g, gr->ln_pre_b, b.lnpart, b.ln_wgs,
+                       s));
+    if (gr->pos || gr->cls) {
+        hipLaunchKernelGGL(pos_grad_kernel, dim3((unsigned)S), dim3(256), 0, s, b.dh32, n_img, S, W, gr->pos, gr->cls);
+        EC_CHECK_HIP(hipGetLastError());
+    }
+    if (gr->conv_w) {
+        const int R = n_img * G;
+        EC_TRY(transpose<2>(dt, b.dh32, W, R, W, Mp, G, S, 1, b.ta, nullptr, s));
+        EC_TRY(transpose<0>(dt, patches, w->kpad, R, w->kpad, Mp, 0, 0, 0, b.tb, nullptr, s));
+        EC_TRY(weight_grad(dt, b.ta, b.tb, W, w->kpad, b, gr->conv_w, 3 * w->patch * w->patch, stream));
+    }
+    return EC_OK;
+}
+
+EC_API int ec_pack_weight16(const float *wsrc, int rows, int cols, void *hi, void *lo, void *hi_t, int dtype,
+                            ec_stream_t stream)
+{
+    EC_REQUIRE(rows > 0 && cols > 0, "ec_pack_weight16: %d x %d", rows, cols);
+    EC_REQUIRE(wsrc && (hi || lo || hi_t), "ec_pack_weight16: null buffer");
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(pack_weight_kernel<EC_F16>, grid, dim3(256), 0, s, wsrc, rows, cols, hi, lo, hi_t);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<EC_BF16>, grid, dim3(256), 0, s, wsrc, rows, cols, hi, lo, hi_t);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_pack_weight16: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API size_t ec_layernorm_backward_partials(int rows, int width)
+{
+    if (rows <= 0 || width <= 0) return 0;
+    const int wgs = (rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024;
+    return (size_t)wgs * 2 * width;
+}
+
+EC_API int ec_layernorm_backward(const float *x, long ldx, const float *dy, long ldy, const float *gamma, int rows,
+                                 int width, float eps, float *dx, long ldo, int accumulate, float *d_gamma, float *d_beta,
+                                 float *partials, ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && width <= LN_MAXV * 256,
+               "ec_layernorm_backward: width=%d must be a multiple of 4 and <= %d", width, LN_MAXV * 256);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(x && dy && gamma && dx, "ec_layernorm_backward: null buffer");
+    EC_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0, "ec_layernorm_backward: strides must be multiples of 4");
+    EC_REQUIRE(!(d_gamma || d_beta) || partials, "ec_layernorm_backward: d_gamma / d_beta need the partials scratch");
+    EC_REQUIRE(eps == LN_EPS, "ec_layernorm_backward: eps is fixed at 1e-5");
+    return ln_backward(x, ldx, dy, ldy, gamma, rows, width, dx, ldo, accumulate, d_gamma, d_beta, partials, 1024,
+                       static_cast<hipStream_t>(stream));
+}
+
+EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf, ec_stream_t stream)
+{
+    EC_REQUIRE(n >= 0, "ec_grad_unscale_check: n=%lld", (long long)n);
+    if (n == 0) return EC_OK;
+    EC_REQUIRE(grad && found_inf, "ec_grad_unscale_check: null buffer");
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), grad, (long)n, inv_scale, found_inf);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels, const float *text_param,
+                           int B, int T, int D, int K, float logit_scale, int agg, int use_probs_loss, float grad_scale,
+                           float *loss, float *grad_text, float *grad_img, float *agg_logits, void *workspace,
+                           size_t workspace_bytes, ec_stream_t stream)
+{
+    EC_REQUIRE(B > 0 && T > 0 && D > 0 && K > 0, "ec_ft_loss_grad: bad shape");
+    EC_REQUIRE(img_feats && valid && labels && text_param && loss && grad_img && workspace, "ec_ft_loss_grad: null buffer");
+    const size_t base = ec_fs_text_train_workspace_bytes(B, T, D, K);
+    const size_t R = (size_t)B * T;
+    EC_REQUIRE(workspace_bytes >= base + (R > (size_t)K ? R : (size_t)K) * D * 4, "ec_ft_loss_grad: workspace too small");
+    // the few-shot head leaves Fn (normalised views), dL (per-view logit gradients) and u (normalised text) at
+    // the front of its workspace, in this order (train.hip: ec_fs_text_loss_grad)
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    float *gt = grad_text ? grad_text : reinterpret_cast<float *>(ws + base);   // unused text gradient: scratch
+    EC_TRY(ec_fs_text_loss_grad(img_feats, valid, labels, text_param, B, T, D, K, logit_scale, agg, use_probs_loss, loss, gt,
+                                agg_logits, workspace, base, stream));
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    const float *Fn = reinterpret_cast<const float *>(ws);
+    const float *dL = reinterpret_cast<const float *>(ws + a256(R * D * 4));
+    const float *u = reinterpret_cast<const float *>(ws + a256(R * D * 4) + a256(R * K * 4));
+    float *dfn = reinterpret_cast<float *>(ws + base);
+    // dFn[R, D] = logit_scale * dL[R, K] . u[K, D]
+    EC_TRY(ec_sgemm(dL, K, 1, u, D, 1, (int)R, D, K, logit_scale, 0.f, dfn, D, stream));
+    hipLaunchKernelGGL(feat_grad_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       img_feats, Fn, dfn, valid, (int)R, D, grad_scale, grad_img);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,536 @@
+"""Fine-tuning CLIP's vision tower on the MI355X path.
+
+What the reference does with torch autograd around its FTCLIPClassifier -- decide which tensors of
+``model.visual`` train (models/clip_cls_ft.py:44-80), inject LoRA factors into every attention block
+(models/lora.py), forward / loss (:196-256), backward, Adam with one learning rate for the classifier's own
+parameters and another for the tower (method.py:152-186), optionally under ``torch.cuda.amp`` (`--fp16`,
+train.py:121) -- is here three layers over the C ABI:
+
+``VisualTower``   fp32 master weights of ``clip.visual`` + the 16-bit operand copies the kernels read
+                  (``ec_pack_weight16``), ``forward`` (``ec_vit_train_forward``) and ``backward``
+                  (``ec_vit_train_backward``) returning gradients by state-dict name;
+``LoraFactors``   the low-rank factors with the reference's key names, the merged weights they act through
+                  (lora.py:138-150, :50-52) and the chain rule back onto them (``ec_sgemm``);
+``FTTrainer``     one optimisation step: loss and feature gradients (``ec_ft_loss_grad``), the gradient scaler
+                  of mixed precision (``ec_grad_unscale_check``), one all-reduce of the flat gradient buffer
+                  across ranks, ``ec_adam_step`` per tensor with the warm-up + cosine schedule.
+No CPU fallback: every numeric step is a HIP kernel.
+"""
+import ctypes
+import re
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .train import _AGG, adam_step, cosine_warmup_lr
+
+_BLOCK = (('ln1_g', 'ln_1.weight'), ('ln1_b', 'ln_1.bias'), ('qkv_w', 'attn.in_proj_weight'),
+          ('qkv_b', 'attn.in_proj_bias'), ('out_w', 'attn.out_proj.weight'), ('out_b', 'attn.out_proj.bias'),
+          ('ln2_g', 'ln_2.weight'), ('ln2_b', 'ln_2.bias'), ('fc1_w', 'mlp.c_fc.weight'), ('fc1_b', 'mlp.c_fc.bias'),
+          ('fc2_w', 'mlp.c_proj.weight'), ('fc2_b', 'mlp.c_proj.bias'))
+_TOP = (('conv_w', 'conv1.weight'), ('cls', 'class_embedding'), ('pos', 'positional_embedding'),
+        ('ln_pre_g', 'ln_pre.weight'), ('ln_pre_b', 'ln_pre.bias'), ('ln_post_g', 'ln_post.weight'),
+        ('ln_post_b', 'ln_post.bias'), ('proj', 'proj'))
+_MATRICES = ('qkv_w', 'out_w', 'fc1_w', 'fc2_w')
+
+
+def _block_name(i, leaf):
+    return f'transformer.resblocks.{i}.{leaf}'
+
+
+def pack_weight16(w, dtype_code, hi=None, lo=None, hi_t=None):
+    """fp32 CUDA [rows, cols] -> the 16-bit copies asked for (``ec_pack_weight16``)."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+    rc = _lib.lib().ec_pack_weight16(_lib.ptr(w), w.shape[0], w.shape[1], _lib.ptr(hi), _lib.ptr(lo),
+                                     _lib.ptr(hi_t), dtype_code, _lib.stream_ptr())
+    _lib.check(rc, 'ec_pack_weight16')
+
+
+def sgemm(a, b, out, alpha=1.0, beta=0.0):
+    """out[M, N] = alpha * a[M, K] @ b[K, N] + beta * out; a / b any 2-D strided fp32 CUDA views."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and a.is_cuda and a.dim() == b.dim() == 2
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2 and tuple(out.shape) == (M, N) and out.stride(1) == 1
+    rc = _lib.lib().ec_sgemm(_lib.ptr(a), a.stride(0), a.stride(1), _lib.ptr(b), b.stride(0), b.stride(1), M, N, K,
+                             float(alpha), float(beta), _lib.ptr(out), out.stride(0), _lib.stream_ptr())
+    _lib.check(rc, 'ec_sgemm')
+    return out
+
+
+class VisualTower:
+    """The vision tower of an ``eventclip_amd.clip.CLIP`` in training form.
+
+    ``master[name]`` are the module's own fp32 parameters (state-dict names under ``visual.``), updated in
+    place by the optimiser; ``effective[name]`` is what gets packed for a matrix (the master itself, or a
+    LoRA-merged scratch); LayerNorm terms, biases and the embeddings are read by the kernels as fp32, straight
+    from the masters."""
+
+    def __init__(self, clip_model):
+        dev = _lib.require_gpu()
+        if clip_model.logit_scale.device.type != 'cuda':
+            raise _lib.HipLibraryError('CLIP weights are on the CPU: call model.cuda() first (there is no CPU fallback)')
+        if clip_model.image_precise:
+            raise NotImplementedError('the split-precision image tower has no training form')
+        self.clip, self.dev = clip_model, dev
+        c = clip_model.cfg
+        self.cfg = c
+        self.W, self.L, self.P, self.D = c['width'], c['layers'], c['patch'], c['embed_dim']
+        self.G = (c['image_size'] // c['patch']) ** 2
+        self.S = self.G + 1
+        self.cd = clip_model.compute_dtype
+        self.code = _lib.EC_F16 if self.cd == torch.float16 else _lib.EC_BF16
+        self.master = {}
+        for name, p in clip_model.visual.named_parameters():
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                p.data = p.data.to(dev, torch.float32).contiguous()
+            self.master[name] = p.data
+        self.effective = {}
+        k = 3 * self.P * self.P
+        self.k, self.kpad, self.klo = k, ((2 * k + 63) // 64) * 64, ((k + 63) // 64) * 64
+        W, D = self.W, self.D
+        z16 = lambda *shape: torch.zeros(shape, dtype=self.cd, device=dev)      # noqa: E731
+        self.packed = dict(conv=z16(W, self.kpad), conv_lo=z16(W, self.klo), conv_hi_tmp=z16(W, k),
+                           conv_lo_tmp=z16(W, k), proj_t=z16(D, W), proj_lo_tmp=z16(W, D), proj_lo_t=z16(D, W))
+        shapes = dict(qkv_w=(3 * W, W), out_w=(W, W), fc1_w=(4 * W, W), fc2_w=(W, 4 * W))
+        for i in range(self.L):
+            for f in _MATRICES:
+                r, cdim = shapes[f]
+                self.packed[(i, f)] = z16(r, cdim)
+                self.packed[(i, f, 't')] = z16(cdim, r)
+        self._build_structs()
+        self.pack()
+        self._ws = None
+        self._tape = None
+        self._grad_slots = {}
+
+    # ---- structs ----
+    def _build_structs(self):
+        m, pk = self.master, self.packed
+        blocks = (_lib.EcBlockWeights * self.L)()
+        blocks_t = (_lib.EcBlockWeightsT * self.L)()
+        for i in range(self.L):
+            b = blocks[i]
+            for field, leaf in _BLOCK:
+                if field in _MATRICES:
+                    setattr(b, field, pk[(i, field)].data_ptr())
+                    setattr(blocks_t[i], field + 't', pk[(i, field, 't')].data_ptr())
+                else:
+                    setattr(b, field, m[_block_name(i, leaf)].data_ptr())
+        v = _lib.EcVitWeights()
+        c = self.cfg
+        v.dtype, v.image_size, v.patch, v.width = self.code, c['image_size'], self.P, self.W
+        v.layers, v.heads, v.out_dim, v.kpad = self.L, self.W // 64, self.D, self.kpad
+        v.conv_w, v.conv_w_lo = pk['conv'].data_ptr(), pk['conv_lo'].data_ptr()
+        v.cls, v.pos = m['class_embedding'].data_ptr(), m['positional_embedding'].data_ptr()
+        v.ln_pre_g, v.ln_pre_b = m['ln_pre.weight'].data_ptr(), m['ln_pre.bias'].data_ptr()
+        v.ln_post_g, v.ln_post_b = m['ln_post.weight'].data_ptr(), m['ln_post.bias'].data_ptr()
+        v.proj_w, v.proj_w_lo = pk['proj_t'].data_ptr(), pk['proj_lo_t'].data_ptr()
+        v.blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.EcBlockWeights))
+        v.precise, v.full_last_block = 0, 1
+        t = _lib.EcVitTrainWeights()
+        t.blocks = ctypes.cast(blocks_t, ctypes.POINTER(_lib.EcBlockWeightsT))
+        t.proj = m['proj'].data_ptr()
+        self._vit, self._vit_t, self._keep = v, t, (blocks, blocks_t)
+
+    def matrix_names(self):
+        out = ['conv1.weight', 'proj']
+        for i in range(self.L):
+            out += [_block_name(i, leaf) for f, leaf in _BLOCK if f in _MATRICES]
+        return out
+
+    def pack(self, names=None):
+        """(Re)build the 16-bit operand copies of the named matrices (default: all) from ``effective``."""
+        pk = self.packed
+        todo = set(self.matrix_names() if names is None else names)
+        src = lambda n: self.effective.get(n, self.master[n])                  # noqa: E731
+        if 'conv1.weight' in todo:
+            w = src('conv1.weight').reshape(self.W, self.k)
+            pack_weight16(w, self.code, hi=pk['conv_hi_tmp'], lo=pk['conv_lo_tmp'])
+            pk['conv'][:, :self.k] = pk['conv_hi_tmp']                          # [w_hi | w_hi | 0]
+            pk['conv'][:, self.k:2 * self.k] = pk['conv_hi_tmp']
+            pk['conv_lo'][:, :self.k] = pk['conv_lo_tmp']                       # [w_lo | 0]
+        if 'proj' in todo:
+            pack_weight16(src('proj'), self.code, lo=pk['proj_lo_tmp'], hi_t=pk['proj_t'])
+            pk['proj_lo_t'].copy_(pk['proj_lo_tmp'].t())
+        for i in range(self.L):
+            for f, leaf in _BLOCK:
+                if f in _MATRICES and _block_name(i, leaf) in todo:
+                    pack_weight16(src(_block_name(i, leaf)), self.code, hi=pk[(i, f)], hi_t=pk[(i, f, 't')])
+        self.clip._packed = None       # the inference copies of clip.py are stale once a master moved
+
+    # ---- passes ----
+    def _workspace(self, n):
+        need = int(_lib.lib().ec_vit_train_workspace_bytes(ctypes.byref(self._vit), n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.dev)
+        return self._ws
+
+    def forward(self, patches):
+        """patches: 16-bit CUDA [N, G, kpad] -> fp32 features [N, D]; keeps the tape for ``backward``."""
+        assert patches.is_cuda and patches.dtype == self.cd and patches.is_contiguous()
+        n = patches.shape[0]
+        assert tuple(patches.shape) == (n, self.G, self.kpad), f'patches {tuple(patches.shape)}'
+        ws = self._workspace(n)
+        feats = torch.empty((n, self.D), dtype=torch.float32, device=self.dev)
+        rc = _lib.lib().ec_vit_train_forward(ctypes.byref(self._vit), _lib.ptr(patches), n, _lib.ptr(feats),
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, 'ec_vit_train_forward')
+        self._tape = (patches, n)
+        return feats
+
+    def encode_patches(self, patches):
+        """Inference through the SAME (possibly LoRA-merged) operand copies, every token of the last block:
+        evaluation in the middle of a fine-tuning run."""
+        n = patches.shape[0]
+        need = int(_lib.lib().ec_vit_workspace_bytes(ctypes.byref(self._vit), min(n, 256)))
+        ws = torch.empty((need,), dtype=torch.uint8, device=self.dev)
+        feats = torch.empty((n, self.D), dtype=torch.float32, device=self.dev)
+        rc = _lib.lib().ec_vit_encode(ctypes.byref(self._vit), _lib.ptr(patches), n, _lib.ptr(feats), _lib.ptr(ws),
+                                      ws.numel(), min(n, 256), _lib.stream_ptr())
+        _lib.check(rc, 'ec_vit_encode')
+        return feats
+
+    def grad_buffer(self, want):
+        """One flat fp32 buffer with a slot per wanted gradient (a single all-reduce / unscale covers it)."""
+        key = tuple(want)
+        if key not in self._grad_slots:
+            sizes = [self.master[n].numel() for n in want]
+            flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=self.dev)
+            views, off = {}, 0
+            for n, sz in zip(want, sizes):
+                views[n] = flat[off:off + sz].view(self.master[n].shape)
+                off += sz
+            self._grad_slots[key] = (flat, views)
+        return self._grad_slots[key]
+
+    def backward(self, d_feats, want):
+        """d_feats fp32 [N, D] -> {name: gradient} for the state-dict names in ``want`` (views of one flat
+        buffer, also returned)."""
+        assert self._tape is not None, 'backward without a forward'
+        patches, n = self._tape
+        assert d_feats.is_cuda and d_feats.dtype == torch.float32 and tuple(d_feats.shape) == (n, self.D)
+        d_feats = d_feats.contiguous()
+        flat, views = self.grad_buffer(want)
+        bg = (_lib.EcBlockGrads * self.L)()
+        g = _lib.EcVitGrads()
+        top = {leaf: f for f, leaf in _TOP}
+        blk = {leaf: f for f, leaf in _BLOCK}
+        for name, t in views.items():
+            if name in top:
+                setattr(g, top[name], t.data_ptr())
+            else:
+                m = re.match(r'^transformer\.resblocks\.(\d+)\.(.+)$', name)
+                if not m or m.group(2) not in blk:
+                    raise KeyError(f'{name!r} is not a parameter of the vision tower')
+                setattr(bg[int(m.group(1))], blk[m.group(2)], t.data_ptr())
+        g.blocks = ctypes.cast(bg, ctypes.POINTER(_lib.EcBlockGrads))
+        ws = self._workspace(n)
+        rc = _lib.lib().ec_vit_train_backward(ctypes.byref(self._vit), ctypes.byref(self._vit_t), _lib.ptr(patches), n,
+                                              _lib.ptr(d_feats), ctypes.byref(g), _lib.ptr(ws), ws.numel(),
+                                              _lib.stream_ptr())
+        _lib.check(rc, 'ec_vit_train_backward')
+        return views, flat
+
+
+# ---- which tensors train, LoRA ------------------------------------------------------------------------
+def parse_lora(spec):
+    """models/lora.py:352-365 -> None or (r, lora_k, lora_o)."""
+    if isinstance(spec, str):
+        if not ('q' in spec and 'v' in spec):
+            raise AssertionError("LoRA spec must name q and v ('qv-R', 'qkv-R', 'qkvo-R')")
+        return int(spec.split('-')[-1]), 'k' in spec, 'o' in spec
+    if spec is None or spec <= 0:
+        return None
+    return int(spec), True, False
+
+
+def trainable_visual(names, clip_dict):
+    """The parameters of ``model.visual`` the reference leaves trainable (clip_cls_ft.py:44-80), LoRA
+    factors not included (they are not module parameters here)."""
+    g = clip_dict.get
+    picked = set()
+    if g('only_conv1', False):
+        picked.add('conv1.weight')
+    if g('only_bias', False):
+        picked |= {n for n in names if 'bias' in n}
+    if g('only_ln', False):
+        picked |= {n for n in names if re.search(r'(^|\.)ln_(pre|post|1|2)\.', n)}
+    if g('only_cls_fc', False):
+        picked.add('proj')
+    if g('only_cls_token', False):
+        picked.add('class_embedding')
+    if parse_lora(g('lora', -1)) is None and not picked:
+        picked = set(names)
+    return [n for n in names if n in picked]
+
+
+class LoraFactors:
+    """Low-rank factors of every attention block, keyed like the reference's injected modules
+    (``...attn.in_proj_weight.lora_down_q`` / ``lora_up_q`` / ``_k`` / ``_v``, ``...attn.out_proj.lora_down.weight``
+    / ``lora_up.weight``), initialised as lora.py:8-11 (down ~ N(0, 1 / r), up = 0)."""
+
+    def __init__(self, tower, spec):
+        self.tower = tower
+        self.r, self.lora_k, self.lora_o = parse_lora(spec)
+        W, dev = tower.W, tower.dev
+        self.params = {}
+        for i in range(tower.L):
+            pre = _block_name(i, 'attn')
+            for nm in ('q', 'v') + (('k',) if self.lora_k else ()):
+                self.params[f'{pre}.in_proj_weight.lora_down_{nm}'] = (torch.randn(self.r, W) / self.r).to(dev)
+                self.params[f'{pre}.in_proj_weight.lora_up_{nm}'] = torch.zeros(W, self.r, device=dev)
+            if self.lora_o:
+                self.params[f'{pre}.out_proj.lora_down.weight'] = (torch.randn(self.r, W) / self.r).to(dev)
+                self.params[f'{pre}.out_proj.lora_up.weight'] = torch.zeros(W, self.r, device=dev)
+        self.merged_names = []
+        for i in range(tower.L):
+            names = [_block_name(i, 'attn.in_proj_weight')] + ([_block_name(i, 'attn.out_proj.weight')] if self.lora_o else [])
+            for n in names:
+                tower.effective[n] = torch.empty_like(tower.master[n])
+                self.merged_names.append(n)
+
+    def merge(self):
+        """effective = base + up @ down per projection (lora.py:138-150, :50-52), then repack those matrices."""
+        t, W = self.tower, self.tower.W
+        for i in range(t.L):
+            pre = _block_name(i, 'attn')
+            eff = t.effective[pre + '.in_proj_weight']
+            eff.copy_(t.master[pre + '.in_proj_weight'])
+            for j, nm in enumerate('qkv'):
+                up = self.params.get(f'{pre}.in_proj_weight.lora_up_{nm}')
+                if up is not None:
+                    sgemm(up, self.params[f'{pre}.in_proj_weight.lora_down_{nm}'], eff[j * W:(j + 1) * W], 1.0, 1.0)
+            if self.lora_o:
+                eo = t.effective[pre + '.out_proj.weight']
+                eo.copy_(t.master[pre + '.out_proj.weight'])
+                sgemm(self.params[pre + '.out_proj.lora_up.weight'], self.params[pre + '.out_proj.lora_down.weight'],
+                      eo, 1.0, 1.0)
+        t.pack(self.merged_names)
+
+    def chain(self, grads, out):
+        """Merged-weight gradients -> factor gradients: d up = dW down^T, d down = up^T dW (written into
+        ``out[name]``)."""
+        t, W = self.tower, self.tower.W
+        for i in range(t.L):
+            pre = _block_name(i, 'attn')
+            dW = grads[pre + '.in_proj_weight']
+            for j, nm in enumerate('qkv'):
+                kd, ku = f'{pre}.in_proj_weight.lora_down_{nm}', f'{pre}.in_proj_weight.lora_up_{nm}'
+                if ku in self.params:
+                    blk = dW[j * W:(j + 1) * W]
+                    sgemm(blk, self.params[kd].t(), out[ku])
+                    sgemm(self.params[ku].t(), blk, out[kd])
+            if self.lora_o:
+                dWo = grads[pre + '.out_proj.weight']
+                kd, ku = pre + '.out_proj.lora_down.weight', pre + '.out_proj.lora_up.weight'
+                sgemm(dWo, self.params[kd].t(), out[ku])
+                sgemm(self.params[ku].t(), dWo, out[kd])
+
+    def state_dict_entries(self):
+        """The tower's attention entries as the reference's LoRA-injected modules name them."""
+        t, out = self.tower, {}
+        for i in range(t.L):
+            pre = _block_name(i, 'attn')
+            out[pre + '.in_proj_weight.merged_proj'] = t.master[pre + '.in_proj_weight']
+            if self.lora_o:
+                out[pre + '.out_proj.linear.weight'] = t.master[pre + '.out_proj.weight']
+                out[pre + '.out_proj.linear.bias'] = t.master[pre + '.out_proj.bias']
+        out.update(self.params)
+        return out
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler's policy (what `--fp16` gives the reference, train.py:121): gradients flow
+    scaled, a step with a non-finite gradient is skipped and halves the scale, ``growth_interval`` clean steps
+    double it."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor = growth_factor, backoff_factor
+        self.growth_interval, self.enabled, self._good = growth_interval, enabled, 0
+
+    def update(self, found_inf):
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+
+def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', use_probs_loss=False, grad_scale=1.0,
+                 want_text_grad=True):
+    """The classifier head in train mode (``ec_ft_loss_grad``): img_feats fp32 CUDA [B, T, D] with zero rows
+    on invalid views.  Returns (loss, d loss / d img_feats * grad_scale [B, T, D], d loss / d text_param or None,
+    aggregated logits [B, K])."""
+    dev = _lib.require_gpu()
+    if agg not in _AGG:
+        raise NotImplementedError(f'agg_func {agg!r}: the reference trains with sum / mean')
+    f = img_feats.float().contiguous()
+    B, T, D = f.shape
+    t = text_param.detach().float().contiguous()
+    K = t.shape[0]
+    v8 = valid.to(torch.uint8).contiguous()
+    lab = labels.to(torch.int32).contiguous()
+    need = int(_lib.lib().ec_fs_text_train_workspace_bytes(B, T, D, K)) + max(B * T, K) * D * 4
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    gimg = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    gtext = torch.empty((K, D), dtype=torch.float32, device=dev) if want_text_grad else None
+    logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+    rc = _lib.lib().ec_ft_loss_grad(_lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
+                                    float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), float(grad_scale),
+                                    _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(gimg), _lib.ptr(logits), _lib.ptr(ws),
+                                    ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, 'ec_ft_loss_grad')
+    return loss[0], gimg, gtext, logits
+
+
+class FTTrainer:
+    """One optimisation step of the reference's fine-tuning (train.py / method.py with ``model = 'FTCLIP'``)
+    for an ``eventclip_amd.clip_cls_ft.FTCLIPClassifier``.
+
+    ``lr`` drives the classifier's own parameters (``text_feats``), ``clip_lr`` those under ``model.visual``
+    (method.py:166-178); both follow the warm-up + cosine schedule (min = max / 100, :179-186).
+    ``mixed_precision`` keeps torch.cuda.amp.GradScaler's policy around the 16-bit gradient path."""
+
+    def __init__(self, classifier, lr, clip_lr=None, total_steps=1000, warmup_steps_pct=0.05, optimizer='Adam',
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0., mixed_precision=True, init_scale=65536.0,
+                 growth_interval=2000):
+        if optimizer.lower() not in ('adam', 'adamw'):
+            raise ValueError('Should use Adam or AdamW optimizer!')                     # method.py:160
+        assert weight_decay == 0.                                                       # method.py:161
+        self.clf = classifier
+        self.tower = VisualTower(classifier.model)
+        cd = classifier.clip_dict
+        names = list(self.tower.master)
+        self.visual_train = trainable_visual(names, cd)
+        self.lora = LoraFactors(self.tower, cd.get('lora', -1)) if parse_lora(cd.get('lora', -1)) else None
+        self.tensors, self.lrs = {}, {}
+        if classifier.prompt_tuning:
+            self.tensors['text_feats'] = classifier.text_feats.data
+        for n in self.visual_train:
+            self.tensors['model.visual.' + n] = self.tower.master[n]
+        if self.lora:
+            for n, p in self.lora.params.items():
+                self.tensors['model.visual.' + n] = p
+        self.lr = float(lr)
+        self.clip_lr = float(lr if clip_lr is None else clip_lr)
+        self.total_steps = int(total_steps)
+        self.warmup_steps = warmup_steps_pct * self.total_steps
+        self.betas, self.eps = betas, float(eps)
+        self.state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.tensors.items()}
+        self.scaler = GradScaler(init_scale, growth_interval=growth_interval, enabled=mixed_precision)
+        self.steps = 0            # scheduler steps (every call, as the reference steps its scheduler)
+        self.opt_steps = 0        # optimiser steps actually taken (a skipped step does not advance Adam)
+        # what the tower has to differentiate: the trainable masters + the merged matrices LoRA acts through
+        self.want = list(self.visual_train)
+        if self.lora:
+            self.want += [n for n in self.lora.merged_names if n not in self.want]
+        self._found = torch.zeros((1,), dtype=torch.int32, device=self.tower.dev)
+        self._lora_grads = {n: torch.zeros_like(p) for n, p in self.lora.params.items()} if self.lora else {}
+        if self.lora:
+            self.lora.merge()
+        classifier._tower, classifier._trainer = self.tower, self
+        self.last = {}
+
+    def trainable_names(self):
+        return sorted(self.tensors)
+
+    def _patches(self, data_dict):
+        valid = data_dict['valid_mask']
+        if 'patches' in data_dict:
+            return data_dict['patches'], valid
+        imgs = data_dict['img']
+        t = self.tower
+        x = imgs[valid].to(t.dev, torch.float32).contiguous()
+        R = t.cfg['image_size']
+        patches = torch.empty((x.shape[0], t.G, t.kpad), dtype=t.cd, device=t.dev)
+        rc = _lib.lib().ec_patchify(_lib.ptr(x), x.shape[0], R, t.P, t.kpad, _lib.ptr(patches), t.code,
+                                    _lib.stream_ptr())
+        _lib.check(rc, 'ec_patchify')
+        return patches, valid
+
+    @torch.no_grad()
+    def step(self, data_dict):
+        """data_dict: 'img' [B, T, 3, R, R] (or 'patches' [Nv, G, kpad] of the valid views in (b, t) order),
+        'valid_mask' [B, T], 'label' [B].  Returns the loss (0-dim CUDA tensor)."""
+        clf, t = self.clf, self.tower
+        patches, valid = self._patches(data_dict)
+        valid = valid.to(t.dev)
+        labels = data_dict['label'].to(t.dev)
+        B, T = valid.shape
+        feats = t.forward(patches)                                                  # [Nv, D]
+        full = torch.zeros((B, T, t.D), dtype=torch.float32, device=t.dev)
+        full[valid] = feats                                                         # clip_cls_ft.py:208-209
+        text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
+        S = self.scaler.scale
+        loss, gimg, gtext, logits = ft_loss_grad(full, valid, labels, text, clf.logit_scale, clf.agg_func,
+                                                 clf.use_probs_loss, grad_scale=S, want_text_grad=clf.prompt_tuning)
+        self.last = dict(logits=logits, feats=feats)
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        grads = {}
+        if self.want:
+            views, flat = t.backward(gimg[valid], self.want)
+            if ddp:
+                dist.all_reduce(flat)                 # one collective for the whole tower (RCCL over xGMI)
+                flat /= dist.get_world_size()
+            self._found.zero_()
+            rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(flat), flat.numel(), 1.0 / S, _lib.ptr(self._found),
+                                                  _lib.stream_ptr())
+            _lib.check(rc, 'ec_grad_unscale_check')
+            for n in self.visual_train:
+                grads['model.visual.' + n] = views[n]
+            if self.lora:
+                self.lora.chain(views, self._lora_grads)
+                for n, g in self._lora_grads.items():
+                    grads['model.visual.' + n] = g
+        if clf.prompt_tuning:
+            if ddp:
+                dist.all_reduce(gtext)
+                gtext /= dist.get_world_size()
+            grads['text_feats'] = gtext
+        found = bool(self._found.item()) if (self.want and self.scaler.enabled) else False
+        lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
+        clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
+        self.steps += 1
+        if not found:
+            self.opt_steps += 1
+            for k, p in self.tensors.items():
+                m, v = self.state[k]
+                adam_step(p, grads[k].contiguous(), m, v, self.opt_steps, clip_lr if k.startswith('model.visual.') else lr,
+                          self.betas, self.eps, 0.)
+            if self.lora:
+                self.lora.merge()
+            moved = [n for n in self.visual_train if n in set(t.matrix_names())]
+            if moved:
+                t.pack(moved)
+            else:
+                t.clip._packed = None
+            if hasattr(clf, '_invalidate_text_cache'):
+                clf._invalidate_text_cache()
+        self.scaler.update(found)
+        self.last['grads'] = grads
+        self.last['skipped'] = found
+        return loss
+
+    def visual_state_dict(self):
+        """``model.visual.*`` as the reference's checkpoint holds it (LoRA keys when LoRA is on)."""
+        t = self.tower
+        out = dict(t.master)
+        if self.lora:
+            for i in range(t.L):
+                pre = _block_name(i, 'attn')
+                out.pop(pre + '.in_proj_weight')
+                if self.lora.lora_o:
+                    out.pop(pre + '.out_proj.weight')
+                    out.pop(pre + '.out_proj.bias')
+            out.update(self.lora.state_dict_entries())
+        return {'model.visual.' + k: v for k, v in out.items()}

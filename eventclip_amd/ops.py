@@ -17,30 +17,46 @@ def dtype_code(t):
     raise TypeError(f'16-bit dtype expected, got {t}')
 
 
-def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None):
-    """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32.
-    resid32 accumulates into ``out`` (fp32) in place."""
+def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
+         splits=1, K=None):
+    """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
+    gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
+    resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
+    splits > 1: A [M, splits * K], W [N, splits * K] -> out [splits, M, N] partial products (fp32)."""
     import torch
     _lib.require_gpu()
     epi = {'store16': _lib.EC_EPI_STORE16, 'gelu16': _lib.EC_EPI_GELU16,
-           'resid32': _lib.EC_EPI_RESID32, 'store32': _lib.EC_EPI_STORE32}[epilogue]
-    M, K = A.shape
+           'resid32': _lib.EC_EPI_RESID32, 'store32': _lib.EC_EPI_STORE32,
+           'gelu16_save': _lib.EC_EPI_GELU16_SAVE, 'gelu_bwd16': _lib.EC_EPI_GELU_BWD16}[epilogue]
+    M, KA = A.shape
     N = W.shape[0]
-    assert W.shape[1] == K and A.dtype == W.dtype and W.is_contiguous() and A.stride(1) == 1
+    if K is None:
+        assert KA % splits == 0
+        K = KA // splits
+    assert W.shape[1] == KA and A.dtype == W.dtype and W.stride(1) == 1 and A.stride(1) == 1
+    out16 = epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16, _lib.EC_EPI_GELU16_SAVE, _lib.EC_EPI_GELU_BWD16)
+    want = A.dtype if out16 else torch.float32
+    shape = (M, N) if splits == 1 else (splits, M, N)
     if out is None:
-        assert epilogue != 'resid32', 'resid32 needs the fp32 residual tensor as out'
-        odt = A.dtype if epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16) else torch.float32
-        out = torch.empty((M, N), dtype=odt, device=A.device)
-    want = A.dtype if epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16) else torch.float32
-    assert out.dtype == want and tuple(out.shape) == (M, N) and out.stride(1) == 1, \
-        f'{epilogue} writes a {want} [{M}, {N}] tensor, got {out.dtype} {tuple(out.shape)}'
+        assert epilogue != 'resid32' or resid is not None, 'resid32 needs the fp32 residual tensor as out'
+        out = torch.empty(shape, dtype=want, device=A.device)
+    assert out.dtype == want and tuple(out.shape) == shape and out.stride(-1) == 1, \
+        f'{epilogue} writes a {want} {shape} tensor, got {out.dtype} {tuple(out.shape)}'
     a = _lib.EcGemmArgs()
     a.M, a.N, a.K = M, N, K
     a.dtype, a.epilogue, a.variant = dtype_code(A.dtype), epi, variant
     a.A, a.lda = A.data_ptr(), A.stride(0)
-    a.W = W.data_ptr()
+    a.W, a.ldw = W.data_ptr(), W.stride(0)
     a.bias = bias.data_ptr() if bias is not None else None
-    a.C, a.ldc = out.data_ptr(), out.stride(0)
+    a.C, a.ldc = out.data_ptr(), out.stride(-2)
     a.diag = diag.data_ptr() if diag is not None else None    # EC_GEMM_DIAG builds only
+    if resid is not None:
+        assert resid.dtype == torch.float32 and tuple(resid.shape) == (M, N) and resid.stride(0) == out.stride(-2)
+        a.resid = resid.data_ptr()
+    if aux is not None:
+        assert aux.dtype == A.dtype and tuple(aux.shape) == (M, N) and aux.stride(0) == out.stride(-2)
+        a.aux = aux.data_ptr()
+    if splits > 1:
+        a.splits, a.split_stride = splits, out.stride(0)
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
     return out

@@ -231,6 +231,9 @@ enum {
     EC_EPI_GELU16 = 1,  /* C16 = QuickGELU(acc + bias), x * sigmoid(1.702 x) */
     EC_EPI_RESID32 = 2, /* C32 += acc + bias   (fp32 residual stream, in place) */
     EC_EPI_STORE32 = 3, /* C32 = acc + bias */
+    /* training (ec_vit_train_*; default variant only): */
+    EC_EPI_GELU16_SAVE = 4, /* C16 = QuickGELU(acc + bias) and aux16 = acc + bias (kept for the backward pass) */
+    EC_EPI_GELU_BWD16 = 5,  /* C16 = (acc + bias) * QuickGELU'(aux16): the gradient through the activation */
 };
 
 typedef struct {
@@ -247,6 +250,14 @@ typedef struct {
     long ldc;
     void *diag;        /* NULL.  (Only a -DEC_GEMM_DIAG build of the library reads it: device buffer
                           for the s_memtime records of its stamp / timeline variants.) */
+    /* The rest serves the training path (variant 0 only); all zero = the plain GEMM above. */
+    long ldw;          /* row stride of W in elements (0 = K) */
+    const float *resid;/* EC_EPI_RESID32: C = resid + acc + bias with resid [M, N] at stride ldc (NULL = C, in place) */
+    void *aux;         /* 16-bit [M, N] at stride ldc: second output of GELU16_SAVE / input of GELU_BWD16 */
+    int splits;        /* > 1: that many independent products over consecutive K-column ranges of A and W
+                          (batch s reads columns s*K .. (s+1)*K - 1 and writes C + s * split_stride elements):
+                          the partial sums of a weight gradient whose reduction dimension is the batch */
+    long split_stride;
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -278,6 +289,12 @@ EC_API int ec_vit_embed(const float *patch, const float *cls, const float *pos, 
                         const float *beta, int n_img, int seq, int width, float eps, float *x,
                         ec_stream_t stream);
 
+/* The same, additionally keeping the un-normalised embedding `pre` (fp32 [n_img, seq, width]; NULL = none):
+ * ln_pre's backward pass differentiates through it. */
+EC_API int ec_vit_embed_train(const float *patch, const float *cls, const float *pos, const float *gamma,
+                              const float *beta, int n_img, int seq, int width, float eps, float *x,
+                              float *pre, ec_stream_t stream);
+
 /* x[n, s] = token_embedding[tokens[n, s]] + positional_embedding[s]. */
 EC_API int ec_text_embed(const int32_t *tokens, const float *table, const float *pos, int n_txt,
                          int ctx, int width, int vocab, float *x, ec_stream_t stream);
@@ -292,6 +309,17 @@ EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
  * tower needs: encode_image reads nothing but the class token of its output. */
 EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, int S, int width, int heads,
                              int causal, int q_rows, int dtype, ec_stream_t stream);
+
+/* Training forms (fine-tuning the vision tower, models/clip_cls_ft.py:44-80): the same forward that also
+ * keeps, per (sequence, head, query), the log2 of its softmax denominator in the scaled-score domain
+ * (lse fp32 [n_seq, heads, S]), and the backward pass torch autograd runs for nn.MultiheadAttention:
+ * d_out 16-bit [n_seq * S, width] -> d_qkv 16-bit [n_seq * S, 3 * width] (dq | dk | dv).
+ * delta: fp32 scratch [n_seq, heads, S].  No causal mask (the text tower is never trained). */
+EC_API int ec_attention_train(const void *qkv, void *out, float *lse, int n_seq, int S, int width,
+                              int heads, int dtype, ec_stream_t stream);
+EC_API int ec_attention_backward(const void *qkv, const void *out, const float *lse, const void *d_out,
+                                 void *d_qkv, float *delta, int n_seq, int S, int width, int heads,
+                                 int dtype, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CLIP towers.  Replace clip_model.encode_image / encode_text as called from
@@ -483,6 +511,94 @@ EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_t *valid, c
                                  ec_stream_t stream);
 EC_API int ec_dropout_mask(uint64_t seed, uint32_t site, int64_t n, float p, uint8_t *mask,
                            ec_stream_t stream);
+
+/* C[M, N] (row stride ldc) = alpha * sum_k A(m, k) B(k, n) + beta * C with A(m, k) = A[m * sam + k * sak],
+ * B(k, n) = B[k * sbk + n * sbn]: fp32, any layout, for the SMALL products around the towers (LoRA factors
+ * up @ down and their gradients, models/lora.py:50-52,138-150; the projection head). */
+EC_API int ec_sgemm(const float *A, long sam, long sak, const float *B, long sbk, long sbn, int M, int N, int K,
+                    float alpha, float beta, float *C, long ldc, ec_stream_t stream);
+
+/* ---- fine-tuning the vision tower ----------------------------------------------
+ * One training step of FTCLIPClassifier (models/clip_cls_ft.py) runs CLIP's visual encoder under autograd:
+ * forward :180-183 -> F.normalize / logits / aggregation :196-243 -> calc_train_loss :245-256 -> backward
+ * into whatever _build_clip (:44-80) left trainable (all of model.visual, sub-sets, or LoRA factors that act
+ * through merged weights W + up @ down, models/lora.py:138-150) -> Adam (method.py:152-186).  Here:
+ *   ec_vit_train_forward   encode_image keeping what the backward pass needs (per block: both residual
+ *                          inputs, q | k | v, the attention output and its log-sum-exp, the MLP pre-activation);
+ *   ec_ft_loss_grad        the classifier head: loss and d loss / d image features, d loss / d text_feats;
+ *   ec_vit_train_backward  d features -> gradients of every visual parameter asked for, in the layouts of
+ *                          the state dict (fp32); LoRA and sub-set selection are the caller's (chain rule on
+ *                          the merged-weight gradients with ec_sgemm; unused gradients: NULL pointers);
+ *   ec_pack_weight16       fp32 master weight -> the 16-bit operand copies the kernels read;
+ *   ec_grad_unscale_check  the gradient-scaler step of mixed-precision training (`--fp16`, train.py:121).
+ * Arithmetic: 16-bit MFMA operands (activations, weights, activation gradients), fp32 accumulation, fp32
+ * residual-stream gradients, LayerNorm and softmax in fp32 -- what torch.cuda.amp does for the reference.
+ * Gradients of the loss times `scale` flow through when d_feats is scaled (f16's range); they are linear
+ * in d_feats.  Every token of the last block is computed (full_last_block semantics). */
+typedef struct {
+    const void *qkv_wt;  /* attn.in_proj_weight TRANSPOSED [W, 3W] 16-bit (ec_pack_weight16 hi_t) */
+    const void *out_wt;  /* attn.out_proj.weight^T [W, W] */
+    const void *fc1_wt;  /* mlp.c_fc.weight^T [W, 4W] */
+    const void *fc2_wt;  /* mlp.c_proj.weight^T [4W, W] */
+} ec_block_weights_t;
+
+typedef struct {
+    const ec_block_weights_t *blocks; /* host array [layers] */
+    const float *proj;                /* visual.proj [W, out_dim] fp32 */
+} ec_vit_train_weights;
+
+/* Gradient outputs, fp32, overwritten (not accumulated), state-dict layouts.  NULL = not wanted: the work
+ * that only serves that gradient is skipped (a weight gradient is one extra GEMM, biases and LayerNorm
+ * terms are reductions). */
+typedef struct {
+    float *ln1_g, *ln1_b, *qkv_w /* [3W, W] */, *qkv_b, *out_w /* [W, W] */, *out_b;
+    float *ln2_g, *ln2_b, *fc1_w /* [4W, W] */, *fc1_b, *fc2_w /* [W, 4W] */, *fc2_b;
+} ec_block_grads;
+
+typedef struct {
+    float *conv_w;                    /* visual.conv1.weight [W, 3, p, p] */
+    float *cls, *pos;                 /* class_embedding [W], positional_embedding [S, W] */
+    float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    float *proj;                      /* visual.proj [W, out_dim] */
+    const ec_block_grads *blocks;     /* host array [layers] */
+} ec_vit_grads;
+
+/* bytes of workspace for n_img images: the saved activations + the backward pass's scratch.  The forward
+ * call fills it, the backward call must get the same buffer back untouched. */
+EC_API size_t ec_vit_train_workspace_bytes(const ec_vit_weights *w, int n_img);
+EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, int n_img, float *feats,
+                                void *workspace, size_t workspace_bytes, ec_stream_t stream);
+/* d_feats fp32 [n_img, out_dim].  patches: the forward call's input (conv1's gradient reads it). */
+EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches,
+                                 int n_img, const float *d_feats, const ec_vit_grads *grads, void *workspace,
+                                 size_t workspace_bytes, ec_stream_t stream);
+
+/* fp32 [rows, cols] -> any of: hi = round16(w) [rows, cols]; lo = round16(w - hi); hi_t = hi transposed
+ * [cols, rows].  NULL outputs are skipped. */
+EC_API int ec_pack_weight16(const float *w, int rows, int cols, void *hi, void *lo, void *hi_t, int dtype,
+                            ec_stream_t stream);
+
+/* LayerNorm backward (fp32): x rows at stride ldx (the forward input), dy rows at stride ldy.
+ * dx rows at stride ldo: dx = (accumulate ? dx : 0) + dLN; d_gamma / d_beta [width] (NULL = skip; they need
+ * `partials`, fp32 scratch of ec_layernorm_backward_partials(rows, width) floats). */
+EC_API size_t ec_layernorm_backward_partials(int rows, int width);
+EC_API int ec_layernorm_backward(const float *x, long ldx, const float *dy, long ldy, const float *gamma, int rows,
+                                 int width, float eps, float *dx, long ldo, int accumulate, float *d_gamma,
+                                 float *d_beta, float *partials, ec_stream_t stream);
+
+/* The classifier head of FTCLIPClassifier in train mode (clip_cls_ft.py:196-256; identity adapter):
+ * ec_fs_text_loss_grad plus d loss / d img_feats (fp32 [B, T, D], zero rows for invalid views), scaled by
+ * grad_scale (1 = none).  grad_text may be NULL (fixed text features).  Workspace:
+ * ec_fs_text_train_workspace_bytes(B, T, D, K) + max(B * T, K) * D * 4 bytes. */
+EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
+                           const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
+                           int use_probs_loss, float grad_scale, float *loss, float *grad_text, float *grad_img,
+                           float *agg_logits, void *workspace, size_t workspace_bytes, ec_stream_t stream);
+
+/* grad *= inv_scale in place; *found_inf (device int32, caller zeroes it once per step) is set when any
+ * element is not finite -- torch.cuda.amp.GradScaler.unscale_. */
+EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf,
+                                 ec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,12 +49,12 @@ def _blocks(x, sd, prefix, layers, heads, mask=None):
     return x
 
 
-@torch.no_grad()
-def encode_image(sd, cfg, image):
-    """image float32 [N, 3, R, R] -> [N, embed_dim]."""
-    sd = {k: v.float() for k, v in sd.items()}
+def encode_image_autograd(sd, cfg, image):
+    """encode_image without torch.no_grad and in the dtype of ``sd`` (fp32 / fp64 leaves that may require
+    grad): what the reference's fine-tuning differentiates (models/clip_cls_ft.py:180-183)."""
     W, P = cfg['width'], cfg['patch']
-    x = F.conv2d(image.float(), sd['visual.conv1.weight'], stride=P)      # [N, W, g, g]
+    image = image.to(sd['visual.conv1.weight'].dtype)
+    x = F.conv2d(image, sd['visual.conv1.weight'], stride=P)              # [N, W, g, g]
     x = x.reshape(x.shape[0], W, -1).permute(0, 2, 1)                      # [N, g*g, W]
     cls = sd['visual.class_embedding'].expand(x.shape[0], 1, W)
     x = torch.cat([cls, x], dim=1) + sd['visual.positional_embedding']
@@ -62,6 +62,12 @@ def encode_image(sd, cfg, image):
     x = _blocks(x, sd, 'visual.transformer', cfg['layers'], W // 64)
     x = F.layer_norm(x[:, 0, :], (W,), sd['visual.ln_post.weight'], sd['visual.ln_post.bias'], 1e-5)
     return x @ sd['visual.proj']
+
+
+@torch.no_grad()
+def encode_image(sd, cfg, image):
+    """image float32 [N, 3, R, R] -> [N, embed_dim]."""
+    return encode_image_autograd({k: v.float() for k, v in sd.items()}, cfg, image.float())
 
 
 @torch.no_grad()

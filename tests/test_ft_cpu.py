@@ -37,8 +37,8 @@ def test_reference_checkpoint_loads_folds_and_round_trips(tag):
     model2.load_state_dict(back)
     with torch.no_grad():
         torch.testing.assert_close(model2.model.visual(torch.from_numpy(z['probe'])), got)
-    with pytest.raises(NotImplementedError):
-        model.train()
+    assert model.train() is model and model.training and not model.model.training   # clip_cls_ft.py:300-306
+    model.eval()
     with pytest.raises(KeyError):
         build_model(params).load_state_dict({'text_feats': sd['text_feats']})
     with pytest.raises(AssertionError):

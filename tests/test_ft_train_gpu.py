@@ -1,0 +1,421 @@
+"""Fine-tuning the vision tower on the MI355X: the building blocks against torch
+fp32, the tower's gradients against the oracle's autograd, and whole optimisation steps against the
+reference's own FTCLIPClassifier + torch.optim.Adam (tests/golden/ft_train.npz).
+
+Tolerances.  The path is mixed precision as torch.cuda.amp is for the reference: 16-bit MFMA operands
+(activations, weights, activation gradients), fp32 accumulation and residual-stream gradients.  A gradient
+tensor is compared as a whole: relative l2 error <= GRAD_REL (2e-2; measured 2e-3 .. 8e-3) and cosine >= 0.9995
+against fp32 / fp64 autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GRAD_REL = 2e-2
+
+
+def rel_l2(got, want):
+    got, want = got.double().flatten().cpu(), want.double().flatten().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+def cosine(got, want):
+    got, want = got.double().flatten().cpu(), want.double().flatten().cpu()
+    return float((got @ want) / (got.norm() * want.norm()).clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM: the training epilogues and K-batches
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_gemm_residual_source_and_gelu_pair(hip, dtype):
+    from eventclip_amd import ops
+    torch.manual_seed(0)
+    M, N, K = 777, 512, 256
+    A = torch.randn(M, K, device='cuda').to(dtype)
+    W = (torch.randn(N, K, device='cuda') / K ** 0.5).to(dtype)
+    bias = torch.randn(N, device='cuda')
+    ref = A.float() @ W.float().t() + bias
+    # out = resid + acc, resid untouched
+    resid = torch.randn(M, N, device='cuda')
+    keep = resid.clone()
+    out = ops.gemm(A, W, bias, 'resid32', resid=resid)
+    assert torch.equal(resid, keep)
+    torch.testing.assert_close(out, ref + resid, rtol=2e-3, atol=2e-3)
+    # in-place form gives the same bits
+    inplace = resid.clone()
+    ops.gemm(A, W, bias, 'resid32', out=inplace)
+    assert torch.equal(inplace, out)
+    # activation + pre-activation: the activation is bit-identical to the inference epilogue
+    u = torch.empty(M, N, device='cuda', dtype=dtype)
+    g = ops.gemm(A, W, bias, 'gelu16_save', aux=u)
+    assert torch.equal(g, ops.gemm(A, W, bias, 'gelu16'))
+    assert torch.equal(u, ops.gemm(A, W, bias, 'store16'))
+    # gradient through the activation: acc * QuickGELU'(u)
+    d = ops.gemm(A, W, None, 'gelu_bwd16', aux=u)
+    uf = u.float()
+    sg = torch.sigmoid(1.702 * uf)
+    want = (A.float() @ W.float().t()).to(dtype).float() * (sg * (1 + 1.702 * uf * (1 - sg)))
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    torch.testing.assert_close(d.float(), want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('splits', [2, 4, 16])
+def test_gemm_k_batches_are_the_partial_products(hip, splits):
+    from eventclip_amd import ops
+    torch.manual_seed(1)
+    M, N, Kc = 300, 272, 128
+    A = torch.randn(M, Kc * splits, device='cuda').half()
+    W = torch.randn(N, Kc * splits, device='cuda').half()
+    part = ops.gemm(A, W, None, 'store32', splits=splits)
+    assert tuple(part.shape) == (splits, M, N)
+    for s in range(splits):
+        ref = A[:, s * Kc:(s + 1) * Kc].float() @ W[:, s * Kc:(s + 1) * Kc].float().t()
+        torch.testing.assert_close(part[s], ref, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(part.sum(0), A.float() @ W.float().t(), rtol=1e-3, atol=3e-2)
+    # a weight with a row stride (ldw): a column window of a wider matrix
+    wide = torch.randn(N, Kc * splits + 64, device='cuda').half()
+    win = wide[:, 64:]
+    torch.testing.assert_close(ops.gemm(A, win, None, 'store32'), A.float() @ win.float().t(), rtol=1e-3, atol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attention(qkv, n, S, W, heads, lse=True):
+    import ctypes
+    from eventclip_amd import _lib, ops
+    out = torch.empty(n * S, W, device='cuda', dtype=qkv.dtype)
+    l2 = torch.empty(n, heads, S, device='cuda')
+    rc = _lib.lib().ec_attention_train(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(l2), n, S, W, heads,
+                                       ops.dtype_code(qkv.dtype), _lib.stream_ptr())
+    _lib.check(rc, 'ec_attention_train')
+    return out, l2
+
+
+def _attention_bwd(qkv, out, l2, dout, n, S, W, heads):
+    from eventclip_amd import _lib, ops
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.empty(n, heads, S, device='cuda')
+    rc = _lib.lib().ec_attention_backward(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(l2), _lib.ptr(dout), _lib.ptr(dqkv),
+                                          _lib.ptr(delta), n, S, W, heads, ops.dtype_code(qkv.dtype), _lib.stream_ptr())
+    _lib.check(rc, 'ec_attention_backward')
+    return dqkv
+
+
+@pytest.mark.parametrize('S,heads,n', [(5, 1, 3), (50, 2, 4), (197, 2, 2), (257, 3, 3), (577, 2, 2)])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_attention_forward_saves_lse_and_backward_matches_autograd(hip, S, heads, n, dtype):
+    from eventclip_amd import _lib, ops
+    torch.manual_seed(S)
+    W = heads * 64
+    qkv = (torch.randn(n * S, 3 * W, device='cuda') * 1.5).to(dtype)
+    out, l2 = _attention(qkv, n, S, W, heads)
+    # same output bits as the inference entry point
+    plain = torch.empty_like(out)
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(plain), n, S, W, heads, 0, ops.dtype_code(dtype),
+                                       _lib.stream_ptr()), 'ec_attention')
+    assert torch.equal(out, plain)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [t.view(n, S, heads, 64).transpose(1, 2) for t in x.view(n, S, 3 * W).split(W, dim=-1)]
+    sc = (q @ k.transpose(-1, -2)) * 0.125
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(n * S, W)
+    torch.testing.assert_close(l2, torch.logsumexp(sc.detach(), -1) * 1.4426950408889634, rtol=1e-4, atol=2e-3)
+    dout = (torch.randn(n * S, W, device='cuda') * 0.5).to(dtype)
+    ref.backward(dout.float())
+    got = _attention_bwd(qkv, out, l2, dout, n, S, W, heads)
+    assert torch.isfinite(got.float()).all()
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    for j, name in enumerate(('dq', 'dk', 'dv')):
+        a, b = got[:, j * W:(j + 1) * W].float(), x.grad[:, j * W:(j + 1) * W]
+        assert rel_l2(a, b) < tol, (name, rel_l2(a, b))
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm backward, weight packing, small products
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,width,stride', [(1, 64, 64), (37, 768, 768), (1028, 1024, 1024), (9, 1024, 5 * 1024)])
+def test_layernorm_backward_matches_autograd(hip, rows, width, stride):
+    from eventclip_amd import _lib
+    torch.manual_seed(rows)
+    xbuf = torch.randn(rows, stride, device='cuda') * 2 + 0.3
+    dy = torch.randn(rows, width, device='cuda')
+    gamma = 1 + 0.2 * torch.randn(width, device='cuda')
+    beta = torch.randn(width, device='cuda')
+    x = xbuf[:, :width].clone().requires_grad_(True)
+    gp = gamma.clone().requires_grad_(True)
+    bp = beta.clone().requires_grad_(True)
+    F.layer_norm(x, (width,), gp, bp, 1e-5).backward(dy)
+    base = torch.randn(rows, width, device='cuda')
+    for accumulate in (0, 1):
+        dx = base.clone()
+        dg, db = torch.empty(width, device='cuda'), torch.empty(width, device='cuda')
+        part = torch.empty(int(_lib.lib().ec_layernorm_backward_partials(rows, width)), device='cuda')
+        rc = _lib.lib().ec_layernorm_backward(_lib.ptr(xbuf), stride, _lib.ptr(dy), width, _lib.ptr(gamma), rows, width,
+                                              1e-5, _lib.ptr(dx), width, accumulate, _lib.ptr(dg), _lib.ptr(db),
+                                              _lib.ptr(part), _lib.stream_ptr())
+        _lib.check(rc, 'ec_layernorm_backward')
+        torch.testing.assert_close(dx, x.grad + (base if accumulate else 0), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(dg, gp.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(db, bp.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_pack_weight16(hip, dtype):
+    from eventclip_amd import ft, ops
+    torch.manual_seed(2)
+    w = torch.randn(200, 136, device='cuda')
+    hi, lo = torch.empty(200, 136, device='cuda', dtype=dtype), torch.empty(200, 136, device='cuda', dtype=dtype)
+    hi_t = torch.empty(136, 200, device='cuda', dtype=dtype)
+    ft.pack_weight16(w, ops.dtype_code(dtype), hi=hi, lo=lo, hi_t=hi_t)
+    assert torch.equal(hi, w.to(dtype))
+    assert torch.equal(lo, (w - w.to(dtype).float()).to(dtype))
+    assert torch.equal(hi_t, w.to(dtype).t().contiguous())
+
+
+def test_sgemm_any_layout(hip):
+    from eventclip_amd import ft
+    torch.manual_seed(3)
+    a, b = torch.randn(70, 33, device='cuda'), torch.randn(33, 130, device='cuda')
+    out = torch.randn(70, 130, device='cuda')
+    want = 0.5 * a @ b + 2.0 * out
+    torch.testing.assert_close(ft.sgemm(a, b, out, 0.5, 2.0), want, rtol=1e-5, atol=1e-5)
+    at, bt = torch.randn(33, 70, device='cuda'), torch.randn(130, 33, device='cuda')
+    o2 = torch.empty(70, 130, device='cuda')
+    torch.testing.assert_close(ft.sgemm(at.t(), bt.t(), o2), at.t() @ bt.t(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# the tower: forward with a tape, gradients of every parameter
+# ------------------------------------------------------------------------------------------------
+def _tiny_cfg(**kw):
+    cfg = dict(image_size=8, patch=4, width=64, layers=2, embed_dim=16, text_width=64, text_heads=1, text_layers=1,
+               context_length=77, vocab_size=128)
+    cfg.update(kw)
+    return cfg
+
+
+CONFIGS = {
+    'tiny': (_tiny_cfg(), 5),
+    'b32_2blocks': (_tiny_cfg(image_size=224, patch=32, width=768, layers=2, embed_dim=512), 6),
+    'l14_2blocks': (_tiny_cfg(image_size=224, patch=14, width=1024, layers=2, embed_dim=768), 3),
+    'wide_odd': (_tiny_cfg(image_size=48, patch=16, width=128, layers=3, embed_dim=32), 9),
+}
+
+
+def _tower(cfg, seed=0, dtype='float16'):
+    from eventclip_amd import clip as eclip, ft
+    sd = eclip.random_state_dict(cfg, seed=seed)
+    model = eclip.CLIP(cfg, sd, dtype=dtype, full_last_block=True).cuda()
+    return model, ft.VisualTower(model), sd
+
+
+def _patchify(tower, imgs):
+    from eventclip_amd import _lib
+    x = imgs.cuda().float().contiguous()
+    patches = torch.empty((x.shape[0], tower.G, tower.kpad), dtype=tower.cd, device='cuda')
+    _lib.check(_lib.lib().ec_patchify(_lib.ptr(x), x.shape[0], tower.cfg['image_size'], tower.P, tower.kpad,
+                                      _lib.ptr(patches), tower.code, _lib.stream_ptr()), 'ec_patchify')
+    return patches
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_training_forward_is_the_inference_forward(hip, name):
+    cfg, n = CONFIGS[name]
+    model, tower, _ = _tower(cfg)
+    torch.manual_seed(4)
+    imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
+    patches = _patchify(tower, imgs)
+    feats = tower.forward(patches)
+    want = model.encode_patches(patches)
+    assert torch.equal(feats, want)             # same kernels, same operand copies: same bits
+    assert torch.equal(tower.encode_patches(patches), want)
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+def test_tower_gradients_match_the_oracle(hip, name, dtype):
+    from oracle import clip_ref
+    if dtype == 'bfloat16' and name != 'tiny' and name != 'wide_odd':
+        pytest.skip('bf16 operands: covered on the small towers')
+    cfg, n = CONFIGS[name]
+    model, tower, sd = _tower(cfg, seed=1, dtype=dtype)
+    torch.manual_seed(5)
+    R = cfg['image_size']
+    imgs = torch.randn(n, 3, R, R)
+    d_feats = torch.randn(n, cfg['embed_dim'])
+    # oracle: fp64 autograd through the functional tower (the effective 16-bit weights are a separate question:
+    # the comparison is against the fp32 masters, as the reference trains)
+    leaves = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if k.startswith('visual.')}
+    clip_ref.encode_image_autograd(leaves, cfg, imgs.double()).backward(d_feats.double())
+    want = list(tower.master)
+    tower.forward(_patchify(tower, imgs))
+    grads, flat = tower.backward(d_feats.cuda(), want)
+    assert torch.isfinite(flat).all()
+    tol = GRAD_REL if dtype == 'float16' else 8e-2
+    worst = {}
+    for k in want:
+        ref = leaves['visual.' + k].grad
+        got = grads[k].reshape(ref.shape)
+        worst[k] = (rel_l2(got, ref), cosine(got, ref))
+    bad = {k: v for k, v in worst.items() if not (v[0] < tol and v[1] > (0.9995 if dtype == 'float16' else 0.995))}
+    # the key bias has zero gradient in exact arithmetic (softmax does not see it): compare absolutely
+    W = cfg['width']
+    for k in list(bad):
+        if k.endswith('attn.in_proj_bias'):
+            ref = leaves['visual.' + k].grad
+            got = grads[k].cpu().double()
+            ok_qv = rel_l2(torch.cat([got[:W], got[2 * W:]]), torch.cat([ref[:W], ref[2 * W:]])) < tol
+            ok_k = float(got[W:2 * W].abs().max()) < 1e-2 * float(ref.abs().max())
+            if ok_qv and ok_k:
+                bad.pop(k)
+    assert not bad, bad
+
+
+def test_skipping_gradients_does_not_change_the_ones_asked_for(hip):
+    cfg, n = CONFIGS['wide_odd']
+    model, tower, sd = _tower(cfg, seed=2)
+    torch.manual_seed(6)
+    imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
+    d_feats = torch.randn(n, cfg['embed_dim'], device='cuda')
+    patches = _patchify(tower, imgs)
+    tower.forward(patches)
+    full, _ = tower.backward(d_feats, list(tower.master))
+    full = {k: v.clone() for k, v in full.items()}
+    subsets = (['proj'], ['ln_post.weight', 'ln_post.bias'],
+               ['transformer.resblocks.2.attn.in_proj_weight', 'transformer.resblocks.1.attn.out_proj.weight'],
+               [k for k in tower.master if 'bias' in k], ['class_embedding'], ['conv1.weight'],
+               ['transformer.resblocks.1.mlp.c_fc.weight'])
+    for want in subsets:
+        tower.forward(patches)
+        got, _ = tower.backward(d_feats, want)
+        for k in want:
+            assert torch.equal(got[k], full[k]), k
+
+
+# ------------------------------------------------------------------------------------------------
+# whole optimisation steps against the reference's classes
+# ------------------------------------------------------------------------------------------------
+def _golden_case(tag):
+    from conftest import GOLDEN
+    import test_oracle_ft_train as t
+    z = np.load(os.path.join(GOLDEN, 'ft_train.npz'))
+    return z, t.case(z, tag)
+
+
+def _classifier_for(c, mixed_precision=True, init_scale=1024.0):
+    from eventclip_amd import clip as eclip, ft
+    from eventclip_amd.clip_cls_ft import FTCLIPClassifier
+    cfg = _tiny_cfg(**c['cfg'])
+    cfg.pop('heads', None)
+    sd = eclip.random_state_dict(cfg, seed=0)
+    plain = {k: v for k, v in c['visual'].items()}
+    base = {}
+    for k, v in plain.items():                     # the un-merged tower: merged_proj / linear.* back under plain names
+        if '.lora_' in k:
+            continue
+        k2 = k.replace('.in_proj_weight.merged_proj', '.in_proj_weight').replace('.out_proj.linear.', '.out_proj.')
+        base[k2] = v
+    for k, v in base.items():
+        sd['visual.' + k] = v.clone()
+    model = eclip.CLIP(cfg, sd, full_last_block=True).cuda()
+    K = c['text'].shape[0]
+    cd = dict(clip_model=model, prompt='a point cloud image of a {}', class_names=[f'class_{i}' for i in range(K)],
+              agg_func=c['agg'], class_tokens=eclip.synthetic_tokens(K), **c['clip_dict'])
+    clf = FTCLIPClassifier(adapter_dict=dict(adapter_type='text-identity' if c['prompt'] else 'identity', residual=True),
+                           clip_dict=cd, loss_dict=dict(use_logits_loss=not c['probs_loss'],
+                                                        use_probs_loss=c['probs_loss'])).cuda()
+    if c['prompt']:
+        clf.text_feats.data.copy_(c['text'].cuda())
+    else:
+        clf.text_feats = c['text'].cuda().float()          # the fixed (already normalised) text features
+        clf._text_t = None
+    return clf
+
+
+@pytest.mark.parametrize('tag', ['full', 'lora_qkvo', 'lora_int', 'lora_qv', 'bias', 'ln', 'conv_cls'])
+def test_training_step_matches_the_reference(hip, tag):
+    """Loss, every gradient and the parameters after two Adam steps, against the reference's FTCLIPClassifier
+    under torch autograd + torch.optim.Adam (fp32)."""
+    from eventclip_amd import ft
+    z, c = _golden_case(tag)
+    clf = _classifier_for(c)
+    lr, clip_lr = float(z['lr']), float(z['clip_lr'])
+    # constant learning rates (the golden run has no scheduler): total_steps huge, no warm-up
+    tr = ft.FTTrainer(clf, lr=lr, clip_lr=clip_lr, total_steps=10 ** 9, warmup_steps_pct=0.0, init_scale=1024.0)
+    if tr.lora:
+        for k in tr.lora.params:
+            tr.lora.params[k].copy_(c['visual'][k].cuda())
+        tr.lora.merge()
+    assert tr.trainable_names() == c['trainable']
+    data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
+    loss = tr.step(data)
+    assert not tr.last['skipped']
+    assert abs(float(loss) - float(z[f'{tag}/loss'])) < 2e-3 * max(1.0, abs(float(z[f'{tag}/loss'])))
+    np.testing.assert_allclose(tr.last['feats'].cpu().numpy(), z[f'{tag}/feats'], rtol=0,
+                               atol=1e-3 * float(np.abs(z[f'{tag}/feats']).max()))
+    for name in c['trainable']:
+        want = torch.from_numpy(z[f'{tag}/grad:{name}'])
+        got = tr.last['grads'][name].reshape(want.shape)
+        if name.endswith('attn.in_proj_bias'):             # zero key-bias gradient: see the tower test
+            W = c['cfg']['width']
+            sel = torch.cat([torch.arange(W), torch.arange(2 * W, 3 * W)])
+            assert rel_l2(got.cpu()[sel], want[sel]) < GRAD_REL, name
+            continue
+        assert rel_l2(got, want) < GRAD_REL and cosine(got, want) > 0.9995, (name, rel_l2(got, want))
+    tr.step(data)
+    sd = clf.state_dict()
+    for name in c['trainable']:
+        want = z[f'{tag}/step2:{name}']
+        got = sd[name].detach().cpu().numpy().reshape(want.shape)
+        g0 = np.abs(z[f'{tag}/grad:{name}'])
+        live = g0 > 1e-2 * g0.max()        # Adam normalises the step: elements with ~zero gradient follow rounding
+        np.testing.assert_allclose(got[live], want[live], rtol=0, atol=0.35 * clip_lr + 1e-6, err_msg=name)
+    # the checkpoint carries the reference's key set for this configuration
+    want_keys = set(z[f'{tag}/sd_keys'].tolist())
+    assert {k for k in sd if k.startswith('model.visual.')} == {k for k in want_keys if k.startswith('model.visual.')}
+
+
+def test_gradient_scaler_skips_and_backs_off(hip):
+    from eventclip_amd import ft
+    z, c = _golden_case('bias')
+    clf = _classifier_for(c)
+    tr = ft.FTTrainer(clf, lr=1e-3, clip_lr=1e-3, total_steps=100, init_scale=2.0 ** 40, growth_interval=2)
+    data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
+    before = {k: v.clone() for k, v in tr.tensors.items()}
+    tr.step(data)                                   # 2^40 overflows the 16-bit gradients: skipped
+    assert tr.last['skipped'] and tr.scaler.scale == 2.0 ** 39 and tr.opt_steps == 0
+    assert all(torch.equal(before[k], v) for k, v in tr.tensors.items())
+    tr.scaler.scale = 256.0
+    tr.step(data)
+    tr.step(data)
+    assert tr.opt_steps == 2 and tr.scaler.scale == 512.0     # two clean steps: growth_interval = 2
+    assert any(not torch.equal(before[k], v) for k, v in tr.tensors.items())
+
+
+def test_eval_between_steps_uses_the_trained_weights(hip):
+    """forward() of the classifier mid-run encodes through the trainer's merged copies; a checkpoint written
+    then and served by a fresh classifier gives the same logits."""
+    from eventclip_amd import ft
+    z, c = _golden_case('lora_qkvo')
+    clf = _classifier_for(c)
+    tr = ft.FTTrainer(clf, lr=1e-2, clip_lr=5e-3, total_steps=50, init_scale=1024.0)
+    data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
+    clf.eval()
+    before = clf(data)['logits'].clone()
+    clf.train()
+    for _ in range(3):
+        tr.step(data)
+    clf.eval()
+    after = clf(data)['logits']
+    assert (after - before).abs().max() > 1e-3
+    ckpt = {k: v.detach().cpu().clone() for k, v in clf.state_dict().items()}
+    assert any('.lora_up_q' in k for k in ckpt)
+    fresh = _classifier_for(c)
+    fresh.load_state_dict(ckpt)
+    fresh.eval()
+    torch.testing.assert_close(fresh(data)['logits'], after, rtol=2e-3, atol=2e-3 * float(after.abs().max()))

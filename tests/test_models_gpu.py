@@ -266,8 +266,8 @@ def test_finetuned_classifier_serves_reference_checkpoints(tag, hip):
         keys = set(model.state_dict())
         assert 'text_feats' in keys and 'adapter.dummy' in keys
         assert {k for k in keys if k.startswith('model.')} == {'model.visual.' + k for k in model.model.visual.state_dict()}
-        with pytest.raises(NotImplementedError):
-            model.train()
+        assert model.train().training and not model.model.training
+        model.eval()
 
 
 def test_finetuned_checkpoint_through_the_real_tower(hip):
