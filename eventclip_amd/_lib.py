@@ -109,6 +109,15 @@ class EcTextWeights(ctypes.Structure):
                 ('proj_w_lo', c_void_p)]
 
 
+class EcLoraItem(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('base', 'up', 'down', 'out', 'dW', 'd_up', 'd_down')]
+
+
+class EcAdamItem(ctypes.Structure):
+    _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p),
+                ('n', ctypes.c_int64), ('group', c_int)]
+
+
 class EcBlockWeightsT(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('qkv_wt', 'out_wt', 'fc1_wt', 'fc2_wt')]
 
@@ -217,6 +226,11 @@ SIGNATURES = {
                                 c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 ctypes.c_size_t, c_void_p]),
     'ec_grad_unscale_check': (c_int, [c_void_p, ctypes.c_int64, c_float, c_void_p, c_void_p]),
+    'ec_lora_merge_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ec_lora_grad_scratch_floats': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    'ec_lora_grad_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ec_adam_step_multi': (c_int, [c_void_p, c_int, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float,
+                                   c_float, c_int, c_void_p]),
 }
 
 _lib = None

@@ -368,7 +368,7 @@ template <int DT> int launch_bwd(const BwdArgs &a, int n_seq, hipStream_t s)
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kkv), 160 * 1024)) return rc;
     const unsigned grid = (unsigned)a.heads * (unsigned)n_seq;
     // 3 + 4 score-sized products of 2 S^2 64 flops per head; reads q k v o dO, writes dq dk dv
-    ec::ProfScope prof(ec::PROF_ATTENTION, s, 14.0 * a.S * a.S * 64.0 * a.heads * n_seq,
+    ec::ProfScope prof(ec::PROF_ATTENTION_BWD, s, 14.0 * a.S * a.S * 64.0 * a.heads * n_seq,
                        (double)n_seq * a.S * a.W * 2.0 * 8.0);
     hipLaunchKernelGGL(kq, dim3(grid), dim3(512), lds_dq, s, a);
     hipLaunchKernelGGL(kkv, dim3(grid), dim3(512), lds_dkv, s, a);

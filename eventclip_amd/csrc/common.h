@@ -32,7 +32,8 @@ int fail(int code, const char *fmt, ...);
 enum ProfClass {
     PROF_EVENTS = 0, PROF_PREPROCESS, PROF_PATCHIFY, PROF_GEMM_STORE16, PROF_GEMM_GELU16,
     PROF_GEMM_RESID32, PROF_GEMM_STORE32, PROF_LAYERNORM, PROF_ATTENTION, PROF_EMBED, PROF_CLASSIFY,
-    PROF_ADAPTER, PROF_NCLASS
+    PROF_ADAPTER, PROF_GEMM_DW, PROF_ATTENTION_BWD, PROF_LN_BWD, PROF_TRANSPOSE, PROF_REDUCE, PROF_SGEMM,
+    PROF_OPTIMIZER, PROF_PACK, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, hipStream_t s, double flops, double bytes);

@@ -67,7 +67,10 @@ constexpr size_t PROF_MAX = 1 << 16;
 const char *const kProfNames[PROF_NCLASS] = {
     "events_to_frames_kernel", "preprocess_kernel", "patchify_kernel", "gemm_kernel<STORE16>",
     "gemm_kernel<GELU16>", "gemm_kernel<RESID32>", "gemm_kernel<STORE32>", "layernorm_kernel",
-    "attention_kernel", "embed_kernel", "classify_kernel", "adapter_kernels"};
+    "attention_kernel", "embed_kernel", "classify_kernel", "adapter_kernels",
+    "gemm_kernel<STORE32 K-batches>", "attention_dq_kernel + attention_dkv_kernel", "ln_bwd_kernel",
+    "transpose_kernel", "colsum_kernel + reduce_kernel", "sgemm_kernel", "adam_kernel + unscale_check_kernel",
+    "pack_weight_kernel"};
 
 hipEvent_t take_event()
 {

@@ -1203,7 +1203,7 @@ template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hi
     constexpr double out_b = EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 ? 2.0
                              : (EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU_BWD16) ? 4.0
                              : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K * g.splits,
+    ec::ProfScope prof(g.splits > 1 ? (int)ec::PROF_GEMM_DW : cls, stream, 2.0 * g.M * g.N * g.K * g.splits,
                        (2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N) * g.splits);
     const int tiles = g.tiles_m * g.tiles_n * g.splits;
     hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), lds, stream, g);

@@ -554,6 +554,7 @@ extern "C" EC_API int ec_adam_step(float *param, const float *grad, float *exp_a
     const double bc1 = 1.0 - __builtin_pow((double)beta1, (double)step);
     const double bc2 = 1.0 - __builtin_pow((double)beta2, (double)step);
     const long blocks = (n + 255) / 256;
+    ec::ProfScope prof(ec::PROF_OPTIMIZER, static_cast<hipStream_t>(stream), 0, 28.0 * n);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1,
                        beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2));
@@ -795,6 +796,7 @@ extern "C" EC_API int ec_sgemm(const float *A, long sam, long sak, const float *
     if (M == 0 || N == 0) return EC_OK;
     EC_REQUIRE(A && B && C, "ec_sgemm: null buffer");
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    ec::ProfScope prof(ec::PROF_SGEMM, static_cast<hipStream_t>(stream), 2.0 * M * N * K, 0);
     hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, sam, sak, B, sbk,
                        sbn, M, N, K, alpha, beta, (const float *)nullptr, C, ldc);
     EC_CHECK_HIP(hipGetLastError());

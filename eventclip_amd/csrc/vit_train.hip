@@ -236,30 +236,58 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float *x, long ldx, c
         }
 }
 
-// column sums of a [M, N] matrix over row slabs: partial[slab][n] (bias gradients)
+// column sums of a [M, N] matrix over row slabs: partial[slab][n] (bias gradients).  A thread owns 16 bytes
+// of a row (8 16-bit or 4 fp32 columns), four rows in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *src, long ld, int M, int N, int slab_rows, float *partial)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(V)));
+    const int n = (blockIdx.x * 256 + threadIdx.x) * V;
     if (n >= N) return;
     const int r0 = blockIdx.y * slab_rows, r1 = r0 + slab_rows < M ? r0 + slab_rows : M;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float acc[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[u][j] = 0.f;
     int r = r0;
     for (; r + 4 <= r1; r += 4) {
-        a0 += (float)src[(long)r * ld + n], a1 += (float)src[(long)(r + 1) * ld + n];
-        a2 += (float)src[(long)(r + 2) * ld + n], a3 += (float)src[(long)(r + 3) * ld + n];
+        vec v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const vec *>(src + (long)(r + u) * ld + n);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[u][j] += (float)v[u][j];
     }
-    for (; r < r1; r++) a0 += (float)src[(long)r * ld + n];
-    partial[(long)blockIdx.y * N + n] = (a0 + a1) + (a2 + a3);
+    for (; r < r1; r++) {
+        const vec v = *reinterpret_cast<const vec *>(src + (long)r * ld + n);
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[0][j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) partial[(long)blockIdx.y * N + n + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
 }
 
-// out[i] = sum_p part[p * stride + i], p ascending
+// out[i] = sum_p part[p * stride + i], p ascending (n, stride multiples of 4)
 __global__ __launch_bounds__(256) void reduce_kernel(const float *part, long stride, int P, long n, float *out)
 {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int p = 0; p < P; p++) s += part[p * stride + i];
-        out[i] = s;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4 *>(part + (p + u) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 4; u++) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+        }
+        for (; p < P; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + p * stride + i);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i) = s;
     }
 }
 // conv1: the patch row is [hi | lo | 0], so d conv1.weight[w][c] = sum_p (part[w][c] + part[w][k + c])
@@ -317,6 +345,116 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, int ro
         const int r = r0 + rl, c = c0 + cl;
         if (r < rows && c < cols) ((elem *)hi_t)[(long)c * rows + r] = tile[rl][cl];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LoRA (models/lora.py): the factors act through merged weights W + up @ down and receive their gradients
+// from the merged weight's: d up = dW down^T, d down = up^T dW.  r <= 64; fp32; a few MB per matrix.
+// ------------------------------------------------------------------------------------------
+constexpr int LORA_MAXR = 64;
+
+// d_down of item z = sum over its slabs of partial[z][slab][r * cols]
+__global__ __launch_bounds__(256) void lora_ddown_reduce_kernel(const ec_lora_item *items, const float *scratch, int slabs,
+                                                                long n)
+{
+    const float *part = scratch + (long)blockIdx.y * slabs * n;
+    float *out = items[blockIdx.y].d_down;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < slabs; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + p * n + i);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i) = s;
+    }
+}
+
+// torch.optim.Adam over a list of tensors in one launch: blockIdx.y = tensor
+__global__ __launch_bounds__(256) void adam_multi_kernel(const ec_adam_item *items, float lr0, float lr1, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2_sqrt)
+{
+    const ec_adam_item it = items[blockIdx.y];
+    const float lr = it.group ? lr1 : lr0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (long)gridDim.x * 256) {
+        float gi = it.grad[i];
+        if (wd != 0.f) gi += wd * it.param[i];
+        const float mi = it.exp_avg[i] * b1 + (1.f - b1) * gi;
+        const float vi = it.exp_avg_sq[i] * b2 + (1.f - b2) * gi * gi;
+        it.exp_avg[i] = mi, it.exp_avg_sq[i] = vi;
+        it.param[i] -= lr / bc1 * mi / (__builtin_sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+// out[i][j] = base[i][j] + sum_k up[i][k] down[k][j]; a thread owns column j of 8 rows
+__global__ __launch_bounds__(256) void lora_merge_kernel(const ec_lora_item *items, int rows, int cols, int r)
+{
+    const ec_lora_item it = items[blockIdx.z];
+    const float *base = it.base, *up = it.up, *down = it.down;
+    float *out = it.out;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float d[LORA_MAXR];
+#pragma unroll
+    for (int k = 0; k < LORA_MAXR; k++) d[k] = k < r ? down[(long)k * cols + j] : 0.f;
+    const int i0 = blockIdx.y * 8;
+    for (int i = i0; i < i0 + 8 && i < rows; i++) {
+        float a = base[(long)i * cols + j];
+#pragma unroll
+        for (int k = 0; k < LORA_MAXR; k++)
+            if (k < r) a = __builtin_fmaf(up[(long)i * r + k], d[k], a);
+        out[(long)i * cols + j] = a;
+    }
+}
+
+// d_up[i][k] = sum_j dW[i][j] down[k][j]: one wave per row, 16 factors at a time
+__global__ __launch_bounds__(256) void lora_dup_kernel(const ec_lora_item *items, int rows, int cols, int r)
+{
+    const ec_lora_item it = items[blockIdx.z];
+    const float *dW = it.dW, *down = it.down;
+    float *d_up = it.d_up;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    for (int k0 = 0; k0 < r; k0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0.f;
+        for (int j = lane; j < cols; j += 64) {
+            const float w = dW[(long)i * cols + j];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k0 + k < r) acc[k] = __builtin_fmaf(w, down[(long)(k0 + k) * cols + j], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float t = wave_sum(acc[k]);
+            if (lane == 0 && k0 + k < r) d_up[(long)i * r + k0 + k] = t;
+        }
+    }
+}
+
+// partial[slab][k][j] = sum over the slab's rows i of up[i][k] dW[i][j]; a thread owns column j
+__global__ __launch_bounds__(256) void lora_ddown_kernel(const ec_lora_item *items, int rows, int cols, int r,
+                                                         int slab_rows, float *scratch)
+{
+    const ec_lora_item it = items[blockIdx.z];
+    const float *dW = it.dW, *up = it.up;
+    float *partial = scratch + (long)blockIdx.z * gridDim.y * r * cols;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const int i0 = blockIdx.y * slab_rows, i1 = i0 + slab_rows < rows ? i0 + slab_rows : rows;
+    float acc[LORA_MAXR];
+#pragma unroll
+    for (int k = 0; k < LORA_MAXR; k++) acc[k] = 0.f;
+    for (int i = i0; i < i1; i++) {
+        const float w = dW[(long)i * cols + j];
+#pragma unroll
+        for (int k = 0; k < LORA_MAXR; k++)
+            if (k < r) acc[k] = __builtin_fmaf(up[(long)i * r + k], w, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < LORA_MAXR; k++)
+        if (k < r) partial[((long)blockIdx.y * r + k) * cols + j] = acc[k];
 }
 
 __global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, float inv_scale, int *found_inf)
@@ -446,6 +584,7 @@ int transpose(int dtype, const void *src, long ld, int M, int N, int Mp, int seq
               void *dst_t, void *dst_rm, hipStream_t s)
 {
     const dim3 grid((unsigned)(Mp / 64), (unsigned)((N + 63) / 64));
+    ec::ProfScope prof(ec::PROF_TRANSPOSE, s, 0, (double)M * N * (MODE == 2 ? 4.0 : 2.0) + 2.0 * Mp * N);
     if (dtype == EC_F16)
         hipLaunchKernelGGL((transpose_kernel<EC_F16, MODE>), grid, dim3(256), 0, s, src, ld, M, N, Mp, seq_out, seq_in,
                            seq_off, dst_t, dst_rm);
@@ -458,7 +597,9 @@ int transpose(int dtype, const void *src, long ld, int M, int N, int Mp, int seq
 
 int reduce(const float *part, long stride, int P, long n, float *out, hipStream_t s)
 {
-    const long blocks = (n + 255) / 256;
+    if (n % 4 != 0 || stride % 4 != 0) return ec::fail(EC_ERR_INVALID, "reduce: %ld elements at stride %ld", n, stride);
+    const long blocks = (n / 4 + 255) / 256;
+    ec::ProfScope prof(ec::PROF_REDUCE, s, 0, 4.0 * n * (P + 1));
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, part, stride, P, n,
                        out);
     EC_CHECK_HIP(hipGetLastError());
@@ -470,8 +611,12 @@ template <typename T> int bias_grad(const T *src, long ld, int M, int N, const T
 {
     const int slab = (M + b.col_slabs - 1) / b.col_slabs;
     const int slabs = (M + slab - 1) / slab;
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)((N + 255) / 256), (unsigned)slabs), dim3(256), 0, s, src, ld, M, N,
-                       slab, b.colpart);
+    {
+        ec::ProfScope prof(ec::PROF_REDUCE, s, 0, (double)M * N * sizeof(T));
+        constexpr int V = 16 / sizeof(T);
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)((N / V + 255) / 256), (unsigned)slabs), dim3(256), 0, s, src, ld, M, N,
+                           slab, b.colpart);
+    }
     return reduce(b.colpart, N, slabs, N, out, s);
 }
 
@@ -505,8 +650,11 @@ int ln_backward(const float *x, long ldx, const float *dy, long ldy, const float
     int wgs = (rows + 3) / 4;
     if (wgs > max_wgs) wgs = max_wgs;
     const bool want = dg || db;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W, LN_EPS, dx, ldo,
-                       accumulate, want ? partials : (float *)nullptr);
+    {
+        ec::ProfScope prof(ec::PROF_LN_BWD, s, 0, (double)rows * W * (accumulate ? 16.0 : 12.0));
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W, LN_EPS, dx, ldo,
+                           accumulate, want ? partials : (float *)nullptr);
+    }
     EC_CHECK_HIP(hipGetLastError());
     if (dg) EC_TRY(reduce(partials, 2L * W, wgs, W, dg, s));
     if (db) EC_TRY(reduce(partials + W, 2L * W, wgs, W, db, s));
@@ -687,6 +835,7 @@ EC_API int ec_pack_weight16(const float *wsrc, int rows, int cols, void *hi, voi
     EC_REQUIRE(wsrc && (hi || lo || hi_t), "ec_pack_weight16: null buffer");
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_PACK, s, 0, (double)rows * cols * (4.0 + 2.0 * ((hi != nullptr) + (lo != nullptr) + (hi_t != nullptr))));
     if (dtype == EC_F16)
         hipLaunchKernelGGL(pack_weight_kernel<EC_F16>, grid, dim3(256), 0, s, wsrc, rows, cols, hi, lo, hi_t);
     else if (dtype == EC_BF16)
@@ -719,12 +868,69 @@ EC_API int ec_layernorm_backward(const float *x, long ldx, const float *dy, long
                        static_cast<hipStream_t>(stream));
 }
 
+EC_API int ec_lora_merge_batched(const ec_lora_item *items, int n_items, int rows, int cols, int r, ec_stream_t stream)
+{
+    EC_REQUIRE(n_items > 0 && rows > 0 && cols > 0 && cols % 4 == 0 && r > 0 && r <= LORA_MAXR,
+               "ec_lora_merge_batched: %d items of %d x %d, r = %d (<= %d)", n_items, rows, cols, r, LORA_MAXR);
+    EC_REQUIRE(items, "ec_lora_merge_batched: null item table");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_SGEMM, s, 2.0 * rows * cols * r * n_items, 8.0 * rows * cols * n_items);
+    hipLaunchKernelGGL(lora_merge_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)((rows + 7) / 8), (unsigned)n_items),
+                       dim3(256), 0, s, items, rows, cols, r);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API size_t ec_lora_grad_scratch_floats(int n_items, int rows, int cols, int r)
+{
+    if (n_items <= 0 || rows <= 0 || cols <= 0 || r <= 0) return 0;
+    return (size_t)n_items * 16 * r * cols;
+}
+
+EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows, int cols, int r, float *scratch,
+                                ec_stream_t stream)
+{
+    EC_REQUIRE(n_items > 0 && rows > 0 && cols > 0 && cols % 4 == 0 && r > 0 && r <= LORA_MAXR,
+               "ec_lora_grad_batched: %d items of %d x %d, r = %d (<= %d)", n_items, rows, cols, r, LORA_MAXR);
+    EC_REQUIRE(items && scratch, "ec_lora_grad_batched: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int slab = (rows + 15) / 16, slabs = (rows + slab - 1) / slab;
+    const long n = (long)r * cols;
+    ec::ProfScope prof(ec::PROF_SGEMM, s, 4.0 * rows * cols * r * n_items, 8.0 * rows * cols * n_items);
+    hipLaunchKernelGGL(lora_dup_kernel, dim3((unsigned)((rows + 3) / 4), 1, (unsigned)n_items), dim3(256), 0, s, items, rows,
+                       cols, r);
+    hipLaunchKernelGGL(lora_ddown_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)slabs, (unsigned)n_items), dim3(256), 0,
+                       s, items, rows, cols, r, slab, scratch);
+    hipLaunchKernelGGL(lora_ddown_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), (unsigned)n_items), dim3(256), 0, s, items,
+                       scratch, slabs, n);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
+                              float beta2, float eps, float weight_decay, int step, ec_stream_t stream)
+{
+    EC_REQUIRE(n_items >= 0 && max_n >= 0 && step >= 1, "ec_adam_step_multi: n_items=%d step=%d", n_items, step);
+    if (n_items == 0 || max_n == 0) return EC_OK;
+    EC_REQUIRE(items, "ec_adam_step_multi: null item table");
+    const double bc1 = 1.0 - __builtin_pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - __builtin_pow((double)beta2, (double)step);
+    const long blocks = ((long)max_n + 255) / 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_OPTIMIZER, s, 0, 0);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512), (unsigned)n_items), dim3(256), 0, s,
+                       items, lr0, lr1, beta1, beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2));
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf, ec_stream_t stream)
 {
     EC_REQUIRE(n >= 0, "ec_grad_unscale_check: n=%lld", (long long)n);
     if (n == 0) return EC_OK;
     EC_REQUIRE(grad && found_inf, "ec_grad_unscale_check: null buffer");
     const long blocks = (n + 255) / 256;
+    ec::ProfScope prof(ec::PROF_OPTIMIZER, static_cast<hipStream_t>(stream), 0, 8.0 * n);
     hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, (long)n, inv_scale, found_inf);
     EC_CHECK_HIP(hipGetLastError());

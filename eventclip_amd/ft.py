@@ -10,7 +10,7 @@ train.py:121) -- is here three layers over the C ABI:
                   (``ec_pack_weight16``), ``forward`` (``ec_vit_train_forward``) and ``backward``
                   (``ec_vit_train_backward``) returning gradients by state-dict name;
 ``LoraFactors``   the low-rank factors with the reference's key names, the merged weights they act through
-                  (lora.py:138-150, :50-52) and the chain rule back onto them (``ec_sgemm``);
+                  (lora.py:138-150, :50-52) and the chain rule back onto them (``ec_lora_merge`` / ``ec_lora_grad``);
 ``FTTrainer``     one optimisation step: loss and feature gradients (``ec_ft_loss_grad``), the gradient scaler
                   of mixed precision (``ec_grad_unscale_check``), one all-reduce of the flat gradient buffer
                   across ranks, ``ec_adam_step`` per tensor with the warm-up + cosine schedule.
@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .train import _AGG, adam_step, cosine_warmup_lr
+from .train import _AGG, cosine_warmup_lr
 
 _BLOCK = (('ln1_g', 'ln_1.weight'), ('ln1_b', 'ln_1.bias'), ('qkv_w', 'attn.in_proj_weight'),
           ('qkv_b', 'attn.in_proj_bias'), ('out_w', 'attn.out_proj.weight'), ('out_b', 'attn.out_proj.bias'),
@@ -57,6 +57,13 @@ def sgemm(a, b, out, alpha=1.0, beta=0.0):
                              float(alpha), float(beta), _lib.ptr(out), out.stride(0), _lib.stream_ptr())
     _lib.check(rc, 'ec_sgemm')
     return out
+
+
+def device_table(items):
+    """ctypes array of structs -> device copy (uint8 CUDA tensor) for the batched kernels' item tables."""
+    import numpy as np
+    host = np.frombuffer(items, dtype=np.uint8).copy()
+    return torch.from_numpy(host).cuda()
 
 
 class VisualTower:
@@ -292,42 +299,55 @@ class LoraFactors:
                 tower.effective[n] = torch.empty_like(tower.master[n])
                 self.merged_names.append(n)
 
-    def merge(self):
-        """effective = base + up @ down per projection (lora.py:138-150, :50-52), then repack those matrices."""
-        t, W = self.tower, self.tower.W
-        for i in range(t.L):
+    def projections(self):
+        """(block, row block of in_proj or None for out_proj, down key, up key) of every injected projection."""
+        out = []
+        for i in range(self.tower.L):
             pre = _block_name(i, 'attn')
-            eff = t.effective[pre + '.in_proj_weight']
-            eff.copy_(t.master[pre + '.in_proj_weight'])
             for j, nm in enumerate('qkv'):
-                up = self.params.get(f'{pre}.in_proj_weight.lora_up_{nm}')
-                if up is not None:
-                    sgemm(up, self.params[f'{pre}.in_proj_weight.lora_down_{nm}'], eff[j * W:(j + 1) * W], 1.0, 1.0)
+                if f'{pre}.in_proj_weight.lora_up_{nm}' in self.params:
+                    out.append((i, j, f'{pre}.in_proj_weight.lora_down_{nm}', f'{pre}.in_proj_weight.lora_up_{nm}'))
             if self.lora_o:
-                eo = t.effective[pre + '.out_proj.weight']
-                eo.copy_(t.master[pre + '.out_proj.weight'])
-                sgemm(self.params[pre + '.out_proj.lora_up.weight'], self.params[pre + '.out_proj.lora_down.weight'],
-                      eo, 1.0, 1.0)
+                out.append((i, None, pre + '.out_proj.lora_down.weight', pre + '.out_proj.lora_up.weight'))
+        return out
+
+    def bind(self, grad_views, factor_grads):
+        """Build the device item table once: every pointer (masters, merged scratch, the flat gradient buffer's
+        views, the factor gradients) is stable for the life of the trainer."""
+        t, W = self.tower, self.tower.W
+        proj = self.projections()
+        items = (_lib.EcLoraItem * len(proj))()
+        for it, (i, j, kd, ku) in zip(items, proj):
+            pre = _block_name(i, 'attn')
+            name = pre + ('.in_proj_weight' if j is not None else '.out_proj.weight')
+            rows = slice(j * W, (j + 1) * W) if j is not None else slice(None)
+            it.base = t.master[name][rows].data_ptr()
+            it.out = t.effective[name][rows].data_ptr()
+            it.dW = grad_views[name][rows].data_ptr()
+            it.up, it.down = self.params[ku].data_ptr(), self.params[kd].data_ptr()
+            it.d_up, it.d_down = factor_grads[ku].data_ptr(), factor_grads[kd].data_ptr()
+        self._n_items = len(proj)
+        self._items = device_table(items)
+        need = int(_lib.lib().ec_lora_grad_scratch_floats(self._n_items, W, W, self.r))
+        self._scratch = torch.empty((need,), dtype=torch.float32, device=t.dev)
+        if not self.lora_k:       # the k rows of in_proj carry no factors: their merged rows are the base rows
+            for i in range(t.L):
+                n = _block_name(i, 'attn.in_proj_weight')
+                t.effective[n][W:2 * W].copy_(t.master[n][W:2 * W])
+
+    def merge(self):
+        """effective = base + up @ down for every projection (lora.py:138-150, :50-52), then repack those matrices."""
+        t = self.tower
+        rc = _lib.lib().ec_lora_merge_batched(_lib.ptr(self._items), self._n_items, t.W, t.W, self.r, _lib.stream_ptr())
+        _lib.check(rc, 'ec_lora_merge_batched')
         t.pack(self.merged_names)
 
-    def chain(self, grads, out):
-        """Merged-weight gradients -> factor gradients: d up = dW down^T, d down = up^T dW (written into
-        ``out[name]``)."""
-        t, W = self.tower, self.tower.W
-        for i in range(t.L):
-            pre = _block_name(i, 'attn')
-            dW = grads[pre + '.in_proj_weight']
-            for j, nm in enumerate('qkv'):
-                kd, ku = f'{pre}.in_proj_weight.lora_down_{nm}', f'{pre}.in_proj_weight.lora_up_{nm}'
-                if ku in self.params:
-                    blk = dW[j * W:(j + 1) * W]
-                    sgemm(blk, self.params[kd].t(), out[ku])
-                    sgemm(self.params[ku].t(), blk, out[kd])
-            if self.lora_o:
-                dWo = grads[pre + '.out_proj.weight']
-                kd, ku = pre + '.out_proj.lora_down.weight', pre + '.out_proj.lora_up.weight'
-                sgemm(dWo, self.params[kd].t(), out[ku])
-                sgemm(self.params[ku].t(), dWo, out[kd])
+    def chain(self):
+        """Merged-weight gradients (in the flat buffer) -> factor gradients: d up = dW down^T, d down = up^T dW."""
+        t = self.tower
+        rc = _lib.lib().ec_lora_grad_batched(_lib.ptr(self._items), self._n_items, t.W, t.W, self.r,
+                                             _lib.ptr(self._scratch), _lib.stream_ptr())
+        _lib.check(rc, 'ec_lora_grad_batched')
 
     def state_dict_entries(self):
         """The tower's attention entries as the reference's LoRA-injected modules name them."""
@@ -366,7 +386,7 @@ class GradScaler:
 
 
 def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', use_probs_loss=False, grad_scale=1.0,
-                 want_text_grad=True):
+                 want_text_grad=True, text_grad_out=None):
     """The classifier head in train mode (``ec_ft_loss_grad``): img_feats fp32 CUDA [B, T, D] with zero rows
     on invalid views.  Returns (loss, d loss / d img_feats * grad_scale [B, T, D], d loss / d text_param or None,
     aggregated logits [B, K])."""
@@ -383,7 +403,10 @@ def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', 
     ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     gimg = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-    gtext = torch.empty((K, D), dtype=torch.float32, device=dev) if want_text_grad else None
+    gtext = None
+    if want_text_grad:
+        gtext = text_grad_out if text_grad_out is not None else torch.empty((K, D), dtype=torch.float32, device=dev)
+        assert gtext.is_contiguous() and tuple(gtext.shape) == (K, D) and gtext.dtype == torch.float32
     logits = torch.empty((B, K), dtype=torch.float32, device=dev)
     rc = _lib.lib().ec_ft_loss_grad(_lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
                                     float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), float(grad_scale),
@@ -436,8 +459,27 @@ class FTTrainer:
             self.want += [n for n in self.lora.merged_names if n not in self.want]
         self._found = torch.zeros((1,), dtype=torch.int32, device=self.tower.dev)
         self._lora_grads = {n: torch.zeros_like(p) for n, p in self.lora.params.items()} if self.lora else {}
-        if self.lora:
-            self.lora.merge()
+        # gradients live at fixed addresses: views of the tower's flat buffer, the factor gradients, text_feats'
+        self._grads = {}
+        if self.want:
+            self._flat, views = self.tower.grad_buffer(self.want)
+            for n in self.visual_train:
+                self._grads['model.visual.' + n] = views[n]
+            if self.lora:
+                self.lora.bind(views, self._lora_grads)
+                for n, g in self._lora_grads.items():
+                    self._grads['model.visual.' + n] = g
+                self.lora.merge()
+        if classifier.prompt_tuning:
+            self._grads['text_feats'] = torch.zeros_like(classifier.text_feats.data)
+        items = (_lib.EcAdamItem * len(self.tensors))()
+        for it, (k, p) in zip(items, self.tensors.items()):
+            assert p.is_contiguous() and self._grads[k].is_contiguous()
+            m, v = self.state[k]
+            it.param, it.grad, it.exp_avg, it.exp_avg_sq = p.data_ptr(), self._grads[k].data_ptr(), m.data_ptr(), v.data_ptr()
+            it.n, it.group = p.numel(), int(k.startswith('model.visual.'))
+        self._adam_items = device_table(items) if len(self.tensors) else None
+        self._adam_max = max([p.numel() for p in self.tensors.values()] + [0])
         classifier._tower, classifier._trainer = self.tower, self
         self.last = {}
 
@@ -473,12 +515,12 @@ class FTTrainer:
         text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
         S = self.scaler.scale
         loss, gimg, gtext, logits = ft_loss_grad(full, valid, labels, text, clf.logit_scale, clf.agg_func,
-                                                 clf.use_probs_loss, grad_scale=S, want_text_grad=clf.prompt_tuning)
+                                                 clf.use_probs_loss, grad_scale=S, want_text_grad=clf.prompt_tuning,
+                                                 text_grad_out=self._grads.get('text_feats'))
         self.last = dict(logits=logits, feats=feats)
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        grads = {}
         if self.want:
-            views, flat = t.backward(gimg[valid], self.want)
+            _, flat = t.backward(gimg[valid], self.want)
             if ddp:
                 dist.all_reduce(flat)                 # one collective for the whole tower (RCCL over xGMI)
                 flat /= dist.get_world_size()
@@ -486,30 +528,25 @@ class FTTrainer:
             rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(flat), flat.numel(), 1.0 / S, _lib.ptr(self._found),
                                                   _lib.stream_ptr())
             _lib.check(rc, 'ec_grad_unscale_check')
-            for n in self.visual_train:
-                grads['model.visual.' + n] = views[n]
             if self.lora:
-                self.lora.chain(views, self._lora_grads)
-                for n, g in self._lora_grads.items():
-                    grads['model.visual.' + n] = g
-        if clf.prompt_tuning:
-            if ddp:
-                dist.all_reduce(gtext)
-                gtext /= dist.get_world_size()
-            grads['text_feats'] = gtext
+                self.lora.chain()
+        if clf.prompt_tuning and ddp:
+            dist.all_reduce(gtext)
+            gtext /= dist.get_world_size()
         found = bool(self._found.item()) if (self.want and self.scaler.enabled) else False
         lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
         clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
         self.steps += 1
-        if not found:
+        if not found and self._adam_items is not None:
             self.opt_steps += 1
-            for k, p in self.tensors.items():
-                m, v = self.state[k]
-                adam_step(p, grads[k].contiguous(), m, v, self.opt_steps, clip_lr if k.startswith('model.visual.') else lr,
-                          self.betas, self.eps, 0.)
+            rc = _lib.lib().ec_adam_step_multi(_lib.ptr(self._adam_items), len(self.tensors), self._adam_max, lr, clip_lr,
+                                               self.betas[0], self.betas[1], self.eps, 0., self.opt_steps,
+                                               _lib.stream_ptr())
+            _lib.check(rc, 'ec_adam_step_multi')
             if self.lora:
                 self.lora.merge()
-            moved = [n for n in self.visual_train if n in set(t.matrix_names())]
+            matrices = set(t.matrix_names())
+            moved = [n for n in self.visual_train if n in matrices]
             if moved:
                 t.pack(moved)
             else:
@@ -517,7 +554,7 @@ class FTTrainer:
             if hasattr(clf, '_invalidate_text_cache'):
                 clf._invalidate_text_cache()
         self.scaler.update(found)
-        self.last['grads'] = grads
+        self.last['grads'] = self._grads
         self.last['skipped'] = found
         return loss
 

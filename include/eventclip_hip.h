@@ -595,6 +595,33 @@ EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const i
                            int use_probs_loss, float grad_scale, float *loss, float *grad_text, float *grad_img,
                            float *agg_logits, void *workspace, size_t workspace_bytes, ec_stream_t stream);
 
+/* LoRA factors (models/lora.py), every injected projection of the tower in one launch.  Per projection:
+ * out = base + up @ down (base / out fp32 [rows, cols], up [rows, r], down [r, cols], r <= 64; lora.py:50-52,
+ * :138-150), and the chain rule from the merged weight's gradient: d_up = dW down^T, d_down = up^T dW.
+ * `items` is a DEVICE array; all items share rows, cols, r (CLIP's q / k / v / out projections are W x W). */
+typedef struct {
+    const float *base, *up, *down;
+    float *out;
+    const float *dW;
+    float *d_up, *d_down;
+} ec_lora_item;
+EC_API int ec_lora_merge_batched(const ec_lora_item *items, int n_items, int rows, int cols, int r, ec_stream_t stream);
+EC_API size_t ec_lora_grad_scratch_floats(int n_items, int rows, int cols, int r);
+EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows, int cols, int r, float *scratch,
+                                ec_stream_t stream);
+
+/* ec_adam_step over a list of tensors in one launch (`items`: DEVICE array; group selects lr0 / lr1: the
+ * classifier's own parameters vs model.visual, method.py:166-178); max_n = the largest item's n. */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    int64_t n;
+    int group;
+} ec_adam_item;
+EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
+                              float beta2, float eps, float weight_decay, int step, ec_stream_t stream);
+
 /* grad *= inv_scale in place; *found_inf (device int32, caller zeroes it once per step) is set when any
  * element is not finite -- torch.cuda.amp.GradScaler.unscale_. */
 EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf,

@@ -189,6 +189,54 @@ def test_sgemm_any_layout(hip):
     torch.testing.assert_close(ft.sgemm(at.t(), bt.t(), o2), at.t() @ bt.t(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('rows,cols,r,n_items', [(64, 64, 2, 1), (1024, 1024, 16, 5), (768, 768, 4, 3), (200, 136, 64, 2)])
+def test_lora_merge_and_chain_rule(hip, rows, cols, r, n_items):
+    from eventclip_amd import _lib, ft
+    torch.manual_seed(r)
+    mk = lambda *shape: [torch.randn(*shape, device='cuda') for _ in range(n_items)]      # noqa: E731
+    base, dW, up, down = mk(rows, cols), mk(rows, cols), mk(rows, r), mk(r, cols)
+    out, d_up, d_down = mk(rows, cols), mk(rows, r), mk(r, cols)
+    items = (_lib.EcLoraItem * n_items)()
+    for i, it in enumerate(items):
+        it.base, it.up, it.down, it.out = base[i].data_ptr(), up[i].data_ptr(), down[i].data_ptr(), out[i].data_ptr()
+        it.dW, it.d_up, it.d_down = dW[i].data_ptr(), d_up[i].data_ptr(), d_down[i].data_ptr()
+    table = ft.device_table(items)
+    _lib.check(_lib.lib().ec_lora_merge_batched(_lib.ptr(table), n_items, rows, cols, r, _lib.stream_ptr()), 'merge')
+    scratch = torch.empty(int(_lib.lib().ec_lora_grad_scratch_floats(n_items, rows, cols, r)), device='cuda')
+    _lib.check(_lib.lib().ec_lora_grad_batched(_lib.ptr(table), n_items, rows, cols, r, _lib.ptr(scratch),
+                                               _lib.stream_ptr()), 'grad')
+    for i in range(n_items):
+        torch.testing.assert_close(out[i], base[i] + up[i] @ down[i], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(d_up[i], dW[i] @ down[i].t(), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(d_down[i], up[i].t() @ dW[i], rtol=1e-4, atol=1e-3)
+
+
+def test_adam_over_a_tensor_list_matches_torch(hip):
+    from eventclip_amd import _lib, ft
+    torch.manual_seed(9)
+    shapes = [(1000, 37), (5,), (64, 64), (3, 1, 7)]
+    params = [torch.randn(*s, device='cuda') for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam([{'params': ref[:2], 'lr': 1e-2}, {'params': ref[2:], 'lr': 3e-3}])
+    grads = [torch.zeros_like(p) for p in params]
+    m, v = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    items = (_lib.EcAdamItem * len(params))()
+    for i, it in enumerate(items):
+        it.param, it.grad, it.exp_avg, it.exp_avg_sq = params[i].data_ptr(), grads[i].data_ptr(), m[i].data_ptr(), v[i].data_ptr()
+        it.n, it.group = params[i].numel(), int(i >= 2)
+    table = ft.device_table(items)
+    for step in (1, 2, 3):
+        for g, r in zip(grads, ref):
+            g.copy_(torch.randn_like(g))
+            r.grad = g.clone()
+        opt.step()
+        rc = _lib.lib().ec_adam_step_multi(_lib.ptr(table), len(params), max(p.numel() for p in params), 1e-2, 3e-3, 0.9,
+                                           0.999, 1e-8, 0., step, _lib.stream_ptr())
+        _lib.check(rc, 'ec_adam_step_multi')
+    for p, r in zip(params, ref):
+        torch.testing.assert_close(p, r.detach(), rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------
 # the tower: forward with a tape, gradients of every parameter
 # ------------------------------------------------------------------------------------------------
