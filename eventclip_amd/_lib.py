@@ -113,6 +113,10 @@ class EcLoraItem(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('base', 'up', 'down', 'out', 'dW', 'd_up', 'd_down')]
 
 
+class EcPackItem(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('w', 'hi', 'lo', 'hi_t')]
+
+
 class EcAdamItem(ctypes.Structure):
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p),
                 ('n', ctypes.c_int64), ('group', c_int)]
@@ -218,11 +222,11 @@ SIGNATURES = {
     'ec_vit_train_backward': (c_int, [ctypes.POINTER(EcVitWeights), ctypes.POINTER(EcVitTrainWeights), c_void_p,
                                       c_int, c_void_p, ctypes.POINTER(EcVitGrads), c_void_p, ctypes.c_size_t,
                                       c_void_p]),
-    'ec_pack_weight16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'ec_pack_weight16_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_layernorm_backward_partials': (ctypes.c_size_t, [c_int, c_int]),
     'ec_layernorm_backward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float,
                                       c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'ec_ft_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+    'ec_ft_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                 c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 ctypes.c_size_t, c_void_p]),
     'ec_grad_unscale_check': (c_int, [c_void_p, ctypes.c_int64, c_float, c_void_p, c_void_p]),
@@ -230,7 +234,7 @@ SIGNATURES = {
     'ec_lora_grad_scratch_floats': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     'ec_lora_grad_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ec_adam_step_multi': (c_int, [c_void_p, c_int, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float,
-                                   c_float, c_int, c_void_p]),
+                                   c_float, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

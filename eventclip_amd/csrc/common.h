@@ -48,6 +48,13 @@ int ensure_dynamic_lds(const void *kern, int bytes);
 // compute units of the current device (cached per device); 0 on error
 int cu_count();
 
+// ec_fs_text_loss_grad with the image features optionally compact over the valid views (train.hip; shared with
+// the fine-tuning head in vit_train.hip)
+int fs_text_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid, const int32_t *labels,
+                      const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
+                      int use_probs_loss, float *loss, float *grad_text, float *agg_logits, void *workspace,
+                      size_t workspace_bytes, ec_stream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

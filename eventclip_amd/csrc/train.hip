@@ -74,7 +74,8 @@ __global__ __launch_bounds__(64) void text_norm_kernel(const float *t, int D, fl
 // LDS: fn [T][D] | logits [T][K] | reduction scratch
 __global__ __launch_bounds__(TR_THREADS) void fs_loss_grad_kernel(
     const float *feats, const unsigned char *valid, const int *labels, const float *u, int B, int T, int D,
-    int K, float scale, int agg, int probs_loss, float *Fn, float *dL, float *loss_b, float *agg_logits)
+    int K, float scale, int agg, int probs_loss, float *Fn, float *dL, float *loss_b, float *agg_logits,
+    const int *row_idx)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *fn = sm, *lg = sm + (size_t)T * D, *red = lg + (size_t)T * K;
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(TR_THREADS) void fs_loss_grad_kernel(
 
     // ---- F.normalize per view, invalid views zero (clip_cls.py:325-329) ----
     for (int v = wave; v < T; v += TR_WAVES) {
-        const float *f = feats + ((long)b * T + v) * D;
+        // row_idx (optional): the features are compact over the valid views, row_idx[b, v] = their row
+        const long frow = row_idx ? (valid[b * T + v] ? row_idx[b * T + v] : 0) : (long)b * T + v;
+        const float *f = feats + frow * D;
         float s = 0.f;
         for (int d = lane; d < D; d += 64) s += f[d] * f[d];
         const float inv = valid[b * T + v] ? 1.f / fmaxf(__builtin_sqrtf(wave_sum_f(s)), 1e-12f) : 0.f;
@@ -504,6 +507,16 @@ extern "C" EC_API int ec_fs_text_loss_grad(const float *img_feats, const uint8_t
                                            float *grad_text, float *agg_logits, void *workspace,
                                            size_t workspace_bytes, ec_stream_t stream)
 {
+    return ec::fs_text_loss_grad(img_feats, nullptr, valid, labels, text_param, B, T, D, K, logit_scale, agg,
+                                 use_probs_loss, loss, grad_text, agg_logits, workspace, workspace_bytes, stream);
+}
+
+// row_idx (optional, int32 [B, T]): img_feats holds only the valid views, row_idx[b, v] = the row of view (b, v)
+int ec::fs_text_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid, const int32_t *labels,
+                          const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
+                          int use_probs_loss, float *loss, float *grad_text, float *agg_logits, void *workspace,
+                          size_t workspace_bytes, ec_stream_t stream)
+{
     EC_REQUIRE(B > 0 && T > 0 && D > 0 && K > 0, "ec_fs_text_loss_grad: bad shape");
     EC_REQUIRE(agg == EC_AGG_SUM || agg == EC_AGG_MEAN,
                "ec_fs_text_loss_grad: agg must be sum or mean ('max' raises in the reference, clip_cls.py:117)");
@@ -535,7 +548,7 @@ extern "C" EC_API int ec_fs_text_loss_grad(const float *img_feats, const uint8_t
     }
     hipLaunchKernelGGL(text_norm_kernel, dim3(K), dim3(64), 0, s, text_param, D, u, inv_norm);
     hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, img_feats, valid, labels, u, B, T,
-                       D, K, logit_scale, agg, use_probs_loss, Fn, dL, loss_b, agg_logits);
+                       D, K, logit_scale, agg, use_probs_loss, Fn, dL, loss_b, agg_logits, row_idx);
     hipLaunchKernelGGL(sgemm_tn_kernel, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, dL, Fn, (int)R, K, D,
                        logit_scale, dU);
     hipLaunchKernelGGL(text_grad_finish_kernel, dim3(K), dim3(64), 0, s, u, dU, inv_norm, D, loss_b, B,
@@ -730,7 +743,7 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
     // ---------------- loss, dL, text gradient (shared with 'text-identity') ----------------
     hipLaunchKernelGGL(text_norm_kernel, dim3(K), dim3(64), 0, s, text_param, D, t.u, t.inv_norm);
     hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, t.mixed, valid, labels, t.u, B, T, D, K,
-                       logit_scale, agg, use_probs_loss, t.Fn, t.dL, t.loss_b, agg_logits);
+                       logit_scale, agg, use_probs_loss, t.Fn, t.dL, t.loss_b, agg_logits, (const int *)nullptr);
     hipLaunchKernelGGL(sgemm_tn_kernel, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, t.dL, t.Fn, R, K, D,
                        logit_scale, t.dU);
     hipLaunchKernelGGL(text_grad_finish_kernel, dim3(K), dim3(64), 0, s, t.u, t.dU, t.inv_norm, D, t.loss_b, B,

@@ -318,12 +318,14 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float *de, int n_im
     }
 }
 
-// fp32 [rows, cols] -> hi (rounded), lo (rounded remainder), hi transposed
+// fp32 [rows, cols] -> hi (rounded), lo (rounded remainder), hi transposed; blockIdx.z = matrix of a same-shape list
 template <int DT>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, int rows, int cols, void *hi, void *lo,
-                                                          void *hi_t)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const ec_pack_item *items, int rows, int cols)
 {
     typedef typename T16<DT>::elem elem;
+    const ec_pack_item it = items[blockIdx.z];
+    const float *w = it.w;
+    void *hi = it.hi, *lo = it.lo, *hi_t = it.hi_t;
     __shared__ elem tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -371,8 +373,9 @@ __global__ __launch_bounds__(256) void lora_ddown_reduce_kernel(const ec_lora_it
 
 // torch.optim.Adam over a list of tensors in one launch: blockIdx.y = tensor
 __global__ __launch_bounds__(256) void adam_multi_kernel(const ec_adam_item *items, float lr0, float lr1, float b1, float b2,
-                                                         float eps, float wd, float bc1, float bc2_sqrt)
+                                                         float eps, float wd, float bc1, float bc2_sqrt, const int *skip)
 {
+    if (skip && *skip) return;     // a non-finite gradient somewhere: the whole step is dropped (GradScaler.step)
     const ec_adam_item it = items[blockIdx.y];
     const float lr = it.group ? lr1 : lr0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (long)gridDim.x * 256) {
@@ -406,30 +409,44 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const ec_lora_item *ite
     }
 }
 
-// d_up[i][k] = sum_j dW[i][j] down[k][j]: one wave per row, 16 factors at a time
+// d_up[i][k] = sum_j dW[i][j] down[k][j]: a wave takes four rows (each `down` value it loads serves all four),
+// eight factors at a time
 __global__ __launch_bounds__(256) void lora_dup_kernel(const ec_lora_item *items, int rows, int cols, int r)
 {
     const ec_lora_item it = items[blockIdx.z];
     const float *dW = it.dW, *down = it.down;
     float *d_up = it.d_up;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= rows) return;
-    for (int k0 = 0; k0 < r; k0 += 16) {
-        float acc[16];
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (i0 >= rows) return;
+    for (int k0 = 0; k0 < r; k0 += 8) {
+        float acc[4][8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = 0.f;
-        for (int j = lane; j < cols; j += 64) {
-            const float w = dW[(long)i * cols + j];
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k0 + k < r) acc[k] = __builtin_fmaf(w, down[(long)(k0 + k) * cols + j], acc[k]);
+            for (int k = 0; k < 8; k++) acc[u][k] = 0.f;
+        for (int j = lane * 4; j < cols; j += 256) {
+            float4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                w[u] = i0 + u < rows ? *reinterpret_cast<const float4 *>(dW + (long)(i0 + u) * cols + j)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k0 + k >= r) continue;
+                const float4 d = *reinterpret_cast<const float4 *>(down + (long)(k0 + k) * cols + j);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    acc[u][k] += (w[u].x * d.x + w[u].y * d.y) + (w[u].z * d.z + w[u].w * d.w);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float t = wave_sum(acc[k]);
-            if (lane == 0 && k0 + k < r) d_up[(long)i * r + k0 + k] = t;
-        }
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float t = wave_sum(acc[u][k]);
+                if (lane == 0 && k0 + k < r && i0 + u < rows) d_up[(long)(i0 + u) * r + k0 + k] = t;
+            }
     }
 }
 
@@ -469,21 +486,24 @@ __global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, fl
 }
 
 // through F.normalize + the validity mask (clip_cls_ft.py:214-217): d f = valid ? (dfn - fn (fn . dfn)) / |f| : 0
+// (row_idx: feats / dfeats hold the valid views only, view r lives in row row_idx[r]; invalid views have no row)
 __global__ __launch_bounds__(256) void feat_grad_kernel(const float *feats, const float *fn, const float *dfn,
-                                                        const unsigned char *valid, int R, int D, float scale,
-                                                        float *dfeats)
+                                                        const unsigned char *valid, const int *row_idx, int R, int D,
+                                                        float scale, float *dfeats)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
+    if (row_idx && !valid[r]) return;
+    const long row = row_idx ? row_idx[r] : r;
     float s = 0.f, dot = 0.f;
     for (int j = lane; j < D; j += 64) {
-        const float m = feats[(long)r * D + j];
+        const float m = feats[row * D + j];
         s += m * m, dot += fn[(long)r * D + j] * dfn[(long)r * D + j];
     }
     const float inv = valid[r] ? scale / fmaxf(__builtin_sqrtf(wave_sum(s)), 1e-12f) : 0.f;
     dot = wave_sum(dot);
     for (int j = lane; j < D; j += 64)
-        dfeats[(long)r * D + j] = (dfn[(long)r * D + j] - fn[(long)r * D + j] * dot) * inv;
+        dfeats[row * D + j] = (dfn[(long)r * D + j] - fn[(long)r * D + j] * dot) * inv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -828,20 +848,20 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
     return EC_OK;
 }
 
-EC_API int ec_pack_weight16(const float *wsrc, int rows, int cols, void *hi, void *lo, void *hi_t, int dtype,
-                            ec_stream_t stream)
+EC_API int ec_pack_weight16_batched(const ec_pack_item *items, int n_items, int rows, int cols, int dtype,
+                                    ec_stream_t stream)
 {
-    EC_REQUIRE(rows > 0 && cols > 0, "ec_pack_weight16: %d x %d", rows, cols);
-    EC_REQUIRE(wsrc && (hi || lo || hi_t), "ec_pack_weight16: null buffer");
-    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    EC_REQUIRE(n_items > 0 && rows > 0 && cols > 0, "ec_pack_weight16_batched: %d items of %d x %d", n_items, rows, cols);
+    EC_REQUIRE(items, "ec_pack_weight16_batched: null item table");
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)n_items);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ec::ProfScope prof(ec::PROF_PACK, s, 0, (double)rows * cols * (4.0 + 2.0 * ((hi != nullptr) + (lo != nullptr) + (hi_t != nullptr))));
+    ec::ProfScope prof(ec::PROF_PACK, s, 0, (double)rows * cols * 10.0 * n_items);
     if (dtype == EC_F16)
-        hipLaunchKernelGGL(pack_weight_kernel<EC_F16>, grid, dim3(256), 0, s, wsrc, rows, cols, hi, lo, hi_t);
+        hipLaunchKernelGGL(pack_weight_kernel<EC_F16>, grid, dim3(256), 0, s, items, rows, cols);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<EC_BF16>, grid, dim3(256), 0, s, wsrc, rows, cols, hi, lo, hi_t);
+        hipLaunchKernelGGL(pack_weight_kernel<EC_BF16>, grid, dim3(256), 0, s, items, rows, cols);
     else
-        return ec::fail(EC_ERR_INVALID, "ec_pack_weight16: unknown dtype %d", dtype);
+        return ec::fail(EC_ERR_INVALID, "ec_pack_weight16_batched: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
@@ -897,7 +917,7 @@ EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows
     const int slab = (rows + 15) / 16, slabs = (rows + slab - 1) / slab;
     const long n = (long)r * cols;
     ec::ProfScope prof(ec::PROF_SGEMM, s, 4.0 * rows * cols * r * n_items, 8.0 * rows * cols * n_items);
-    hipLaunchKernelGGL(lora_dup_kernel, dim3((unsigned)((rows + 3) / 4), 1, (unsigned)n_items), dim3(256), 0, s, items, rows,
+    hipLaunchKernelGGL(lora_dup_kernel, dim3((unsigned)((rows + 15) / 16), 1, (unsigned)n_items), dim3(256), 0, s, items, rows,
                        cols, r);
     hipLaunchKernelGGL(lora_ddown_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)slabs, (unsigned)n_items), dim3(256), 0,
                        s, items, rows, cols, r, slab, scratch);
@@ -908,7 +928,8 @@ EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows
 }
 
 EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
-                              float beta2, float eps, float weight_decay, int step, ec_stream_t stream)
+                              float beta2, float eps, float weight_decay, int step, const int32_t *skip_flag,
+                              ec_stream_t stream)
 {
     EC_REQUIRE(n_items >= 0 && max_n >= 0 && step >= 1, "ec_adam_step_multi: n_items=%d step=%d", n_items, step);
     if (n_items == 0 || max_n == 0) return EC_OK;
@@ -919,7 +940,7 @@ EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t ma
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_OPTIMIZER, s, 0, 0);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512), (unsigned)n_items), dim3(256), 0, s,
-                       items, lr0, lr1, beta1, beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2));
+                       items, lr0, lr1, beta1, beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2), skip_flag);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
@@ -937,8 +958,9 @@ EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_
     return EC_OK;
 }
 
-EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels, const float *text_param,
-                           int B, int T, int D, int K, float logit_scale, int agg, int use_probs_loss, float grad_scale,
+EC_API int ec_ft_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid, const int32_t *labels,
+                           const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
+                           int use_probs_loss, float grad_scale,
                            float *loss, float *grad_text, float *grad_img, float *agg_logits, void *workspace,
                            size_t workspace_bytes, ec_stream_t stream)
 {
@@ -951,8 +973,8 @@ EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const i
     // the front of its workspace, in this order (train.hip: ec_fs_text_loss_grad)
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     float *gt = grad_text ? grad_text : reinterpret_cast<float *>(ws + base);   // unused text gradient: scratch
-    EC_TRY(ec_fs_text_loss_grad(img_feats, valid, labels, text_param, B, T, D, K, logit_scale, agg, use_probs_loss, loss, gt,
-                                agg_logits, workspace, base, stream));
+    EC_TRY(ec::fs_text_loss_grad(img_feats, row_idx, valid, labels, text_param, B, T, D, K, logit_scale, agg, use_probs_loss,
+                                 loss, gt, agg_logits, workspace, base, stream));
     auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
     const float *Fn = reinterpret_cast<const float *>(ws);
     const float *dL = reinterpret_cast<const float *>(ws + a256(R * D * 4));
@@ -961,7 +983,7 @@ EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const i
     // dFn[R, D] = logit_scale * dL[R, K] . u[K, D]
     EC_TRY(ec_sgemm(dL, K, 1, u, D, 1, (int)R, D, K, logit_scale, 0.f, dfn, D, stream));
     hipLaunchKernelGGL(feat_grad_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       img_feats, Fn, dfn, valid, (int)R, D, grad_scale, grad_img);
+                       img_feats, Fn, dfn, valid, row_idx, (int)R, D, grad_scale, grad_img);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

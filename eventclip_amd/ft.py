@@ -39,12 +39,28 @@ def _block_name(i, leaf):
     return f'transformer.resblocks.{i}.{leaf}'
 
 
+def pack_weights16(jobs, dtype_code):
+    """jobs: list of (w fp32 CUDA [rows, cols], hi, lo, hi_t) with 16-bit outputs or None, all the same shape ->
+    one ``ec_pack_weight16_batched`` launch."""
+    if not jobs:
+        return
+    rows, cols = jobs[0][0].shape
+    items = (_lib.EcPackItem * len(jobs))()
+    for it, (w, hi, lo, hi_t) in zip(items, jobs):
+        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (rows, cols)
+        it.w = w.data_ptr()
+        it.hi = hi.data_ptr() if hi is not None else None
+        it.lo = lo.data_ptr() if lo is not None else None
+        it.hi_t = hi_t.data_ptr() if hi_t is not None else None
+    table = device_table(items)
+    rc = _lib.lib().ec_pack_weight16_batched(_lib.ptr(table), len(jobs), rows, cols, dtype_code, _lib.stream_ptr())
+    _lib.check(rc, 'ec_pack_weight16_batched')
+    return table
+
+
 def pack_weight16(w, dtype_code, hi=None, lo=None, hi_t=None):
-    """fp32 CUDA [rows, cols] -> the 16-bit copies asked for (``ec_pack_weight16``)."""
-    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
-    rc = _lib.lib().ec_pack_weight16(_lib.ptr(w), w.shape[0], w.shape[1], _lib.ptr(hi), _lib.ptr(lo),
-                                     _lib.ptr(hi_t), dtype_code, _lib.stream_ptr())
-    _lib.check(rc, 'ec_pack_weight16')
+    """fp32 CUDA [rows, cols] -> the 16-bit copies asked for."""
+    pack_weights16([(w, hi, lo, hi_t)], dtype_code)
 
 
 def sgemm(a, b, out, alpha=1.0, beta=0.0):
@@ -106,6 +122,7 @@ class VisualTower:
                 r, cdim = shapes[f]
                 self.packed[(i, f)] = z16(r, cdim)
                 self.packed[(i, f, 't')] = z16(cdim, r)
+        self._pack_plans = {}
         self._build_structs()
         self.pack()
         self._ws = None
@@ -148,10 +165,29 @@ class VisualTower:
         return out
 
     def pack(self, names=None):
-        """(Re)build the 16-bit operand copies of the named matrices (default: all) from ``effective``."""
+        """(Re)build the 16-bit operand copies of the named matrices (default: all) from ``effective``: one
+        launch per distinct shape (q k v / out / c_fc / c_proj of every block together), item tables cached."""
         pk = self.packed
-        todo = set(self.matrix_names() if names is None else names)
+        todo = tuple(sorted(self.matrix_names() if names is None else set(names)))
         src = lambda n: self.effective.get(n, self.master[n])                  # noqa: E731
+        plan = self._pack_plans.get(todo)
+        if plan is None:
+            groups = {}
+            for i in range(self.L):
+                for f, leaf in _BLOCK:
+                    n = _block_name(i, leaf)
+                    if f in _MATRICES and n in todo:
+                        groups.setdefault(tuple(src(n).shape), []).append((src(n), pk[(i, f)], None, pk[(i, f, 't')]))
+            plan = []
+            for (rows, cols), jobs in groups.items():
+                items = (_lib.EcPackItem * len(jobs))()
+                for it, (w, hi, lo, hi_t) in zip(items, jobs):
+                    it.w, it.hi, it.hi_t = w.data_ptr(), hi.data_ptr(), hi_t.data_ptr()
+                plan.append((device_table(items), len(jobs), rows, cols))
+            self._pack_plans[todo] = plan
+        for table, n, rows, cols in plan:
+            rc = _lib.lib().ec_pack_weight16_batched(_lib.ptr(table), n, rows, cols, self.code, _lib.stream_ptr())
+            _lib.check(rc, 'ec_pack_weight16_batched')
         if 'conv1.weight' in todo:
             w = src('conv1.weight').reshape(self.W, self.k)
             pack_weight16(w, self.code, hi=pk['conv_hi_tmp'], lo=pk['conv_lo_tmp'])
@@ -161,10 +197,6 @@ class VisualTower:
         if 'proj' in todo:
             pack_weight16(src('proj'), self.code, lo=pk['proj_lo_tmp'], hi_t=pk['proj_t'])
             pk['proj_lo_t'].copy_(pk['proj_lo_tmp'].t())
-        for i in range(self.L):
-            for f, leaf in _BLOCK:
-                if f in _MATRICES and _block_name(i, leaf) in todo:
-                    pack_weight16(src(_block_name(i, leaf)), self.code, hi=pk[(i, f)], hi_t=pk[(i, f, 't')])
         self.clip._packed = None       # the inference copies of clip.py are stale once a master moved
 
     # ---- passes ----
@@ -386,15 +418,22 @@ class GradScaler:
 
 
 def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', use_probs_loss=False, grad_scale=1.0,
-                 want_text_grad=True, text_grad_out=None):
-    """The classifier head in train mode (``ec_ft_loss_grad``): img_feats fp32 CUDA [B, T, D] with zero rows
-    on invalid views.  Returns (loss, d loss / d img_feats * grad_scale [B, T, D], d loss / d text_param or None,
+                 want_text_grad=True, text_grad_out=None, row_idx=None):
+    """The classifier head in train mode (``ec_ft_loss_grad``).  img_feats fp32 CUDA: [B, T, D] with zero rows on
+    invalid views, or -- with ``row_idx`` int32 [B, T] (-1 = invalid) -- compact [Nv, D] over the valid views.
+    Returns (loss, d loss / d img_feats * grad_scale in the same layout, d loss / d text_param or None,
     aggregated logits [B, K])."""
     dev = _lib.require_gpu()
     if agg not in _AGG:
         raise NotImplementedError(f'agg_func {agg!r}: the reference trains with sum / mean')
     f = img_feats.float().contiguous()
-    B, T, D = f.shape
+    B, T = valid.shape
+    D = f.shape[-1]
+    if row_idx is None:
+        assert tuple(f.shape) == (B, T, D)
+    else:
+        row_idx = row_idx.to(torch.int32).contiguous()
+        assert f.dim() == 2 and tuple(row_idx.shape) == (B, T)
     t = text_param.detach().float().contiguous()
     K = t.shape[0]
     v8 = valid.to(torch.uint8).contiguous()
@@ -402,13 +441,13 @@ def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', 
     need = int(_lib.lib().ec_fs_text_train_workspace_bytes(B, T, D, K)) + max(B * T, K) * D * 4
     ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
-    gimg = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    gimg = torch.zeros_like(f)
     gtext = None
     if want_text_grad:
         gtext = text_grad_out if text_grad_out is not None else torch.empty((K, D), dtype=torch.float32, device=dev)
         assert gtext.is_contiguous() and tuple(gtext.shape) == (K, D) and gtext.dtype == torch.float32
     logits = torch.empty((B, K), dtype=torch.float32, device=dev)
-    rc = _lib.lib().ec_ft_loss_grad(_lib.ptr(f), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
+    rc = _lib.lib().ec_ft_loss_grad(_lib.ptr(f), _lib.ptr(row_idx), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
                                     float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), float(grad_scale),
                                     _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(gimg), _lib.ptr(logits), _lib.ptr(ws),
                                     ws.numel(), _lib.stream_ptr())
@@ -480,6 +519,12 @@ class FTTrainer:
             it.n, it.group = p.numel(), int(k.startswith('model.visual.'))
         self._adam_items = device_table(items) if len(self.tensors) else None
         self._adam_max = max([p.numel() for p in self.tensors.values()] + [0])
+        # the scaler's verdict on a step is read back asynchronously (pinned host word + event) and applied
+        # before the next step needs the scale: the host never waits for the step it has just queued
+        matrices = set(self.tower.matrix_names())
+        self._moved = [n for n in self.visual_train if n in matrices]
+        self._found_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._pending = None
         classifier._tower, classifier._trainer = self.tower, self
         self.last = {}
 
@@ -487,9 +532,14 @@ class FTTrainer:
         return sorted(self.tensors)
 
     def _patches(self, data_dict):
-        valid = data_dict['valid_mask']
+        """-> patches [Nv, G, kpad] of the valid views, valid [B, T], row_idx [B, T] (no host synchronisation when
+        the batch comes with its own 'patches' + 'row_idx', e.g. from Event2ImagePipeline)."""
+        valid = data_dict['valid_mask'].to(self.tower.dev)
         if 'patches' in data_dict:
-            return data_dict['patches'], valid
+            return data_dict['patches'], valid, data_dict['row_idx']
+        flat = valid.reshape(-1)
+        row_idx = torch.where(flat, torch.cumsum(flat.int(), 0) - 1, torch.full_like(flat, -1, dtype=torch.int64))
+        row_idx = row_idx.to(torch.int32).reshape(valid.shape)
         imgs = data_dict['img']
         t = self.tower
         x = imgs[valid].to(t.dev, torch.float32).contiguous()
@@ -498,29 +548,41 @@ class FTTrainer:
         rc = _lib.lib().ec_patchify(_lib.ptr(x), x.shape[0], R, t.P, t.kpad, _lib.ptr(patches), t.code,
                                     _lib.stream_ptr())
         _lib.check(rc, 'ec_patchify')
-        return patches, valid
+        return patches, valid, row_idx
+
+    def resolve(self):
+        """Apply the gradient scaler's verdict on the last queued step (waits for that step if it is still
+        running).  Called by the next ``step``; call it yourself before reading ``last['skipped']``,
+        ``opt_steps`` or ``scaler.scale`` right after a step."""
+        if self._pending is None:
+            return
+        self._pending.synchronize()
+        self._pending = None
+        found = bool(int(self._found_host[0]))
+        if not found:
+            self.opt_steps += 1
+        self.scaler.update(found)
+        self.last['skipped'] = found
 
     @torch.no_grad()
     def step(self, data_dict):
         """data_dict: 'img' [B, T, 3, R, R] (or 'patches' [Nv, G, kpad] of the valid views in (b, t) order),
         'valid_mask' [B, T], 'label' [B].  Returns the loss (0-dim CUDA tensor)."""
         clf, t = self.clf, self.tower
-        patches, valid = self._patches(data_dict)
-        valid = valid.to(t.dev)
+        patches, valid, row_idx = self._patches(data_dict)
         labels = data_dict['label'].to(t.dev)
-        B, T = valid.shape
-        feats = t.forward(patches)                                                  # [Nv, D]
-        full = torch.zeros((B, T, t.D), dtype=torch.float32, device=t.dev)
-        full[valid] = feats                                                         # clip_cls_ft.py:208-209
+        feats = t.forward(patches)                                 # [Nv, D]; scattered by row_idx inside the head
         text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
+        self.resolve()                                # the previous step's verdict: this step's scale
         S = self.scaler.scale
-        loss, gimg, gtext, logits = ft_loss_grad(full, valid, labels, text, clf.logit_scale, clf.agg_func,
+        loss, gimg, gtext, logits = ft_loss_grad(feats, valid, labels, text, clf.logit_scale, clf.agg_func,
                                                  clf.use_probs_loss, grad_scale=S, want_text_grad=clf.prompt_tuning,
-                                                 text_grad_out=self._grads.get('text_feats'))
-        self.last = dict(logits=logits, feats=feats)
+                                                 text_grad_out=self._grads.get('text_feats'), row_idx=row_idx)
+        self.last = dict(logits=logits, feats=feats, grads=self._grads, skipped=False)
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        check = bool(self.want) and self.scaler.enabled
         if self.want:
-            _, flat = t.backward(gimg[valid], self.want)
+            _, flat = t.backward(gimg, self.want)
             if ddp:
                 dist.all_reduce(flat)                 # one collective for the whole tower (RCCL over xGMI)
                 flat /= dist.get_world_size()
@@ -533,29 +595,28 @@ class FTTrainer:
         if clf.prompt_tuning and ddp:
             dist.all_reduce(gtext)
             gtext /= dist.get_world_size()
-        found = bool(self._found.item()) if (self.want and self.scaler.enabled) else False
         lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
         clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
         self.steps += 1
-        if not found and self._adam_items is not None:
-            self.opt_steps += 1
+        if self._adam_items is not None:
             rc = _lib.lib().ec_adam_step_multi(_lib.ptr(self._adam_items), len(self.tensors), self._adam_max, lr, clip_lr,
-                                               self.betas[0], self.betas[1], self.eps, 0., self.opt_steps,
-                                               _lib.stream_ptr())
+                                               self.betas[0], self.betas[1], self.eps, 0., self.opt_steps + 1,
+                                               _lib.ptr(self._found) if check else None, _lib.stream_ptr())
             _lib.check(rc, 'ec_adam_step_multi')
             if self.lora:
                 self.lora.merge()
-            matrices = set(t.matrix_names())
-            moved = [n for n in self.visual_train if n in matrices]
-            if moved:
-                t.pack(moved)
+            if self._moved:
+                t.pack(self._moved)
             else:
                 t.clip._packed = None
             if hasattr(clf, '_invalidate_text_cache'):
                 clf._invalidate_text_cache()
-        self.scaler.update(found)
-        self.last['grads'] = self._grads
-        self.last['skipped'] = found
+        if check:
+            self._found_host.copy_(self._found, non_blocking=True)
+            self._pending = torch.cuda.Event()
+            self._pending.record()
+        else:
+            self.opt_steps += 1
         return loss
 
     def visual_state_dict(self):

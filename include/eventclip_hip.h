@@ -529,7 +529,7 @@ EC_API int ec_sgemm(const float *A, long sam, long sak, const float *B, long sbk
  *   ec_vit_train_backward  d features -> gradients of every visual parameter asked for, in the layouts of
  *                          the state dict (fp32); LoRA and sub-set selection are the caller's (chain rule on
  *                          the merged-weight gradients with ec_sgemm; unused gradients: NULL pointers);
- *   ec_pack_weight16       fp32 master weight -> the 16-bit operand copies the kernels read;
+ *   ec_pack_weight16_batched  fp32 master weights -> the 16-bit operand copies the kernels read;
  *   ec_grad_unscale_check  the gradient-scaler step of mixed-precision training (`--fp16`, train.py:121).
  * Arithmetic: 16-bit MFMA operands (activations, weights, activation gradients), fp32 accumulation, fp32
  * residual-stream gradients, LayerNorm and softmax in fp32 -- what torch.cuda.amp does for the reference.
@@ -574,9 +574,14 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
                                  size_t workspace_bytes, ec_stream_t stream);
 
 /* fp32 [rows, cols] -> any of: hi = round16(w) [rows, cols]; lo = round16(w - hi); hi_t = hi transposed
- * [cols, rows].  NULL outputs are skipped. */
-EC_API int ec_pack_weight16(const float *w, int rows, int cols, void *hi, void *lo, void *hi_t, int dtype,
-                            ec_stream_t stream);
+ * [cols, rows] (NULL outputs are skipped), for a list of same-shape matrices in one launch (`items`: DEVICE array):
+ * what the optimiser moved is repacked once per step. */
+typedef struct {
+    const float *w;
+    void *hi, *lo, *hi_t;
+} ec_pack_item;
+EC_API int ec_pack_weight16_batched(const ec_pack_item *items, int n_items, int rows, int cols, int dtype,
+                                    ec_stream_t stream);
 
 /* LayerNorm backward (fp32): x rows at stride ldx (the forward input), dy rows at stride ldy.
  * dx rows at stride ldo: dx = (accumulate ? dx : 0) + dLN; d_gamma / d_beta [width] (NULL = skip; they need
@@ -587,13 +592,18 @@ EC_API int ec_layernorm_backward(const float *x, long ldx, const float *dy, long
                                  float *d_beta, float *partials, ec_stream_t stream);
 
 /* The classifier head of FTCLIPClassifier in train mode (clip_cls_ft.py:196-256; identity adapter):
- * ec_fs_text_loss_grad plus d loss / d img_feats (fp32 [B, T, D], zero rows for invalid views), scaled by
- * grad_scale (1 = none).  grad_text may be NULL (fixed text features).  Workspace:
- * ec_fs_text_train_workspace_bytes(B, T, D, K) + max(B * T, K) * D * 4 bytes. */
-EC_API int ec_ft_loss_grad(const float *img_feats, const uint8_t *valid, const int32_t *labels,
-                           const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
-                           int use_probs_loss, float grad_scale, float *loss, float *grad_text, float *grad_img,
-                           float *agg_logits, void *workspace, size_t workspace_bytes, ec_stream_t stream);
+ * ec_fs_text_loss_grad plus d loss / d img_feats scaled by grad_scale (1 = none).
+ * row_idx NULL: img_feats / grad_img are fp32 [B, T, D] (zero gradient rows for invalid views).
+ * row_idx int32 [B, T] (row of view (b, t), -1 = invalid view): img_feats / grad_img are compact [Nv, D] over
+ * the valid views, exactly what the encoder produced and what ec_vit_train_backward takes -- the scatter
+ * of :208-209 and its gather in the backward pass never materialise.
+ * grad_text may be NULL (fixed text features).  Workspace: ec_fs_text_train_workspace_bytes(B, T, D, K) +
+ * max(B * T, K) * D * 4 bytes. */
+EC_API int ec_ft_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid,
+                           const int32_t *labels, const float *text_param, int B, int T, int D, int K,
+                           float logit_scale, int agg, int use_probs_loss, float grad_scale, float *loss,
+                           float *grad_text, float *grad_img, float *agg_logits, void *workspace,
+                           size_t workspace_bytes, ec_stream_t stream);
 
 /* LoRA factors (models/lora.py), every injected projection of the tower in one launch.  Per projection:
  * out = base + up @ down (base / out fp32 [rows, cols], up [rows, r], down [r, cols], r <= 64; lora.py:50-52,
@@ -611,7 +621,9 @@ EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows
                                 ec_stream_t stream);
 
 /* ec_adam_step over a list of tensors in one launch (`items`: DEVICE array; group selects lr0 / lr1: the
- * classifier's own parameters vs model.visual, method.py:166-178); max_n = the largest item's n. */
+ * classifier's own parameters vs model.visual, method.py:166-178); max_n = the largest item's n.
+ * skip_flag (device int32 or NULL): when it reads non-zero at execution time nothing is updated -- the
+ * found_inf of ec_grad_unscale_check, so that a dropped mixed-precision step needs no host round trip. */
 typedef struct {
     float *param;
     const float *grad;
@@ -620,7 +632,8 @@ typedef struct {
     int group;
 } ec_adam_item;
 EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
-                              float beta2, float eps, float weight_decay, int step, ec_stream_t stream);
+                              float beta2, float eps, float weight_decay, int step, const int32_t *skip_flag,
+                              ec_stream_t stream);
 
 /* grad *= inv_scale in place; *found_inf (device int32, caller zeroes it once per step) is set when any
  * element is not finite -- torch.cuda.amp.GradScaler.unscale_. */

@@ -175,6 +175,15 @@ def test_pack_weight16(hip, dtype):
     assert torch.equal(hi, w.to(dtype))
     assert torch.equal(lo, (w - w.to(dtype).float()).to(dtype))
     assert torch.equal(hi_t, w.to(dtype).t().contiguous())
+    # a list of same-shape matrices in one launch, outputs optional per matrix
+    ws = [torch.randn(200, 136, device='cuda') for _ in range(3)]
+    his = [torch.empty(200, 136, device='cuda', dtype=dtype) for _ in ws]
+    hts = [torch.empty(136, 200, device='cuda', dtype=dtype) for _ in ws]
+    ft.pack_weights16([(ws[0], his[0], None, hts[0]), (ws[1], None, None, hts[1]), (ws[2], his[2], None, None)],
+                      ops.dtype_code(dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(his[0], ws[0].to(dtype)) and torch.equal(hts[1], ws[1].to(dtype).t().contiguous())
+    assert torch.equal(his[2], ws[2].to(dtype)) and torch.equal(hts[0], ws[0].to(dtype).t().contiguous())
 
 
 def test_sgemm_any_layout(hip):
@@ -231,10 +240,16 @@ def test_adam_over_a_tensor_list_matches_torch(hip):
             r.grad = g.clone()
         opt.step()
         rc = _lib.lib().ec_adam_step_multi(_lib.ptr(table), len(params), max(p.numel() for p in params), 1e-2, 3e-3, 0.9,
-                                           0.999, 1e-8, 0., step, _lib.stream_ptr())
+                                           0.999, 1e-8, 0., step, None, _lib.stream_ptr())
         _lib.check(rc, 'ec_adam_step_multi')
     for p, r in zip(params, ref):
         torch.testing.assert_close(p, r.detach(), rtol=1e-5, atol=1e-6)
+    # a raised skip flag leaves everything untouched
+    flag = torch.ones(1, dtype=torch.int32, device='cuda')
+    keep = [p.clone() for p in params]
+    _lib.check(_lib.lib().ec_adam_step_multi(_lib.ptr(table), len(params), max(p.numel() for p in params), 1e-2, 3e-3, 0.9,
+                                             0.999, 1e-8, 0., 4, _lib.ptr(flag), _lib.stream_ptr()), 'ec_adam_step_multi')
+    assert all(torch.equal(a, b) for a, b in zip(keep, params))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -402,6 +417,7 @@ def test_training_step_matches_the_reference(hip, tag):
     assert tr.trainable_names() == c['trainable']
     data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
     loss = tr.step(data)
+    tr.resolve()
     assert not tr.last['skipped']
     assert abs(float(loss) - float(z[f'{tag}/loss'])) < 2e-3 * max(1.0, abs(float(z[f'{tag}/loss'])))
     np.testing.assert_allclose(tr.last['feats'].cpu().numpy(), z[f'{tag}/feats'], rtol=0,
@@ -436,11 +452,13 @@ def test_gradient_scaler_skips_and_backs_off(hip):
     data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
     before = {k: v.clone() for k, v in tr.tensors.items()}
     tr.step(data)                                   # 2^40 overflows the 16-bit gradients: skipped
+    tr.resolve()
     assert tr.last['skipped'] and tr.scaler.scale == 2.0 ** 39 and tr.opt_steps == 0
     assert all(torch.equal(before[k], v) for k, v in tr.tensors.items())
     tr.scaler.scale = 256.0
     tr.step(data)
     tr.step(data)
+    tr.resolve()
     assert tr.opt_steps == 2 and tr.scaler.scale == 512.0     # two clean steps: growth_interval = 2
     assert any(not torch.equal(before[k], v) for k, v in tr.tensors.items())
 

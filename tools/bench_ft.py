@@ -60,6 +60,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             loss = tr.step(data)
+        tr.resolve()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         prof = _lib.profile_end()
