@@ -143,6 +143,14 @@ class EcVitGrads(ctypes.Structure):
                                         'proj')] + [('blocks', ctypes.POINTER(EcBlockGrads))]
 
 
+class EcBlockLora(ctypes.Structure):
+    _fields_ = [('down16', c_void_p * 4), ('up16_t', c_void_p * 4), ('d_up', c_void_p * 4), ('d_down', c_void_p * 4)]
+
+
+class EcVitLora(ctypes.Structure):
+    _fields_ = [('rank', c_int), ('blocks', ctypes.POINTER(EcBlockLora))]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check that every
 # symbol of the header is exported.
 SIGNATURES = {
@@ -220,8 +228,8 @@ SIGNATURES = {
     'ec_vit_train_forward': (c_int, [ctypes.POINTER(EcVitWeights), c_void_p, c_int, c_void_p, c_void_p,
                                      ctypes.c_size_t, c_void_p]),
     'ec_vit_train_backward': (c_int, [ctypes.POINTER(EcVitWeights), ctypes.POINTER(EcVitTrainWeights), c_void_p,
-                                      c_int, c_void_p, ctypes.POINTER(EcVitGrads), c_void_p, ctypes.c_size_t,
-                                      c_void_p]),
+                                      c_int, c_void_p, ctypes.POINTER(EcVitGrads), ctypes.POINTER(EcVitLora), c_void_p,
+                                      ctypes.c_size_t, c_void_p]),
     'ec_pack_weight16_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_layernorm_backward_partials': (ctypes.c_size_t, [c_int, c_int]),
     'ec_layernorm_backward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float,

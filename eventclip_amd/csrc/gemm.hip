@@ -1107,10 +1107,6 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     bar();
     for (;;) {
         tstamp(2);
-        // rows m0 + 128 wm + 64 .. of this wave all past M?  (uniform per wave; both wave rows agree when the
-        // tile holds at most 64 rows, and a wave row whose rows are all invalid computes zeros anyway)
-        const bool short_tile = g.M - m0 - wm * 128 <= 64;
-        const bool empty_half = g.M - m0 - wm * 128 <= 0;
         if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -1131,11 +1127,9 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 EC_VMCNT(0);
             }
             bar_l();
-            if (!empty_half) mma2(0, 0, fn0, 1, fn1);
+            mma2(0, 0, fn0, 1, fn1);
             bar();
             // ---- phase B ----
-            // (a tile whose rows past the first 64 of each wave half lie beyond M -- the last row of tiles of
-            // a short batch -- skips this phase's MFMAs: half the tile's arithmetic for rows nobody stores)
             load_m(buf, 1);
             if (has2) {
                 issue(0, buf);
@@ -1146,7 +1140,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 EC_VMCNT(2);
             }
             bar_l();
-            if (!short_tile) mma2(1, 1, fn1, 0, fn0);
+            mma2(1, 1, fn1, 0, fn0);
             bar();
         }
         if (wm == 0) bar();   // balance the stagger barrier: every wave is out of the staging buffers

@@ -388,25 +388,41 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const ec_adam_item *ite
     }
 }
 
-// out[i][j] = base[i][j] + sum_k up[i][k] down[k][j]; a thread owns column j of 8 rows
+// out[i][j] = base[i][j] + sum_k up[i][k] down[k][j]; a thread owns four columns of 16 rows, 16 factors at a time
 __global__ __launch_bounds__(256) void lora_merge_kernel(const ec_lora_item *items, int rows, int cols, int r)
 {
     const ec_lora_item it = items[blockIdx.z];
     const float *base = it.base, *up = it.up, *down = it.down;
     float *out = it.out;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= cols) return;
-    float d[LORA_MAXR];
+    const int i0 = blockIdx.y * 16;
+    float4 a[16];
 #pragma unroll
-    for (int k = 0; k < LORA_MAXR; k++) d[k] = k < r ? down[(long)k * cols + j] : 0.f;
-    const int i0 = blockIdx.y * 8;
-    for (int i = i0; i < i0 + 8 && i < rows; i++) {
-        float a = base[(long)i * cols + j];
+    for (int u = 0; u < 16; u++)
+        a[u] = i0 + u < rows ? *reinterpret_cast<const float4 *>(base + (long)(i0 + u) * cols + j)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < r; k0 += 16) {
+        float4 d[16];
 #pragma unroll
-        for (int k = 0; k < LORA_MAXR; k++)
-            if (k < r) a = __builtin_fmaf(up[(long)i * r + k], d[k], a);
-        out[(long)i * cols + j] = a;
+        for (int k = 0; k < 16; k++)
+            d[k] = k0 + k < r ? *reinterpret_cast<const float4 *>(down + (long)(k0 + k) * cols + j)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (i0 + u >= rows) continue;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k0 + k >= r) continue;
+                const float w = up[(long)(i0 + u) * r + k0 + k];      // uniform over the workgroup
+                a[u].x = __builtin_fmaf(w, d[k].x, a[u].x), a[u].y = __builtin_fmaf(w, d[k].y, a[u].y);
+                a[u].z = __builtin_fmaf(w, d[k].z, a[u].z), a[u].w = __builtin_fmaf(w, d[k].w, a[u].w);
+            }
+        }
     }
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+        if (i0 + u < rows) *reinterpret_cast<float4 *>(out + (long)(i0 + u) * cols + j) = a[u];
 }
 
 // d_up[i][k] = sum_j dW[i][j] down[k][j]: a wave takes four rows (each `down` value it loads serves all four),
@@ -450,28 +466,216 @@ __global__ __launch_bounds__(256) void lora_dup_kernel(const ec_lora_item *items
     }
 }
 
-// partial[slab][k][j] = sum over the slab's rows i of up[i][k] dW[i][j]; a thread owns column j
+// partial[slab][k][j] = sum over the slab's rows i of up[i][k] dW[i][j]; a thread owns four columns, 16 factors at
+// a time
 __global__ __launch_bounds__(256) void lora_ddown_kernel(const ec_lora_item *items, int rows, int cols, int r,
                                                          int slab_rows, float *scratch)
 {
     const ec_lora_item it = items[blockIdx.z];
     const float *dW = it.dW, *up = it.up;
     float *partial = scratch + (long)blockIdx.z * gridDim.y * r * cols;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= cols) return;
     const int i0 = blockIdx.y * slab_rows, i1 = i0 + slab_rows < rows ? i0 + slab_rows : rows;
-    float acc[LORA_MAXR];
+    for (int k0 = 0; k0 < r; k0 += 16) {
+        float4 acc[16];
 #pragma unroll
-    for (int k = 0; k < LORA_MAXR; k++) acc[k] = 0.f;
-    for (int i = i0; i < i1; i++) {
-        const float w = dW[(long)i * cols + j];
+        for (int k = 0; k < 16; k++) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = i0; i < i1; i++) {
+            const float4 w = *reinterpret_cast<const float4 *>(dW + (long)i * cols + j);
 #pragma unroll
-        for (int k = 0; k < LORA_MAXR; k++)
-            if (k < r) acc[k] = __builtin_fmaf(up[(long)i * r + k], w, acc[k]);
+            for (int k = 0; k < 16; k++) {
+                if (k0 + k >= r) continue;
+                const float u = up[(long)i * r + k0 + k];             // uniform over the workgroup
+                acc[k].x = __builtin_fmaf(u, w.x, acc[k].x), acc[k].y = __builtin_fmaf(u, w.y, acc[k].y);
+                acc[k].z = __builtin_fmaf(u, w.z, acc[k].z), acc[k].w = __builtin_fmaf(u, w.w, acc[k].w);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k0 + k < r)
+                *reinterpret_cast<float4 *>(partial + ((long)blockIdx.y * r + k0 + k) * cols + j) = acc[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LoRA gradients straight from the activations.  y = x (W + up down)^T, so with P = x down^T and Q = dy up
+// (both [rows, r]):  d up = dy^T P,  d down = Q^T x -- the W x W gradient of the merged weight never exists.
+//   lowrank_project_kernel  out[m][0 .. 16 RT) = In[m][:] . F[.][:]^T  (MFMA: the 16 factors of a tile are
+//                           one 16 x 16 x 32 row block; a wave owns 16 rows of In, read straight from HBM)
+//   lowrank_outer_kernel    partial[slab][k][c] = sum over the slab's rows m of coef[m][k] In[m][c]  (a thread
+//                           owns four feature columns; the 16 coefficients of a row are wave-uniform)
+// Up to four (input, factor) pairs per launch (q, k, v, o of a block).
+// ------------------------------------------------------------------------------------------
+struct ProjectItem {
+    const void *in;     // [M, C] 16-bit at row stride ld
+    long ld;
+    const void *f;      // [16 RT, C] 16-bit factor rows (zero rows past r)
+    float *out;         // [M, 16 RT]
+    int C;
+};
+struct ProjectArgs {
+    ProjectItem it[4];
+    int M, RT;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void lowrank_project_kernel(const ProjectArgs a)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    const ProjectItem it = a.it[blockIdx.y];
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= a.M) return;
+    const int m = m0 + c16 < a.M ? m0 + c16 : a.M - 1;
+    const elem *in = (const elem *)it.in + (long)m * it.ld + g * 8;
+    const elem *f = (const elem *)it.f + (long)c16 * it.C + g * 8;
+    f32x4 acc[4];
 #pragma unroll
-    for (int k = 0; k < LORA_MAXR; k++)
-        if (k < r) partial[((long)blockIdx.y * r + k) * cols + j] = acc[k];
+    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // four 32-wide steps of loads in flight per round (C is a multiple of 64; a lone last pair is done singly)
+    int k0 = 0;
+    for (; k0 + 128 <= it.C; k0 += 128) {
+        v8 x[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            x[u] = *reinterpret_cast<const v8 *>(in + k0 + 32 * u);
+            w[u] = *reinterpret_cast<const v8 *>(f + k0 + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc[0] = mfma16(w[u], x[u], acc[0]);
+#pragma unroll
+            for (int t = 1; t < 4; t++)
+                if (t < a.RT)
+                    acc[t] = mfma16(*reinterpret_cast<const v8 *>(f + (long)t * 16 * it.C + k0 + 32 * u), x[u], acc[t]);
+        }
+    }
+    for (; k0 < it.C; k0 += 32) {
+        const v8 x = *reinterpret_cast<const v8 *>(in + k0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < a.RT) acc[t] = mfma16(*reinterpret_cast<const v8 *>(f + (long)t * 16 * it.C + k0), x, acc[t]);
+    }
+    // acc[t][r] = out[m0 + c16][16 t + 4 g + r]
+    if (m0 + c16 < a.M) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < a.RT) *reinterpret_cast<f32x4 *>(it.out + (long)(m0 + c16) * 16 * a.RT + 16 * t + 4 * g) = acc[t];
+    }
+}
+
+struct OuterItem {
+    const void *in;      // [M, C] 16-bit at row stride ld
+    long ld;
+    const float *coef;   // [M, cstride], the item's r coefficients at column offset 0
+    int cstride;
+    float *partial;      // [slabs][r][C]
+};
+struct OuterArgs {
+    OuterItem it[4];
+    int M, C, r, slab_rows;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void lowrank_outer_kernel(const OuterArgs a)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef elem v2 __attribute__((ext_vector_type(2)));
+    constexpr int ROWS = 64;                     // rows of coefficients staged in LDS at a time
+    __shared__ __attribute__((aligned(16))) float cs[ROWS * 16];
+    const OuterItem it = a.it[blockIdx.z];
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const bool live = c < a.C;
+    const int m0 = blockIdx.y * a.slab_rows, m1 = m0 + a.slab_rows < a.M ? m0 + a.slab_rows : a.M;
+    for (int k0 = 0; k0 < a.r; k0 += 16) {
+        float2 acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = make_float2(0.f, 0.f);
+        for (int mb = m0; mb < m1; mb += ROWS) {
+            const int nrow = m1 - mb < ROWS ? m1 - mb : ROWS;
+            __syncthreads();
+            {   // stage coef[mb .. mb + nrow)[k0 .. k0 + 16): one float4 per thread (64 rows x 4 quads)
+                const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < nrow) {
+                    const float *src = it.coef + (long)(mb + row) * it.cstride + k0 + 4 * q;
+                    if (k0 + 4 * q + 3 < a.r) v = *reinterpret_cast<const float4 *>(src);
+                    else {
+                        if (k0 + 4 * q < a.r) v.x = src[0];
+                        if (k0 + 4 * q + 1 < a.r) v.y = src[1];
+                        if (k0 + 4 * q + 2 < a.r) v.z = src[2];
+                    }
+                }
+                *reinterpret_cast<float4 *>(&cs[row * 16 + 4 * q]) = v;
+            }
+            __syncthreads();
+            if (!live) continue;
+            const elem *in = (const elem *)it.in + (long)mb * it.ld + c;
+            int m = 0;
+            for (; m + 4 <= nrow; m += 4) {
+                v2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const v2 *>(in + (long)(m + u) * it.ld);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float x0 = (float)x[u][0], x1 = (float)x[u][1];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 w = *reinterpret_cast<const float4 *>(&cs[(m + u) * 16 + 4 * q]);
+                        acc[4 * q].x = __builtin_fmaf(w.x, x0, acc[4 * q].x), acc[4 * q].y = __builtin_fmaf(w.x, x1, acc[4 * q].y);
+                        acc[4 * q + 1].x = __builtin_fmaf(w.y, x0, acc[4 * q + 1].x), acc[4 * q + 1].y = __builtin_fmaf(w.y, x1, acc[4 * q + 1].y);
+                        acc[4 * q + 2].x = __builtin_fmaf(w.z, x0, acc[4 * q + 2].x), acc[4 * q + 2].y = __builtin_fmaf(w.z, x1, acc[4 * q + 2].y);
+                        acc[4 * q + 3].x = __builtin_fmaf(w.w, x0, acc[4 * q + 3].x), acc[4 * q + 3].y = __builtin_fmaf(w.w, x1, acc[4 * q + 3].y);
+                    }
+                }
+            }
+            for (; m < nrow; m++) {
+                const v2 x = *reinterpret_cast<const v2 *>(in + (long)m * it.ld);
+                const float x0 = (float)x[0], x1 = (float)x[1];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float w = cs[m * 16 + k];
+                    acc[k].x = __builtin_fmaf(w, x0, acc[k].x), acc[k].y = __builtin_fmaf(w, x1, acc[k].y);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k0 + k < a.r)
+                    *reinterpret_cast<float2 *>(it.partial + ((long)blockIdx.y * a.r + k0 + k) * a.C + c) = acc[k];
+        }
+    }
+}
+
+// out = sum over slabs of partial[slab][r][C], written [r, C] (transposed = 0) or [C, r] (transposed = 1)
+struct OuterReduceArgs {
+    const float *partial[4];
+    float *out[4];
+    int transposed[4];
+    int slabs, r, C;
+};
+__global__ __launch_bounds__(256) void lowrank_reduce_kernel(const OuterReduceArgs a)
+{
+    const float *part = a.partial[blockIdx.y];
+    float *out = a.out[blockIdx.y];
+    const long n = (long)a.r * a.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        int p = 0;
+        for (; p + 8 <= a.slabs; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = part[(p + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; p < a.slabs; p++) s += part[p * n + i];
+        const long k = i / a.C, c = i - k * a.C;
+        out[a.transposed[blockIdx.y] ? c * a.r + k : i] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, float inv_scale, int *found_inf)
@@ -539,6 +743,9 @@ struct TrainBufs {
     void *dx16, *da16, *ta, *tb;
     int Mp, ln_wgs, col_slabs;
     size_t part_floats;
+    // LoRA gradients from the activations: P / Q projections [M, 64] x 4 and the outer products' partial sums
+    float *lr_proj, *lr_part;
+    int lr_slab, lr_slabs;
 };
 
 size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
@@ -582,6 +789,10 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
     b.lnpart = (float *)sc.take((size_t)b.ln_wgs * 2 * W * 4);
     b.col_slabs = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
     b.colpart = (float *)sc.take((size_t)b.col_slabs * 4 * W * 4);
+    b.lr_slab = 256;
+    b.lr_slabs = (int)((M + b.lr_slab - 1) / b.lr_slab);
+    b.lr_proj = (float *)sc.take(M * 64 * 4 * 4);                          // four [M, <= 64] coefficient blocks
+    b.lr_part = (float *)sc.take((size_t)b.lr_slabs * 64 * W * 4 * 4);     // four [slabs, <= 64, W] partial blocks
     return sc.off;
 }
 
@@ -664,6 +875,61 @@ int weight_grad(int dtype, const void *a_t, const void *b_t, int n_out, int n_in
     return reduce(b.part, (long)n_out * n_in, splits, (long)n_out * n_in, out, s);
 }
 
+// ---- LoRA gradients of one block (ec_block_lora): P / Q projections, outer products, reduction ----
+template <int DT> void launch_project(const ProjectArgs &a, int n_items, hipStream_t s)
+{
+    hipLaunchKernelGGL(lowrank_project_kernel<DT>, dim3((unsigned)((a.M + 63) / 64), (unsigned)n_items), dim3(256), 0, s, a);
+}
+template <int DT> void launch_outer(const OuterArgs &a, int n_items, int slabs, hipStream_t s)
+{
+    hipLaunchKernelGGL(lowrank_outer_kernel<DT>, dim3((unsigned)((a.C / 2 + 255) / 256), (unsigned)slabs, (unsigned)n_items),
+                       dim3(256), 0, s, a);
+}
+
+// One group of projections sharing the row count: inputs x_p (what the projection multiplies) and dy_p (the
+// gradient of its output), factors down16_p [16 RT, C] and up16t_p [16 RT, C].  d_up_p [C, r], d_down_p [r, C].
+struct LoraJob {
+    const void *x, *dy;
+    long ldx, ldy;
+    const void *down16, *up16t;
+    float *d_up, *d_down;
+};
+int lora_grads(int dtype, const LoraJob *jobs, int n, int M, int W, int r, const TrainBufs &b, hipStream_t s)
+{
+    const int RT = (r + 15) / 16, PS = 16 * RT;
+    ec::ProfScope prof(ec::PROF_SGEMM, s, 8.0 * M * W * r * n, 4.0 * M * W * n);
+    // P_p = x_p down_p^T into slots 0 .. n-1, Q_p = dy_p up_p into slots 4 .. : [M, PS] each
+    for (int half = 0; half < 2; half++) {
+        ProjectArgs pa;
+        pa.M = M, pa.RT = RT;
+        for (int i = 0; i < n; i++) {
+            ProjectItem &it = pa.it[i];
+            it.in = half ? jobs[i].dy : jobs[i].x, it.ld = half ? jobs[i].ldy : jobs[i].ldx;
+            it.f = half ? jobs[i].up16t : jobs[i].down16, it.C = W;
+        }
+        // (the four coefficient slots are reused: first P -> d_up, then Q -> d_down)
+        OuterArgs oa;
+        oa.M = M, oa.C = W, oa.r = r, oa.slab_rows = b.lr_slab;
+        OuterReduceArgs ra;
+        ra.slabs = b.lr_slabs, ra.r = r, ra.C = W;
+        for (int i = 0; i < n; i++) {
+            pa.it[i].out = b.lr_proj + (size_t)i * M * 64;
+            OuterItem &o = oa.it[i];
+            o.in = half ? jobs[i].x : jobs[i].dy, o.ld = half ? jobs[i].ldx : jobs[i].ldy;
+            o.coef = pa.it[i].out, o.cstride = PS;
+            o.partial = b.lr_part + (size_t)i * b.lr_slabs * 64 * W;
+            ra.partial[i] = o.partial;
+            ra.out[i] = half ? jobs[i].d_down : jobs[i].d_up;
+            ra.transposed[i] = half ? 0 : 1;
+        }
+        if (dtype == EC_F16) launch_project<EC_F16>(pa, n, s), launch_outer<EC_F16>(oa, n, b.lr_slabs, s);
+        else launch_project<EC_BF16>(pa, n, s), launch_outer<EC_BF16>(oa, n, b.lr_slabs, s);
+        hipLaunchKernelGGL(lowrank_reduce_kernel, dim3((unsigned)(((long)r * W + 255) / 256), (unsigned)n), dim3(256), 0, s, ra);
+    }
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 int ln_backward(const float *x, long ldx, const float *dy, long ldy, const float *gamma, int rows, int W, float *dx,
                 long ldo, int accumulate, float *dg, float *db, float *partials, int max_wgs, hipStream_t s)
 {
@@ -735,15 +1001,18 @@ EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, in
 }
 
 EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches, int n_img,
-                                 const float *d_feats, const ec_vit_grads *gr, void *workspace, size_t workspace_bytes,
-                                 ec_stream_t stream)
+                                 const float *d_feats, const ec_vit_grads *gr, const ec_vit_lora *lora, void *workspace,
+                                 size_t workspace_bytes, ec_stream_t stream)
 {
     EC_TRY(check_geometry(w, "ec_vit_train_backward"));
     EC_REQUIRE(n_img > 0, "ec_vit_train_backward: n_img=%d", n_img);
     EC_REQUIRE(wt && wt->blocks && wt->proj && gr && gr->blocks, "ec_vit_train_backward: null weight / gradient structs");
     EC_REQUIRE(patches && d_feats && workspace, "ec_vit_train_backward: null buffer");
+    EC_REQUIRE(!lora || (lora->blocks && lora->rank > 0 && lora->rank <= 64), "ec_vit_train_backward: LoRA rank %d (1 .. 64)",
+               lora ? lora->rank : 0);
     const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype, L = w->layers;
     const int M = n_img * S, D = w->out_dim;
+    auto has_lora = [&](int l, int p) { return lora && lora->blocks[l].d_up[p] != nullptr; };
     Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
     TrainBufs b;
     const size_t need = carve_train(sc, w, n_img, b);
@@ -760,7 +1029,7 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
         for (int l = 0; l < L; l++) {
             const ec_block_grads &q = gr->blocks[l];
             if (q.ln1_g || q.ln1_b || q.qkv_w || q.qkv_b || q.out_w || q.out_b || q.ln2_g || q.ln2_b || q.fc1_w ||
-                q.fc1_b || q.fc2_w || q.fc2_b) {
+                q.fc1_b || q.fc2_w || q.fc2_b || has_lora(l, 0) || has_lora(l, 1) || has_lora(l, 2) || has_lora(l, 3)) {
                 lowest = l;
                 break;
             }
@@ -820,11 +1089,34 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
             if (dt == EC_F16) EC_TRY(bias_grad<_Float16>((const _Float16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
             else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
         }
+        const bool lora_qkv = has_lora(l, 0) || has_lora(l, 1) || has_lora(l, 2);
+        if (q.qkv_w || lora_qkv)
+            EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
         if (q.qkv_w) {
             EC_TRY(transpose<0>(dt, b.g16, 3L * W, M, 3 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
-            EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
             EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
             EC_TRY(weight_grad(dt, b.ta, b.tb, 3 * W, W, b, q.qkv_w, 0, stream));
+        }
+        if (lora_qkv || has_lora(l, 3)) {
+            // q, k, v multiply ln_1(x) and receive dq | dk | dv; out_proj multiplies the attention output and
+            // receives the residual gradient of xm (its 16-bit copy is still in dx16)
+            const ec_block_lora &lb = lora->blocks[l];
+            LoraJob jobs[4];
+            int n = 0;
+            const size_t esz = 2;
+            for (int pj = 0; pj < 4; pj++) {
+                if (!has_lora(l, pj)) continue;
+                EC_REQUIRE(lb.down16[pj] && lb.up16_t[pj] && lb.d_down[pj], "ec_vit_train_backward: block %d LoRA item %d incomplete", l, pj);
+                LoraJob &j = jobs[n++];
+                if (pj < 3) {
+                    j.x = b.h16, j.ldx = W;
+                    j.dy = static_cast<const unsigned char *>(b.g16) + (size_t)pj * W * esz, j.ldy = 3L * W;
+                } else {
+                    j.x = b.att[l], j.ldx = W, j.dy = b.dx16, j.ldy = W;
+                }
+                j.down16 = lb.down16[pj], j.up16t = lb.up16_t[pj], j.d_up = lb.d_up[pj], j.d_down = lb.d_down[pj];
+            }
+            EC_TRY(lora_grads(dt, jobs, n, M, W, lora->rank, b, s));
         }
         if (l == lowest && !q.ln1_g && !q.ln1_b) break;   // nothing below needs d x[l]
         EC_TRY(gemm_x(M, W, 3 * W, dt, EC_EPI_STORE32, b.g16, pt.qkv_wt, b.dh32, nullptr, nullptr, nullptr, stream));
@@ -895,7 +1187,7 @@ EC_API int ec_lora_merge_batched(const ec_lora_item *items, int n_items, int row
     EC_REQUIRE(items, "ec_lora_merge_batched: null item table");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_SGEMM, s, 2.0 * rows * cols * r * n_items, 8.0 * rows * cols * n_items);
-    hipLaunchKernelGGL(lora_merge_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)((rows + 7) / 8), (unsigned)n_items),
+    hipLaunchKernelGGL(lora_merge_kernel, dim3((unsigned)((cols / 4 + 255) / 256), (unsigned)((rows + 15) / 16), (unsigned)n_items),
                        dim3(256), 0, s, items, rows, cols, r);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
@@ -914,12 +1206,12 @@ EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows
                "ec_lora_grad_batched: %d items of %d x %d, r = %d (<= %d)", n_items, rows, cols, r, LORA_MAXR);
     EC_REQUIRE(items && scratch, "ec_lora_grad_batched: null buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int slab = (rows + 15) / 16, slabs = (rows + slab - 1) / slab;
+    const int slab = (rows + 15) / 16, slabs = (rows + slab - 1) / slab;   // 16 slabs: the scratch's size
     const long n = (long)r * cols;
     ec::ProfScope prof(ec::PROF_SGEMM, s, 4.0 * rows * cols * r * n_items, 8.0 * rows * cols * n_items);
     hipLaunchKernelGGL(lora_dup_kernel, dim3((unsigned)((rows + 15) / 16), 1, (unsigned)n_items), dim3(256), 0, s, items, rows,
                        cols, r);
-    hipLaunchKernelGGL(lora_ddown_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)slabs, (unsigned)n_items), dim3(256), 0,
+    hipLaunchKernelGGL(lora_ddown_kernel, dim3((unsigned)((cols / 4 + 255) / 256), (unsigned)slabs, (unsigned)n_items), dim3(256), 0,
                        s, items, rows, cols, r, slab, scratch);
     hipLaunchKernelGGL(lora_ddown_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), (unsigned)n_items), dim3(256), 0, s, items,
                        scratch, slabs, n);

@@ -10,7 +10,7 @@ train.py:121) -- is here three layers over the C ABI:
                   (``ec_pack_weight16``), ``forward`` (``ec_vit_train_forward``) and ``backward``
                   (``ec_vit_train_backward``) returning gradients by state-dict name;
 ``LoraFactors``   the low-rank factors with the reference's key names, the merged weights they act through
-                  (lora.py:138-150, :50-52) and the chain rule back onto them (``ec_lora_merge`` / ``ec_lora_grad``);
+                  (lora.py:138-150, :50-52); their gradients come straight from the activations inside the backward pass;
 ``FTTrainer``     one optimisation step: loss and feature gradients (``ec_ft_loss_grad``), the gradient scaler
                   of mixed precision (``ec_grad_unscale_check``), one all-reduce of the flat gradient buffer
                   across ranks, ``ec_adam_step`` per tensor with the warm-up + cosine schedule.
@@ -237,7 +237,7 @@ class VisualTower:
         key = tuple(want)
         if key not in self._grad_slots:
             sizes = [self.master[n].numel() for n in want]
-            flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=self.dev)
+            flat = torch.zeros((max(sum(sizes), 4),), dtype=torch.float32, device=self.dev)
             views, off = {}, 0
             for n, sz in zip(want, sizes):
                 views[n] = flat[off:off + sz].view(self.master[n].shape)
@@ -245,9 +245,9 @@ class VisualTower:
             self._grad_slots[key] = (flat, views)
         return self._grad_slots[key]
 
-    def backward(self, d_feats, want):
+    def backward(self, d_feats, want, lora=None):
         """d_feats fp32 [N, D] -> {name: gradient} for the state-dict names in ``want`` (views of one flat
-        buffer, also returned)."""
+        buffer, also returned).  lora: an ``EcVitLora`` whose factor gradients are written alongside."""
         assert self._tape is not None, 'backward without a forward'
         patches, n = self._tape
         assert d_feats.is_cuda and d_feats.dtype == torch.float32 and tuple(d_feats.shape) == (n, self.D)
@@ -268,8 +268,9 @@ class VisualTower:
         g.blocks = ctypes.cast(bg, ctypes.POINTER(_lib.EcBlockGrads))
         ws = self._workspace(n)
         rc = _lib.lib().ec_vit_train_backward(ctypes.byref(self._vit), ctypes.byref(self._vit_t), _lib.ptr(patches), n,
-                                              _lib.ptr(d_feats), ctypes.byref(g), _lib.ptr(ws), ws.numel(),
-                                              _lib.stream_ptr())
+                                              _lib.ptr(d_feats), ctypes.byref(g),
+                                              ctypes.byref(lora) if lora is not None else None, _lib.ptr(ws),
+                                              ws.numel(), _lib.stream_ptr())
         _lib.check(rc, 'ec_vit_train_backward')
         return views, flat
 
@@ -343,43 +344,60 @@ class LoraFactors:
                 out.append((i, None, pre + '.out_proj.lora_down.weight', pre + '.out_proj.lora_up.weight'))
         return out
 
-    def bind(self, grad_views, factor_grads):
-        """Build the device item table once: every pointer (masters, merged scratch, the flat gradient buffer's
-        views, the factor gradients) is stable for the life of the trainer."""
-        t, W = self.tower, self.tower.W
+    def bind(self, factor_grads):
+        """Build the item tables and the gradient struct once: every pointer (masters, merged scratch, the
+        factors, their 16-bit operand copies and gradients) is stable for the life of the trainer."""
+        t, W, r = self.tower, self.tower.W, self.r
         proj = self.projections()
         items = (_lib.EcLoraItem * len(proj))()
+        rp = (r + 15) // 16 * 16
+        # 16-bit operand copies for the backward pass: down [r, W] and up^T [r, W], rows padded to 16 with zeros
+        self.down16 = {kd: torch.zeros((rp, W), dtype=t.cd, device=t.dev) for _, _, kd, _ in proj}
+        self.up16t = {ku: torch.zeros((rp, W), dtype=t.cd, device=t.dev) for _, _, _, ku in proj}
+        blocks = (_lib.EcBlockLora * t.L)()
         for it, (i, j, kd, ku) in zip(items, proj):
             pre = _block_name(i, 'attn')
             name = pre + ('.in_proj_weight' if j is not None else '.out_proj.weight')
             rows = slice(j * W, (j + 1) * W) if j is not None else slice(None)
             it.base = t.master[name][rows].data_ptr()
             it.out = t.effective[name][rows].data_ptr()
-            it.dW = grad_views[name][rows].data_ptr()
             it.up, it.down = self.params[ku].data_ptr(), self.params[kd].data_ptr()
-            it.d_up, it.d_down = factor_grads[ku].data_ptr(), factor_grads[kd].data_ptr()
+            slot = 3 if j is None else j
+            blocks[i].down16[slot], blocks[i].up16_t[slot] = self.down16[kd].data_ptr(), self.up16t[ku].data_ptr()
+            blocks[i].d_up[slot], blocks[i].d_down[slot] = factor_grads[ku].data_ptr(), factor_grads[kd].data_ptr()
         self._n_items = len(proj)
         self._items = device_table(items)
-        need = int(_lib.lib().ec_lora_grad_scratch_floats(self._n_items, W, W, self.r))
-        self._scratch = torch.empty((need,), dtype=torch.float32, device=t.dev)
+        self._blocks = blocks
+        self.struct = _lib.EcVitLora()
+        self.struct.rank = r
+        self.struct.blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.EcBlockLora))
+        self._pack_down = [(self.params[kd], self.down16[kd], None, None) for _, _, kd, _ in proj]
+        self._pack_up = [(self.params[ku], None, None, self.up16t[ku]) for _, _, _, ku in proj]
+        self._pack_tables = None
         if not self.lora_k:       # the k rows of in_proj carry no factors: their merged rows are the base rows
             for i in range(t.L):
                 n = _block_name(i, 'attn.in_proj_weight')
                 t.effective[n][W:2 * W].copy_(t.master[n][W:2 * W])
 
     def merge(self):
-        """effective = base + up @ down for every projection (lora.py:138-150, :50-52), then repack those matrices."""
+        """effective = base + up @ down for every projection (lora.py:138-150, :50-52) and the repack of those
+        matrices; the factors' own 16-bit copies (the backward pass's operands) follow."""
         t = self.tower
         rc = _lib.lib().ec_lora_merge_batched(_lib.ptr(self._items), self._n_items, t.W, t.W, self.r, _lib.stream_ptr())
         _lib.check(rc, 'ec_lora_merge_batched')
         t.pack(self.merged_names)
-
-    def chain(self):
-        """Merged-weight gradients (in the flat buffer) -> factor gradients: d up = dW down^T, d down = up^T dW."""
-        t = self.tower
-        rc = _lib.lib().ec_lora_grad_batched(_lib.ptr(self._items), self._n_items, t.W, t.W, self.r,
-                                             _lib.ptr(self._scratch), _lib.stream_ptr())
-        _lib.check(rc, 'ec_lora_grad_batched')
+        if self._pack_tables is None:
+            def table(jobs):
+                items = (_lib.EcPackItem * len(jobs))()
+                for it, (w, hi, lo, hi_t) in zip(items, jobs):
+                    it.w = w.data_ptr()
+                    it.hi = hi.data_ptr() if hi is not None else None
+                    it.hi_t = hi_t.data_ptr() if hi_t is not None else None
+                return device_table(items)
+            self._pack_tables = (table(self._pack_down), table(self._pack_up))
+        for tbl, (rows, cols) in zip(self._pack_tables, ((self.r, t.W), (t.W, self.r))):
+            rc = _lib.lib().ec_pack_weight16_batched(_lib.ptr(tbl), self._n_items, rows, cols, t.code, _lib.stream_ptr())
+            _lib.check(rc, 'ec_pack_weight16_batched')
 
     def state_dict_entries(self):
         """The tower's attention entries as the reference's LoRA-injected modules name them."""
@@ -494,21 +512,25 @@ class FTTrainer:
         self.opt_steps = 0        # optimiser steps actually taken (a skipped step does not advance Adam)
         # what the tower has to differentiate: the trainable masters + the merged matrices LoRA acts through
         self.want = list(self.visual_train)
-        if self.lora:
-            self.want += [n for n in self.lora.merged_names if n not in self.want]
         self._found = torch.zeros((1,), dtype=torch.int32, device=self.tower.dev)
-        self._lora_grads = {n: torch.zeros_like(p) for n, p in self.lora.params.items()} if self.lora else {}
+        self._lora_grads = {}
+        if self.lora:                                   # the factor gradients share one flat buffer too
+            total = sum(p.numel() for p in self.lora.params.values())
+            self._lora_flat = torch.zeros((total,), dtype=torch.float32, device=self.tower.dev)
+            off = 0
+            for n, p in self.lora.params.items():
+                self._lora_grads[n] = self._lora_flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
         # gradients live at fixed addresses: views of the tower's flat buffer, the factor gradients, text_feats'
         self._grads = {}
-        if self.want:
-            self._flat, views = self.tower.grad_buffer(self.want)
-            for n in self.visual_train:
-                self._grads['model.visual.' + n] = views[n]
-            if self.lora:
-                self.lora.bind(views, self._lora_grads)
-                for n, g in self._lora_grads.items():
-                    self._grads['model.visual.' + n] = g
-                self.lora.merge()
+        self._flat, views = self.tower.grad_buffer(self.want)
+        for n in self.visual_train:
+            self._grads['model.visual.' + n] = views[n]
+        if self.lora:
+            self.lora.bind(self._lora_grads)
+            for n, g in self._lora_grads.items():
+                self._grads['model.visual.' + n] = g
+            self.lora.merge()
         if classifier.prompt_tuning:
             self._grads['text_feats'] = torch.zeros_like(classifier.text_feats.data)
         items = (_lib.EcAdamItem * len(self.tensors))()
@@ -580,18 +602,18 @@ class FTTrainer:
                                                  text_grad_out=self._grads.get('text_feats'), row_idx=row_idx)
         self.last = dict(logits=logits, feats=feats, grads=self._grads, skipped=False)
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        check = bool(self.want) and self.scaler.enabled
-        if self.want:
-            _, flat = t.backward(gimg, self.want)
-            if ddp:
-                dist.all_reduce(flat)                 # one collective for the whole tower (RCCL over xGMI)
-                flat /= dist.get_world_size()
+        through_tower = bool(self.want) or self.lora is not None
+        check = through_tower and self.scaler.enabled
+        if through_tower:
+            _, flat = t.backward(gimg, self.want, self.lora.struct if self.lora else None)
             self._found.zero_()
-            rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(flat), flat.numel(), 1.0 / S, _lib.ptr(self._found),
-                                                  _lib.stream_ptr())
-            _lib.check(rc, 'ec_grad_unscale_check')
-            if self.lora:
-                self.lora.chain()
+            for buf in ([flat] if self.want else []) + ([self._lora_flat] if self.lora else []):
+                if ddp:
+                    dist.all_reduce(buf)              # one collective per flat buffer (RCCL over xGMI)
+                    buf /= dist.get_world_size()
+                rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(buf), buf.numel(), 1.0 / S, _lib.ptr(self._found),
+                                                      _lib.stream_ptr())
+                _lib.check(rc, 'ec_grad_unscale_check')
         if clf.prompt_tuning and ddp:
             dist.all_reduce(gtext)
             gtext /= dist.get_world_size()

@@ -563,6 +563,21 @@ typedef struct {
     const ec_block_grads *blocks;     /* host array [layers] */
 } ec_vit_grads;
 
+/* LoRA factors of the attention projections (models/lora.py), differentiated straight from the activations:
+ * y = x (W + up down)^T gives d up = dy^T (x down^T) and d down = (dy up)^T x, two rank-r products per
+ * projection -- the W x W gradient of the merged weight is never formed.  Index 0 .. 3 = q, k, v, out_proj;
+ * a projection without factors has d_up NULL.  down16: the factor [r, W] as 16 bit, rows padded with zeros to a
+ * multiple of 16; up16_t: up TRANSPOSED [r, W], padded the same way (ec_pack_weight16_batched writes both);
+ * d_up [W, r] and d_down [r, W]: fp32 out, the factors' own layouts. */
+typedef struct {
+    const void *down16[4], *up16_t[4];
+    float *d_up[4], *d_down[4];
+} ec_block_lora;
+typedef struct {
+    int rank;                        /* r <= 64 */
+    const ec_block_lora *blocks;     /* host array [layers] */
+} ec_vit_lora;
+
 /* bytes of workspace for n_img images: the saved activations + the backward pass's scratch.  The forward
  * call fills it, the backward call must get the same buffer back untouched. */
 EC_API size_t ec_vit_train_workspace_bytes(const ec_vit_weights *w, int n_img);
@@ -570,7 +585,8 @@ EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, in
                                 void *workspace, size_t workspace_bytes, ec_stream_t stream);
 /* d_feats fp32 [n_img, out_dim].  patches: the forward call's input (conv1's gradient reads it). */
 EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches,
-                                 int n_img, const float *d_feats, const ec_vit_grads *grads, void *workspace,
+                                 int n_img, const float *d_feats, const ec_vit_grads *grads,
+                                 const ec_vit_lora *lora /* NULL = none */, void *workspace,
                                  size_t workspace_bytes, ec_stream_t stream);
 
 /* fp32 [rows, cols] -> any of: hi = round16(w) [rows, cols]; lo = round16(w - hi); hi_t = hi transposed
