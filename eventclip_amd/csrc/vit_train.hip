@@ -956,6 +956,65 @@ int gemm_x(int M, int N, int K, int dtype, int epi, const void *A, const void *W
     return ec_gemm(&g, s);
 }
 
+// C[m0 + m][n] = (resid ? resid : 0) + bias[n] + sum over K-batches of partial[s][m][n]
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float *partial, int splits, int rows, int N, const float *bias,
+                                                         const float *resid, float *C)
+{
+    const long n4 = (long)rows * N / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int col = (int)((i * 4) % N);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < splits; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial + (long)p * rows * N + i * 4);
+            a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4 *>(resid + i * 4);
+            a.x += r.x, a.y += r.y, a.z += r.z, a.w += r.w;
+        }
+        *reinterpret_cast<float4 *>(C + i * 4) = a;
+    }
+}
+
+// fp32-output GEMM (STORE32 / RESID32) over a row count that leaves a short last row of tiles, K >= 2048.  The
+// persistent kernel would spend a whole extra round on those few tiles, each streaming all of K alone (its K loop
+// is latency bound: +64 us at K = 4096 whatever the row count).  Here the full row tiles go through one launch and the
+// last `rem` rows through a second one cut into K-batches -- tiles_n x splits workgroups, each a fraction of K --
+// whose fp32 partial sums a small kernel adds up with bias and residual.  (The rows of the tail see a different
+// summation order than rows elsewhere in the batch: fine for training, not used on the inference path, whose results
+// do not depend on where in a batch a frame sits.)
+int gemm_rows32(int M, int N, int K, int dtype, int epi, const void *A, const void *W, float *C, const float *resid,
+                const float *bias, float *partial, size_t partial_floats, ec_stream_t stream)
+{
+    const int cus = ec::cu_count();
+    const int rem = M % 256, full = M - rem, tiles_n = (N + 255) / 256;
+    const long tiles_main = (long)(full / 256) * tiles_n;
+    const bool extra_round = cus > 0 && full > 0 && rem > 0 && rem <= 128 &&
+                             (tiles_main + cus - 1) / cus < (tiles_main + tiles_n + cus - 1) / cus;
+    int splits = 1;
+    if (extra_round && K >= 2048)
+        while (splits < 8 && tiles_n * splits * 2 <= cus && (K / 64) % (splits * 2) == 0 && K / (splits * 2) >= 256) splits *= 2;
+    if (splits < 2 || (size_t)splits * rem * N > partial_floats || (epi != EC_EPI_STORE32 && epi != EC_EPI_RESID32))
+        return gemm_x(M, N, K, dtype, epi, A, W, C, resid, nullptr, bias, stream);
+    const size_t esz = 2;
+    EC_TRY(gemm_x(full, N, K, dtype, epi, A, W, C, resid, nullptr, bias, stream));
+    ec_gemm_args g = {};
+    g.M = rem, g.N = N, g.K = K / splits, g.dtype = dtype, g.epilogue = EC_EPI_STORE32, g.variant = 0;
+    g.A = static_cast<const unsigned char *>(A) + (size_t)full * K * esz, g.lda = K, g.W = W, g.ldw = K;
+    g.C = partial, g.ldc = N, g.splits = splits, g.split_stride = (long)rem * N;
+    EC_TRY(ec_gemm(&g, stream));
+    const float *rsrc = epi == EC_EPI_RESID32 ? (resid ? resid : C) + (size_t)full * N : nullptr;
+    const long n4 = (long)rem * N / 4;
+    hipLaunchKernelGGL(tail_fixup_kernel, dim3((unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), partial, splits, rem, N, bias, rsrc, C + (size_t)full * N);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -993,7 +1052,8 @@ EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, in
         EC_TRY(gemm_x(M, W, W, dt, EC_EPI_RESID32, b.att[l], p.out_w, b.xm[l], b.x[l], nullptr, p.out_b, stream));
         EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h16, W, dt, stream));
         EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h16, p.fc1_w, b.g16, nullptr, b.u[l], p.fc1_b, stream));
-        EC_TRY(gemm_x(M, W, 4 * W, dt, EC_EPI_RESID32, b.g16, p.fc2_w, b.x[l + 1], b.xm[l], nullptr, p.fc2_b, stream));
+        EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_RESID32, b.g16, p.fc2_w, b.x[l + 1], b.xm[l], p.fc2_b, b.part,
+                           b.part_floats, stream));
     }
     EC_TRY(ec_layernorm_split(b.x[L], (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n_img, W, LN_EPS, b.cls_hi,
                               b.cls_lo, W, dt, stream));
@@ -1073,7 +1133,8 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
             EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
             EC_TRY(weight_grad(dt, b.ta, b.tb, 4 * W, W, b, q.fc1_w, 0, stream));
         }
-        EC_TRY(gemm_x(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, nullptr, stream));
+        EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, b.part,
+                           b.part_floats, stream));
         EC_TRY(ln_backward(b.xm[l], W, b.dh32, W, p.ln2_g, M, W, b.dx, W, 1, q.ln2_g, q.ln2_b, b.lnpart, b.ln_wgs, s));
         // xm = x[l] + out_proj(attention(in_proj(ln_1(x[l]))))
         EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, q.out_w ? b.ta : nullptr, b.dx16, s));
@@ -1119,7 +1180,8 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
             EC_TRY(lora_grads(dt, jobs, n, M, W, lora->rank, b, s));
         }
         if (l == lowest && !q.ln1_g && !q.ln1_b) break;   // nothing below needs d x[l]
-        EC_TRY(gemm_x(M, W, 3 * W, dt, EC_EPI_STORE32, b.g16, pt.qkv_wt, b.dh32, nullptr, nullptr, nullptr, stream));
+        EC_TRY(gemm_rows32(M, W, 3 * W, dt, EC_EPI_STORE32, b.g16, pt.qkv_wt, b.dh32, nullptr, nullptr, b.part,
+                           b.part_floats, stream));
         EC_TRY(ln_backward(b.x[l], W, b.dh32, W, p.ln1_g, M, W, b.dx, W, 1, q.ln1_g, q.ln1_b, b.lnpart, b.ln_wgs, s));
     }
     if (lowest >= 0) return EC_OK;
