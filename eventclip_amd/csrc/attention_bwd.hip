@@ -361,17 +361,21 @@ template <int DT> int launch_bwd(const BwdArgs &a, int n_seq, hipStream_t s)
     const int SP = 32 * ((a.S + 31) / 32);
     const int CP = SP < CHUNK ? SP : CHUNK;
     const int lds_dq = 3 * CP * 128, lds_dkv = 4 * CP * 128 + 2 * CP * 4;
-    // 8 waves: the dK / dV body needs 171 registers, which two waves per SIMD have and four do not
-    void (*kq)(const BwdArgs) = attention_dq_kernel<DT, 8>;
-    void (*kkv)(const BwdArgs) = attention_dkv_kernel<DT, 8>;
+    // One workgroup per CU (the images fill the LDS), so the wave count decides how many passes the ceil(S / 16) row
+    // tiles take: 17 tiles (S = 257) are three passes of 8 waves -- the last with one wave busy -- but two passes of 9.
+    // Registers allow three waves per SIMD for the dQ body (133) and, held to 168, for the dK / dV body.
+    const int n_t = (a.S + 15) / 16;
+    const bool nine = lds_dq > 80 * 1024 && (n_t + 8) / 9 < (n_t + 7) / 8;
+    void (*kq)(const BwdArgs) = nine ? attention_dq_kernel<DT, 9> : attention_dq_kernel<DT, 8>;
+    void (*kkv)(const BwdArgs) = nine ? attention_dkv_kernel<DT, 9> : attention_dkv_kernel<DT, 8>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kq), 160 * 1024)) return rc;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kkv), 160 * 1024)) return rc;
     const unsigned grid = (unsigned)a.heads * (unsigned)n_seq;
     // 3 + 4 score-sized products of 2 S^2 64 flops per head; reads q k v o dO, writes dq dk dv
     ec::ProfScope prof(ec::PROF_ATTENTION_BWD, s, 14.0 * a.S * a.S * 64.0 * a.heads * n_seq,
                        (double)n_seq * a.S * a.W * 2.0 * 8.0);
-    hipLaunchKernelGGL(kq, dim3(grid), dim3(512), lds_dq, s, a);
-    hipLaunchKernelGGL(kkv, dim3(grid), dim3(512), lds_dkv, s, a);
+    hipLaunchKernelGGL(kq, dim3(grid), dim3(nine ? 576 : 512), lds_dq, s, a);
+    hipLaunchKernelGGL(kkv, dim3(grid), dim3(nine ? 576 : 512), lds_dkv, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -109,10 +109,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void *src, long ld
 // d_gamma / d_beta: per-lane column sums over the rows a workgroup walks, reduced over its 4 waves in
 // LDS, one partial row pair per workgroup (summed by reduce_kernel in a fixed order).
 // ------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *x, long ldx, const float *dy, long ldy,
                                                      const float *gamma, int rows, int width, float eps, float *dx,
-                                                     long ldo, int accumulate, float *partials)
+                                                     long ldo, int accumulate, float *partials, void *dx16)
 {
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v4 v4;
     __shared__ float red[3][2 * LN_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = units(width, lane);
@@ -167,6 +170,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *x, long ldx, c
                 r.z += rstd * (d[i].z - s1 - v[i].z * s2);
                 r.w += rstd * (d[i].w - s1 - v[i].w * s2);
                 *reinterpret_cast<float4 *>(o) = r;
+                if (dx16) {   // the 16-bit copy the next dX GEMM reads (same row stride)
+                    const v4 h = {to16(r.x, elem()), to16(r.y, elem()), to16(r.z, elem()), to16(r.w, elem())};
+                    *reinterpret_cast<v4 *>((elem *)dx16 + row * ldo + (i * 64 + lane) * 4) = h;
+                }
             }
     }
     if (!partials) return;
@@ -931,15 +938,20 @@ int lora_grads(int dtype, const LoraJob *jobs, int n, int M, int W, int r, const
 }
 
 int ln_backward(const float *x, long ldx, const float *dy, long ldy, const float *gamma, int rows, int W, float *dx,
-                long ldo, int accumulate, float *dg, float *db, float *partials, int max_wgs, hipStream_t s)
+                long ldo, int accumulate, float *dg, float *db, float *partials, int max_wgs, hipStream_t s,
+                void *dx16 = nullptr, int dtype = EC_F16)
 {
     int wgs = (rows + 3) / 4;
     if (wgs > max_wgs) wgs = max_wgs;
     const bool want = dg || db;
     {
         ec::ProfScope prof(ec::PROF_LN_BWD, s, 0, (double)rows * W * (accumulate ? 16.0 : 12.0));
-        hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W, LN_EPS, dx, ldo,
-                           accumulate, want ? partials : (float *)nullptr);
+        if (dtype == EC_BF16)
+            hipLaunchKernelGGL(ln_bwd_kernel<EC_BF16>, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W,
+                               LN_EPS, dx, ldo, accumulate, want ? partials : (float *)nullptr, dx16);
+        else
+            hipLaunchKernelGGL(ln_bwd_kernel<EC_F16>, dim3((unsigned)wgs), dim3(256), 0, s, x, ldx, dy, ldy, gamma, rows, W,
+                               LN_EPS, dx, ldo, accumulate, want ? partials : (float *)nullptr, dx16);
     }
     EC_CHECK_HIP(hipGetLastError());
     if (dg) EC_TRY(reduce(partials, 2L * W, wgs, W, dg, s));
@@ -1105,9 +1117,12 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
     if (lowest == L && !gr->ln_post_g && !gr->ln_post_b) return EC_OK;
     // d cls_ln[n, W] = d_feats . proj^T
     EC_TRY(ec_sgemm(d_feats, D, 1, wt->proj, 1, D, n_img, W, D, 1.f, 0.f, b.dclsln, W, stream));
+    // the residual-stream gradient starts as zero except for the class rows; its 16-bit copy (the dX GEMMs'
+    // operand) is written by whichever kernel last touched dx
     EC_CHECK_HIP(hipMemsetAsync(b.dx, 0, (size_t)M * W * 4, s));
+    EC_CHECK_HIP(hipMemsetAsync(b.dx16, 0, (size_t)M * W * 2, s));
     EC_TRY(ln_backward(b.x[L], ldc, b.dclsln, W, w->ln_post_g, n_img, W, b.dx, ldc, 0, gr->ln_post_g, gr->ln_post_b,
-                       b.lnpart, b.ln_wgs, s));
+                       b.lnpart, b.ln_wgs, s, b.dx16, dt));
 
     // ---- blocks, last to first; b.dx = d loss / d x[l + 1] on entry ----
     for (int l = L - 1; l >= 0 && l >= lowest; l--) {
@@ -1116,7 +1131,7 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
         const ec_block_grads &q = gr->blocks[l];
         EC_REQUIRE(pt.qkv_wt && pt.out_wt && pt.fc1_wt && pt.fc2_wt, "ec_vit_train_backward: block %d lacks transposed weights", l);
         // x[l + 1] = xm + c_proj(QuickGELU(c_fc(ln_2(xm))))
-        EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, q.fc2_w ? b.ta : nullptr, b.dx16, s));
+        if (q.fc2_w) EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, b.ta, nullptr, s));
         if (q.fc2_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.fc2_b, s));
         if (q.fc2_w) {
             EC_TRY(transpose<1>(dt, b.u[l], 4L * W, M, 4 * W, Mp, 0, 0, 0, b.tb, nullptr, s));
@@ -1135,9 +1150,10 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
         }
         EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, b.part,
                            b.part_floats, stream));
-        EC_TRY(ln_backward(b.xm[l], W, b.dh32, W, p.ln2_g, M, W, b.dx, W, 1, q.ln2_g, q.ln2_b, b.lnpart, b.ln_wgs, s));
+        EC_TRY(ln_backward(b.xm[l], W, b.dh32, W, p.ln2_g, M, W, b.dx, W, 1, q.ln2_g, q.ln2_b, b.lnpart, b.ln_wgs, s, b.dx16,
+                           dt));
         // xm = x[l] + out_proj(attention(in_proj(ln_1(x[l]))))
-        EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, q.out_w ? b.ta : nullptr, b.dx16, s));
+        if (q.out_w) EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, b.ta, nullptr, s));
         if (q.out_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.out_b, s));
         if (q.out_w) {
             EC_TRY(transpose<0>(dt, b.att[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
@@ -1182,7 +1198,8 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
         if (l == lowest && !q.ln1_g && !q.ln1_b) break;   // nothing below needs d x[l]
         EC_TRY(gemm_rows32(M, W, 3 * W, dt, EC_EPI_STORE32, b.g16, pt.qkv_wt, b.dh32, nullptr, nullptr, b.part,
                            b.part_floats, stream));
-        EC_TRY(ln_backward(b.x[l], W, b.dh32, W, p.ln1_g, M, W, b.dx, W, 1, q.ln1_g, q.ln1_b, b.lnpart, b.ln_wgs, s));
+        EC_TRY(ln_backward(b.x[l], W, b.dh32, W, p.ln1_g, M, W, b.dx, W, 1, q.ln1_g, q.ln1_b, b.lnpart, b.ln_wgs, s, b.dx16,
+                           dt));
     }
     if (lowest >= 0) return EC_OK;
 
