@@ -297,6 +297,41 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float *part, long str
         *reinterpret_cast<float4 *>(out + i) = s;
     }
 }
+// The same sum when there are MANY partial rows and few columns (LayerNorm's per-workgroup partials, the bias
+// gradients' row slabs): a workgroup owns 64 columns, its 16 thread rows walk the partials 16 apart, LDS adds them up
+// in a fixed order.
+__global__ __launch_bounds__(256) void reduce_tall_kernel(const float *part, long stride, int P, long n, float *out)
+{
+    __shared__ float4 red[16][16];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long i = ((long)blockIdx.x * 16 + cg) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        int p = rl;
+        for (; p + 48 < P; p += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4 *>(part + (long)(p + 16 * u) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 4; u++) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+        }
+        for (; p < P; p += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (long)p * stride + i);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    }
+    red[rl][cg] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+#pragma unroll
+        for (int r = 1; r < 16; r++) {
+            const float4 v = red[r][cg];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i) = s;
+    }
+}
+
 // conv1: the patch row is [hi | lo | 0], so d conv1.weight[w][c] = sum_p (part[w][c] + part[w][k + c])
 __global__ __launch_bounds__(256) void reduce_conv_kernel(const float *part, long stride, int P, int W, int k, int kpad,
                                                           float *out)
@@ -838,6 +873,11 @@ int reduce(const float *part, long stride, int P, long n, float *out, hipStream_
     if (n % 4 != 0 || stride % 4 != 0) return ec::fail(EC_ERR_INVALID, "reduce: %ld elements at stride %ld", n, stride);
     const long blocks = (n / 4 + 255) / 256;
     ec::ProfScope prof(ec::PROF_REDUCE, s, 0, 4.0 * n * (P + 1));
+    if (P >= 64 && n <= 65536) {
+        hipLaunchKernelGGL(reduce_tall_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, s, part, stride, P, n, out);
+        EC_CHECK_HIP(hipGetLastError());
+        return EC_OK;
+    }
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, part, stride, P, n,
                        out);
     EC_CHECK_HIP(hipGetLastError());
