@@ -517,3 +517,23 @@ def test_eval_between_steps_uses_the_trained_weights(hip):
     fresh.load_state_dict(ckpt)
     fresh.eval()
     torch.testing.assert_close(fresh(data)['logits'], after, rtol=2e-3, atol=2e-3 * float(after.abs().max()))
+
+
+@pytest.mark.parametrize('mode', ['full', 'lora'])
+def test_two_ranks_average_their_gradients(hip, mode):
+    """FTTrainer under torch.distributed (two gloo ranks sharing the GPU): one all-reduce of the flat gradient
+    buffer per step makes the ranks' step equal to a single process stepping on the whole batch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29547', 'tools/ft_ddp_check.py', mode]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['world'] == 2 and not d['skipped'] and d['tensors'] > 10
+    assert abs(d['loss_mean_of_ranks'] - d['loss_whole']) < 1e-3 * max(1.0, abs(d['loss_whole']))
+    # the ranks' averaged gradients are the whole batch's (16-bit operands: not bit for bit)
+    assert d['worst_grad_rel_l2'] < 1e-2, d
