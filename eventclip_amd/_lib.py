@@ -230,6 +230,9 @@ SIGNATURES = {
     'ec_vit_train_backward': (c_int, [ctypes.POINTER(EcVitWeights), ctypes.POINTER(EcVitTrainWeights), c_void_p,
                                       c_int, c_void_p, ctypes.POINTER(EcVitGrads), ctypes.POINTER(EcVitLora), c_void_p,
                                       ctypes.c_size_t, c_void_p]),
+    'ec_vit_train_backward_stages': (c_int, [ctypes.POINTER(EcVitWeights), ctypes.POINTER(EcVitTrainWeights), c_void_p,
+                                             c_int, c_void_p, ctypes.POINTER(EcVitGrads), ctypes.POINTER(EcVitLora), c_int,
+                                             c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     'ec_pack_weight16_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_layernorm_backward_partials': (ctypes.c_size_t, [c_int, c_int]),
     'ec_layernorm_backward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float,

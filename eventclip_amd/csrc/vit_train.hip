@@ -1116,7 +1116,21 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
                                  const float *d_feats, const ec_vit_grads *gr, const ec_vit_lora *lora, void *workspace,
                                  size_t workspace_bytes, ec_stream_t stream)
 {
+    return ec_vit_train_backward_stages(w, wt, patches, n_img, d_feats, gr, lora, 0, w ? w->layers + 2 : 0, workspace,
+                                        workspace_bytes, stream);
+}
+
+// Stages: 0 = the head (ln_post, proj), 1 .. L = blocks L - 1 .. 0, L + 1 = the embedding.  The state between
+// stages (the residual-stream gradient and its 16-bit copy) lives in the workspace, so a caller can run a few
+// blocks, hand their finished gradients to a collective on another stream, and carry on.
+EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches,
+                                        int n_img, const float *d_feats, const ec_vit_grads *gr, const ec_vit_lora *lora,
+                                        int stage_begin, int stage_end, void *workspace, size_t workspace_bytes,
+                                        ec_stream_t stream)
+{
     EC_TRY(check_geometry(w, "ec_vit_train_backward"));
+    EC_REQUIRE(stage_begin >= 0 && stage_begin <= stage_end && stage_end <= w->layers + 2,
+               "ec_vit_train_backward: stages %d .. %d of %d", stage_begin, stage_end, w->layers + 2);
     EC_REQUIRE(n_img > 0, "ec_vit_train_backward: n_img=%d", n_img);
     EC_REQUIRE(wt && wt->blocks && wt->proj && gr && gr->blocks, "ec_vit_train_backward: null weight / gradient structs");
     EC_REQUIRE(patches && d_feats && workspace, "ec_vit_train_backward: null buffer");
@@ -1149,23 +1163,30 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
 
     // ---- head: feats = ln_post(x[:, 0]) @ proj ----
     const long ldc = (long)S * W;
-    hipLaunchKernelGGL(ln_f32_kernel, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, s, b.x[L], ldc, w->ln_post_g,
-                       w->ln_post_b, n_img, W, LN_EPS, b.clsln, (long)W);
-    EC_CHECK_HIP(hipGetLastError());
-    if (gr->proj)   // d proj[W, D] = cls_ln^T . d_feats
-        EC_TRY(ec_sgemm(b.clsln, 1, W, d_feats, D, 1, W, D, n_img, 1.f, 0.f, gr->proj, D, stream));
-    if (lowest == L && !gr->ln_post_g && !gr->ln_post_b) return EC_OK;
-    // d cls_ln[n, W] = d_feats . proj^T
-    EC_TRY(ec_sgemm(d_feats, D, 1, wt->proj, 1, D, n_img, W, D, 1.f, 0.f, b.dclsln, W, stream));
-    // the residual-stream gradient starts as zero except for the class rows; its 16-bit copy (the dX GEMMs'
-    // operand) is written by whichever kernel last touched dx
-    EC_CHECK_HIP(hipMemsetAsync(b.dx, 0, (size_t)M * W * 4, s));
-    EC_CHECK_HIP(hipMemsetAsync(b.dx16, 0, (size_t)M * W * 2, s));
-    EC_TRY(ln_backward(b.x[L], ldc, b.dclsln, W, w->ln_post_g, n_img, W, b.dx, ldc, 0, gr->ln_post_g, gr->ln_post_b,
-                       b.lnpart, b.ln_wgs, s, b.dx16, dt));
+    const bool below_head = lowest < L || gr->ln_post_g || gr->ln_post_b;
+    if (stage_begin == 0 && stage_end > 0) {
+        hipLaunchKernelGGL(ln_f32_kernel, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, s, b.x[L], ldc, w->ln_post_g,
+                           w->ln_post_b, n_img, W, LN_EPS, b.clsln, (long)W);
+        EC_CHECK_HIP(hipGetLastError());
+        if (gr->proj)   // d proj[W, D] = cls_ln^T . d_feats
+            EC_TRY(ec_sgemm(b.clsln, 1, W, d_feats, D, 1, W, D, n_img, 1.f, 0.f, gr->proj, D, stream));
+        if (below_head) {
+            // d cls_ln[n, W] = d_feats . proj^T
+            EC_TRY(ec_sgemm(d_feats, D, 1, wt->proj, 1, D, n_img, W, D, 1.f, 0.f, b.dclsln, W, stream));
+            // the residual-stream gradient starts as zero except for the class rows; its 16-bit copy (the dX GEMMs'
+            // operand) is written by whichever kernel last touched dx
+            EC_CHECK_HIP(hipMemsetAsync(b.dx, 0, (size_t)M * W * 4, s));
+            EC_CHECK_HIP(hipMemsetAsync(b.dx16, 0, (size_t)M * W * 2, s));
+            EC_TRY(ln_backward(b.x[L], ldc, b.dclsln, W, w->ln_post_g, n_img, W, b.dx, ldc, 0, gr->ln_post_g,
+                               gr->ln_post_b, b.lnpart, b.ln_wgs, s, b.dx16, dt));
+        }
+    }
+    if (!below_head) return EC_OK;
 
     // ---- blocks, last to first; b.dx = d loss / d x[l + 1] on entry ----
     for (int l = L - 1; l >= 0 && l >= lowest; l--) {
+        if (L - l < stage_begin) continue;
+        if (L - l >= stage_end) return EC_OK;
         const ec_block_weights &p = w->blocks[l];
         const ec_block_weights_t &pt = wt->blocks[l];
         const ec_block_grads &q = gr->blocks[l];
@@ -1241,7 +1262,7 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
         EC_TRY(ln_backward(b.x[l], W, b.dh32, W, p.ln1_g, M, W, b.dx, W, 1, q.ln1_g, q.ln1_b, b.lnpart, b.ln_wgs, s, b.dx16,
                            dt));
     }
-    if (lowest >= 0) return EC_OK;
+    if (lowest >= 0 || stage_end <= L + 1) return EC_OK;
 
     // ---- embedding: x[0] = ln_pre([cls; patches . conv1^T] + pos) ----
     EC_TRY(ln_backward(b.pre, W, b.dx, W, w->ln_pre_g, M, W, b.dh32, W, 0, gr->ln_pre_g, gr->ln_pre_b, b.lnpart, b.ln_wgs,

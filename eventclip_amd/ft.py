@@ -128,6 +128,7 @@ class VisualTower:
         self._ws = None
         self._tape = None
         self._grad_slots = {}
+        self._grad_structs = {}
 
     # ---- structs ----
     def _build_structs(self):
@@ -245,34 +246,91 @@ class VisualTower:
             self._grad_slots[key] = (flat, views)
         return self._grad_slots[key]
 
-    def backward(self, d_feats, want, lora=None):
+    def _grad_struct(self, want):
+        """(EcVitGrads over the flat buffer's views, views, flat, {name: (offset, numel)}) for a want list, cached."""
+        key = tuple(want)
+        if key not in self._grad_structs:
+            flat, views = self.grad_buffer(want)
+            bg = (_lib.EcBlockGrads * self.L)()
+            g = _lib.EcVitGrads()
+            top = {leaf: f for f, leaf in _TOP}
+            blk = {leaf: f for f, leaf in _BLOCK}
+            spans, off = {}, 0
+            for name, t in views.items():
+                spans[name] = (off, t.numel())
+                off += t.numel()
+                if name in top:
+                    setattr(g, top[name], t.data_ptr())
+                else:
+                    m = re.match(r'^transformer\.resblocks\.(\d+)\.(.+)$', name)
+                    if not m or m.group(2) not in blk:
+                        raise KeyError(f'{name!r} is not a parameter of the vision tower')
+                    setattr(bg[int(m.group(1))], blk[m.group(2)], t.data_ptr())
+            g.blocks = ctypes.cast(bg, ctypes.POINTER(_lib.EcBlockGrads))
+            self._grad_structs[key] = (g, bg, views, flat, spans)
+        g, _, views, flat, spans = self._grad_structs[key]
+        return g, views, flat, spans
+
+    def backward(self, d_feats, want, lora=None, stages=None):
         """d_feats fp32 [N, D] -> {name: gradient} for the state-dict names in ``want`` (views of one flat
-        buffer, also returned).  lora: an ``EcVitLora`` whose factor gradients are written alongside."""
+        buffer, also returned).  lora: an ``EcVitLora`` whose factor gradients are written alongside.
+        stages = (begin, end): only that part of the pass (0 = head, 1 .. L = blocks L - 1 .. 0, L + 1 = the
+        embedding; ``ec_vit_train_backward_stages``), for a gradient exchange overlapped with the rest."""
         assert self._tape is not None, 'backward without a forward'
         patches, n = self._tape
         assert d_feats.is_cuda and d_feats.dtype == torch.float32 and tuple(d_feats.shape) == (n, self.D)
-        d_feats = d_feats.contiguous()
-        flat, views = self.grad_buffer(want)
-        bg = (_lib.EcBlockGrads * self.L)()
-        g = _lib.EcVitGrads()
-        top = {leaf: f for f, leaf in _TOP}
-        blk = {leaf: f for f, leaf in _BLOCK}
-        for name, t in views.items():
-            if name in top:
-                setattr(g, top[name], t.data_ptr())
-            else:
-                m = re.match(r'^transformer\.resblocks\.(\d+)\.(.+)$', name)
-                if not m or m.group(2) not in blk:
-                    raise KeyError(f'{name!r} is not a parameter of the vision tower')
-                setattr(bg[int(m.group(1))], blk[m.group(2)], t.data_ptr())
-        g.blocks = ctypes.cast(bg, ctypes.POINTER(_lib.EcBlockGrads))
+        assert d_feats.is_contiguous()
+        g, views, flat, _ = self._grad_struct(want)
+        sb, se = (0, self.L + 2) if stages is None else stages
         ws = self._workspace(n)
-        rc = _lib.lib().ec_vit_train_backward(ctypes.byref(self._vit), ctypes.byref(self._vit_t), _lib.ptr(patches), n,
-                                              _lib.ptr(d_feats), ctypes.byref(g),
-                                              ctypes.byref(lora) if lora is not None else None, _lib.ptr(ws),
-                                              ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, 'ec_vit_train_backward')
+        rc = _lib.lib().ec_vit_train_backward_stages(ctypes.byref(self._vit), ctypes.byref(self._vit_t), _lib.ptr(patches),
+                                                     n, _lib.ptr(d_feats), ctypes.byref(g),
+                                                     ctypes.byref(lora) if lora is not None else None, int(sb), int(se),
+                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, 'ec_vit_train_backward_stages')
         return views, flat
+
+    def canonical(self, names):
+        """The names in gradient-buffer order: embedding | blocks 0 .. L-1 | head, so that the part of the buffer a
+        stretch of the backward pass completes is one contiguous slice."""
+        emb = ('conv1.weight', 'class_embedding', 'positional_embedding', 'ln_pre.weight', 'ln_pre.bias')
+        head = ('ln_post.weight', 'ln_post.bias', 'proj')
+        leaf = {lf: i for i, (_, lf) in enumerate(_BLOCK)}
+
+        def rank(n):
+            if n in emb:
+                return (0, 0, emb.index(n))
+            if n in head:
+                return (2, 0, head.index(n))
+            m = re.match(r'^transformer\.resblocks\.(\d+)\.(.+)$', n)
+            if not m or m.group(2) not in leaf:
+                raise KeyError(f'{n!r} is not a parameter of the vision tower')
+            return (1, int(m.group(1)), leaf[m.group(2)])
+        return sorted(names, key=rank)
+
+    def bucket_plan(self, want, blocks_per_bucket=4):
+        """[(stage_begin, stage_end, flat_lo, flat_hi)]: the backward pass cut into the head, groups of
+        ``blocks_per_bucket`` blocks (last block first) and the embedding, each with the contiguous slice of the flat
+        gradient buffer it completes (the buffer follows the state dict's order: embedding | blocks 0 .. L-1 | head)."""
+        assert list(want) == self.canonical(want), 'bucket_plan needs the names in canonical() order'
+        _, _, _, spans = self._grad_struct(want)
+
+        def span(pred):
+            hit = [spans[n] for n in want if pred(n)]
+            return (min(o for o, _ in hit), max(o + c for o, c in hit)) if hit else (0, 0)
+
+        def block_of(n):
+            m = re.match(r'^transformer\.resblocks\.(\d+)\.', n)
+            return int(m.group(1)) if m else None
+        L, plan = self.L, []
+        plan.append((0, 1) + span(lambda n: n in ('ln_post.weight', 'ln_post.bias', 'proj')))
+        hi = L - 1
+        while hi >= 0:
+            lo = max(hi - blocks_per_bucket + 1, 0)
+            plan.append((L - hi, L - lo + 1) + span(lambda n, lo=lo, hi=hi: block_of(n) is not None and lo <= block_of(n) <= hi))
+            hi = lo - 1
+        plan.append((L + 1, L + 2) + span(lambda n: block_of(n) is None and n not in ('ln_post.weight', 'ln_post.bias', 'proj')))
+        return plan
 
 
 # ---- which tensors train, LoRA ------------------------------------------------------------------------
@@ -483,7 +541,7 @@ class FTTrainer:
 
     def __init__(self, classifier, lr, clip_lr=None, total_steps=1000, warmup_steps_pct=0.05, optimizer='Adam',
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0., mixed_precision=True, init_scale=65536.0,
-                 growth_interval=2000):
+                 growth_interval=2000, blocks_per_bucket=4):
         if optimizer.lower() not in ('adam', 'adamw'):
             raise ValueError('Should use Adam or AdamW optimizer!')                     # method.py:160
         assert weight_decay == 0.                                                       # method.py:161
@@ -511,7 +569,7 @@ class FTTrainer:
         self.steps = 0            # scheduler steps (every call, as the reference steps its scheduler)
         self.opt_steps = 0        # optimiser steps actually taken (a skipped step does not advance Adam)
         # what the tower has to differentiate: the trainable masters + the merged matrices LoRA acts through
-        self.want = list(self.visual_train)
+        self.want = self.tower.canonical(self.visual_train)
         self._found = torch.zeros((1,), dtype=torch.int32, device=self.tower.dev)
         self._lora_grads = {}
         if self.lora:                                   # the factor gradients share one flat buffer too
@@ -545,6 +603,7 @@ class FTTrainer:
         # before the next step needs the scale: the host never waits for the step it has just queued
         matrices = set(self.tower.matrix_names())
         self._moved = [n for n in self.visual_train if n in matrices]
+        self._buckets = self.tower.bucket_plan(self.want, blocks_per_bucket) if self.want else []
         self._found_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self._pending = None
         classifier._tower, classifier._trainer = self.tower, self
@@ -605,18 +664,31 @@ class FTTrainer:
         through_tower = bool(self.want) or self.lora is not None
         check = through_tower and self.scaler.enabled
         if through_tower:
-            _, flat = t.backward(gimg, self.want, self.lora.struct if self.lora else None)
+            lora_struct = self.lora.struct if self.lora else None
+            world = dist.get_world_size() if ddp else 1
+            if ddp and self.want:
+                # DistributedDataParallel's bucketed exchange: a few blocks of the backward pass, then the all-reduce
+                # of the slice of the flat buffer they completed starts on the collective's stream (RCCL over xGMI)
+                # while the next blocks compute; everything is waited for before the optimiser reads it
+                works, flat = [], self._flat
+                for sb, se, lo, hi in self._buckets:
+                    t.backward(gimg, self.want, lora_struct, stages=(sb, se))
+                    if hi > lo:
+                        works.append(dist.all_reduce(flat[lo:hi], async_op=True))
+                for wk in works:
+                    wk.wait()
+            else:
+                _, flat = t.backward(gimg, self.want, lora_struct)
             self._found.zero_()
             for buf in ([flat] if self.want else []) + ([self._lora_flat] if self.lora else []):
-                if ddp:
-                    dist.all_reduce(buf)              # one collective per flat buffer (RCCL over xGMI)
-                    buf /= dist.get_world_size()
-                rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(buf), buf.numel(), 1.0 / S, _lib.ptr(self._found),
-                                                      _lib.stream_ptr())
+                if ddp and buf is not flat:
+                    dist.all_reduce(buf)              # the LoRA factors' gradients: one small collective
+                rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(buf), buf.numel(), 1.0 / (S * world),
+                                                      _lib.ptr(self._found), _lib.stream_ptr())
                 _lib.check(rc, 'ec_grad_unscale_check')
         if clf.prompt_tuning and ddp:
             dist.all_reduce(gtext)
-            gtext /= dist.get_world_size()
+            gtext /= dist.get_world_size()      # (not scaled: the head's text gradient never sees the loss scale)
         lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
         clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
         self.steps += 1

@@ -589,6 +589,16 @@ EC_API int ec_vit_train_backward(const ec_vit_weights *w, const ec_vit_train_wei
                                  const ec_vit_lora *lora /* NULL = none */, void *workspace,
                                  size_t workspace_bytes, ec_stream_t stream);
 
+/* The same pass in pieces: stage 0 = the head (ln_post, proj), stages 1 .. layers = blocks layers - 1 .. 0, stage
+ * layers + 1 = the embedding; [stage_begin, stage_end) of them run, in order, and the state in between lives in
+ * the workspace.  For data-parallel training the caller runs a few blocks, starts the all-reduce of their
+ * (finished) slice of the gradient buffer on the collective's own stream, and carries on with the next blocks:
+ * the bucketed, overlapped gradient exchange of DistributedDataParallel (train.py --ddp). */
+EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_train_weights *wt, const void *patches,
+                                        int n_img, const float *d_feats, const ec_vit_grads *grads,
+                                        const ec_vit_lora *lora, int stage_begin, int stage_end, void *workspace,
+                                        size_t workspace_bytes, ec_stream_t stream);
+
 /* fp32 [rows, cols] -> any of: hi = round16(w) [rows, cols]; lo = round16(w - hi); hi_t = hi transposed
  * [cols, rows] (NULL outputs are skipped), for a list of same-shape matrices in one launch (`items`: DEVICE array):
  * what the optimiser moved is repacked once per step. */

@@ -339,6 +339,36 @@ def test_tower_gradients_match_the_oracle(hip, name, dtype):
     assert not bad, bad
 
 
+def test_gradients_at_the_full_depth_of_vit_l14(hip):
+    """All 24 blocks of ViT-L/14 (the shipped fine-tuning configs' tower), two frames, against fp32 autograd of the
+    oracle tower: the error of the 16-bit backward pass does not grow with depth beyond the tolerance."""
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-L/14')
+    model, tower, sd = _tower(cfg, seed=4)
+    torch.manual_seed(7)
+    n = 2
+    imgs = torch.randn(n, 3, 224, 224)
+    d_feats = torch.randn(n, cfg['embed_dim'])
+    leaves = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith('visual.')}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    clip_ref.encode_image_autograd(leaves, cfg, imgs).backward(d_feats)
+    names = list(tower.master)
+    tower.forward(_patchify(tower, imgs))
+    grads, flat = tower.backward(d_feats.cuda(), names)
+    assert torch.isfinite(flat).all()
+    worst = ('', 0.0)
+    for k in names:
+        if k.endswith('attn.in_proj_bias'):
+            continue
+        ref = leaves['visual.' + k].grad
+        got = grads[k].reshape(ref.shape)
+        e = rel_l2(got, ref)
+        assert e < GRAD_REL and cosine(got, ref) > 0.9995, (k, e)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print('worst relative l2 over', len(names), 'tensors:', worst)
+
+
 def test_k_batched_tail_rows_of_a_reference_sized_batch(hip):
     """64 frames of ViT-L/14 are 64.25 row tiles: the K >= 2048 GEMMs send the last 64 rows through K-batches
     (csrc/vit_train.hip: gemm_rows32).  Features stay within fp32 reordering of the inference path, and the
@@ -369,6 +399,37 @@ def test_k_batched_tail_rows_of_a_reference_sized_batch(hip):
         if k.endswith('attn.in_proj_bias'):
             continue                                   # zero key-bias gradient: see the tower test
         assert rel_l2(whole[k], halves[k]) < 2e-3, (k, rel_l2(whole[k], halves[k]))
+
+
+@pytest.mark.parametrize('subset', ['all', 'bias', 'blocks_1_2'])
+def test_staged_backward_is_the_single_pass_and_its_buckets_tile_the_gradient_buffer(hip, subset):
+    cfg, n = CONFIGS['wide_odd']
+    model, tower, sd = _tower(cfg, seed=2)
+    torch.manual_seed(6)
+    imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
+    d_feats = torch.randn(n, cfg['embed_dim'], device='cuda')
+    patches = _patchify(tower, imgs)
+    want = {'all': list(tower.master), 'bias': [k for k in tower.master if 'bias' in k],
+            'blocks_1_2': [k for k in tower.master if '.1.' in k or '.2.' in k]}[subset]
+    want = tower.canonical(want)
+    tower.forward(patches)
+    _, flat = tower.backward(d_feats, want)
+    whole = flat.clone()
+    plan = tower.bucket_plan(want, blocks_per_bucket=2)
+    assert [p[:2] for p in plan] == [(0, 1), (1, 3), (3, 4), (4, 5)]          # head | blocks 2, 1 | block 0 | embedding
+    covered = sorted((lo, hi) for _, _, lo, hi in plan if hi > lo)
+    total = sum(tower.master[k].numel() for k in want)
+    assert covered[0][0] == 0 and covered[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))            # contiguous, no overlap
+    tower.forward(patches)
+    flat.fill_(float('nan'))
+    seen = torch.zeros_like(flat, dtype=torch.bool)
+    for sb, se, lo, hi in plan:
+        tower.backward(d_feats, want, stages=(sb, se))
+        seen[lo:hi] = True
+        # what this stage completed is final: equal to the single pass already
+        assert torch.equal(flat[lo:hi], whole[lo:hi]), (sb, se)
+    assert bool(seen[:total].all()) and torch.equal(flat[:total], whole[:total])
 
 
 def test_skipping_gradients_does_not_change_the_ones_asked_for(hip):
