@@ -69,6 +69,7 @@ class EcGemmArgs(ctypes.Structure):
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
 EC_EPI_GELU16_SAVE, EC_EPI_GELU_BWD16 = 4, 5
+EC_STEP_LR0, EC_STEP_LR1, EC_STEP_BC1, EC_STEP_BC2_SQRT, EC_STEP_GRAD_SCALE, EC_STEP_INV_SCALE, EC_STEP_COUNT = 0, 1, 2, 3, 4, 5, 8
 EC_PRE_CHW_F32, EC_PRE_PATCHES16, EC_PRE_HWC_U8 = 0, 1, 2
 EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
 
@@ -238,14 +239,15 @@ SIGNATURES = {
     'ec_layernorm_backward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_float,
                                       c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ec_ft_loss_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                                c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 ctypes.c_size_t, c_void_p]),
-    'ec_grad_unscale_check': (c_int, [c_void_p, ctypes.c_int64, c_float, c_void_p, c_void_p]),
+    'ec_grad_unscale_check': (c_int, [c_void_p, ctypes.c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     'ec_lora_merge_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_lora_grad_scratch_floats': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     'ec_lora_grad_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ec_adam_step_multi': (c_int, [c_void_p, c_int, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float,
-                                   c_float, c_int, c_void_p, c_void_p]),
+                                   c_float, c_int, c_void_p, c_void_p, c_void_p]),
+
 }
 
 _lib = None

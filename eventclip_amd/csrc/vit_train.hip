@@ -415,9 +415,11 @@ __global__ __launch_bounds__(256) void lora_ddown_reduce_kernel(const ec_lora_it
 
 // torch.optim.Adam over a list of tensors in one launch: blockIdx.y = tensor
 __global__ __launch_bounds__(256) void adam_multi_kernel(const ec_adam_item *items, float lr0, float lr1, float b1, float b2,
-                                                         float eps, float wd, float bc1, float bc2_sqrt, const int *skip)
+                                                         float eps, float wd, float bc1, float bc2_sqrt, const int *skip,
+                                                         const float *scalars)
 {
     if (skip && *skip) return;     // a non-finite gradient somewhere: the whole step is dropped (GradScaler.step)
+    if (scalars) lr0 = scalars[EC_STEP_LR0], lr1 = scalars[EC_STEP_LR1], bc1 = scalars[EC_STEP_BC1], bc2_sqrt = scalars[EC_STEP_BC2_SQRT];
     const ec_adam_item it = items[blockIdx.y];
     const float lr = it.group ? lr1 : lr0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (long)gridDim.x * 256) {
@@ -720,8 +722,10 @@ __global__ __launch_bounds__(256) void lowrank_reduce_kernel(const OuterReduceAr
     }
 }
 
-__global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, float inv_scale, int *found_inf)
+__global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, float inv_scale, int *found_inf,
+                                                            const float *scalars)
 {
+    if (scalars) inv_scale = scalars[EC_STEP_INV_SCALE];
     bool bad = false;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = g[i] * inv_scale;
@@ -735,10 +739,11 @@ __global__ __launch_bounds__(256) void unscale_check_kernel(float *g, long n, fl
 // (row_idx: feats / dfeats hold the valid views only, view r lives in row row_idx[r]; invalid views have no row)
 __global__ __launch_bounds__(256) void feat_grad_kernel(const float *feats, const float *fn, const float *dfn,
                                                         const unsigned char *valid, const int *row_idx, int R, int D,
-                                                        float scale, float *dfeats)
+                                                        float scale, float *dfeats, const float *scalars)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
+    if (scalars) scale = scalars[EC_STEP_GRAD_SCALE];
     if (row_idx && !valid[r]) return;
     const long row = row_idx ? row_idx[r] : r;
     float s = 0.f, dot = 0.f;
@@ -1361,9 +1366,10 @@ EC_API int ec_lora_grad_batched(const ec_lora_item *items, int n_items, int rows
 
 EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
                               float beta2, float eps, float weight_decay, int step, const int32_t *skip_flag,
-                              ec_stream_t stream)
+                              const float *step_scalars, ec_stream_t stream)
 {
-    EC_REQUIRE(n_items >= 0 && max_n >= 0 && step >= 1, "ec_adam_step_multi: n_items=%d step=%d", n_items, step);
+    EC_REQUIRE(n_items >= 0 && max_n >= 0 && (step >= 1 || step_scalars), "ec_adam_step_multi: n_items=%d step=%d", n_items, step);
+    if (step < 1) step = 1;      // the bias corrections come from step_scalars
     if (n_items == 0 || max_n == 0) return EC_OK;
     EC_REQUIRE(items, "ec_adam_step_multi: null item table");
     const double bc1 = 1.0 - __builtin_pow((double)beta1, (double)step);
@@ -1372,12 +1378,13 @@ EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t ma
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_OPTIMIZER, s, 0, 0);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512), (unsigned)n_items), dim3(256), 0, s,
-                       items, lr0, lr1, beta1, beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2), skip_flag);
+                       items, lr0, lr1, beta1, beta2, eps, weight_decay, (float)bc1, (float)__builtin_sqrt(bc2), skip_flag, step_scalars);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
 
-EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf, ec_stream_t stream)
+EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf, const float *step_scalars,
+                                 ec_stream_t stream)
 {
     EC_REQUIRE(n >= 0, "ec_grad_unscale_check: n=%lld", (long long)n);
     if (n == 0) return EC_OK;
@@ -1385,14 +1392,14 @@ EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_
     const long blocks = (n + 255) / 256;
     ec::ProfScope prof(ec::PROF_OPTIMIZER, static_cast<hipStream_t>(stream), 0, 8.0 * n);
     hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad, (long)n, inv_scale, found_inf);
+                       static_cast<hipStream_t>(stream), grad, (long)n, inv_scale, found_inf, step_scalars);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
 
 EC_API int ec_ft_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid, const int32_t *labels,
                            const float *text_param, int B, int T, int D, int K, float logit_scale, int agg,
-                           int use_probs_loss, float grad_scale,
+                           int use_probs_loss, float grad_scale, const float *step_scalars,
                            float *loss, float *grad_text, float *grad_img, float *agg_logits, void *workspace,
                            size_t workspace_bytes, ec_stream_t stream)
 {
@@ -1415,7 +1422,7 @@ EC_API int ec_ft_loss_grad(const float *img_feats, const int32_t *row_idx, const
     // dFn[R, D] = logit_scale * dL[R, K] . u[K, D]
     EC_TRY(ec_sgemm(dL, K, 1, u, D, 1, (int)R, D, K, logit_scale, 0.f, dfn, D, stream));
     hipLaunchKernelGGL(feat_grad_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       img_feats, Fn, dfn, valid, row_idx, (int)R, D, grad_scale, grad_img);
+                       img_feats, Fn, dfn, valid, row_idx, (int)R, D, grad_scale, grad_img, step_scalars);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -179,24 +179,31 @@ class VisualTower:
                     n = _block_name(i, leaf)
                     if f in _MATRICES and n in todo:
                         groups.setdefault(tuple(src(n).shape), []).append((src(n), pk[(i, f)], None, pk[(i, f, 't')]))
+            if 'conv1.weight' in todo:          # -> hi / lo of the [W, 3 p^2] matrix; laid out against the patch row below
+                groups.setdefault(('conv',), []).append((src('conv1.weight').reshape(self.W, self.k), pk['conv_hi_tmp'],
+                                                         pk['conv_lo_tmp'], None))
+            if 'proj' in todo:
+                groups.setdefault(('proj',), []).append((src('proj'), None, pk['proj_lo_tmp'], pk['proj_t']))
             plan = []
-            for (rows, cols), jobs in groups.items():
+            for jobs in groups.values():
+                rows, cols = jobs[0][0].shape
                 items = (_lib.EcPackItem * len(jobs))()
                 for it, (w, hi, lo, hi_t) in zip(items, jobs):
-                    it.w, it.hi, it.hi_t = w.data_ptr(), hi.data_ptr(), hi_t.data_ptr()
+                    assert w.is_contiguous() and w.dtype == torch.float32
+                    it.w = w.data_ptr()
+                    it.hi = hi.data_ptr() if hi is not None else None
+                    it.lo = lo.data_ptr() if lo is not None else None
+                    it.hi_t = hi_t.data_ptr() if hi_t is not None else None
                 plan.append((device_table(items), len(jobs), rows, cols))
             self._pack_plans[todo] = plan
         for table, n, rows, cols in plan:
             rc = _lib.lib().ec_pack_weight16_batched(_lib.ptr(table), n, rows, cols, self.code, _lib.stream_ptr())
             _lib.check(rc, 'ec_pack_weight16_batched')
         if 'conv1.weight' in todo:
-            w = src('conv1.weight').reshape(self.W, self.k)
-            pack_weight16(w, self.code, hi=pk['conv_hi_tmp'], lo=pk['conv_lo_tmp'])
             pk['conv'][:, :self.k] = pk['conv_hi_tmp']                          # [w_hi | w_hi | 0]
             pk['conv'][:, self.k:2 * self.k] = pk['conv_hi_tmp']
             pk['conv_lo'][:, :self.k] = pk['conv_lo_tmp']                       # [w_lo | 0]
         if 'proj' in todo:
-            pack_weight16(src('proj'), self.code, lo=pk['proj_lo_tmp'], hi_t=pk['proj_t'])
             pk['proj_lo_t'].copy_(pk['proj_lo_tmp'].t())
         self.clip._packed = None       # the inference copies of clip.py are stale once a master moved
 
@@ -494,7 +501,7 @@ class GradScaler:
 
 
 def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', use_probs_loss=False, grad_scale=1.0,
-                 want_text_grad=True, text_grad_out=None, row_idx=None):
+                 want_text_grad=True, text_grad_out=None, row_idx=None, step_scalars=None):
     """The classifier head in train mode (``ec_ft_loss_grad``).  img_feats fp32 CUDA: [B, T, D] with zero rows on
     invalid views, or -- with ``row_idx`` int32 [B, T] (-1 = invalid) -- compact [Nv, D] over the valid views.
     Returns (loss, d loss / d img_feats * grad_scale in the same layout, d loss / d text_param or None,
@@ -525,7 +532,8 @@ def ft_loss_grad(img_feats, valid, labels, text_param, logit_scale, agg='mean', 
     logits = torch.empty((B, K), dtype=torch.float32, device=dev)
     rc = _lib.lib().ec_ft_loss_grad(_lib.ptr(f), _lib.ptr(row_idx), _lib.ptr(v8), _lib.ptr(lab), _lib.ptr(t), B, T, D, K,
                                     float(logit_scale), _AGG[agg], int(bool(use_probs_loss)), float(grad_scale),
-                                    _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(gimg), _lib.ptr(logits), _lib.ptr(ws),
+                                    _lib.ptr(step_scalars), _lib.ptr(loss), _lib.ptr(gtext), _lib.ptr(gimg),
+                                    _lib.ptr(logits), _lib.ptr(ws),
                                     ws.numel(), _lib.stream_ptr())
     _lib.check(rc, 'ec_ft_loss_grad')
     return loss[0], gimg, gtext, logits
@@ -541,7 +549,7 @@ class FTTrainer:
 
     def __init__(self, classifier, lr, clip_lr=None, total_steps=1000, warmup_steps_pct=0.05, optimizer='Adam',
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0., mixed_precision=True, init_scale=65536.0,
-                 growth_interval=2000, blocks_per_bucket=4):
+                 growth_interval=2000, blocks_per_bucket=4, graph=False, graph_warmup=2):
         if optimizer.lower() not in ('adam', 'adamw'):
             raise ValueError('Should use Adam or AdamW optimizer!')                     # method.py:160
         assert weight_decay == 0.                                                       # method.py:161
@@ -605,6 +613,9 @@ class FTTrainer:
         self._moved = [n for n in self.visual_train if n in matrices]
         self._buckets = self.tower.bucket_plan(self.want, blocks_per_bucket) if self.want else []
         self._found_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._scalars_dev = torch.zeros((_lib.EC_STEP_COUNT,), dtype=torch.float32, device=self.tower.dev)
+        self.graph, self.graph_warmup, self._graph, self._static = bool(graph), int(graph_warmup), None, None
+        self._fixed_text = None
         self._pending = None
         classifier._tower, classifier._trainer = self.tower, self
         self.last = {}
@@ -645,27 +656,35 @@ class FTTrainer:
         self.scaler.update(found)
         self.last['skipped'] = found
 
-    @torch.no_grad()
-    def step(self, data_dict):
-        """data_dict: 'img' [B, T, 3, R, R] (or 'patches' [Nv, G, kpad] of the valid views in (b, t) order),
-        'valid_mask' [B, T], 'label' [B].  Returns the loss (0-dim CUDA tensor)."""
+    def _scalars(self, S, world):
+        """The per-step scalars as the kernels read them from device memory (EC_STEP_*)."""
+        lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
+        clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
+        t = self.opt_steps + 1
+        h = [0.0] * _lib.EC_STEP_COUNT
+        h[_lib.EC_STEP_LR0], h[_lib.EC_STEP_LR1] = lr, clip_lr
+        h[_lib.EC_STEP_BC1] = 1.0 - self.betas[0] ** t
+        h[_lib.EC_STEP_BC2_SQRT] = (1.0 - self.betas[1] ** t) ** 0.5
+        h[_lib.EC_STEP_GRAD_SCALE], h[_lib.EC_STEP_INV_SCALE] = S, 1.0 / (S * world)
+        # a fresh pinned block per step: the copy is asynchronous and the host may be a step ahead of the GPU
+        self._scalars_dev.copy_(torch.tensor(h, dtype=torch.float32).pin_memory(), non_blocking=True)
+
+    def _body(self, patches, valid, labels, row_idx, ddp, world):
+        """Everything of a step that runs on the GPU, in stream order, with no host decision in it: the forward pass,
+        the head, the backward pass (with its gradient exchange), unscale + check, Adam, re-merge / re-pack.  The
+        per-step scalars come from ``self._scalars_dev``, so the same sequence can be replayed from a hipGraph."""
         clf, t = self.clf, self.tower
-        patches, valid, row_idx = self._patches(data_dict)
-        labels = data_dict['label'].to(t.dev)
+        sc = self._scalars_dev
         feats = t.forward(patches)                                 # [Nv, D]; scattered by row_idx inside the head
-        text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
-        self.resolve()                                # the previous step's verdict: this step's scale
-        S = self.scaler.scale
+        text = clf.text_feats.data if clf.prompt_tuning else self._fixed_text
         loss, gimg, gtext, logits = ft_loss_grad(feats, valid, labels, text, clf.logit_scale, clf.agg_func,
-                                                 clf.use_probs_loss, grad_scale=S, want_text_grad=clf.prompt_tuning,
-                                                 text_grad_out=self._grads.get('text_feats'), row_idx=row_idx)
-        self.last = dict(logits=logits, feats=feats, grads=self._grads, skipped=False)
-        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                                                 clf.use_probs_loss, want_text_grad=clf.prompt_tuning,
+                                                 text_grad_out=self._grads.get('text_feats'), row_idx=row_idx,
+                                                 step_scalars=sc)
         through_tower = bool(self.want) or self.lora is not None
         check = through_tower and self.scaler.enabled
         if through_tower:
             lora_struct = self.lora.struct if self.lora else None
-            world = dist.get_world_size() if ddp else 1
             if ddp and self.want:
                 # DistributedDataParallel's bucketed exchange: a few blocks of the backward pass, then the all-reduce
                 # of the slice of the flat buffer they completed starts on the collective's stream (RCCL over xGMI)
@@ -683,19 +702,16 @@ class FTTrainer:
             for buf in ([flat] if self.want else []) + ([self._lora_flat] if self.lora else []):
                 if ddp and buf is not flat:
                     dist.all_reduce(buf)              # the LoRA factors' gradients: one small collective
-                rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(buf), buf.numel(), 1.0 / (S * world),
-                                                      _lib.ptr(self._found), _lib.stream_ptr())
+                rc = _lib.lib().ec_grad_unscale_check(_lib.ptr(buf), buf.numel(), 1.0, _lib.ptr(self._found), _lib.ptr(sc),
+                                                      _lib.stream_ptr())
                 _lib.check(rc, 'ec_grad_unscale_check')
         if clf.prompt_tuning and ddp:
             dist.all_reduce(gtext)
-            gtext /= dist.get_world_size()      # (not scaled: the head's text gradient never sees the loss scale)
-        lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
-        clip_lr = cosine_warmup_lr(self.steps, self.total_steps, self.clip_lr, self.clip_lr / 100., self.warmup_steps)
-        self.steps += 1
+            gtext /= world                      # (not scaled: the head's text gradient never sees the loss scale)
         if self._adam_items is not None:
-            rc = _lib.lib().ec_adam_step_multi(_lib.ptr(self._adam_items), len(self.tensors), self._adam_max, lr, clip_lr,
-                                               self.betas[0], self.betas[1], self.eps, 0., self.opt_steps + 1,
-                                               _lib.ptr(self._found) if check else None, _lib.stream_ptr())
+            rc = _lib.lib().ec_adam_step_multi(_lib.ptr(self._adam_items), len(self.tensors), self._adam_max, 0., 0.,
+                                               self.betas[0], self.betas[1], self.eps, 0., 0,
+                                               _lib.ptr(self._found) if check else None, _lib.ptr(sc), _lib.stream_ptr())
             _lib.check(rc, 'ec_adam_step_multi')
             if self.lora:
                 self.lora.merge()
@@ -703,15 +719,59 @@ class FTTrainer:
                 t.pack(self._moved)
             else:
                 t.clip._packed = None
-            if hasattr(clf, '_invalidate_text_cache'):
-                clf._invalidate_text_cache()
         if check:
             self._found_host.copy_(self._found, non_blocking=True)
+        return loss, logits, feats
+
+    @torch.no_grad()
+    def step(self, data_dict):
+        """data_dict: 'img' [B, T, 3, R, R] (or 'patches' [Nv, G, kpad] of the valid views in (b, t) order with
+        'row_idx'), 'valid_mask' [B, T], 'label' [B].  Returns the loss (0-dim CUDA tensor).
+
+        With ``graph=True`` the GPU work of a step is recorded once into a hipGraph (after ``graph_warmup`` eager
+        steps, for batches that arrive as 'patches' + 'row_idx' with every step the same shapes and no process
+        group) and replayed: the ~700 launches of a step cost the host one call."""
+        clf, t = self.clf, self.tower
+        patches, valid, row_idx = self._patches(data_dict)
+        labels = data_dict['label'].to(t.dev)
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        world = dist.get_world_size() if ddp else 1
+        if not clf.prompt_tuning:
+            self._fixed_text = clf.get_text_feats().float()
+        self.resolve()                                # the previous step's verdict: this step's scale
+        self._scalars(self.scaler.scale, world)
+        check = (bool(self.want) or self.lora is not None) and self.scaler.enabled
+        use_graph = self.graph and not ddp and 'patches' in data_dict
+        if use_graph and self._graph is None and self.steps >= self.graph_warmup:
+            self._capture(patches, valid, labels, row_idx)
+        if use_graph and self._graph is not None and self._static['patches'].shape == patches.shape and \
+                self._static['valid'].shape == valid.shape:
+            st = self._static
+            st['patches'].copy_(patches), st['valid'].copy_(valid), st['labels'].copy_(labels), st['row_idx'].copy_(row_idx)
+            self._graph.replay()
+            loss, logits, feats = st['out']
+        else:
+            loss, logits, feats = self._body(patches, valid, labels, row_idx, ddp, world)
+        self.last = dict(logits=logits, feats=feats, grads=self._grads, skipped=False)
+        self.steps += 1
+        if hasattr(clf, '_invalidate_text_cache') and self._adam_items is not None:
+            clf._invalidate_text_cache()
+        if check:
             self._pending = torch.cuda.Event()
             self._pending.record()
         else:
             self.opt_steps += 1
         return loss
+
+    def _capture(self, patches, valid, labels, row_idx):
+        """Record ``_body`` over static input buffers into a hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm)."""
+        st = dict(patches=patches.clone(), valid=valid.clone(), labels=labels.clone(), row_idx=row_idx.clone())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st['out'] = self._body(st['patches'], st['valid'], st['labels'], st['row_idx'], False, 1)
+        # (the capture does not execute: the recorded step runs at the first replay)
+        self._graph, self._static = g, st
 
     def visual_state_dict(self):
         """``model.visual.*`` as the reference's checkpoint holds it (LoRA keys when LoRA is on)."""

@@ -578,6 +578,12 @@ typedef struct {
     const ec_block_lora *blocks;     /* host array [layers] */
 } ec_vit_lora;
 
+/* The scalars that change from step to step (learning rates and Adam's bias corrections, the loss scale and
+ * its inverse) can be read from a DEVICE array of EC_STEP_COUNT floats instead of the by-value arguments: a
+ * step recorded into a hipGraph is then replayed with new values by overwriting that array.  NULL = by value. */
+enum { EC_STEP_LR0 = 0, EC_STEP_LR1 = 1, EC_STEP_BC1 = 2, EC_STEP_BC2_SQRT = 3, EC_STEP_GRAD_SCALE = 4,
+       EC_STEP_INV_SCALE = 5, EC_STEP_COUNT = 8 };
+
 /* bytes of workspace for n_img images: the saved activations + the backward pass's scratch.  The forward
  * call fills it, the backward call must get the same buffer back untouched. */
 EC_API size_t ec_vit_train_workspace_bytes(const ec_vit_weights *w, int n_img);
@@ -627,7 +633,8 @@ EC_API int ec_layernorm_backward(const float *x, long ldx, const float *dy, long
  * max(B * T, K) * D * 4 bytes. */
 EC_API int ec_ft_loss_grad(const float *img_feats, const int32_t *row_idx, const uint8_t *valid,
                            const int32_t *labels, const float *text_param, int B, int T, int D, int K,
-                           float logit_scale, int agg, int use_probs_loss, float grad_scale, float *loss,
+                           float logit_scale, int agg, int use_probs_loss, float grad_scale,
+                           const float *step_scalars /* NULL, or [EC_STEP_GRAD_SCALE] replaces grad_scale */, float *loss,
                            float *grad_text, float *grad_img, float *agg_logits, void *workspace,
                            size_t workspace_bytes, ec_stream_t stream);
 
@@ -659,11 +666,13 @@ typedef struct {
 } ec_adam_item;
 EC_API int ec_adam_step_multi(const ec_adam_item *items, int n_items, int64_t max_n, float lr0, float lr1, float beta1,
                               float beta2, float eps, float weight_decay, int step, const int32_t *skip_flag,
+                              const float *step_scalars /* NULL, or lr0 / lr1 / 1 - beta1^t / sqrt(1 - beta2^t) */,
                               ec_stream_t stream);
 
 /* grad *= inv_scale in place; *found_inf (device int32, caller zeroes it once per step) is set when any
  * element is not finite -- torch.cuda.amp.GradScaler.unscale_. */
 EC_API int ec_grad_unscale_check(float *grad, int64_t n, float inv_scale, int32_t *found_inf,
+                                 const float *step_scalars /* NULL, or [EC_STEP_INV_SCALE] replaces inv_scale */,
                                  ec_stream_t stream);
 
 #ifdef __cplusplus

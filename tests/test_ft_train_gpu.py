@@ -240,7 +240,7 @@ def test_adam_over_a_tensor_list_matches_torch(hip):
             r.grad = g.clone()
         opt.step()
         rc = _lib.lib().ec_adam_step_multi(_lib.ptr(table), len(params), max(p.numel() for p in params), 1e-2, 3e-3, 0.9,
-                                           0.999, 1e-8, 0., step, None, _lib.stream_ptr())
+                                           0.999, 1e-8, 0., step, None, None, _lib.stream_ptr())
         _lib.check(rc, 'ec_adam_step_multi')
     for p, r in zip(params, ref):
         torch.testing.assert_close(p, r.detach(), rtol=1e-5, atol=1e-6)
@@ -248,7 +248,7 @@ def test_adam_over_a_tensor_list_matches_torch(hip):
     flag = torch.ones(1, dtype=torch.int32, device='cuda')
     keep = [p.clone() for p in params]
     _lib.check(_lib.lib().ec_adam_step_multi(_lib.ptr(table), len(params), max(p.numel() for p in params), 1e-2, 3e-3, 0.9,
-                                             0.999, 1e-8, 0., 4, _lib.ptr(flag), _lib.stream_ptr()), 'ec_adam_step_multi')
+                                             0.999, 1e-8, 0., 4, _lib.ptr(flag), None, _lib.stream_ptr()), 'ec_adam_step_multi')
     assert all(torch.equal(a, b) for a, b in zip(keep, params))
 
 
@@ -554,6 +554,40 @@ def test_gradient_scaler_skips_and_backs_off(hip):
     tr.resolve()
     assert tr.opt_steps == 2 and tr.scaler.scale == 512.0     # two clean steps: growth_interval = 2
     assert any(not torch.equal(before[k], v) for k, v in tr.tensors.items())
+
+
+def test_graph_replay_takes_the_same_steps_as_eager_launches(hip):
+    """graph=True records the GPU work of a step into a hipGraph and replays it; learning rates, Adam's bias
+    corrections and the loss scale reach the kernels through device memory.  Five steps either way end at the same
+    parameters (same kernels, same order: bit for bit)."""
+    from eventclip_amd import ft
+    z, c = _golden_case('lora_qkvo')
+    results = []
+    for graph in (False, True):
+        clf = _classifier_for(c)
+        torch.manual_seed(21)
+        tr = ft.FTTrainer(clf, lr=1e-2, clip_lr=5e-3, total_steps=20, warmup_steps_pct=0.2, init_scale=512.0,
+                          growth_interval=2, graph=graph, graph_warmup=2)
+        t = tr.tower
+        imgs = c['imgs'].cuda()[c['valid']]
+        from eventclip_amd import _lib
+        patches = torch.empty((imgs.shape[0], t.G, t.kpad), dtype=t.cd, device='cuda')
+        _lib.check(_lib.lib().ec_patchify(_lib.ptr(imgs.float().contiguous()), imgs.shape[0], t.cfg['image_size'], t.P,
+                                          t.kpad, _lib.ptr(patches), t.code, _lib.stream_ptr()), 'ec_patchify')
+        valid = c['valid'].cuda()
+        flat = valid.reshape(-1)
+        row_idx = torch.where(flat, torch.cumsum(flat.int(), 0) - 1, torch.full_like(flat, -1, dtype=torch.int64))
+        data = {'patches': patches, 'row_idx': row_idx.to(torch.int32).reshape(valid.shape), 'valid_mask': valid,
+                'label': c['labels'].cuda()}
+        losses = [float(tr.step(data)) for _ in range(5)]
+        tr.resolve()
+        assert (tr._graph is not None) == graph and tr.opt_steps == 5
+        assert tr.scaler.scale == 512.0 * 4                     # two growths of two clean steps each
+        results.append((losses, {k: v.clone() for k, v in tr.tensors.items()}))
+    (l0, p0), (l1, p1) = results
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
 
 
 def test_eval_between_steps_uses_the_trained_weights(hip):

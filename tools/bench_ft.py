@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--modes', default='lora,full,bias')
     ap.add_argument('--dtype', default='float16')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (recorded after 2 eager steps)')
     a = ap.parse_args()
     from eventclip_amd import _lib, clip as eclip, ft
     from eventclip_amd.clip_cls_ft import FTCLIPClassifier
@@ -43,7 +44,7 @@ def main():
         cd.update(extra)
         clf = FTCLIPClassifier(adapter_dict=dict(adapter_type='text-identity', residual=0.95), clip_dict=cd,
                                loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda().train()
-        tr = ft.FTTrainer(clf, lr=2e-5, clip_lr=2e-5, total_steps=1000, init_scale=4096.0)
+        tr = ft.FTTrainer(clf, lr=2e-5, clip_lr=2e-5, total_steps=1000, init_scale=4096.0, graph=a.graph)
         t = tr.tower
         torch.manual_seed(0)
         n = B * T
@@ -53,7 +54,7 @@ def main():
         labels = torch.randint(0, K, (B,), device=dev)
         row_idx = torch.arange(n, device=dev, dtype=torch.int32).view(B, T)
         data = {'patches': patches, 'row_idx': row_idx, 'valid_mask': valid, 'label': labels}
-        for _ in range(a.warmup):
+        for _ in range(max(a.warmup, 4) if a.graph else a.warmup):
             tr.step(data)
         torch.cuda.synchronize()
         _lib.profile_begin()
@@ -77,7 +78,7 @@ def main():
             flops = 2 * lin + 3.5 * att
         ws_gb = t._ws.numel() / 2 ** 30
         print(json.dumps(dict(mode=mode, arch=a.arch, frames_per_step=n, classes=K, dtype=a.dtype,
-                              ms_per_step=round(dt * 1e3, 2), frames_per_s=round(n / dt, 1),
+                              graph=bool(a.graph), ms_per_step=round(dt * 1e3, 2), frames_per_s=round(n / dt, 1),
                               algorithmic_tflop_per_step=round(flops / 1e12, 2),
                               tflops=round(flops / dt / 1e12, 1), trainable_tensors=len(tr.tensors),
                               workspace_gib=round(ws_gb, 2), loss=round(float(loss), 4),
