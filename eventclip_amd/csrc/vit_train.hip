@@ -7,8 +7,8 @@
 // {x += MHA(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))} -> ln_post(CLS) @ proj).
 //
 // Layout of a step (M = n_img * S token rows, W = width):
-//   forward   the inference kernels, keeping per block both residual-stream inputs (fp32), q | k | v, the
-//             attention output with its log-sum-exp and the MLP pre-activation (16-bit): 24 M W bytes;
+//   forward   the inference kernels, keeping per block both residual-stream inputs (fp32), both LayerNorm outputs,
+//             q | k | v, the attention output with its log-sum-exp and the MLP pre-activation (16 bit): 28 M W bytes;
 //   backward  the residual-stream gradient dx stays fp32.  Every nn.Linear is two 16-bit MFMA GEMMs:
 //               dX = dY W        ec_gemm with the weight's transposed copy as the [N, K] operand;
 //               dW = dY^T X      ec_gemm over TRANSPOSED copies [features, rows] of both activations, the
@@ -781,9 +781,10 @@ struct TrainBufs {
     float *x[65];               // x[l]: input of block l; x[L]: the tower's last residual stream
     float *xm[64];              // after the attention branch
     void *qkv[64], *att[64], *u[64];
+    void *h1[64], *h2[64];      // the two LayerNorm outputs (16 bit): the weight / LoRA gradients' right-hand operands
     float *lse[64];
     // scratch shared by both passes
-    void *h16, *g16;            // LayerNorm output [M, W]; QuickGELU output [M, 4W] (forward) / du, dqkv (backward)
+    void *g16;                  // QuickGELU output [M, 4W] (forward) / du, dqkv (backward)
     void *cls_hi, *cls_lo;
     // backward scratch
     float *dx, *dh32, *delta, *clsln, *dclsln, *part, *lnpart, *colpart;
@@ -808,9 +809,10 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
         b.qkv[l] = sc.take(M * 3 * W * 2);
         b.att[l] = sc.take(M * W * 2);
         b.u[l] = sc.take(M * 4 * W * 2);
+        b.h1[l] = sc.take(M * W * 2);
+        b.h2[l] = sc.take(M * W * 2);
         b.lse[l] = (float *)sc.take((size_t)n * w->heads * S * 4);
     }
-    b.h16 = sc.take(M * W * 2);
     b.g16 = sc.take(M * 4 * W * 2);          // >= n G W 4 bytes: also the patch GEMM's fp32 output
     b.cls_hi = sc.take((size_t)n * W * 2);
     b.cls_lo = sc.take((size_t)n * W * 2);
@@ -1103,12 +1105,12 @@ EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, in
                               stream));
     for (int l = 0; l < L; l++) {
         const ec_block_weights &p = w->blocks[l];
-        EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
-        EC_TRY(gemm_x(M, 3 * W, W, dt, EC_EPI_STORE16, b.h16, p.qkv_w, b.qkv[l], nullptr, nullptr, p.qkv_b, stream));
+        EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h1[l], W, dt, stream));
+        EC_TRY(gemm_x(M, 3 * W, W, dt, EC_EPI_STORE16, b.h1[l], p.qkv_w, b.qkv[l], nullptr, nullptr, p.qkv_b, stream));
         EC_TRY(ec_attention_train(b.qkv[l], b.att[l], b.lse[l], n_img, S, W, w->heads, dt, stream));
         EC_TRY(gemm_x(M, W, W, dt, EC_EPI_RESID32, b.att[l], p.out_w, b.xm[l], b.x[l], nullptr, p.out_b, stream));
-        EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h16, W, dt, stream));
-        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h16, p.fc1_w, b.g16, nullptr, b.u[l], p.fc1_b, stream));
+        EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h2[l], W, dt, stream));
+        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h2[l], p.fc1_w, b.g16, nullptr, b.u[l], p.fc1_b, stream));
         EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_RESID32, b.g16, p.fc2_w, b.x[l + 1], b.xm[l], p.fc2_b, b.part,
                            b.part_floats, stream));
     }
@@ -1210,8 +1212,7 @@ EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_tr
         }
         if (q.fc1_w) {
             EC_TRY(transpose<0>(dt, b.g16, 4L * W, M, 4 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
-            EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h16, W, dt, stream));
-            EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(transpose<0>(dt, b.h2[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
             EC_TRY(weight_grad(dt, b.ta, b.tb, 4 * W, W, b, q.fc1_w, 0, stream));
         }
         EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, b.part,
@@ -1233,11 +1234,9 @@ EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_tr
             else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
         }
         const bool lora_qkv = has_lora(l, 0) || has_lora(l, 1) || has_lora(l, 2);
-        if (q.qkv_w || lora_qkv)
-            EC_TRY(ec_layernorm(b.x[l], W, nullptr, p.ln1_g, p.ln1_b, M, W, LN_EPS, b.h16, W, dt, stream));
         if (q.qkv_w) {
             EC_TRY(transpose<0>(dt, b.g16, 3L * W, M, 3 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
-            EC_TRY(transpose<0>(dt, b.h16, W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
+            EC_TRY(transpose<0>(dt, b.h1[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
             EC_TRY(weight_grad(dt, b.ta, b.tb, 3 * W, W, b, q.qkv_w, 0, stream));
         }
         if (lora_qkv || has_lora(l, 3)) {
@@ -1252,7 +1251,7 @@ EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_tr
                 EC_REQUIRE(lb.down16[pj] && lb.up16_t[pj] && lb.d_down[pj], "ec_vit_train_backward: block %d LoRA item %d incomplete", l, pj);
                 LoraJob &j = jobs[n++];
                 if (pj < 3) {
-                    j.x = b.h16, j.ldx = W;
+                    j.x = b.h1[l], j.ldx = W;
                     j.dy = static_cast<const unsigned char *>(b.g16) + (size_t)pj * W * esz, j.ldy = 3L * W;
                 } else {
                     j.x = b.att[l], j.ldx = W, j.dy = b.dx16, j.ldy = W;

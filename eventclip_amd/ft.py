@@ -559,7 +559,7 @@ class FTTrainer:
         names = list(self.tower.master)
         self.visual_train = trainable_visual(names, cd)
         self.lora = LoraFactors(self.tower, cd.get('lora', -1)) if parse_lora(cd.get('lora', -1)) else None
-        self.tensors, self.lrs = {}, {}
+        self.tensors = {}
         if classifier.prompt_tuning:
             self.tensors['text_feats'] = classifier.text_feats.data
         for n in self.visual_train:
@@ -576,7 +576,7 @@ class FTTrainer:
         self.scaler = GradScaler(init_scale, growth_interval=growth_interval, enabled=mixed_precision)
         self.steps = 0            # scheduler steps (every call, as the reference steps its scheduler)
         self.opt_steps = 0        # optimiser steps actually taken (a skipped step does not advance Adam)
-        # what the tower has to differentiate: the trainable masters + the merged matrices LoRA acts through
+        # what the tower has to differentiate (the LoRA factors' gradients come out of the same pass, separately)
         self.want = self.tower.canonical(self.visual_train)
         self._found = torch.zeros((1,), dtype=torch.int32, device=self.tower.dev)
         self._lora_grads = {}
