@@ -7,10 +7,9 @@
 //   random_flip_events_along_x (:18-23: x -> W - 1 - x)
 // The random draws stay on the host (same numpy calls in the same order, eventclip_amd/augment.py);
 // this kernel applies them.  Dropping events changes the event count and with it every later chunk
-// boundary of split_event_count, so the survivors are compacted in order: one workgroup per sample,
-// every thread owns a contiguous run of the (possibly reversed) stream, counts its survivors, a block
-// scan gives each run its output offset, and the run is written out.  HBM-bound: 16 B in + <= 16 B
-// out per event.
+// boundary of split_event_count, so the survivors are compacted in order: one workgroup per sample walks
+// the (possibly reversed) stream in coalesced tiles of 1024 events, a ballot + the waves' counts place every
+// survivor.  HBM-bound: 16 B in + <= 16 B out per event.
 #include "common.h"
 
 namespace {
@@ -21,46 +20,45 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_events_kernel(const float
                                                                      const int *params, int H, int W, float4 *out,
                                                                      long long *counts)
 {
-    __shared__ long long scan[AUG_THREADS / 64];
+    __shared__ int wave_cnt[2][AUG_THREADS / 64];
     const int b = blockIdx.x;
     const long long e0 = range[2 * b], n = range[2 * b + 1] - e0;
     const float4 *ev = events + e0;
     float4 *dst = out + e0;
     const int dx = params[4 * b], dy = params[4 * b + 1], flip_x = params[4 * b + 2], flip_t = params[4 * b + 3];
     const float t_last = n > 0 ? ev[n - 1].z : 0.f;        // events[0, 2] of the reversed stream (utils.py:32)
-    const long long per = (n + AUG_THREADS - 1) / AUG_THREADS;
-    const long long i0 = min(n, (long long)threadIdx.x * per), i1 = min(n, i0 + per);
-    auto transformed = [&](long long i, float4 &e) {
-        // i indexes the stream AFTER the optional time flip
-        e = ev[flip_t ? n - 1 - i : i];
-        if (flip_t) e.z = t_last - e.z, e.w = -e.w;
-        e.x += (float)dx, e.y += (float)dy;                                        // utils.py:8-9
-        const bool ok = e.x >= 0.f && e.x < (float)W && e.y >= 0.f && e.y < (float)H;   // :11-12
-        if (flip_x) e.x = (float)(W - 1) - e.x;                                    // :22
-        return ok;
-    };
-    long long cnt = 0;
-    float4 e;
-    for (long long i = i0; i < i1; i++) cnt += transformed(i, e) ? 1 : 0;
-    // exclusive scan of the per-thread counts over the workgroup
-    long long incl = cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // The stream is walked in tiles of 1024 consecutive events, one per thread (coalesced, also when the time flip
+    // reverses it); survivors keep their order: a ballot gives the position inside the wave, the waves' counts go
+    // through LDS (double-buffered: one barrier per tile), the running total carries over to the next tile.
+    long long done = 0;
+    int buf = 0;
+    for (long long t0 = 0; t0 < n; t0 += AUG_THREADS, buf ^= 1) {
+        const long long i = t0 + threadIdx.x;            // index in the stream AFTER the optional time flip
+        bool ok = false;
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            e = ev[flip_t ? n - 1 - i : i];
+            if (flip_t) e.z = t_last - e.z, e.w = -e.w;
+            e.x += (float)dx, e.y += (float)dy;                                        // utils.py:8-9
+            ok = e.x >= 0.f && e.x < (float)W && e.y >= 0.f && e.y < (float)H;         // :11-12
+            if (flip_x) e.x = (float)(W - 1) - e.x;                                    // :22
+        }
+        const unsigned long long mask = __ballot(ok);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[buf][wave] = __popcll(mask);
+        __syncthreads();
+        int base = 0, total = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long t = __shfl_up(incl, o, 64);
-        if ((int)(threadIdx.x & 63) >= o) incl += t;
+        for (int w = 0; w < AUG_THREADS / 64; w++) {
+            const int c = wave_cnt[buf][w];
+            base += w < wave ? c : 0;
+            total += c;
+        }
+        if (ok) dst[done + base + before] = e;
+        done += total;
     }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) scan[wave] = incl;
-    __syncthreads();
-    long long base = 0, total = 0;
-    for (int w = 0; w < AUG_THREADS / 64; w++) {
-        if (w < wave) base += scan[w];
-        total += scan[w];
-    }
-    long long o = base + incl - cnt;
-    for (long long i = i0; i < i1; i++)
-        if (transformed(i, e)) dst[o++] = e;
-    if (threadIdx.x == 0) counts[b] = total;
+    if (threadIdx.x == 0) counts[b] = done;
 }
 
 }  // namespace

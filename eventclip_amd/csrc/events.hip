@@ -720,15 +720,29 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
 
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
 // t -= min t; x -= ((x_max + x_min + 1) - W) // 2; y likewise (float32 arithmetic).
-__global__ __launch_bounds__(256) void center_events_kernel(float4 *events, const long long *range,
+// (1024 threads, four events in flight per thread per pass: one workgroup per sample has to keep a CU's share of
+// the HBM bandwidth busy on its own)
+__global__ __launch_bounds__(1024) void center_events_kernel(float4 *events, const long long *range,
                                                             int H, int W)
 {
-    __shared__ float red[5][4];
+    __shared__ float red[5][16];
     const long long e0 = range[2 * blockIdx.x], e1 = range[2 * blockIdx.x + 1];
     float4 *ev = events + e0;
     const long long n = e1 - e0;
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, tmin = INFINITY;
-    for (long long i = threadIdx.x; i < n; i += 256) {
+    long long i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        float4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = ev[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            xmin = fminf(xmin, e[u].x), xmax = fmaxf(xmax, e[u].x);
+            ymin = fminf(ymin, e[u].y), ymax = fmaxf(ymax, e[u].y);
+            tmin = fminf(tmin, e[u].z);
+        }
+    }
+    for (; i < n; i += 1024) {
         const float4 e = ev[i];
         xmin = fminf(xmin, e.x), xmax = fmaxf(xmax, e.x);
         ymin = fminf(ymin, e.y), ymax = fmaxf(ymax, e.y);
@@ -745,14 +759,27 @@ __global__ __launch_bounds__(256) void center_events_kernel(float4 *events, cons
         red[0][wave] = xmin, red[1][wave] = xmax, red[2][wave] = ymin, red[3][wave] = ymax,
         red[4][wave] = tmin;
     __syncthreads();
-    xmin = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
-    xmax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-    ymin = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
-    ymax = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
-    tmin = fminf(fminf(red[4][0], red[4][1]), fminf(red[4][2], red[4][3]));
+    xmin = red[0][0], xmax = red[1][0], ymin = red[2][0], ymax = red[3][0], tmin = red[4][0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) {
+        xmin = fminf(xmin, red[0][w]), xmax = fmaxf(xmax, red[1][w]);
+        ymin = fminf(ymin, red[2][w]), ymax = fmaxf(ymax, red[3][w]);
+        tmin = fminf(tmin, red[4][w]);
+    }
     const float xs = floorf(((xmax + xmin + 1.f) - (float)W) / 2.f);   // utils.py:53
     const float ys = floorf(((ymax + ymin + 1.f) - (float)H) / 2.f);   // utils.py:54
-    for (long long i = threadIdx.x; i < n; i += 256) {
+    i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        float4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = ev[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            e[u].x -= xs, e[u].y -= ys, e[u].z -= tmin;
+            ev[i + u * 1024] = e[u];
+        }
+    }
+    for (; i < n; i += 1024) {
         float4 e = ev[i];
         e.x -= xs, e.y -= ys, e.z -= tmin;
         ev[i] = e;
@@ -764,21 +791,28 @@ __global__ __launch_bounds__(256) void center_events_kernel(float4 *events, cons
 // utils.py:53-54's float floor-division equals the arithmetic shift of the integer sum);
 // a coordinate shifted below zero wraps to >= 32768 and is dropped by the binning kernel like
 // any other out-of-sensor event.  t is kept relative to the sample's first event.
-__global__ __launch_bounds__(256) void center_packed_kernel(packed_t *events, const long long *range,
+__global__ __launch_bounds__(1024) void center_packed_kernel(packed_t *events, const long long *range,
                                                             int H, int W)
 {
-    __shared__ unsigned red[5][4];
+    __shared__ unsigned red[5][16];
     const long long e0 = range[2 * blockIdx.x], e1 = range[2 * blockIdx.x + 1];
     packed_t *ev = events + e0;
     const long long n = e1 - e0;
     unsigned xmin = ~0u, xmax = 0, ymin = ~0u, ymax = 0, tmin = ~0u;
-    for (long long i = threadIdx.x; i < n; i += 256) {
-        const packed_t e = ev[i];
-        const unsigned x = (unsigned)(e & 0xffffu), y = (unsigned)((e >> 16) & 0xffffu),
-                       t = (unsigned)(e >> 34);
+    auto see = [&](packed_t e) {
+        const unsigned x = (unsigned)(e & 0xffffu), y = (unsigned)((e >> 16) & 0xffffu), t = (unsigned)(e >> 34);
         xmin = min(xmin, x), xmax = max(xmax, x), ymin = min(ymin, y), ymax = max(ymax, y);
         tmin = min(tmin, t);
+    };
+    long long i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        packed_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = ev[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; u++) see(e[u]);
     }
+    for (; i < n; i += 1024) see(ev[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         xmin = min(xmin, (unsigned)__shfl_xor((int)xmin, o, 64));
@@ -792,20 +826,30 @@ __global__ __launch_bounds__(256) void center_packed_kernel(packed_t *events, co
         red[0][wave] = xmin, red[1][wave] = xmax, red[2][wave] = ymin, red[3][wave] = ymax,
         red[4][wave] = tmin;
     __syncthreads();
-    xmin = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
-    xmax = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
-    ymin = min(min(red[2][0], red[2][1]), min(red[2][2], red[2][3]));
-    ymax = max(max(red[3][0], red[3][1]), max(red[3][2], red[3][3]));
-    tmin = min(min(red[4][0], red[4][1]), min(red[4][2], red[4][3]));
+    xmin = red[0][0], xmax = red[1][0], ymin = red[2][0], ymax = red[3][0], tmin = red[4][0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) {
+        xmin = min(xmin, red[0][w]), xmax = max(xmax, red[1][w]);
+        ymin = min(ymin, red[2][w]), ymax = max(ymax, red[3][w]);
+        tmin = min(tmin, red[4][w]);
+    }
     const int xs = ((int)(xmax + xmin + 1) - W) >> 1;   // floor division by 2 (utils.py:53)
     const int ys = ((int)(ymax + ymin + 1) - H) >> 1;   // utils.py:54
-    for (long long i = threadIdx.x; i < n; i += 256) {
-        const packed_t e = ev[i];
+    auto moved = [&](packed_t e) {
         const unsigned x = ((unsigned)(e & 0xffffu) - (unsigned)xs) & 0xffffu;
         const unsigned y = ((unsigned)((e >> 16) & 0xffffu) - (unsigned)ys) & 0xffffu;
         const packed_t t = (e >> 34) - tmin;
-        ev[i] = (packed_t)x | ((packed_t)y << 16) | (e & (3ull << 32)) | (t << 34);
+        return (packed_t)x | ((packed_t)y << 16) | (e & (3ull << 32)) | (t << 34);
+    };
+    i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        packed_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = ev[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; u++) ev[i + u * 1024] = moved(e[u]);
     }
+    for (; i < n; i += 1024) ev[i] = moved(ev[i]);
 }
 
 // float32 (x, y, t, p) -> packed: parse_events' truncating casts (vis.py:50), t in microseconds
@@ -843,7 +887,7 @@ extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_rang
     if (B == 0) return EC_OK;
     EC_REQUIRE(events && sample_range, "ec_center_events: null buffer");
     EC_REQUIRE(((uintptr_t)events & 15) == 0, "ec_center_events: events must be 16-byte aligned");
-    hipLaunchKernelGGL(center_events_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(center_events_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<float4 *>(events),
                        reinterpret_cast<const long long *>(sample_range), H, W);
     EC_CHECK_HIP(hipGetLastError());
@@ -1034,7 +1078,7 @@ extern "C" EC_API int ec_center_events_packed(uint64_t *events, const int64_t *s
     if (B == 0) return EC_OK;
     EC_REQUIRE(events && sample_range, "ec_center_events_packed: null buffer");
     EC_REQUIRE(((uintptr_t)events & 7) == 0, "ec_center_events_packed: events must be 8-byte aligned");
-    hipLaunchKernelGGL(center_packed_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(center_packed_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<packed_t *>(events),
                        reinterpret_cast<const long long *>(sample_range), H, W);
     EC_CHECK_HIP(hipGetLastError());

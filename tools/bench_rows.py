@@ -1,0 +1,84 @@
+"""The widened rows of SURVEY.md 8(f) measured on the MI355X, each against its HBM roofline (8 TB/s):
+centring (float and packed events), packing, the training augmentation of events, RandAugment on frames, the
+TTA view flags of the events kernel, pseudo-label selection.  N-Caltech geometry, the bench's batch (256 samples).
+
+    python tools/bench_rows.py
+
+One JSON line per row: ms per launch, algorithmic bytes, GB/s, fraction of the HBM peak."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eventclip_amd import _lib, augment, pseudo_label, randaugment, vis  # noqa: E402
+from eventclip_amd.synthetic import make_events  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def line(row, ms, nbytes, **kw):
+    gbps = nbytes / ms / 1e6
+    print(json.dumps(dict(row=row, ms=round(ms, 4), algorithmic_bytes=int(nbytes), GBps=round(gbps, 1),
+                          frac_of_hbm_peak=round(gbps / PEAK, 4), **kw)), flush=True)
+
+
+def main():
+    _lib.require_gpu()
+    H, W = 180, 240
+    B, n_ev = 256, 200000                      # 256 samples x 10 frames x 20 000 events
+    uniq = 16
+    ev = np.concatenate([make_events(n_ev, (H, W), seed=i) for i in range(uniq)] * (B // uniq))
+    events = torch.from_numpy(ev).cuda()
+    offs = torch.arange(B + 1, dtype=torch.int64) * n_ev
+    sr = torch.stack([offs[:-1], offs[1:]], 1).cuda()
+    n_tot = B * n_ev
+    # centring in place: read + write every event
+    work = events.clone()
+    line('center_events (float32 [n, 4])', timed(lambda: vis.center_events_device(work, sr, (H, W))), 32 * n_tot, events=n_tot)
+    packed = vis.pack_events_device(events)
+    line('pack_events (16 B -> 8 B)', timed(lambda: vis.pack_events_device(events)), 24 * n_tot, events=n_tot)
+    pw = packed.clone()
+    line('center_events (packed)', timed(lambda: vis.center_events_device(pw, sr, (H, W))), 16 * n_tot, events=n_tot)
+    # training augmentation of events: read all, write the survivors (~ all)
+    prm = augment.draw_event_augment(B, 20, False, np.random.RandomState(0))
+    line('augment_events (shift / flips, drop outside)',
+         timed(lambda: augment.augment_events_device(events, [n_ev] * B, prm, (H, W)), n=5), 32 * n_tot, events=n_tot)
+    # TTA: the four views are flags of the events kernel (same bytes as the plain launch)
+    F = B * 10
+    fr = torch.tensor([[i * 20000, (i + 1) * 20000] for i in range(F)], dtype=torch.int64).cuda()
+    out = torch.empty((F, H, W, 3), dtype=torch.uint8, device='cuda')
+    for name, kw in (('events -> frames', {}), ('events -> frames, flip_x + negate_p view', dict(flip_x=True, negate_p=True))):
+        line(name, timed(lambda: vis.events_to_frames_device(events, fr, (H, W), grayscale=False, out=out,
+                                                             max_frame_events=20000, **kw)), F * (16 * 20000 + 3 * H * W), frames=F)
+    # RandAugment: two operators per frame, the same pair for the 10 views of a sample
+    frames = out.clone()
+    for pair in ((('Rotate', 17.6), ('Contrast', 0.34)), (('ShearX', 0.2), ('Equalize', 0.0)), (('TranslateY', 40.0), ('Sharpness', 0.5)),
+                 (('Posterize', 5.0), ('Solarize', 120.0))):
+        ops = [list(pair)] * F
+        line('randaugment ' + ' + '.join(p[0] for p in pair), timed(lambda: randaugment.apply_ops(frames, ops, (255, 255, 255)), n=5),
+             2 * 2 * frames.numel(), frames=F)
+    # pseudo-label selection: 4 TTA views, N-ImageNet's 1000 classes
+    Bp, K = 4096, 1000
+    probs = torch.softmax(torch.randn(Bp * 4, K, device='cuda') * 3, -1)
+    line('pseudo_label select (4 views, K = 1000)', timed(lambda: pseudo_label.select(probs, 0.5, tta=True, tta_consistent=True,
+                                                                                    tta_min_prob=True)), probs.numel() * 4 + Bp * K * 4, samples=Bp)
+
+
+if __name__ == '__main__':
+    main()
