@@ -64,7 +64,7 @@ class EcGemmArgs(ctypes.Structure):
                 ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
                 ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p),
                 ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
-                ('split_stride', c_long)]
+                ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
@@ -98,7 +98,8 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_pre_g', c_void_p), ('ln_pre_b', c_void_p), ('ln_post_g', c_void_p),
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
-                ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int)]
+                ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
+                ('low_latency', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):

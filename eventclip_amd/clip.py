@@ -154,7 +154,7 @@ class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
-                 image_precise=False, full_last_block=None):
+                 image_precise=False, full_last_block=None, low_latency=False):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -175,6 +175,9 @@ class CLIP(nn.Module):
         if full_last_block is None:
             full_last_block = os.environ.get('EVENTCLIP_FULL_LAST_BLOCK', '0') not in ('', '0')
         self.full_last_block = bool(full_last_block)
+        # serving a few frames at a time: under-filled GEMM launches run K-batched (about half the latency of a
+        # single frame); a frame's features then differ from its large-batch ones in the last fp32 bits
+        self.low_latency = bool(low_latency)
         self.workspace_budget = 24 << 30   # bytes of tower scratch at most
         self._packed = None
         self._ws = None
@@ -266,6 +269,7 @@ class CLIP(nn.Module):
         v.proj_w = dev16(sd['visual.proj'].t())
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
+        v.low_latency = int(self.low_latency)
         v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
         vb = blocks('visual.transformer', c['layers'], self.image_precise)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))

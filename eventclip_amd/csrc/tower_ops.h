@@ -20,12 +20,26 @@ struct Scratch {
     }
 };
 
+// K-batch scratch of the low-latency mode (ec_vit_weights.low_latency): set by the tower driver for the duration of
+// one call on the calling thread; NULL = every launch in a single pass
+struct LatencyScratch {
+    void *ws;
+    size_t bytes;
+};
+inline LatencyScratch &latency_scratch()
+{
+    static thread_local LatencyScratch s = {nullptr, 0};
+    return s;
+}
+constexpr size_t LATENCY_WS_BYTES = (size_t)80 << 20;   // 256 workgroups x one 256 x 256 fp32 tile, with slack
+
 inline int gemm(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
                 void *C, ec_stream_t s, long ldc = 0, long lda = 0)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
     g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
+    g.ws = latency_scratch().ws, g.ws_bytes = latency_scratch().bytes;
     return ec_gemm(&g, s);
 }
 

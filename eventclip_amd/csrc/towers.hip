@@ -156,7 +156,7 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
         return carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
     }
     BlockBufs b;
-    return carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
+    return carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx) + (w->low_latency ? LATENCY_WS_BYTES : 0);
 }
 
 EC_API size_t ec_text_workspace_bytes(const ec_text_weights *w, int chunk)
@@ -217,7 +217,15 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     BlockBufs b;
     void *cls16, *cls16_lo;
     int *idx;
-    const size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
+    size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
+    // low-latency mode: under-filled GEMM launches (a few frames) run K-batched through this scratch
+    struct ScratchGuard {
+        ~ScratchGuard() { latency_scratch() = {nullptr, 0}; }
+    } guard;
+    if (w->low_latency) {
+        latency_scratch() = {sc.take(LATENCY_WS_BYTES), LATENCY_WS_BYTES};
+        need = sc.off;
+    }
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes", workspace_bytes,
                         need);

@@ -18,7 +18,7 @@ def dtype_code(t):
 
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
-         splits=1, K=None):
+         splits=1, K=None, ws=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
@@ -58,5 +58,8 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
         a.aux = aux.data_ptr()
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
+    if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
+        assert ws.is_cuda and ws.is_contiguous()
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
     return out

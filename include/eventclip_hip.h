@@ -258,6 +258,12 @@ typedef struct {
                           (batch s reads columns s*K .. (s+1)*K - 1 and writes C + s * split_stride elements):
                           the partial sums of a weight gradient whose reduction dimension is the batch */
     long split_stride;
+    void *ws;          /* optional fp32 scratch (ws_bytes).  When given and the launch would leave most CUs idle
+                          (tiles x 2 <= CUs: a few frames), the product is cut into K-batches whose partial sums a
+                          second kernel adds up and finishes with the epilogue: the launch takes a fraction of one
+                          tile's K loop instead of all of it (serving latency).  The fp32 summation order then
+                          depends on M; NULL keeps every row's result independent of the batch it sits in. */
+    size_t ws_bytes;
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -364,6 +370,10 @@ typedef struct {
                                    0 (default): that block computes keys / values for every token but the
                                    attention query, out_proj, ln_2 and the MLP for the class token only --
                                    the same features bit for bit.  != 0: every token, like the reference. */
+    int low_latency;            /* != 0: under-filled GEMM launches (batches of a few frames) run K-batched
+                                   (ec_gemm_args.ws): a single frame of ViT-L/14 in about half the time, at the
+                                   price of results that differ from the large-batch ones in the last fp32 bits.
+                                   0 (default): a frame's features do not depend on the batch it is in. */
 } ec_vit_weights;
 
 typedef struct {

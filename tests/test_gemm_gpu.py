@@ -91,3 +91,36 @@ def test_gemm_rejects_bad_shapes(hip):
     W = torch.zeros(64, 100, device='cuda', dtype=torch.float16)
     with pytest.raises(RuntimeError):
         ops.gemm(A, W)
+
+
+@pytest.mark.parametrize('M,N,K', [(257, 1024, 1024), (50, 768, 3072), (300, 3072, 1024), (1028, 4096, 1024), (7, 64, 128)])
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+def test_low_latency_k_batched_launch_matches_the_single_pass(hip, M, N, K, dtype):
+    """With scratch (ec_gemm_args.ws) an under-filled launch is cut into K-batches + a fixup kernel (serving latency);
+    every epilogue gives the single-pass result up to the fp32 summation order."""
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dtype)
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device='cuda').to(dtype)
+    W = (torch.randn(N, K, device='cuda') / K ** 0.5).to(dtype)
+    bias = torch.randn(N, device='cuda')
+    ws = torch.empty(80 << 20, dtype=torch.uint8, device='cuda')
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1.6e-2, atol=1.6e-2)
+    for epi in ('store16', 'gelu16', 'store32'):
+        torch.testing.assert_close(ops.gemm(A, W, bias, epi, ws=ws).float(), ops.gemm(A, W, bias, epi).float(), **tol)
+    resid = torch.randn(M, N, device='cuda')
+    torch.testing.assert_close(ops.gemm(A, W, bias, 'resid32', resid=resid, ws=ws), ops.gemm(A, W, bias, 'resid32', resid=resid),
+                               rtol=1e-4, atol=1e-4)
+    x1, x2 = resid.clone(), resid.clone()
+    ops.gemm(A, W, bias, 'resid32', out=x1, ws=ws), ops.gemm(A, W, bias, 'resid32', out=x2)
+    torch.testing.assert_close(x1, x2, rtol=1e-4, atol=1e-4)
+    u1, u2 = torch.empty(M, N, device='cuda', dtype=dtype), torch.empty(M, N, device='cuda', dtype=dtype)
+    g1, g2 = ops.gemm(A, W, bias, 'gelu16_save', aux=u1, ws=ws), ops.gemm(A, W, bias, 'gelu16_save', aux=u2)
+    torch.testing.assert_close(g1.float(), g2.float(), **tol)
+    torch.testing.assert_close(u1.float(), u2.float(), **tol)
+    torch.testing.assert_close(ops.gemm(A, W, None, 'gelu_bwd16', aux=u2, ws=ws).float(),
+                               ops.gemm(A, W, None, 'gelu_bwd16', aux=u2).float(), **tol)
+    # a launch that fills the chip (tiles * 2 > 256 CUs for every N here) ignores the scratch: same bits
+    big = torch.randn(256 * 96, K, device='cuda').to(dtype)
+    assert torch.equal(ops.gemm(big, W, bias, 'store16', ws=ws), ops.gemm(big, W, bias, 'store16'))

@@ -266,3 +266,20 @@ def test_cpu_model_fails_loudly(hip):
     m = eclip.CLIP(cfg, eclip.random_state_dict(cfg, 0))
     with pytest.raises(_lib.HipLibraryError):
         m.encode_image(torch.zeros(1, 3, 224, 224))
+
+
+@pytest.mark.parametrize('arch,n', [('ViT-B/32', 1), ('ViT-B/32', 7), ('ViT-L/14', 1), ('ViT-L/14', 3)])
+def test_low_latency_mode_gives_the_same_features(hip, arch, n):
+    """CLIP(low_latency=True) runs the under-filled GEMM launches of a small request K-batched: the features agree
+    with the default mode to the fp32 summation order (and so stay inside the 1e-3 of the fp32 oracle)."""
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config(arch)
+    sd = eclip.random_state_dict(cfg, seed=3)
+    torch.manual_seed(n)
+    imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
+    base = eclip.CLIP(cfg, sd).cuda().encode_image(imgs.cuda())
+    fast = eclip.CLIP(cfg, sd, low_latency=True).cuda().encode_image(imgs.cuda())
+    assert torch.isfinite(fast).all()
+    assert float((fast - base).abs().max()) < 3e-4 * float(base.abs().max())
+    assert not torch.equal(fast, base)          # the K-batched route really ran
