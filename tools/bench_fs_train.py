@@ -5,7 +5,10 @@ views T, D = 768.
 
     python tools/bench_fs_train.py [--batch 128] [--steps 50]
 
-One JSON line per (adapter type, geometry): ms per step and samples/s.  Synthetic features, seeded weights."""
+One JSON line per (adapter type, geometry): ms per step and samples/s, and `cpu_baseline`: the oracle's step (loss +
+gradients in float64 -- numpy for `text-identity`, torch CPU autograd over the explicit forward for `text-trans` --
+plus its numpy Adam over every trained tensor) on the same batch, on the box's host cores.  Synthetic features,
+seeded weights.  The CPU leg is the only place the oracle is touched."""
 import argparse
 import json
 import os
@@ -14,7 +17,32 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+
+def cpu_step(kind, clf, feats, valid, labels, repeat=3):
+    from oracle import train as ot
+    f, v, y = feats.cpu().numpy(), valid.cpu().numpy(), labels.cpu().numpy()
+    text = clf.text_feats.detach().cpu().numpy().astype(np.float64)
+    sd = {k: t.detach().cpu().numpy() for k, t in clf.adapter.state_dict().items()} if kind == 'text-trans' else {}
+    params = dict({k: a.astype(np.float64) for k, a in sd.items()}, text_feats=text)
+    m1 = {k: np.zeros_like(a) for k, a in params.items()}
+    m2 = {k: np.zeros_like(a) for k, a in params.items()}
+    best = float('inf')
+    for it in range(repeat):
+        t0 = time.perf_counter()
+        if kind == 'text-identity':
+            _, g, _ = ot.fs_text_loss_and_grad(f, v, y, params['text_feats'], 100.0, 'mean', False)
+            grads = dict(text_feats=g)
+        else:
+            _, grads, _ = ot.fs_trans_loss_and_grads({k: params[k] for k in sd}, f, v, y, params['text_feats'], 100.0, 4, 0.95,
+                                                     'mean', False)
+        for k in params:
+            ot.adam_step(params[k], grads[k], m1[k], m2[k], it + 1, 2e-5)
+        best = min(best, time.perf_counter() - t0)
+    return dict(ms_per_step=round(best * 1e3, 2), kind='port', dtype='float64', threads=torch.get_num_threads(),
+                sample='the same batch, best of %d steps' % repeat)
 
 
 def main():
@@ -49,9 +77,11 @@ def main():
                 loss = tr.step(feats, valid, labels)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.steps
+            cb = cpu_step(kind, clf, feats, valid, labels)
+            cb['speedup'] = round(cb['ms_per_step'] / (dt * 1e3), 1)
             print(json.dumps(dict(adapter_type=kind, geometry=name, batch=B, views=T, classes=K,
                                   ms_per_step=round(dt * 1e3, 3), samples_per_s=round(B / dt, 1),
-                                  loss=round(float(loss), 4))), flush=True)
+                                  loss=round(float(loss), 4), cpu_baseline=cb)), flush=True)
 
 
 if __name__ == '__main__':

@@ -7,7 +7,10 @@ configs/ftclip/ft_text_fsclip_nin_params*.py -- ViT-L/14, N-ImageNet geometry, 1
 
 Prints one JSON line per mode: ms per step, frames/s, the split forward / loss / backward / update, the
 algorithmic flops (3 x the forward's 2 M N K for a full step; LoRA skips the MLP's weight gradients) and the
-rate they amount to.  Synthetic frames, seeded random weights (no datasets / checkpoints on the box)."""
+rate they amount to, and `cpu_baseline`: forward + backward of the oracle's tower (torch CPU fp32 autograd over
+oracle/clip_ref.py, every visual gradient, no optimiser) on a few frames with the box's host cores.  Synthetic
+frames, seeded random weights (no datasets / checkpoints on the box).  The CPU leg is the only place the oracle is
+touched."""
 import argparse
 import json
 import os
@@ -17,6 +20,28 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: E402
+
+
+def cpu_baseline(arch, frames=4, repeat=2):
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config(arch)
+    sd = eclip.random_state_dict(cfg, 0)
+    leaves = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith('visual.')}
+    threads = min(64, os.cpu_count() or 8)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    imgs = torch.randn(frames, 3, cfg['image_size'], cfg['image_size'])
+    best = float('inf')
+    for _ in range(repeat):
+        for v in leaves.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        feats = clip_ref.encode_image_autograd(leaves, cfg, imgs)
+        feats.backward(torch.ones_like(feats))
+        best = min(best, time.perf_counter() - t0)
+    return dict(frames_per_s=round(frames / best, 2), kind='port', dtype='float32', cores=threads,
+                sample='%d frames, forward + backward of every visual parameter, best of %d (%.1f s)' % (frames, repeat, best))
 
 
 def main():
@@ -29,12 +54,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--modes', default='lora,full,bias')
     ap.add_argument('--dtype', default='float16')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (recorded after 2 eager steps)')
     a = ap.parse_args()
     from eventclip_amd import _lib, clip as eclip, ft
     from eventclip_amd.clip_cls_ft import FTCLIPClassifier
     dev = _lib.require_gpu()
     B, T, K = a.samples, a.views, a.classes
+    cb = None if a.no_cpu_baseline else cpu_baseline(a.arch)
     for mode in a.modes.split(','):
         model = eclip.build_random(a.arch, seed=0, dtype=a.dtype)
         extra = dict(lora='qkvo-16') if mode == 'lora' else (dict(lora=-1, only_bias=True) if mode == 'bias' else dict(lora=-1))
@@ -83,6 +110,7 @@ def main():
                               tflops=round(flops / dt / 1e12, 1), trainable_tensors=len(tr.tensors),
                               workspace_gib=round(ws_gb, 2), loss=round(float(loss), 4),
                               loss_scale=tr.scaler.scale, skipped_last=bool(tr.last['skipped']),
+                              cpu_baseline=cb,
                               kernel_ms_per_step={p['name']: round(p['total_ms'] / a.steps, 2) for p in prof
                                                   if p['launches']})), flush=True)
         del tr, clf, model
