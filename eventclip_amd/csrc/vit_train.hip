@@ -545,152 +545,252 @@ __global__ __launch_bounds__(256) void lora_ddown_kernel(const ec_lora_item *ite
 // ------------------------------------------------------------------------------------------
 // LoRA gradients straight from the activations.  y = x (W + up down)^T, so with P = x down^T and Q = dy up
 // (both [rows, r]):  d up = dy^T P,  d down = Q^T x -- the W x W gradient of the merged weight never exists.
-//   lowrank_project_kernel  out[m][0 .. 16 RT) = In[m][:] . F[.][:]^T  (MFMA: the 16 factors of a tile are
-//                           one 16 x 16 x 32 row block; a wave owns 16 rows of In, read straight from HBM)
-//   lowrank_outer_kernel    partial[slab][k][c] = sum over the slab's rows m of coef[m][k] In[m][c]  (a thread
-//                           owns four feature columns; the 16 coefficients of a row are wave-uniform)
-// Up to four (input, factor) pairs per launch (q, k, v, o of a block).
+//   lowrank_project_kernel     coefficients c[m][0 .. 16 RT) = In[m][:] . F[.][:]^T  (MFMA: the 16 factors of a
+//                              tile are one 16 x 16 x 32 row block; a wave owns 16 rows of In, read straight from
+//                              HBM), for up to three factor sets that multiply the same In (q, k, v all read
+//                              ln_1(x)).  Written TRANSPOSED, [16 RT][Mp] in the 16-bit compute type, as two
+//                              planes: hi = c rounded, lo = (c - hi) * 2^LO_SHIFT (same exponent range as hi, so
+//                              the pair carries ~22 bits even where f16 goes subnormal); rows m >= M are zero.
+//   lowrank_outer_mfma_kernel  partial[slab][k][c] = sum over the slab's rows m of c[m][k] In[m][c], the row index
+//                              being the MFMA's contraction index: the coefficient planes are the A operand as
+//                              they lie; In's [32 rows][64 columns] tile goes through a wave-private LDS image and
+//                              comes back column-major through ds_read_b64_tr_b16.  hi and lo accumulate apart
+//                              and meet at the store.  Up to three coefficient sets share one In (d down of
+//                              q, k, v).
 // ------------------------------------------------------------------------------------------
+template <int DT> struct LoShift;
+template <> struct LoShift<0> { static constexpr float up = 2048.f, down = 1.f / 2048.f; };
+template <> struct LoShift<1> { static constexpr float up = 256.f, down = 1.f / 256.f; };
+
 struct ProjectItem {
     const void *in;     // [M, C] 16-bit at row stride ld
     long ld;
-    const void *f;      // [16 RT, C] 16-bit factor rows (zero rows past r)
-    float *out;         // [M, 16 RT]
+    int nf;             // factor sets applied to this input (1 .. 3; more than 1 only with RT == 1)
+    const void *f[3];   // [16 RT, C] 16-bit factor rows (zero rows past r)
+    void *out_t[3];     // [2][16 RT][Mp] 16-bit: hi plane, lo plane
     int C;
 };
 struct ProjectArgs {
     ProjectItem it[4];
-    int M, RT;
+    int M, Mp;
 };
 
-template <int DT>
-__global__ __launch_bounds__(256) void lowrank_project_kernel(const ProjectArgs a)
+// NF factor sets of RT 16-row tiles each (more than one set only with RT == 1).  The count is a template
+// parameter of the body, not a runtime guard: with guards every MFMA sits behind a branch and the compiler can
+// no longer count the loads in flight (it waits for all of them: measured, no overlap between rounds).
+template <int DT, int NF, int RT>
+__device__ __forceinline__ void lowrank_project_body(const ProjectArgs &a, const ProjectItem &it)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
-    const ProjectItem it = a.it[blockIdx.y];
+    static_assert(NF == 1 || RT == 1, "several factor sets only with one factor tile each");
+    constexpr int NA = NF * RT;
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-    if (m0 >= a.M) return;
+    if (m0 >= a.Mp) return;
     const int m = m0 + c16 < a.M ? m0 + c16 : a.M - 1;
     const elem *in = (const elem *)it.in + (long)m * it.ld + g * 8;
-    const elem *f = (const elem *)it.f + (long)c16 * it.C + g * 8;
-    f32x4 acc[4];
+    // accumulator t: NF == 1 -> tile t of set 0; NF == 3 -> the tile of set t
+    const elem *f[NA];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // four 32-wide steps of loads in flight per round (C is a multiple of 64; a lone last pair is done singly)
-    int k0 = 0;
-    for (; k0 + 128 <= it.C; k0 += 128) {
-        v8 x[4], w[4];
+    for (int t = 0; t < NA; t++) {
+        const elem *base = (const elem *)(NF == 1 ? it.f[0] : it.f[t]);
+        f[t] = base + (long)((NF == 1 ? 16 * t : 0) + c16) * it.C + g * 8;
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // rounds of four 32-wide steps, two rounds of loads in flight: a wave lives for C / 128 rounds only, so the
+    // HBM latency of every round it waits out in full is the kernel's time (C is a multiple of 64; a lone last
+    // pair of steps is done singly)
+    auto load = [&](int k0, v8(&x)[4], v8(&w)[NA][4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             x[u] = *reinterpret_cast<const v8 *>(in + k0 + 32 * u);
-            w[u] = *reinterpret_cast<const v8 *>(f + k0 + 32 * u);
+#pragma unroll
+            for (int t = 0; t < NA; t++)
+                w[t][u] = *reinterpret_cast<const v8 *>(f[t] + k0 + 32 * u);
         }
+    };
+    auto mma = [&](const v8(&x)[4], const v8(&w)[NA][4]) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            acc[0] = mfma16(w[u], x[u], acc[0]);
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int t = 1; t < 4; t++)
-                if (t < a.RT)
-                    acc[t] = mfma16(*reinterpret_cast<const v8 *>(f + (long)t * 16 * it.C + k0 + 32 * u), x[u], acc[t]);
+            for (int t = 0; t < NA; t++)
+                acc[t] = mfma16(w[t][u], x[u], acc[t]);
+    };
+    const int rounds = it.C / 128;
+    v8 xa[4], xb[4], wa[NA][4], wb[NA][4];
+    if (rounds > 0) load(0, xa, wa);
+    for (int r = 0; r < rounds; r += 2) {
+        if (r + 1 < rounds) load((r + 1) * 128, xb, wb);
+        mma(xa, wa);
+        if (r + 1 < rounds) {
+            if (r + 2 < rounds) load((r + 2) * 128, xa, wa);
+            mma(xb, wb);
         }
     }
-    for (; k0 < it.C; k0 += 32) {
+    for (int k0 = rounds * 128; k0 < it.C; k0 += 32) {
         const v8 x = *reinterpret_cast<const v8 *>(in + k0);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (t < a.RT) acc[t] = mfma16(*reinterpret_cast<const v8 *>(f + (long)t * 16 * it.C + k0), x, acc[t]);
+        for (int t = 0; t < NA; t++)
+            acc[t] = mfma16(*reinterpret_cast<const v8 *>(f[t] + k0), x, acc[t]);
     }
-    // acc[t][r] = out[m0 + c16][16 t + 4 g + r]
-    if (m0 + c16 < a.M) {
+    // acc[t][r] = c[m0 + c16][4 g + r] of tile t; sixteen lanes write sixteen consecutive m
+    const bool inside = m0 + c16 < a.M;
+    const long plane = (long)16 * RT * a.Mp;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (t < a.RT) *reinterpret_cast<f32x4 *>(it.out + (long)(m0 + c16) * 16 * a.RT + 16 * t + 4 * g) = acc[t];
+    for (int t = 0; t < NA; t++) {
+        elem *dst = (elem *)(NF == 1 ? it.out_t[0] : it.out_t[t]) + (long)((NF == 1 ? 16 * t : 0) + 4 * g) * a.Mp + m0 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = inside ? acc[t][r] : 0.f;
+            const elem hi = (elem)v;
+            dst[(long)r * a.Mp] = hi;
+            dst[plane + (long)r * a.Mp] = (elem)((v - (float)hi) * LoShift<DT>::up);
+        }
+    }
+}
+
+// MAXF = 3: items carry one to three factor sets (RT == 1); MAXF = 1: one set of RT tiles
+template <int DT, int MAXF, int RT>
+__global__ __launch_bounds__(256) void lowrank_project_kernel(const ProjectArgs a)
+{
+    const ProjectItem &it = a.it[blockIdx.y];
+    if constexpr (MAXF == 1) {
+        lowrank_project_body<DT, 1, RT>(a, it);
+    } else {
+        if (it.nf == 3) lowrank_project_body<DT, 3, 1>(a, it);
+        else if (it.nf == 2) lowrank_project_body<DT, 2, 1>(a, it);
+        else lowrank_project_body<DT, 1, 1>(a, it);
     }
 }
 
 struct OuterItem {
-    const void *in;      // [M, C] 16-bit at row stride ld
+    const void *in;        // [M, C] 16-bit at row stride ld
     long ld;
-    const float *coef;   // [M, cstride], the item's r coefficients at column offset 0
-    int cstride;
-    float *partial;      // [slabs][r][C]
+    int ns;                // coefficient sets multiplying this input (1 .. 3; more than 1 only with RT == 1)
+    const void *coef_t[3]; // [2][16 RT][Mp] 16-bit planes of lowrank_project_kernel
+    float *partial[3];     // [slabs][r][C]
 };
 struct OuterArgs {
     OuterItem it[4];
-    int M, C, r, slab_rows;
+    int M, Mp, C, r, slab_rows;       // slab_rows: a multiple of 32
 };
 
-template <int DT>
-__global__ __launch_bounds__(256) void lowrank_outer_kernel(const OuterArgs a)
+// byte offset of 16-byte chunk ch (0 .. 7) of row (0 .. 31) in a wave's [32][64 x 16-bit] image.  A 32-lane half of
+// a transposed read takes 32 bytes of rows {0..3, 8..11} + 4 hh (+ 16): the XOR spreads them over the 8 32-byte
+// windows of the 64 banks.
+__device__ __forceinline__ int outer_off(int row, int ch)
+{
+    return row * 128 + ((ch ^ ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1)) << 4);
+}
+
+template <int DT, int NS, int RT>
+__device__ __forceinline__ void lowrank_outer_body(const OuterArgs &a, const OuterItem &it, unsigned char *lds)
 {
     typedef typename T16<DT>::elem elem;
-    typedef elem v2 __attribute__((ext_vector_type(2)));
-    constexpr int ROWS = 64;                     // rows of coefficients staged in LDS at a time
-    __shared__ __attribute__((aligned(16))) float cs[ROWS * 16];
-    const OuterItem it = a.it[blockIdx.z];
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
-    const bool live = c < a.C;
-    const int m0 = blockIdx.y * a.slab_rows, m1 = m0 + a.slab_rows < a.M ? m0 + a.slab_rows : a.M;
-    for (int k0 = 0; k0 < a.r; k0 += 16) {
-        float2 acc[16];
+    typedef typename T16<DT>::v8 v8;
+    typedef typename T16<DT>::v4 v4;
+    static_assert(NS == 1 || RT == 1, "several coefficient sets only with one factor tile each");
+    constexpr int NA = NS * RT;                   // accumulator groups: RT tiles of one set, or one tile of NS sets
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int c0 = blockIdx.x * 256 + wave * 64;
+    if (c0 >= a.C) return;                        // a whole wave: EXEC stays full for the transposed reads
+    unsigned char *buf = lds + wave * 8192;
+    const int m_lo = blockIdx.y * a.slab_rows;
+    const int m_hi = m_lo + a.slab_rows < a.Mp ? m_lo + a.slab_rows : a.Mp;
+    const int lr = lane >> 3, lch = lane & 7;
+    const elem *ct[NA];
+    const long plane = (long)16 * RT * a.Mp;
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = make_float2(0.f, 0.f);
-        for (int mb = m0; mb < m1; mb += ROWS) {
-            const int nrow = m1 - mb < ROWS ? m1 - mb : ROWS;
-            __syncthreads();
-            {   // stage coef[mb .. mb + nrow)[k0 .. k0 + 16): one float4 per thread (64 rows x 4 quads)
-                const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < nrow) {
-                    const float *src = it.coef + (long)(mb + row) * it.cstride + k0 + 4 * q;
-                    if (k0 + 4 * q + 3 < a.r) v = *reinterpret_cast<const float4 *>(src);
-                    else {
-                        if (k0 + 4 * q < a.r) v.x = src[0];
-                        if (k0 + 4 * q + 1 < a.r) v.y = src[1];
-                        if (k0 + 4 * q + 2 < a.r) v.z = src[2];
-                    }
-                }
-                *reinterpret_cast<float4 *>(&cs[row * 16 + 4 * q]) = v;
+    for (int t = 0; t < NA; t++) {
+        const elem *base = (const elem *)(NS == 1 ? it.coef_t[0] : it.coef_t[t]);
+        ct[t] = base + (long)((NS == 1 ? 16 * t : 0) + c16) * a.Mp + 8 * g;
+    }
+    auto fetch = [&](int m0, v8(&x)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int row = m0 + lr + 8 * i;
+            row = row < a.M ? row : a.M - 1;      // (its coefficients are zero)
+            x[i] = *reinterpret_cast<const v8 *>((const elem *)it.in + (long)row * it.ld + c0 + lch * 8);
+        }
+    };
+    f32x4 acc[2][NA][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int t = 0; t < NA; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[h][t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one 32-row step: x (fetched two steps ago) into the image, the fetch two steps ahead into x, the products
+    auto step = [&](int m0, v8(&x)[4], unsigned char *img) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<v8 *>(img + outer_off(lr + 8 * i, lch)) = x[i];
+        if (m0 + 64 < m_hi) fetch(m0 + 64, x);
+        v8 ch[NA], cl[NA];
+#pragma unroll
+        for (int t = 0; t < NA; t++)
+        {
+            ch[t] = *reinterpret_cast<const v8 *>(ct[t] + m0);
+            cl[t] = *reinterpret_cast<const v8 *>(ct[t] + plane + m0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v8 f;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int row = 8 * g + 4 * hh + (c16 >> 2);
+                const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+                    img + outer_off(row, 2 * j + ((c16 & 3) >> 1)) + 8 * (c16 & 1)));
+                const v4 tv = __builtin_bit_cast(v4, t);
+                f[4 * hh] = tv[0], f[4 * hh + 1] = tv[1], f[4 * hh + 2] = tv[2], f[4 * hh + 3] = tv[3];
             }
-            __syncthreads();
-            if (!live) continue;
-            const elem *in = (const elem *)it.in + (long)mb * it.ld + c;
-            int m = 0;
-            for (; m + 4 <= nrow; m += 4) {
-                v2 x[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const v2 *>(in + (long)(m + u) * it.ld);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float x0 = (float)x[u][0], x1 = (float)x[u][1];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 w = *reinterpret_cast<const float4 *>(&cs[(m + u) * 16 + 4 * q]);
-                        acc[4 * q].x = __builtin_fmaf(w.x, x0, acc[4 * q].x), acc[4 * q].y = __builtin_fmaf(w.x, x1, acc[4 * q].y);
-                        acc[4 * q + 1].x = __builtin_fmaf(w.y, x0, acc[4 * q + 1].x), acc[4 * q + 1].y = __builtin_fmaf(w.y, x1, acc[4 * q + 1].y);
-                        acc[4 * q + 2].x = __builtin_fmaf(w.z, x0, acc[4 * q + 2].x), acc[4 * q + 2].y = __builtin_fmaf(w.z, x1, acc[4 * q + 2].y);
-                        acc[4 * q + 3].x = __builtin_fmaf(w.w, x0, acc[4 * q + 3].x), acc[4 * q + 3].y = __builtin_fmaf(w.w, x1, acc[4 * q + 3].y);
-                    }
-                }
-            }
-            for (; m < nrow; m++) {
-                const v2 x = *reinterpret_cast<const v2 *>(in + (long)m * it.ld);
-                const float x0 = (float)x[0], x1 = (float)x[1];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const float w = cs[m * 16 + k];
-                    acc[k].x = __builtin_fmaf(w, x0, acc[k].x), acc[k].y = __builtin_fmaf(w, x1, acc[k].y);
-                }
+            for (int t = 0; t < NA; t++)
+            {
+                acc[0][t][j] = mfma16(ch[t], f, acc[0][t][j]);
+                acc[1][t][j] = mfma16(cl[t], f, acc[1][t][j]);
             }
         }
-        if (live) {
+    };
+    v8 xa[4], xb[4];
+    fetch(m_lo, xa);
+    if (m_lo + 32 < m_hi) fetch(m_lo + 32, xb);
+    for (int m0 = m_lo; m0 < m_hi; m0 += 64) {
+        step(m0, xa, buf);
+        if (m0 + 32 < m_hi) step(m0 + 32, xb, buf + 4096);
+    }
+    // acc[.][t][j][q] = T[k = 4 g + q of tile t][c0 + 16 j + c16]
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k0 + k < a.r)
-                    *reinterpret_cast<float2 *>(it.partial + ((long)blockIdx.y * a.r + k0 + k) * a.C + c) = acc[k];
+    for (int t = 0; t < NA; t++) {
+        float *part = (NS == 1 ? it.partial[0] : it.partial[t]) + (long)blockIdx.y * a.r * a.C;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = (NS == 1 ? 16 * t : 0) + 4 * g + q;
+            if (k >= a.r) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                part[(long)k * a.C + c0 + 16 * j + c16] = acc[0][t][j][q] + acc[1][t][j][q] * LoShift<DT>::down;
         }
+    }
+}
+
+// MAXS = 3: items carry one to three coefficient sets (RT == 1); MAXS = 1: one set of RT tiles
+template <int DT, int MAXS, int RT>
+__global__ __launch_bounds__(256, 2) void lowrank_outer_mfma_kernel(const OuterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 2 * 4096];
+    const OuterItem &it = a.it[blockIdx.z];
+    if constexpr (MAXS == 1) {
+        lowrank_outer_body<DT, 1, RT>(a, it, lds);
+    } else {
+        if (it.ns == 3) lowrank_outer_body<DT, 3, 1>(a, it, lds);
+        else if (it.ns == 2) lowrank_outer_body<DT, 2, 1>(a, it, lds);
+        else lowrank_outer_body<DT, 1, 1>(a, it, lds);
     }
 }
 
@@ -791,8 +891,10 @@ struct TrainBufs {
     void *dx16, *da16, *ta, *tb;
     int Mp, ln_wgs, col_slabs;
     size_t part_floats;
-    // LoRA gradients from the activations: P / Q projections [M, 64] x 4 and the outer products' partial sums
-    float *lr_proj, *lr_part;
+    // LoRA gradients from the activations: four coefficient slots ([2][<= 64][Mp] 16-bit, P then Q) and the outer
+    // products' partial sums
+    void *lr_proj;
+    float *lr_part;
     int lr_slab, lr_slabs;
 };
 
@@ -838,9 +940,9 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
     b.lnpart = (float *)sc.take((size_t)b.ln_wgs * 2 * W * 4);
     b.col_slabs = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
     b.colpart = (float *)sc.take((size_t)b.col_slabs * 4 * W * 4);
-    b.lr_slab = 256;
+    b.lr_slab = 256;                                                       // the shortest row slab of an outer product
     b.lr_slabs = (int)((M + b.lr_slab - 1) / b.lr_slab);
-    b.lr_proj = (float *)sc.take(M * 64 * 4 * 4);                          // four [M, <= 64] coefficient blocks
+    b.lr_proj = sc.take((M + 32) * 64 * 2 * 2 * 4);                        // four [2][<= 64][Mp] 16-bit coefficient slots
     b.lr_part = (float *)sc.take((size_t)b.lr_slabs * 64 * W * 4 * 4);     // four [slabs, <= 64, W] partial blocks
     return sc.off;
 }
@@ -930,14 +1032,23 @@ int weight_grad(int dtype, const void *a_t, const void *b_t, int n_out, int n_in
 }
 
 // ---- LoRA gradients of one block (ec_block_lora): P / Q projections, outer products, reduction ----
-template <int DT> void launch_project(const ProjectArgs &a, int n_items, hipStream_t s)
+template <int DT> void launch_project(const ProjectArgs &a, int n_items, bool shared, int RT, hipStream_t s)
 {
-    hipLaunchKernelGGL(lowrank_project_kernel<DT>, dim3((unsigned)((a.M + 63) / 64), (unsigned)n_items), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((a.Mp + 63) / 64), (unsigned)n_items);
+    if (shared) hipLaunchKernelGGL((lowrank_project_kernel<DT, 3, 1>), grid, dim3(256), 0, s, a);
+    else if (RT == 1) hipLaunchKernelGGL((lowrank_project_kernel<DT, 1, 1>), grid, dim3(256), 0, s, a);
+    else if (RT == 2) hipLaunchKernelGGL((lowrank_project_kernel<DT, 1, 2>), grid, dim3(256), 0, s, a);
+    else if (RT == 3) hipLaunchKernelGGL((lowrank_project_kernel<DT, 1, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lowrank_project_kernel<DT, 1, 4>), grid, dim3(256), 0, s, a);
 }
-template <int DT> void launch_outer(const OuterArgs &a, int n_items, int slabs, hipStream_t s)
+template <int DT> void launch_outer(const OuterArgs &a, int n_items, int slabs, bool shared, int RT, hipStream_t s)
 {
-    hipLaunchKernelGGL(lowrank_outer_kernel<DT>, dim3((unsigned)((a.C / 2 + 255) / 256), (unsigned)slabs, (unsigned)n_items),
-                       dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((a.C + 255) / 256), (unsigned)slabs, (unsigned)n_items);
+    if (shared) hipLaunchKernelGGL((lowrank_outer_mfma_kernel<DT, 3, 1>), grid, dim3(256), 0, s, a);
+    else if (RT == 1) hipLaunchKernelGGL((lowrank_outer_mfma_kernel<DT, 1, 1>), grid, dim3(256), 0, s, a);
+    else if (RT == 2) hipLaunchKernelGGL((lowrank_outer_mfma_kernel<DT, 1, 2>), grid, dim3(256), 0, s, a);
+    else if (RT == 3) hipLaunchKernelGGL((lowrank_outer_mfma_kernel<DT, 1, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lowrank_outer_mfma_kernel<DT, 1, 4>), grid, dim3(256), 0, s, a);
 }
 
 // One group of projections sharing the row count: inputs x_p (what the projection multiplies) and dy_p (the
@@ -950,34 +1061,67 @@ struct LoraJob {
 };
 int lora_grads(int dtype, const LoraJob *jobs, int n, int M, int W, int r, const TrainBufs &b, hipStream_t s)
 {
-    const int RT = (r + 15) / 16, PS = 16 * RT;
+    const int RT = (r + 15) / 16;
+    const int Mp = (M + 31) / 32 * 32;
+    EC_REQUIRE(W % 64 == 0, "LoRA gradients: width %d is not a multiple of 64", W);
+    const int cus = ec::cu_count();
+    EC_REQUIRE(cus > 0, "LoRA gradients: cannot read the device's compute-unit count");
     ec::ProfScope prof(ec::PROF_SGEMM, s, 8.0 * M * W * r * n, 4.0 * M * W * n);
-    // P_p = x_p down_p^T into slots 0 .. n-1, Q_p = dy_p up_p into slots 4 .. : [M, PS] each
+    // half 0: P_p = x_p down_p^T, d up_p = dy_p^T P_p;   half 1: Q_p = dy_p up_p, d down_p = Q_p^T x_p.
+    // With one 16-row factor tile per projection (r <= 16) the projections that multiply the same x (q, k, v)
+    // read it once: one project item with three factor sets in half 0, one outer item with three coefficient
+    // sets in half 1.
+    const bool share = RT == 1;
+    const size_t slot = (size_t)2 * 64 * Mp;                       // 16-bit elements per coefficient slot
     for (int half = 0; half < 2; half++) {
-        ProjectArgs pa;
-        pa.M = M, pa.RT = RT;
+        ProjectArgs pa = {};
+        pa.M = M, pa.Mp = Mp;
+        OuterArgs oa = {};
+        oa.M = M, oa.Mp = Mp, oa.C = W, oa.r = r;
+        OuterReduceArgs ra = {};
+        ra.r = r, ra.C = W;
+        int np = 0, no = 0;
         for (int i = 0; i < n; i++) {
-            ProjectItem &it = pa.it[i];
-            it.in = half ? jobs[i].dy : jobs[i].x, it.ld = half ? jobs[i].ldy : jobs[i].ldx;
-            it.f = half ? jobs[i].up16t : jobs[i].down16, it.C = W;
-        }
-        // (the four coefficient slots are reused: first P -> d_up, then Q -> d_down)
-        OuterArgs oa;
-        oa.M = M, oa.C = W, oa.r = r, oa.slab_rows = b.lr_slab;
-        OuterReduceArgs ra;
-        ra.slabs = b.lr_slabs, ra.r = r, ra.C = W;
-        for (int i = 0; i < n; i++) {
-            pa.it[i].out = b.lr_proj + (size_t)i * M * 64;
-            OuterItem &o = oa.it[i];
-            o.in = half ? jobs[i].x : jobs[i].dy, o.ld = half ? jobs[i].ldx : jobs[i].ldy;
-            o.coef = pa.it[i].out, o.cstride = PS;
-            o.partial = b.lr_part + (size_t)i * b.lr_slabs * 64 * W;
-            ra.partial[i] = o.partial;
-            ra.out[i] = half ? jobs[i].d_down : jobs[i].d_up;
+            const LoraJob &j = jobs[i];
+            void *coef = static_cast<unsigned short *>(b.lr_proj) + (size_t)i * slot;
+            float *part = b.lr_part + (size_t)i * b.lr_slabs * 64 * W;
+            ra.partial[i] = part;
+            ra.out[i] = half ? j.d_down : j.d_up;
             ra.transposed[i] = half ? 0 : 1;
+            // the projection reads x (half 0) or dy (half 1); the outer product reads the other one
+            const void *pin = half ? j.dy : j.x, *oin = half ? j.x : j.dy;
+            const long pld = half ? j.ldy : j.ldx, old = half ? j.ldx : j.ldy;
+            int pi = np, oi = no;
+            if (share) {
+                for (int q = 0; q < np; q++)
+                    if (pa.it[q].in == pin && pa.it[q].ld == pld && pa.it[q].nf < 3) pi = q;
+                for (int q = 0; q < no; q++)
+                    if (oa.it[q].in == oin && oa.it[q].ld == old && oa.it[q].ns < 3) oi = q;
+            }
+            ProjectItem &p = pa.it[pi];
+            if (pi == np) np++, p.in = pin, p.ld = pld, p.C = W, p.nf = 0;
+            p.f[p.nf] = half ? j.up16t : j.down16, p.out_t[p.nf] = coef, p.nf++;
+            OuterItem &o = oa.it[oi];
+            if (oi == no) no++, o.in = oin, o.ld = old, o.ns = 0;
+            o.coef_t[o.ns] = coef, o.partial[o.ns] = part, o.ns++;
         }
-        if (dtype == EC_F16) launch_project<EC_F16>(pa, n, s), launch_outer<EC_F16>(oa, n, b.lr_slabs, s);
-        else launch_project<EC_BF16>(pa, n, s), launch_outer<EC_BF16>(oa, n, b.lr_slabs, s);
+        bool share_p = false, share_o = false;
+        for (int q = 0; q < np; q++) share_p |= pa.it[q].nf > 1;
+        for (int q = 0; q < no; q++) share_o |= oa.it[q].ns > 1;
+        // row slabs: as many workgroups as the CUs hold at once (two each with three coefficient sets in
+        // registers, four otherwise) in ONE round -- a few more and a second round runs nearly empty; at least
+        // b.lr_slab rows each (the partial sums' scratch is sized for that)
+        const int col_groups = (W + 255) / 256;
+        int want = (share_o || RT > 1 ? 2 : 4) * cus / (no * col_groups);
+        want = want < 1 ? 1 : want;
+        int slab = ((Mp + want - 1) / want + 31) / 32 * 32;
+        slab = slab < b.lr_slab ? b.lr_slab : slab;
+        const int slabs = (Mp + slab - 1) / slab;
+        oa.slab_rows = slab, ra.slabs = slabs;
+        if (dtype == EC_F16)
+            launch_project<EC_F16>(pa, np, share_p, RT, s), launch_outer<EC_F16>(oa, no, slabs, share_o, RT, s);
+        else
+            launch_project<EC_BF16>(pa, np, share_p, RT, s), launch_outer<EC_BF16>(oa, no, slabs, share_o, RT, s);
         hipLaunchKernelGGL(lowrank_reduce_kernel, dim3((unsigned)(((long)r * W + 255) / 256), (unsigned)n), dim3(256), 0, s, ra);
     }
     EC_CHECK_HIP(hipGetLastError());

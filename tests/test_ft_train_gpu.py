@@ -403,6 +403,51 @@ def test_k_batched_tail_rows_of_a_reference_sized_batch(hip):
         assert rel_l2(whole[k], halves[k]) < 2e-3, (k, rel_l2(whole[k], halves[k]))
 
 
+@pytest.mark.parametrize('spec,name,dtype', [('qkvo-4', 'b32_2blocks', 'float16'), ('qkvo-16', 'l14_2blocks', 'float16'),
+                                             ('qv-16', 'l14_2blocks', 'bfloat16'), ('qkvo-24', 'wide_odd', 'float16'),
+                                             ('qkvo-64', 'b32_2blocks', 'bfloat16'), (40, 'tiny', 'float16'),
+                                             ('qkv-3', 'l14_336_1block', 'float16')])
+def test_lora_gradients_from_the_activations_follow_the_chain_rule(hip, spec, name, dtype):
+    """The factor gradients the backward pass takes straight from the activations (csrc/vit_train.hip: lora_grads --
+    projections written as transposed hi / lo planes, MFMA outer products over the row index, q / k / v sharing
+    one read of ln_1(x) when r <= 16) against d up = dW down^T, d down = up^T dW with dW the merged weight's
+    gradient from the same tower in full mode.  Ranks on both sides of one 16-row factor tile, both dtypes, row
+    counts that are not multiples of 32."""
+    from eventclip_amd import ft
+    cfg, n = CONFIGS[name]
+    model, tower, _ = _tower(cfg, seed=5, dtype=dtype)
+    lf = ft.LoraFactors(tower, spec)
+    torch.manual_seed(11)
+    for k, p in lf.params.items():
+        if 'lora_up' in k:
+            p.copy_(torch.randn_like(p) * 0.02)
+    grads = {k: torch.full_like(p, float('nan')) for k, p in lf.params.items()}
+    lf.bind(grads)
+    lf.merge()
+    imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
+    d_feats = torch.randn(n, cfg['embed_dim'], device='cuda')
+    patches = _patchify(tower, imgs)
+    tower.forward(patches)
+    tower.backward(d_feats, [], lf.struct)
+    tower.forward(patches)
+    full, _ = tower.backward(d_feats, list(lf.merged_names))
+    W = tower.W
+    tol = 3e-3 if dtype == 'float16' else 2e-2
+    worst = 0.0
+    for i, j, kd, ku in lf.projections():
+        pre = f'transformer.resblocks.{i}.attn'
+        dW = full[pre + ('.in_proj_weight' if j is not None else '.out_proj.weight')].view(-1, W)
+        dW = dW[j * W:(j + 1) * W] if j is not None else dW
+        # the kernels multiply by the 16-bit copies of the factors
+        down, up = lf.down16[kd][:lf.r].float(), lf.up16t[ku][:lf.r].float().T
+        for got, want in ((grads[ku], dW @ down.T), (grads[kd], up.T @ dW)):
+            assert torch.isfinite(got).all()
+            e = rel_l2(got, want)
+            assert e < tol, (kd, e)
+            worst = max(worst, e)
+    print('worst relative l2:', worst)
+
+
 @pytest.mark.parametrize('subset', ['all', 'bias', 'blocks_1_2'])
 def test_staged_backward_is_the_single_pass_and_its_buckets_tile_the_gradient_buffer(hip, subset):
     cfg, n = CONFIGS['wide_odd']
