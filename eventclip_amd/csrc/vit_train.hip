@@ -566,7 +566,7 @@ struct ProjectItem {
     const void *in;     // [M, C] 16-bit at row stride ld
     long ld;
     int nf;             // factor sets applied to this input (1 .. 3; more than 1 only with RT == 1)
-    const void *f[3];   // [16 RT, C] 16-bit factor rows (zero rows past r)
+    const void *ff[3];  // the factor rows [16 RT, C] (zero rows past r) in fragment order (lowrank_frag_kernel)
     void *out_t[3];     // [2][16 RT][Mp] 16-bit: hi plane, lo plane
     int C;
 };
@@ -579,62 +579,81 @@ struct ProjectArgs {
 // parameter of the body, not a runtime guard: with guards every MFMA sits behind a branch and the compiler can
 // no longer count the loads in flight (it waits for all of them: measured, no overlap between rounds).
 template <int DT, int NF, int RT>
-__device__ __forceinline__ void lowrank_project_body(const ProjectArgs &a, const ProjectItem &it)
+__device__ __forceinline__ void lowrank_project_body(const ProjectArgs &a, const ProjectItem &it, unsigned char *lds)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     static_assert(NF == 1 || RT == 1, "several factor sets only with one factor tile each");
     constexpr int NA = NF * RT;
-    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int m0 = (blockIdx.x * 4 + wave) * 16;
     if (m0 >= a.Mp) return;
-    const int m = m0 + c16 < a.M ? m0 + c16 : a.M - 1;
-    const elem *in = (const elem *)it.in + (long)m * it.ld + g * 8;
-    // accumulator t: NF == 1 -> tile t of set 0; NF == 3 -> the tile of set t
-    const elem *f[NA];
+    unsigned char *img = lds + wave * 8192;
+    // In's round [16 rows][128 columns] arrives row-contiguous (a quarter wave reads 256 contiguous bytes; the
+    // operand order -- lane = row -- straight from memory costs one cache-line look-up per lane: measured, the
+    // kernel ran at the texture unit's rate, not the memory's) and is re-read from a wave-private LDS image.
+    // The factors come in fragment order (lowrank_frag_kernel): 1 KiB contiguous per load.
+    const elem *src[4];
 #pragma unroll
-    for (int t = 0; t < NA; t++) {
-        const elem *base = (const elem *)(NF == 1 ? it.f[0] : it.f[t]);
-        f[t] = base + (long)((NF == 1 ? 16 * t : 0) + c16) * it.C + g * 8;
+    for (int i = 0; i < 4; i++) {
+        int m = m0 + g + 4 * i;
+        m = m < a.M ? m : a.M - 1;
+        src[i] = (const elem *)it.in + (long)m * it.ld + c16 * 8;
     }
+    const int ksteps = it.C / 32;
+    const v8 *wf[NA];
+#pragma unroll
+    for (int t = 0; t < NA; t++)
+        wf[t] = (const v8 *)(NF == 1 ? it.ff[0] : it.ff[t]) + (long)(NF == 1 ? t : 0) * ksteps * 64 + lane;
     f32x4 acc[NA];
 #pragma unroll
     for (int t = 0; t < NA; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // rounds of four 32-wide steps, two rounds of loads in flight: a wave lives for C / 128 rounds only, so the
-    // HBM latency of every round it waits out in full is the kernel's time (C is a multiple of 64; a lone last
-    // pair of steps is done singly)
-    auto load = [&](int k0, v8(&x)[4], v8(&w)[NA][4]) {
+    auto load = [&](int r, v8(&x)[4], v8(&w)[NA][4]) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            x[u] = *reinterpret_cast<const v8 *>(in + k0 + 32 * u);
-#pragma unroll
-            for (int t = 0; t < NA; t++)
-                w[t][u] = *reinterpret_cast<const v8 *>(f[t] + k0 + 32 * u);
-        }
-    };
-    auto mma = [&](const v8(&x)[4], const v8(&w)[NA][4]) {
+        for (int i = 0; i < 4; i++) x[i] = *reinterpret_cast<const v8 *>(src[i] + r * 128);
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int t = 0; t < NA; t++)
-                acc[t] = mfma16(w[t][u], x[u], acc[t]);
+            for (int t = 0; t < NA; t++) w[t][u] = wf[t][(long)(4 * r + u) * 64];
     };
+    auto compute = [&](const v8(&x)[4], const v8(&w)[NA][4], unsigned char *im) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = g + 4 * i;
+            *reinterpret_cast<v8 *>(im + row * 256 + ((c16 ^ row) << 4)) = x[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const v8 xf = *reinterpret_cast<const v8 *>(im + c16 * 256 + (((4 * u + g) ^ c16) << 4));
+#pragma unroll
+            for (int t = 0; t < NA; t++) acc[t] = mfma16(w[t][u], xf, acc[t]);
+        }
+    };
+    // two rounds in flight: a wave lives for C / 128 rounds only, so a latency it waits out in full shows
     const int rounds = it.C / 128;
     v8 xa[4], xb[4], wa[NA][4], wb[NA][4];
     if (rounds > 0) load(0, xa, wa);
+    if (rounds > 1) load(1, xb, wb);
     for (int r = 0; r < rounds; r += 2) {
-        if (r + 1 < rounds) load((r + 1) * 128, xb, wb);
-        mma(xa, wa);
+        compute(xa, wa, img);
+        if (r + 2 < rounds) load(r + 2, xa, wa);
         if (r + 1 < rounds) {
-            if (r + 2 < rounds) load((r + 2) * 128, xa, wa);
-            mma(xb, wb);
+            compute(xb, wb, img + 4096);
+            if (r + 3 < rounds) load(r + 3, xb, wb);
         }
     }
-    for (int k0 = rounds * 128; k0 < it.C; k0 += 32) {
-        const v8 x = *reinterpret_cast<const v8 *>(in + k0);
+    // a last half round (C = 64 (2 n + 1)): operand order straight from memory
+    if (rounds * 128 < it.C) {
+        const int m = m0 + c16 < a.M ? m0 + c16 : a.M - 1;
+        const elem *in = (const elem *)it.in + (long)m * it.ld + g * 8;
+        for (int ks = rounds * 4; ks < ksteps; ks++) {
+            const v8 x = *reinterpret_cast<const v8 *>(in + ks * 32);
 #pragma unroll
-        for (int t = 0; t < NA; t++)
-            acc[t] = mfma16(*reinterpret_cast<const v8 *>(f[t] + k0), x, acc[t]);
+            for (int t = 0; t < NA; t++) acc[t] = mfma16(wf[t][(long)ks * 64], x, acc[t]);
+        }
     }
     // acc[t][r] = c[m0 + c16][4 g + r] of tile t; sixteen lanes write sixteen consecutive m
     const bool inside = m0 + c16 < a.M;
@@ -656,14 +675,35 @@ __device__ __forceinline__ void lowrank_project_body(const ProjectArgs &a, const
 template <int DT, int MAXF, int RT>
 __global__ __launch_bounds__(256) void lowrank_project_kernel(const ProjectArgs a)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 2 * 4096];
     const ProjectItem &it = a.it[blockIdx.y];
     if constexpr (MAXF == 1) {
-        lowrank_project_body<DT, 1, RT>(a, it);
+        lowrank_project_body<DT, 1, RT>(a, it, lds);
     } else {
-        if (it.nf == 3) lowrank_project_body<DT, 3, 1>(a, it);
-        else if (it.nf == 2) lowrank_project_body<DT, 2, 1>(a, it);
-        else lowrank_project_body<DT, 1, 1>(a, it);
+        if (it.nf == 3) lowrank_project_body<DT, 3, 1>(a, it, lds);
+        else if (it.nf == 2) lowrank_project_body<DT, 2, 1>(a, it, lds);
+        else lowrank_project_body<DT, 1, 1>(a, it, lds);
     }
+}
+
+// Factor rows [16 RT][C] -> MFMA fragment order: 16-byte piece (tile t, k step ks, lane) = rows 16 t + (lane & 15),
+// columns 32 ks + 8 (lane >> 4) .. + 8, so that a wave's operand load is 1 KiB contiguous.
+struct FragArgs {
+    const void *src[8];
+    void *dst[8];
+    int C, RT;
+};
+__global__ __launch_bounds__(256) void lowrank_frag_kernel(const FragArgs a)
+{
+    const int ksteps = a.C / 32;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.RT * ksteps * 64) return;
+    const int lane = (int)(idx & 63);
+    const long fs = idx >> 6;
+    const int t = (int)(fs / ksteps), ks = (int)(fs - (long)t * ksteps);
+    const unsigned short *src = static_cast<const unsigned short *>(a.src[blockIdx.y]);
+    reinterpret_cast<uint4 *>(a.dst[blockIdx.y])[idx] =
+        *reinterpret_cast<const uint4 *>(src + (long)(16 * t + (lane & 15)) * a.C + 32 * ks + 8 * (lane >> 4));
 }
 
 struct OuterItem {
@@ -893,7 +933,7 @@ struct TrainBufs {
     size_t part_floats;
     // LoRA gradients from the activations: four coefficient slots ([2][<= 64][Mp] 16-bit, P then Q) and the outer
     // products' partial sums
-    void *lr_proj;
+    void *lr_proj, *lr_frag;
     float *lr_part;
     int lr_slab, lr_slabs;
 };
@@ -944,6 +984,7 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
     b.lr_slabs = (int)((M + b.lr_slab - 1) / b.lr_slab);
     b.lr_proj = sc.take((M + 32) * 64 * 2 * 2 * 4);                        // four [2][<= 64][Mp] 16-bit coefficient slots
     b.lr_part = (float *)sc.take((size_t)b.lr_slabs * 64 * W * 4 * 4);     // four [slabs, <= 64, W] partial blocks
+    b.lr_frag = sc.take((size_t)8 * 64 * W * 2);                           // eight factors [<= 64, W] in fragment order
     return sc.off;
 }
 
@@ -1073,6 +1114,19 @@ int lora_grads(int dtype, const LoraJob *jobs, int n, int M, int W, int r, const
     // sets in half 1.
     const bool share = RT == 1;
     const size_t slot = (size_t)2 * 64 * Mp;                       // 16-bit elements per coefficient slot
+    // every factor of the block in fragment order: slot 2 i = down of job i, 2 i + 1 = up^T
+    const size_t fslot = (size_t)64 * W;                           // 16-bit elements
+    {
+        FragArgs fa = {};
+        fa.C = W, fa.RT = RT;
+        for (int i = 0; i < n; i++) {
+            fa.src[2 * i] = jobs[i].down16, fa.src[2 * i + 1] = jobs[i].up16t;
+            fa.dst[2 * i] = static_cast<unsigned short *>(b.lr_frag) + (size_t)(2 * i) * fslot;
+            fa.dst[2 * i + 1] = static_cast<unsigned short *>(b.lr_frag) + (size_t)(2 * i + 1) * fslot;
+        }
+        const long pieces = (long)RT * (W / 32) * 64;
+        hipLaunchKernelGGL(lowrank_frag_kernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)(2 * n)), dim3(256), 0, s, fa);
+    }
     for (int half = 0; half < 2; half++) {
         ProjectArgs pa = {};
         pa.M = M, pa.Mp = Mp;
@@ -1100,7 +1154,7 @@ int lora_grads(int dtype, const LoraJob *jobs, int n, int M, int W, int r, const
             }
             ProjectItem &p = pa.it[pi];
             if (pi == np) np++, p.in = pin, p.ld = pld, p.C = W, p.nf = 0;
-            p.f[p.nf] = half ? j.up16t : j.down16, p.out_t[p.nf] = coef, p.nf++;
+            p.ff[p.nf] = static_cast<unsigned short *>(b.lr_frag) + (size_t)(2 * i + half) * fslot, p.out_t[p.nf] = coef, p.nf++;
             OuterItem &o = oa.it[oi];
             if (oi == no) no++, o.in = oin, o.ld = old, o.ns = 0;
             o.coef_t[o.ns] = coef, o.partial[o.ns] = part, o.ns++;
