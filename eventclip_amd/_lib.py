@@ -64,7 +64,8 @@ class EcGemmArgs(ctypes.Structure):
                 ('variant', c_int), ('A', c_void_p), ('lda', c_long), ('W', c_void_p),
                 ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p),
                 ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
-                ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t)]
+                ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t),
+                ('transposed', c_int), ('k_rows', c_int)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3

@@ -48,7 +48,19 @@ struct GemmArgs {
     void *aux;                  // GELU16_SAVE: pre-activation out; GELU_BWD16: pre-activation in (ldc)
     int splits;                 // K-batches: batch s reads columns s*K .. of A and W, writes C + s * split_stride
     long split_stride;          // elements of C between batches
+    // transposed operands (persistent kernel, STORE32): A is [rows, M] and W is [rows, N], the reduction runs over
+    // their ROW index; K = rows per batch (a multiple of 64), k_valid = rows that exist (the rest read as zero)
+    int tn;
+    int k_valid;
 };
+
+// sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
+__device__ __attribute__((aligned(16))) unsigned int tn_zero16[4];
+
+// transposed-operand LDS image: [64 reduction rows][8 units of 32 B]; unit u of row r sits at u ^ tn_key(r), which
+// spreads the 8 rows a 32-lane half of ds_read_b64_tr_b16 takes ({0..3, 8..11} + 4 hh + 16 n) over the 64 banks
+__device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
 
 __device__ __forceinline__ int swz_key(int row) { return (row & 7) ^ ((row >> 3) & 6); }
 
@@ -167,7 +179,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4],
 // consecutive lanes covering 256 contiguous bytes of one row, for the residual loads and the stores.
 // scratch: NBUF x 16 x 68 floats per wave (one buffer is enough: a wave's LDS accesses execute in
 // program order).
-template <int EPI, int TM, int NBUF = 2>
+// NAT: acc[i][j][r] is column n_base + 16 j + 4 (lane >> 4) + r (the transposed-operand kernel's fragments are
+// read in natural column order; no bias there).
+template <int EPI, int TM, int NBUF = 2, bool NAT = false>
 __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
                                                int n_base, int lane, float *scratch)
 {
@@ -206,7 +220,7 @@ __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[T
         float *buf = scratch + (i % NBUF) * 16 * PITCH;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
+            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + (NAT ? j * 16 + q * 4 : q * 16 + j * 4)) = acc[i][j] + bias[j];
         f32x4 v[4];
 #pragma unroll
         for (int p = 0; p < 4; p++)
@@ -950,10 +964,12 @@ template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStre
 // prologue's HBM latency (~2.9 k cycles of a 48 k-cycle tile at K = 1024) is exposed.
 // TL: per-tile timeline records as in gemm2p_kernel<DBG = 9>.
 // ---------------------------------------------------------------------------------------
-template <int DT, int EPI, bool TL = false>
+template <int DT, int EPI, bool TL = false, bool TN = false>
 __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 {
     typedef typename T16<DT>::v8 v8;
+    typedef typename T16<DT>::v4 v4;
+    static_assert(!TN || EPI == EC_EPI_STORE32, "transposed operands: fp32 store only");
     constexpr int BM = 256, BN = 256;
     constexpr int REGION = 128 * 128;
     constexpr int KT = 4 * REGION;
@@ -971,6 +987,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 
     int m0 = 0, n0 = 0, sp0 = 0;
     const unsigned char *src[4][2];
+    // transposed operands: reduction rows of this batch still to be issued per region (rows past k_valid read
+    // tn_zero16), and the bytes one K tile advances an operand's pointer by
+    int rem[4] = {0, 0, 0, 0};
+    const long adv_a = TN ? (long)g.lda * BK * 2 : BK * 2, adv_w = TN ? (long)g.ldw * BK * 2 : BK * 2;
     auto setup = [&](int id) {
         int tm, tn;
         int rid = xcd_remap(id, ntiles);
@@ -982,6 +1002,30 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         const long koff = (long)sp0 * g.K;       // this batch's first column of A and W
         raster(rid, g.tiles_m, g.tiles_n, tm, tn);
         m0 = tm * BM, n0 = tn * BN;
+        if constexpr (TN) {
+            // LDS row = reduction row (4 per 1-KiB DMA piece), 16-byte slot = lane & 15 = 2 (unit ^ key) + half;
+            // unit = 4 wm + mt for the A regions (columns m0 + 128 wm + 64 mq + 16 mt ..), 2 wn + jj for the W
+            // regions (columns n0 + 64 wn + 32 nq + 16 jj ..)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rem[r] = g.k_valid - (int)koff;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int krow = (i * 8 + wave) * 4 + (lane >> 4);
+                    const int unit = ((lane & 15) >> 1) ^ tn_key(krow), h8 = (lane & 1) * 8;
+                    if (r < 2) {
+                        int col = m0 + (unit >> 2) * 128 + r * 64 + (unit & 3) * 16 + h8;
+                        col = col + 8 <= g.M ? col : g.M - 8;
+                        src[r][i] = (const unsigned char *)g.A + ((koff + krow) * g.lda + col) * 2;
+                    } else {
+                        int col = n0 + (unit >> 1) * 64 + (r - 2) * 32 + (unit & 1) * 16 + h8;
+                        col = col + 8 <= g.N ? col : g.N - 8;
+                        src[r][i] = (const unsigned char *)g.W + ((koff + krow) * g.ldw + col) * 2;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -1001,11 +1045,20 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             }
     };
     auto issue = [&](int r, int buf) {
+        if (TN && rem[r] < BK) {       // the batch's last K tile runs past the rows that exist
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
-            src[r][i] += BK * 2;
+            for (int i = 0; i < 2; i++) {
+                const int krow = (i * 8 + wave) * 4 + (lane >> 4);
+                const unsigned char *p = krow < rem[r] ? src[r][i] : reinterpret_cast<const unsigned char *>(tn_zero16);
+                glds16(p, smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++) glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
         }
+#pragma unroll
+        for (int i = 0; i < 2; i++) src[r][i] += r < 2 ? adv_a : adv_w;
+        if (TN) rem[r] -= BK;
     };
 
     int offM[4], offN[2];
@@ -1021,23 +1074,53 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
     }
 
+    if constexpr (TN) {
+        // transposed reads: lane 4 q + p of a 16-lane group addresses row 8 g + 4 hh + q (+ 32 ks), 8-byte piece p
+        // of the fragment's 32-byte unit; the key is the same for every row this lane addresses
+        const int q = (lane & 15) >> 2, p = lane & 3, gg = lane >> 4;
+        const int key = q | ((gg & 1) << 2);
+        const int base = (8 * gg + q) * 256 + ((p >> 1) << 4) + ((p & 1) << 3);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) offM[mt] = base + (((wm * 4 + mt) ^ key) << 5);
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) offN[jj] = base + (((wn * 2 + jj) ^ key) << 5);
+    }
+    auto tr8 = [&](const unsigned char *at) {
+        v8 f;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(at + hh * 1024));
+            const v4 tv = __builtin_bit_cast(v4, t);
+            f[4 * hh] = tv[0], f[4 * hh + 1] = tv[1], f[4 * hh + 2] = tv[2], f[4 * hh + 3] = tv[3];
+        }
+        return f;
+    };
+
     f32x4 acc[8][4];
     v8 fm[4][2], fn0[2][2], fn1[2][2];
     auto load_m = [&](int buf, int mq) {
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
-                                                           (offM[mt] ^ (ks << 6)));
+            for (int ks = 0; ks < 2; ks++) {
+                if constexpr (TN)
+                    fm[mt][ks] = tr8(smem + buf * KT + mq * REGION + offM[mt] + ks * 8192);
+                else
+                    fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
+                                                               (offM[mt] ^ (ks << 6)));
+            }
     };
     auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
 #pragma unroll
         for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
-                                                           (offN[jj] ^ (ks << 6)));
+            for (int ks = 0; ks < 2; ks++) {
+                if constexpr (TN)
+                    fn[jj][ks] = tr8(smem + buf * KT + (2 + nq) * REGION + offN[jj] + ks * 8192);
+                else
+                    fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
+                                                               (offN[jj] ^ (ks << 6)));
+            }
     };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -1159,8 +1242,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             issue(1, 0);
         }
         if constexpr (!epi_is16(EPI))
-            epilogue32_lds<EPI, 8, 1>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                      reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+            epilogue32_lds<EPI, 8, 1, TN>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                          reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
         else
             epilogue16_lds<DT, EPI, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
                                        smem + KT + wave * (2 * 16 * 144));
@@ -1187,13 +1270,13 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     }
 }
 
-template <int DT, int EPI, bool TL = false> int launch2pp(const GemmArgs &g0, hipStream_t stream)
+template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
     g.tiles_m = ec::ceil_div(g.M, 256);
     g.tiles_n = ec::ceil_div(g.N, 256);
     constexpr int lds = 2 * 4 * 128 * 128;
-    auto kern = gemm2pp_kernel<DT, EPI, TL>;
+    auto kern = gemm2pp_kernel<DT, EPI, TL, TN>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
     EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
@@ -1631,6 +1714,22 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.diag = static_cast<unsigned long long *>(a->diag);
     g.ldw = a->ldw ? a->ldw : a->K, g.resid = a->resid, g.aux = a->aux;
     g.splits = a->splits > 1 ? a->splits : 1, g.split_stride = a->split_stride;
+    g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
+    if (g.tn) {
+        g.lda = a->lda ? a->lda : a->M, g.ldw = a->ldw ? a->ldw : a->N;
+        EC_REQUIRE(a->epilogue == EC_EPI_STORE32 && a->variant == 0 && !a->bias && !a->ws,
+                   "ec_gemm: transposed operands go with EC_EPI_STORE32, variant 0, no bias, no ws");
+        EC_REQUIRE(g.M % 8 == 0 && g.M >= 8 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.lda >= g.M && g.ldw >= g.N,
+                   "ec_gemm: transposed operands need M %% 8 == 0 and row strides (multiples of 8) covering M and N");
+        EC_REQUIRE(g.k_valid > 0 && (long)g.k_valid <= (long)g.K * g.splits,
+                   "ec_gemm: k_rows=%d outside (0, splits * K = %ld]", g.k_valid, (long)g.K * g.splits);
+        EC_REQUIRE(g.splits == 1 || (g.split_stride >= (long)(g.M - 1) * ldc + g.N && g.split_stride % 8 == 0),
+                   "ec_gemm: split_stride %ld too small for an %d x %d output", g.split_stride, g.M, g.N);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (a->dtype == EC_F16) return launch2pp<EC_F16, EC_EPI_STORE32, false, true>(g, st);
+        if (a->dtype == EC_BF16) return launch2pp<EC_BF16, EC_EPI_STORE32, false, true>(g, st);
+        return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown dtype %d", a->dtype);
+    }
     EC_REQUIRE(g.ldw % 8 == 0 && g.ldw >= (long)g.K * g.splits && lda >= (long)g.K * g.splits,
                "ec_gemm: lda / ldw must cover splits * K columns and be multiples of 8 elements");
     EC_REQUIRE((((uintptr_t)a->resid | (uintptr_t)a->aux) & 15) == 0, "ec_gemm: resid / aux must be 16-byte aligned");

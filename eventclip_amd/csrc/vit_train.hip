@@ -243,38 +243,49 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float *x, long ldx, c
         }
 }
 
-// column sums of a [M, N] matrix over row slabs: partial[slab][n] (bias gradients).  A thread owns 16 bytes
-// of a row (8 16-bit or 4 fp32 columns), four rows in flight.
+// column sums of a [M, N] matrix over row slabs: partial[slab][n] (bias gradients).  A workgroup owns 64 x 16
+// bytes of the row (512 16-bit or 256 fp32 columns: every wave load is 1 KiB contiguous) and a slab of rows; its
+// four waves take every fourth row, eight rows in flight per lane, and meet in LDS.  Fixed order: bit-reproducible.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *src, long ld, int M, int N, int slab_rows, float *partial)
 {
     constexpr int V = 16 / sizeof(T);
     typedef T vec __attribute__((ext_vector_type(V)));
-    const int n = (blockIdx.x * 256 + threadIdx.x) * V;
-    if (n >= N) return;
+    __shared__ float red[3][64][V + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + lane) * V;
+    const bool live = n < N;
     const int r0 = blockIdx.y * slab_rows, r1 = r0 + slab_rows < M ? r0 + slab_rows : M;
-    float acc[4][V];
+    float acc[V];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int j = 0; j < V; j++) acc[j] = 0.f;
+    if (live) {
+        int r = r0 + wave;
+        for (; r + 28 < r1; r += 32) {
+            vec v[8];
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[u][j] = 0.f;
-    int r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        vec v[4];
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const vec *>(src + (long)(r + 4 * u) * ld + n);
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const vec *>(src + (long)(r + u) * ld + n);
+            for (int u = 0; u < 8; u++)
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+                for (int j = 0; j < V; j++) acc[j] += (float)v[u][j];
+        }
+        for (; r < r1; r += 4) {
+            const vec v = *reinterpret_cast<const vec *>(src + (long)r * ld + n);
 #pragma unroll
-            for (int j = 0; j < V; j++) acc[u][j] += (float)v[u][j];
+            for (int j = 0; j < V; j++) acc[j] += (float)v[j];
+        }
     }
-    for (; r < r1; r++) {
-        const vec v = *reinterpret_cast<const vec *>(src + (long)r * ld + n);
+    if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[0][j] += (float)v[j];
+        for (int j = 0; j < V; j++) red[wave - 1][lane][j] = acc[j];
     }
+    __syncthreads();
+    if (wave == 0 && live) {
 #pragma unroll
-    for (int j = 0; j < V; j++) partial[(long)blockIdx.y * N + n + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+        for (int j = 0; j < V; j++)
+            partial[(long)blockIdx.y * N + n + j] = (acc[j] + red[0][lane][j]) + (red[1][lane][j] + red[2][lane][j]);
+    }
 }
 
 // out[i] = sum_p part[p * stride + i], p ascending (n, stride multiples of 4)
@@ -915,12 +926,22 @@ inline int pick_splits(int n_out, int n_in, int mp, int cus)
     return s;
 }
 
+// the same for the row batches of a weight gradient taken straight from the row-major operands
+inline int pick_splits_rows(int n_out, int n_in, int rows, int cus)
+{
+    const int tiles = ((n_out + 255) / 256) * ((n_in + 255) / 256);
+    int s = 1;
+    while (s < 16 && tiles * s * 2 <= cus && rows / (s * 2) >= 256) s *= 2;
+    return s;
+}
+
 struct TrainBufs {
     // tape
     float *pre;                 // [M, W] un-normalised embedding
     float *x[65];               // x[l]: input of block l; x[L]: the tower's last residual stream
     float *xm[64];              // after the attention branch
     void *qkv[64], *att[64], *u[64];
+    void *gact[64];             // QuickGELU(u), 16 bit: c_proj's input, kept for its weight gradient
     void *h1[64], *h2[64];      // the two LayerNorm outputs (16 bit): the weight / LoRA gradients' right-hand operands
     float *lse[64];
     // scratch shared by both passes
@@ -929,7 +950,7 @@ struct TrainBufs {
     // backward scratch
     float *dx, *dh32, *delta, *clsln, *dclsln, *part, *lnpart, *colpart;
     void *dx16, *da16, *ta, *tb;
-    int Mp, ln_wgs, col_slabs;
+    int Mp, ln_wgs, col_slabs, W;
     size_t part_floats;
     // LoRA gradients from the activations: four coefficient slots ([2][<= 64][Mp] 16-bit, P then Q) and the outer
     // products' partial sums
@@ -951,6 +972,7 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
         b.qkv[l] = sc.take(M * 3 * W * 2);
         b.att[l] = sc.take(M * W * 2);
         b.u[l] = sc.take(M * 4 * W * 2);
+        b.gact[l] = sc.take(M * 4 * W * 2);
         b.h1[l] = sc.take(M * W * 2);
         b.h2[l] = sc.take(M * W * 2);
         b.lse[l] = (float *)sc.take((size_t)n * w->heads * S * 4);
@@ -965,20 +987,23 @@ size_t carve_train(Scratch &sc, const ec_vit_weights *w, int n, TrainBufs &b)
     b.dclsln = (float *)sc.take((size_t)n * W * 4);
     b.dx16 = sc.take(M * W * 2);
     b.da16 = sc.take(M * W * 2);
-    const size_t wide = (size_t)(4 * W > w->kpad ? 4 * W : w->kpad);
-    b.ta = sc.take(wide * Mp * 2);
-    b.tb = sc.take(wide * Mp * 2);
+    // transposed copies: only the patch embedding's weight gradient still takes them (its rows skip the class tokens)
+    b.ta = sc.take((size_t)W * Mp * 2);
+    b.tb = sc.take((size_t)w->kpad * Mp * 2);
     size_t pf = 0;
     const int shapes[5][2] = {{3 * W, W}, {W, W}, {4 * W, W}, {W, 4 * W}, {W, w->kpad}};
     for (int i = 0; i < 5; i++) {
         const size_t f = (size_t)pick_splits(shapes[i][0], shapes[i][1], Mp, SIZING_CUS) * shapes[i][0] * shapes[i][1];
+        const size_t fr = (size_t)pick_splits_rows(shapes[i][0], shapes[i][1], (int)M, SIZING_CUS) * shapes[i][0] * shapes[i][1];
         pf = f > pf ? f : pf;
+        pf = fr > pf ? fr : pf;
     }
     b.part_floats = pf;
     b.part = (float *)sc.take(pf * 4);
     b.ln_wgs = (int)((M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024);
     b.lnpart = (float *)sc.take((size_t)b.ln_wgs * 2 * W * 4);
-    b.col_slabs = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
+    b.W = W;
+    b.col_slabs = 256;
     b.colpart = (float *)sc.take((size_t)b.col_slabs * 4 * W * 4);
     b.lr_slab = 256;                                                       // the shortest row slab of an outer product
     b.lr_slabs = (int)((M + b.lr_slab - 1) / b.lr_slab);
@@ -1037,13 +1062,20 @@ int reduce(const float *part, long stride, int P, long n, float *out, hipStream_
 // db[N] = column sums of a [M, N] 16-bit or fp32 matrix
 template <typename T> int bias_grad(const T *src, long ld, int M, int N, const TrainBufs &b, float *out, hipStream_t s)
 {
-    const int slab = (M + b.col_slabs - 1) / b.col_slabs;
+    // about 1024 workgroups (four per CU of the device this was sized for), within the partial buffer
+    constexpr int V = 16 / sizeof(T);
+    const int col_groups = (N / V + 63) / 64;
+    long want = 1024 / col_groups;
+    const long fit = (long)b.col_slabs * 4 * b.W / N;                 // slabs of N floats the buffer holds
+    want = want < fit ? want : fit;
+    want = want < 1 ? 1 : want;
+    int slab = (int)((M + want - 1) / want);
+    slab = slab < 8 ? 8 : slab;
     const int slabs = (M + slab - 1) / slab;
     {
         ec::ProfScope prof(ec::PROF_REDUCE, s, 0, (double)M * N * sizeof(T));
-        constexpr int V = 16 / sizeof(T);
-        hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)((N / V + 255) / 256), (unsigned)slabs), dim3(256), 0, s, src, ld, M, N,
-                           slab, b.colpart);
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)col_groups, (unsigned)slabs), dim3(256), 0, s, src, ld, M, N, slab,
+                           b.colpart);
     }
     return reduce(b.colpart, N, slabs, N, out, s);
 }
@@ -1070,6 +1102,25 @@ int weight_grad(int dtype, const void *a_t, const void *b_t, int n_out, int n_in
         return EC_OK;
     }
     return reduce(b.part, (long)n_out * n_in, splits, (long)n_out * n_in, out, s);
+}
+
+// dW[n_out, n_in] = dy^T x straight from the row-major activations (ec_gemm_args.transposed: the reduction runs over
+// the operands' rows, their tiles are read column-major out of LDS) -- no transposed copies.  K-batches over row
+// ranges, reduced into `out`.
+int weight_grad_rows(int dtype, const void *dy, long ldy, const void *x, long ldx, int n_out, int n_in, int rows,
+                     const TrainBufs &b, float *out, ec_stream_t stream)
+{
+    const int cus = ec::cu_count();
+    EC_REQUIRE(cus > 0, "ec_vit_train_backward: cannot read the device's compute-unit count");
+    int splits = pick_splits_rows(n_out, n_in, rows, cus);
+    while ((size_t)splits * n_out * n_in > b.part_floats) splits /= 2;   // a device with more CUs than sized for
+    ec_gemm_args g = {};
+    g.M = n_out, g.N = n_in, g.K = ((rows + splits - 1) / splits + 63) / 64 * 64, g.dtype = dtype;
+    g.epilogue = EC_EPI_STORE32, g.variant = 0, g.transposed = 1, g.k_rows = rows;
+    g.A = dy, g.lda = ldy, g.W = x, g.ldw = ldx, g.C = b.part, g.ldc = n_in;
+    g.splits = splits, g.split_stride = (long)n_out * n_in;
+    EC_TRY(ec_gemm(&g, stream));
+    return reduce(b.part, (long)n_out * n_in, splits, (long)n_out * n_in, out, static_cast<hipStream_t>(stream));
 }
 
 // ---- LoRA gradients of one block (ec_block_lora): P / Q projections, outer products, reduction ----
@@ -1308,8 +1359,8 @@ EC_API int ec_vit_train_forward(const ec_vit_weights *w, const void *patches, in
         EC_TRY(ec_attention_train(b.qkv[l], b.att[l], b.lse[l], n_img, S, W, w->heads, dt, stream));
         EC_TRY(gemm_x(M, W, W, dt, EC_EPI_RESID32, b.att[l], p.out_w, b.xm[l], b.x[l], nullptr, p.out_b, stream));
         EC_TRY(ec_layernorm(b.xm[l], W, nullptr, p.ln2_g, p.ln2_b, M, W, LN_EPS, b.h2[l], W, dt, stream));
-        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h2[l], p.fc1_w, b.g16, nullptr, b.u[l], p.fc1_b, stream));
-        EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_RESID32, b.g16, p.fc2_w, b.x[l + 1], b.xm[l], p.fc2_b, b.part,
+        EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU16_SAVE, b.h2[l], p.fc1_w, b.gact[l], nullptr, b.u[l], p.fc1_b, stream));
+        EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_RESID32, b.gact[l], p.fc2_w, b.x[l + 1], b.xm[l], p.fc2_b, b.part,
                            b.part_floats, stream));
     }
     EC_TRY(ec_layernorm_split(b.x[L], (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n_img, W, LN_EPS, b.cls_hi,
@@ -1397,33 +1448,22 @@ EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_tr
         const ec_block_grads &q = gr->blocks[l];
         EC_REQUIRE(pt.qkv_wt && pt.out_wt && pt.fc1_wt && pt.fc2_wt, "ec_vit_train_backward: block %d lacks transposed weights", l);
         // x[l + 1] = xm + c_proj(QuickGELU(c_fc(ln_2(xm))))
-        if (q.fc2_w) EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, b.ta, nullptr, s));
+        // (b.dx16 is the 16-bit copy of b.dx: written by the LayerNorm backward that produced it)
         if (q.fc2_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.fc2_b, s));
-        if (q.fc2_w) {
-            EC_TRY(transpose<1>(dt, b.u[l], 4L * W, M, 4 * W, Mp, 0, 0, 0, b.tb, nullptr, s));
-            EC_TRY(weight_grad(dt, b.ta, b.tb, W, 4 * W, b, q.fc2_w, 0, stream));
-        }
+        if (q.fc2_w) EC_TRY(weight_grad_rows(dt, b.dx16, W, b.gact[l], 4L * W, W, 4 * W, M, b, q.fc2_w, stream));
         EC_TRY(gemm_x(M, 4 * W, W, dt, EC_EPI_GELU_BWD16, b.dx16, pt.fc2_wt, b.g16, nullptr, b.u[l], nullptr, stream));
         if (q.fc1_b) {
             if (dt == EC_F16) EC_TRY(bias_grad<_Float16>((const _Float16 *)b.g16, 4L * W, M, 4 * W, b, q.fc1_b, s));
             else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 4L * W, M, 4 * W, b, q.fc1_b, s));
         }
-        if (q.fc1_w) {
-            EC_TRY(transpose<0>(dt, b.g16, 4L * W, M, 4 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
-            EC_TRY(transpose<0>(dt, b.h2[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
-            EC_TRY(weight_grad(dt, b.ta, b.tb, 4 * W, W, b, q.fc1_w, 0, stream));
-        }
+        if (q.fc1_w) EC_TRY(weight_grad_rows(dt, b.g16, 4L * W, b.h2[l], W, 4 * W, W, M, b, q.fc1_w, stream));
         EC_TRY(gemm_rows32(M, W, 4 * W, dt, EC_EPI_STORE32, b.g16, pt.fc1_wt, b.dh32, nullptr, nullptr, b.part,
                            b.part_floats, stream));
         EC_TRY(ln_backward(b.xm[l], W, b.dh32, W, p.ln2_g, M, W, b.dx, W, 1, q.ln2_g, q.ln2_b, b.lnpart, b.ln_wgs, s, b.dx16,
                            dt));
         // xm = x[l] + out_proj(attention(in_proj(ln_1(x[l]))))
-        if (q.out_w) EC_TRY(transpose<2>(dt, b.dx, W, M, W, Mp, 0, 0, 0, b.ta, nullptr, s));
         if (q.out_b) EC_TRY(bias_grad<float>(b.dx, W, M, W, b, q.out_b, s));
-        if (q.out_w) {
-            EC_TRY(transpose<0>(dt, b.att[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
-            EC_TRY(weight_grad(dt, b.ta, b.tb, W, W, b, q.out_w, 0, stream));
-        }
+        if (q.out_w) EC_TRY(weight_grad_rows(dt, b.dx16, W, b.att[l], W, W, W, M, b, q.out_w, stream));
         EC_TRY(gemm_x(M, W, W, dt, EC_EPI_STORE16, b.dx16, pt.out_wt, b.da16, nullptr, nullptr, nullptr, stream));
         EC_TRY(ec_attention_backward(b.qkv[l], b.att[l], b.lse[l], b.da16, b.g16, b.delta, n_img, S, W, w->heads, dt,
                                      stream));
@@ -1432,11 +1472,7 @@ EC_API int ec_vit_train_backward_stages(const ec_vit_weights *w, const ec_vit_tr
             else EC_TRY(bias_grad<__bf16>((const __bf16 *)b.g16, 3L * W, M, 3 * W, b, q.qkv_b, s));
         }
         const bool lora_qkv = has_lora(l, 0) || has_lora(l, 1) || has_lora(l, 2);
-        if (q.qkv_w) {
-            EC_TRY(transpose<0>(dt, b.g16, 3L * W, M, 3 * W, Mp, 0, 0, 0, b.ta, nullptr, s));
-            EC_TRY(transpose<0>(dt, b.h1[l], W, M, W, Mp, 0, 0, 0, b.tb, nullptr, s));
-            EC_TRY(weight_grad(dt, b.ta, b.tb, 3 * W, W, b, q.qkv_w, 0, stream));
-        }
+        if (q.qkv_w) EC_TRY(weight_grad_rows(dt, b.g16, 3L * W, b.h1[l], W, 3 * W, W, M, b, q.qkv_w, stream));
         if (lora_qkv || has_lora(l, 3)) {
             // q, k, v multiply ln_1(x) and receive dq | dk | dv; out_proj multiplies the attention output and
             // receives the residual gradient of xm (its 16-bit copy is still in dx16)

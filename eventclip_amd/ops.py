@@ -63,3 +63,30 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
     return out
+
+
+def gemm_rows(A, W, splits=1, out=None):
+    """out[s] = A[rows_s, M]^T @ W[rows_s, N] (fp32) over ``splits`` consecutive row ranges of the two row-major
+    16-bit operands (ec_gemm_args.transposed: a weight gradient dY^T X without transposed copies).  Returns
+    [M, N] (splits == 1) or the [splits, M, N] partial products."""
+    import torch
+    _lib.require_gpu()
+    rows, M = A.shape
+    N = W.shape[1]
+    assert W.shape[0] == rows and A.dtype == W.dtype and A.stride(1) == 1 and W.stride(1) == 1
+    K = ((rows + splits - 1) // splits + 63) // 64 * 64
+    shape = (M, N) if splits == 1 else (splits, M, N)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and tuple(out.shape) == shape and out.stride(-1) == 1
+    a = _lib.EcGemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.dtype, a.epilogue, a.variant = dtype_code(A.dtype), _lib.EC_EPI_STORE32, 0
+    a.A, a.lda = A.data_ptr(), A.stride(0)
+    a.W, a.ldw = W.data_ptr(), W.stride(0)
+    a.C, a.ldc = out.data_ptr(), out.stride(-2)
+    a.transposed, a.k_rows = 1, rows
+    if splits > 1:
+        a.splits, a.split_stride = splits, out.stride(0)
+    _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
+    return out

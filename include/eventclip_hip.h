@@ -264,6 +264,12 @@ typedef struct {
                           tile's K loop instead of all of it (serving latency).  The fp32 summation order then
                           depends on M; NULL keeps every row's result independent of the batch it sits in. */
     size_t ws_bytes;
+    int transposed;    /* 1: both operands lie TRANSPOSED -- A is [rows, M] at row stride lda, W is [rows, N] at row
+                          stride ldw, and C[m][n] = sum over rows of A[row][m] W[row][n] (a weight gradient dY^T X
+                          straight from the activations as the forward and backward passes left them: no transposed
+                          copies).  K = rows per batch (a multiple of 64), batch s reads rows s*K ..; EC_EPI_STORE32,
+                          no bias, variant 0, M a multiple of 8. */
+    int k_rows;        /* transposed: the rows that exist (<= splits * K); rows past it read as zero */
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);

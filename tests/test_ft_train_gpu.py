@@ -107,6 +107,33 @@ def _attention_bwd(qkv, out, l2, dout, n, S, W, heads):
     return dqkv
 
 
+@pytest.mark.parametrize('rows,M,N,splits,dtype', [
+    (64, 256, 256, 1, torch.float16), (1000, 256, 512, 1, torch.float16), (77, 72, 80, 1, torch.bfloat16),
+    (16448, 1024, 3072, 4, torch.float16), (16448, 4096, 1024, 2, torch.bfloat16), (5000, 768, 768, 8, torch.float16),
+    (300, 8, 16, 2, torch.float16), (4100, 1024, 1024, 16, torch.float16)])
+def test_gemm_over_the_rows_of_transposed_operands(hip, rows, M, N, splits, dtype):
+    """ec_gemm_args.transposed: C = A^T W over the ROW index of two row-major operands (column slices of wider
+    matrices here, as dq | dk | dv are), in row batches whose last K tile runs past the rows that exist; against
+    fp32 matmul of the same 16-bit values, and bit-identical when repeated."""
+    from eventclip_amd import ops
+    torch.manual_seed(rows + M)
+    wideA = torch.randn(rows, M + 64, device='cuda').to(dtype)
+    wideW = torch.randn(rows, N + 32, device='cuda').to(dtype)
+    A, W = wideA[:, 32:32 + M], wideW[:, 16:16 + N]
+    got = ops.gemm_rows(A, W, splits)
+    K = ((rows + splits - 1) // splits + 63) // 64 * 64
+    want = A.float().T @ W.float()
+    total = got if splits == 1 else got.sum(0)
+    scale = float(want.abs().max())
+    assert float((total - want).abs().max()) < 2e-5 * scale * max(1.0, rows / 1000) + 1e-3
+    if splits > 1:
+        for sidx in range(splits):
+            lo, hi = sidx * K, min((sidx + 1) * K, rows)
+            part = A[lo:hi].float().T @ W[lo:hi].float() if lo < rows else torch.zeros_like(want)
+            assert float((got[sidx] - part).abs().max()) < 2e-5 * scale + 1e-3, sidx
+    assert torch.equal(got, ops.gemm_rows(A, W, splits))
+
+
 @pytest.mark.parametrize('S,heads,n', [(5, 1, 3), (50, 2, 4), (197, 2, 2), (257, 3, 3), (577, 2, 2)])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_attention_forward_saves_lse_and_backward_matches_autograd(hip, S, heads, n, dtype):
