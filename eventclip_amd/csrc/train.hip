@@ -15,6 +15,7 @@
 // The encoder is frozen, so its features are an input (cached once per epoch); everything here is a
 // few MFLOP per sample and latency / launch bound: five small kernels on one stream.
 #include "common.h"
+#include "mfma.h"
 
 namespace {
 
@@ -70,56 +71,38 @@ __global__ __launch_bounds__(64) void text_norm_kernel(const float *t, int D, fl
     if (lane == 0) inv_norm[k] = inv;
 }
 
-// One workgroup per sample: normalised views -> Fn rows, per-view logits in LDS, loss and dL rows.
-// LDS: fn [T][D] | logits [T][K] | reduction scratch
+// F.normalize per view, invalid views zero (clip_cls.py:325-329): one wave per view row.
+// row_idx (optional): the features are compact over the valid views, row_idx[b, v] = their row
+__global__ __launch_bounds__(TR_THREADS) void fs_normalize_kernel(const float *feats, const unsigned char *valid,
+                                                                  const int *row_idx, int R, int D, float *Fn)
+{
+    const int lane = threadIdx.x & 63, r = blockIdx.x * TR_WAVES + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const bool ok = valid[r] != 0;
+    const long frow = row_idx ? (ok ? row_idx[r] : 0) : (long)r;
+    const float *f = feats + frow * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += f[d] * f[d];
+    const float inv = ok ? 1.f / fmaxf(__builtin_sqrtf(wave_sum_f(s)), 1e-12f) : 0.f;
+    for (int d = lane; d < D; d += 64) Fn[(long)r * D + d] = ok ? f[d] * inv : 0.f;
+}
+
+// One workgroup per sample: its per-view logits (full_logits[v][k] = scale * fn_v . u_k, :332 -- an fp32 MFMA
+// product of all view rows at once, left in the dL rows) into LDS, loss and dL rows.
+// LDS: logits [T][K] | reduction scratch
 __global__ __launch_bounds__(TR_THREADS) void fs_loss_grad_kernel(
-    const float *feats, const unsigned char *valid, const int *labels, const float *u, int B, int T, int D,
-    int K, float scale, int agg, int probs_loss, float *Fn, float *dL, float *loss_b, float *agg_logits,
-    const int *row_idx)
+    const unsigned char *valid, const int *labels, int B, int T, int K, int agg, int probs_loss, float *dL,
+    float *loss_b, float *agg_logits)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *fn = sm, *lg = sm + (size_t)T * D, *red = lg + (size_t)T * K;
+    float *lg = sm, *red = lg + (size_t)T * K;
     float *pvy = red + TR_WAVES;          // [T] softmax probability of the label, per view
     float *vmax = pvy + T, *vsum = vmax + T;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y = labels[b];
     float n_valid = 0.f;
     for (int v = 0; v < T; v++) n_valid += valid[b * T + v] ? 1.f : 0.f;
-
-    // ---- F.normalize per view, invalid views zero (clip_cls.py:325-329) ----
-    for (int v = wave; v < T; v += TR_WAVES) {
-        // row_idx (optional): the features are compact over the valid views, row_idx[b, v] = their row
-        const long frow = row_idx ? (valid[b * T + v] ? row_idx[b * T + v] : 0) : (long)b * T + v;
-        const float *f = feats + frow * D;
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += f[d] * f[d];
-        const float inv = valid[b * T + v] ? 1.f / fmaxf(__builtin_sqrtf(wave_sum_f(s)), 1e-12f) : 0.f;
-        for (int d = lane; d < D; d += 64) {
-            const float x = valid[b * T + v] ? f[d] * inv : 0.f;
-            fn[v * D + d] = x;
-            Fn[((long)b * T + v) * D + d] = x;
-        }
-    }
-    __syncthreads();
-    // ---- full_logits[v][k] = scale * fn_v . u_k (:332): one wave per class row ----
-    for (int k = wave; k < K; k += TR_WAVES) {
-        const float *uk = u + (long)k * D;
-        for (int v0 = 0; v0 < T; v0 += 4) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int d = lane; d < D; d += 64) {
-                const float w = uk[d];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (v0 + j < T) a[j] += fn[(v0 + j) * D + d] * w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (v0 + j < T) {
-                    const float s = wave_sum_f(a[j]) * scale;
-                    if (lane == 0) lg[(v0 + j) * K + k] = s;
-                }
-        }
-    }
+    for (int i = threadIdx.x; i < T * K; i += TR_THREADS) lg[i] = dL[(long)b * T * K + i];
     __syncthreads();
 
     float loss = 0.f;
@@ -176,42 +159,6 @@ __global__ __launch_bounds__(TR_THREADS) void fs_loss_grad_kernel(
     if (threadIdx.x == 0) loss_b[b] = loss;
 }
 
-// C[K, D] = alpha * A^T . Bm with A [R, K], Bm [R, D] row-major: 64 x 64 tiles, 4 x 4 per thread
-__global__ __launch_bounds__(256) void sgemm_tn_kernel(const float *A, const float *Bm, int R, int K, int D,
-                                                       float alpha, float *C)
-{
-    __shared__ float sa[16][64], sb[16][64];
-    const int k0 = blockIdx.y * 64, d0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4] = {};
-    for (int r0 = 0; r0 < R; r0 += 16) {
-        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-            const int r = r0 + (i >> 6), c = i & 63;
-            sa[i >> 6][c] = (r < R && k0 + c < K) ? A[(long)r * K + k0 + c] : 0.f;
-            sb[i >> 6][c] = (r < R && d0 + c < D) ? Bm[(long)r * D + d0 + c] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float a[4], bb[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = sa[r][ty * 4 + i], bb[i] = sb[r][tx * 4 + i];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * bb[j];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + ty * 4 + i, d = d0 + tx * 4 + j;
-            if (k < K && d < D) C[(long)k * D + d] = alpha * acc[i][j];
-        }
-}
-
 // through F.normalize: dT_k = (dU_k - u_k (u_k . dU_k)) / |t_k|; block 0 also reduces the loss
 __global__ __launch_bounds__(64) void text_grad_finish_kernel(const float *u, const float *dU,
                                                               const float *inv_norm, int D, const float *loss_b,
@@ -249,45 +196,87 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
 // ---- generic fp32 pieces of the transformer-adapter ('text-trans') step --------------------------
 // C[M, N] (row stride ldc) = alpha * sum_k A(m, k) B(k, n) + beta * C + bias[n], optional ReLU.
 // A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]: one kernel for x W^T, dy W and dy^T x.
+// 64 x 64 tiles, four waves of 32 x 32, fp32 MFMA (v_mfma_f32_16x16x4_f32: full fp32 products and sums); K in
+// slabs of 16 through two LDS buffers, the next slab's global loads in flight while this one multiplies (these
+// products are a few hundred k-steps on a handful of workgroups: un-pipelined they ran at the memory latency,
+// 104 us each).  An operand whose k index is the fast one in memory is kept [row][k] in LDS (pitch 17), the other
+// way round [k][row] (pitch 80): conflict-free stores and fragment reads in both.
 template <bool RELU>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float *A, long sam, long sak, const float *Bm, long sbk,
                                                     long sbn, int M, int N, int K, float alpha, float beta,
                                                     const float *bias, float *C, long ldc)
 {
-    __shared__ float sa[16][65], sb[16][65];
+    constexpr int BK = 16, TILE = 1280;               // max(64 * 17, 16 * 80) floats
+    __shared__ float sa[2][TILE], sb[2][TILE];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-            // A: make the fast index follow the smaller stride so the reads coalesce in either layout
-            int kk, mm;
-            if (sak <= sam) kk = i & 15, mm = i >> 4; else mm = i & 63, kk = i >> 6;
-            sa[kk][mm] = (k0 + kk < K && m0 + mm < M) ? A[(long)(m0 + mm) * sam + (long)(k0 + kk) * sak] : 0.f;
-            int kb, nn;
-            if (sbn <= sbk) nn = i & 63, kb = i >> 6; else kb = i & 15, nn = i >> 4;
-            sb[kb][nn] = (k0 + kb < K && n0 + nn < N) ? Bm[(long)(k0 + kb) * sbk + (long)(n0 + nn) * sbn] : 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int wy = wave >> 1, wx = wave & 1;
+    const bool a_kfast = sak <= sam, b_kfast = sbk < sbn;
+    // element u of this thread in a slab: (k, row) with the fast index following the smaller stride
+    int ak[4], am[4], bk[4], bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = threadIdx.x + 256 * u;
+        if (a_kfast) ak[u] = i & 15, am[u] = i >> 4; else am[u] = i & 63, ak[u] = i >> 6;
+        if (b_kfast) bk[u] = i & 15, bn[u] = i >> 4; else bn[u] = i & 63, bk[u] = i >> 6;
+    }
+    float ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ra[u] = (k0 + ak[u] < K && m0 + am[u] < M) ? A[(long)(m0 + am[u]) * sam + (long)(k0 + ak[u]) * sak] : 0.f;
+            rb[u] = (k0 + bk[u] < K && n0 + bn[u] < N) ? Bm[(long)(k0 + bk[u]) * sbk + (long)(n0 + bn[u]) * sbn] : 0.f;
         }
-        __syncthreads();
+    };
+    auto at = [](bool kfast, int k, int row) { return kfast ? row * 17 + k : k * 80 + row; };
+    auto sstore = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = sa[k][ty * 4 + i], b[i] = sb[k][tx * 4 + i];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        for (int u = 0; u < 4; u++) {
+            sa[buf][at(a_kfast, ak[u], am[u])] = ra[u];
+            sb[buf][at(b_kfast, bk[u], bn[u])] = rb[u];
         }
+    };
+    ec::f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = ec::f32x4{0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int k0 = 0, buf = 0; k0 < K; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < K;
+        if (more) gload(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ks++) {
+            const int kq = ks * 4 + g;
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a[t] = sa[buf][at(a_kfast, kq, wy * 32 + t * 16 + c16)];
+                b[t] = sb[buf][at(b_kfast, kq, wx * 32 + t * 16 + c16)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) sstore(buf ^ 1);
         __syncthreads();
     }
+    // acc[i][j][r] = row m0 + 32 wy + 16 i + 4 g + r, column n0 + 32 wx + 16 j + c16
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < N) {
-                float v = alpha * acc[i][j] + (bias ? bias[n] : 0.f);
+        for (int j = 0; j < 2; j++) {
+            const int n = n0 + wx * 32 + j * 16 + c16;
+            if (n >= N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wy * 32 + i * 16 + 4 * g + r;
+                if (m >= M) continue;
+                float v = alpha * acc[i][j][r] + bv;
                 if (beta != 0.f) v += beta * C[(long)m * ldc + n];
                 if (RELU) v = fmaxf(v, 0.f);
                 C[(long)m * ldc + n] = v;
@@ -295,15 +284,31 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float *A, long sam, lo
         }
 }
 
-// out[j] = sum_r X[r, j] (* Y[r, j] when Y): bias gradients and LayerNorm gamma / beta gradients
+// out[j] = sum_r X[r, j] (* Y[r, j] when Y): bias gradients and LayerNorm gamma / beta gradients.  A workgroup
+// owns 64 columns; its 256 threads are 64 columns x 4 row lanes, eight independent loads in flight per thread
+// (one dependent load per row was the whole cost: R / 4 memory latencies in a row).  Fixed order: reproducible.
 __global__ __launch_bounds__(256) void colsum_kernel(const float *X, const float *Y, int R, int N, float *out)
 {
     __shared__ float red[4][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    float s = 0.f;
-    if (j < N)
-        for (int r = part; r < R; r += 4) s += Y ? X[(long)r * N + j] * Y[(long)r * N + j] : X[(long)r * N + j];
-    red[part][threadIdx.x & 63] = s;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc[u] = 0.f;
+    if (j < N) {
+        int r = part;
+        for (; r + 28 < R; r += 32) {
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x[u] = X[(long)(r + 4 * u) * N + j];
+                y[u] = Y ? Y[(long)(r + 4 * u) * N + j] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += x[u] * y[u];
+        }
+        for (; r < R; r += 4) acc[0] += Y ? X[(long)r * N + j] * Y[(long)r * N + j] : X[(long)r * N + j];
+    }
+    red[part][threadIdx.x & 63] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (part == 0 && j < N) out[j] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
@@ -524,8 +529,8 @@ int ec::fs_text_loss_grad(const float *img_feats, const int32_t *row_idx, const 
                "ec_fs_text_loss_grad: null buffer");
     EC_REQUIRE(workspace_bytes >= ec_fs_text_train_workspace_bytes(B, T, D, K),
                "ec_fs_text_loss_grad: workspace too small");
-    const size_t lds = ((size_t)T * D + (size_t)T * K + TR_WAVES + 3 * (size_t)T) * 4;
-    EC_REQUIRE(lds <= 160 * 1024, "ec_fs_text_loss_grad: T * (D + K) = %d floats exceed the LDS", T * (D + K));
+    const size_t lds = ((size_t)T * K + TR_WAVES + 3 * (size_t)T) * 4;
+    EC_REQUIRE(lds <= 160 * 1024, "ec_fs_text_loss_grad: T * K = %d floats exceed the LDS", T * K);
     unsigned char *w = static_cast<unsigned char *>(workspace);
     const size_t R = (size_t)B * T;
     float *Fn = (float *)w;
@@ -547,10 +552,16 @@ int ec::fs_text_loss_grad(const float *img_feats, const int32_t *row_idx, const 
         attr_lds = lds;
     }
     hipLaunchKernelGGL(text_norm_kernel, dim3(K), dim3(64), 0, s, text_param, D, u, inv_norm);
-    hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, img_feats, valid, labels, u, B, T,
-                       D, K, logit_scale, agg, use_probs_loss, Fn, dL, loss_b, agg_logits, row_idx);
-    hipLaunchKernelGGL(sgemm_tn_kernel, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, dL, Fn, (int)R, K, D,
-                       logit_scale, dU);
+    hipLaunchKernelGGL(fs_normalize_kernel, dim3((unsigned)((R + TR_WAVES - 1) / TR_WAVES)), dim3(TR_THREADS), 0, s, img_feats, valid,
+                       row_idx, (int)R, D, Fn);
+    // full_logits [R, K] = logit_scale * Fn u^T, into the dL rows
+    hipLaunchKernelGGL(sgemm_kernel<false>, dim3((K + 63) / 64, (unsigned)((R + 63) / 64)), dim3(256), 0, s, Fn, (long)D, 1L, u, 1L,
+                       (long)D, (int)R, K, D, logit_scale, 0.f, static_cast<const float *>(nullptr), dL, (long)K);
+    hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, valid, labels, B, T, K, agg, use_probs_loss, dL,
+                       loss_b, agg_logits);
+    // dU[K, D] = logit_scale * dL^T Fn: the reduction runs over the R view rows
+    hipLaunchKernelGGL(sgemm_kernel<false>, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, dL, 1L, (long)K, Fn, (long)D, 1L,
+                       K, D, (int)R, logit_scale, 0.f, static_cast<const float *>(nullptr), dU, (long)D);
     hipLaunchKernelGGL(text_grad_finish_kernel, dim3(K), dim3(64), 0, s, u, dU, inv_norm, D, loss_b, B,
                        grad_text, loss);
     EC_CHECK_HIP(hipGetLastError());
@@ -683,8 +694,8 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
     const size_t need = carve_trans(c, B, T, D, K, d, ffn, heads, layers, t);
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_fs_trans_loss_grad: workspace %zu < %zu bytes", workspace_bytes, need);
-    const size_t lds = ((size_t)T * D + (size_t)T * K + TR_WAVES + 3 * (size_t)T) * 4;
-    EC_REQUIRE(lds <= 160 * 1024, "ec_fs_trans_loss_grad: T * (D + K) = %d floats exceed the LDS", T * (D + K));
+    const size_t lds = ((size_t)T * K + TR_WAVES + 3 * (size_t)T) * 4;
+    EC_REQUIRE(lds <= 160 * 1024, "ec_fs_trans_loss_grad: T * K = %d floats exceed the LDS", T * K);
     hipStream_t s = static_cast<hipStream_t>(stream);
     static size_t attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {
@@ -742,10 +753,14 @@ extern "C" EC_API int ec_fs_trans_loss_grad(const float *img_feats, const uint8_
 
     // ---------------- loss, dL, text gradient (shared with 'text-identity') ----------------
     hipLaunchKernelGGL(text_norm_kernel, dim3(K), dim3(64), 0, s, text_param, D, t.u, t.inv_norm);
-    hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, t.mixed, valid, labels, t.u, B, T, D, K,
-                       logit_scale, agg, use_probs_loss, t.Fn, t.dL, t.loss_b, agg_logits, (const int *)nullptr);
-    hipLaunchKernelGGL(sgemm_tn_kernel, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, t.dL, t.Fn, R, K, D,
-                       logit_scale, t.dU);
+    hipLaunchKernelGGL(fs_normalize_kernel, dim3((unsigned)((R + TR_WAVES - 1) / TR_WAVES)), dim3(TR_THREADS), 0, s, t.mixed, valid,
+                       (const int *)nullptr, R, D, t.Fn);
+    hipLaunchKernelGGL(sgemm_kernel<false>, dim3((K + 63) / 64, (unsigned)((R + 63) / 64)), dim3(256), 0, s, t.Fn, (long)D, 1L, t.u,
+                       1L, (long)D, R, K, D, logit_scale, 0.f, static_cast<const float *>(nullptr), t.dL, (long)K);
+    hipLaunchKernelGGL(fs_loss_grad_kernel, dim3(B), dim3(TR_THREADS), lds, s, valid, labels, B, T, K, agg, use_probs_loss, t.dL,
+                       t.loss_b, agg_logits);
+    hipLaunchKernelGGL(sgemm_kernel<false>, dim3((D + 63) / 64, (K + 63) / 64), dim3(256), 0, s, t.dL, 1L, (long)K, t.Fn, (long)D,
+                       1L, K, D, R, logit_scale, 0.f, static_cast<const float *>(nullptr), t.dU, (long)D);
     hipLaunchKernelGGL(text_grad_finish_kernel, dim3(K), dim3(64), 0, s, t.u, t.dU, t.inv_norm, D, t.loss_b, B,
                        grad_text, loss);
 

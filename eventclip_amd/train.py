@@ -81,12 +81,14 @@ def dropout_mask(seed, site, n, p):
 
 
 def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapter, agg='sum',
-                       use_probs_loss=False, return_logits=False, dropout_p=0., seed=0):
+                       use_probs_loss=False, return_logits=False, dropout_p=0., seed=0, out=None):
     """The `text-trans` step: img_feats fp32 CUDA [B, T, D] with ZERO rows on invalid views
     (clip_cls.py:319-321), ``adapter`` an eventclip_amd.adapter.TransformerAdapter on the GPU.
     Returns (loss, grads) with grads = {adapter state-dict name: tensor, 'text_feats': [K, D]}
     dropout_p > 0: the train-mode dropouts of nn.TransformerEncoderLayer (p = 0.1 upstream), masks from a
-    stateless hash of (seed, site, element); 0: the deterministic eval-mode function."""
+    stateless hash of (seed, site, element); 0: the deterministic eval-mode function.
+    out (optional): {name: tensor} to receive the gradients (every adapter name and 'text_feats'; a trainer's
+    fixed buffers -- nothing is allocated for them then)."""
     import ctypes
     dev = _lib.require_gpu()
     if agg not in _AGG:
@@ -98,7 +100,7 @@ def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapte
     params = {k: v.detach() for k, v in adapter.named_parameters()}
     for k, v in params.items():
         assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous(), k
-    grads = {k: torch.empty_like(v) for k, v in params.items()}
+    grads = {k: out[k] for k in params} if out is not None else {k: torch.empty_like(v) for k, v in params.items()}
     ps, keep_p = _adapter_struct(adapter, params)
     gs, keep_g = _adapter_struct(adapter, grads)
     need = int(_lib.lib().ec_fs_trans_train_workspace_bytes(B, T, D, K, adapter.d_model, adapter.ffn_dim,
@@ -107,7 +109,8 @@ def fs_trans_loss_grad(img_feats, valid, labels, text_param, logit_scale, adapte
     if ws is None or ws.numel() < need:
         ws = _WS[dev.index] = torch.empty((need,), dtype=torch.uint8, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
-    gtext = torch.empty((K, D), dtype=torch.float32, device=dev)
+    gtext = out['text_feats'] if out is not None and 'text_feats' in out else torch.empty((K, D), dtype=torch.float32, device=dev)
+    assert gtext.is_contiguous() and tuple(gtext.shape) == (K, D) and gtext.dtype == torch.float32
     logits = torch.empty((B, K), dtype=torch.float32, device=dev) if return_logits else None
     v8 = valid.to(torch.uint8).contiguous()       # named: a temporary's block would be handed to the next one
     lab = labels.to(torch.int32).contiguous()
@@ -130,6 +133,12 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
                                  param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                  float(weight_decay), int(step), _lib.stream_ptr())
     _lib.check(rc, 'ec_adam_step')
+
+
+def _device_table(items):
+    """ctypes array of structs -> device copy (uint8 CUDA tensor) for the batched kernels' item tables."""
+    import numpy as np
+    return torch.from_numpy(np.frombuffer(items, dtype=np.uint8).copy()).cuda()
 
 
 def cosine_warmup_lr(step, total_steps, max_lr, min_lr, warmup_steps):
@@ -192,23 +201,39 @@ class AdapterTrainer:
             self.tensors['text_feats'] = classifier.text_feats.data
         self.state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.tensors.items()}
         self.steps = 0
+        # gradients at fixed addresses (views of one flat buffer: one all-reduce) and one Adam launch over all of them
+        total = sum(v.numel() for v in self.tensors.values())
+        self._flat = torch.zeros((total,), dtype=torch.float32, device=next(iter(self.tensors.values())).device)
+        self._grads, off = {}, 0
+        for k, v in self.tensors.items():
+            assert v.is_contiguous()
+            self._grads[k] = self._flat[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+        if not classifier.prompt_tuning:
+            self._grads['text_feats'] = torch.empty_like(classifier.get_text_feats().float())   # computed, not trained
+        items = (_lib.EcAdamItem * len(self.tensors))()
+        for it, (k, p) in zip(items, self.tensors.items()):
+            m, v = self.state[k]
+            it.param, it.grad, it.exp_avg, it.exp_avg_sq = p.data_ptr(), self._grads[k].data_ptr(), m.data_ptr(), v.data_ptr()
+            it.n, it.group = p.numel(), 0
+        self._items = _device_table(items)
+        self._max_n = max(p.numel() for p in self.tensors.values())
 
     @torch.no_grad()
     def step(self, img_feats, valid, labels):
         clf = self.clf
         text = clf.text_feats.data if clf.prompt_tuning else clf.get_text_feats().float()
-        loss, grads = fs_trans_loss_grad(img_feats, valid, labels, text, clf.logit_scale, clf.adapter,
-                                         clf.agg_func, clf.use_probs_loss, dropout_p=self.dropout,
-                                         seed=self.seed * 1000003 + self.steps)
-        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        loss, _ = fs_trans_loss_grad(img_feats, valid, labels, text, clf.logit_scale, clf.adapter,
+                                     clf.agg_func, clf.use_probs_loss, dropout_p=self.dropout,
+                                     seed=self.seed * 1000003 + self.steps, out=self._grads)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self._flat)
+            self._flat /= dist.get_world_size()
         lr = cosine_warmup_lr(self.steps, self.total_steps, self.lr, self.lr / 100., self.warmup_steps)
         self.steps += 1
-        for k, p in self.tensors.items():
-            g = grads[k]
-            if ddp:
-                dist.all_reduce(g)
-                g /= dist.get_world_size()
-            m, v = self.state[k]
-            adam_step(p, g.contiguous(), m, v, self.steps, lr, self.betas, self.eps, self.weight_decay)
+        rc = _lib.lib().ec_adam_step_multi(_lib.ptr(self._items), len(self.tensors), self._max_n, float(lr), float(lr),
+                                           float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay,
+                                           int(self.steps), None, None, _lib.stream_ptr())
+        _lib.check(rc, 'ec_adam_step_multi')
         clf.adapter._packed = None          # the forward kernel's transposed copies are stale now
         return loss
