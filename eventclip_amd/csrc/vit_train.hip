@@ -8,13 +8,17 @@
 //
 // Layout of a step (M = n_img * S token rows, W = width):
 //   forward   the inference kernels, keeping per block both residual-stream inputs (fp32), both LayerNorm outputs,
-//             q | k | v, the attention output with its log-sum-exp and the MLP pre-activation (16 bit): 28 M W bytes;
+//             q | k | v, the attention output with its log-sum-exp, the MLP pre-activation and its QuickGELU
+//             (16 bit): 36 M W bytes;
 //   backward  the residual-stream gradient dx stays fp32.  Every nn.Linear is two 16-bit MFMA GEMMs:
 //               dX = dY W        ec_gemm with the weight's transposed copy as the [N, K] operand;
-//               dW = dY^T X      ec_gemm over TRANSPOSED copies [features, rows] of both activations, the
-//                                row dimension cut into K-batches (`splits`) so that the few 256 x 256
-//                                output tiles of a weight gradient still fill 256 CUs; the partial
-//                                sums are reduced in fp32 in a fixed order (no atomics: reproducible);
+//               dW = dY^T X      ec_gemm over the ROW index of the two row-major activations as the passes left
+//                                them (ec_gemm_args.transposed: tiles read column-major out of LDS), the row
+//                                dimension cut into K-batches (`splits`) so that the few 256 x 256 output
+//                                tiles of a weight gradient still fill 256 CUs; the partial sums are reduced
+//                                in fp32 in a fixed order (no atomics: reproducible).  Only the patch
+//                                embedding's gradient still goes through transposed copies (its rows skip
+//                                the class tokens);
 //             the QuickGELU derivative is fused into the GEMM that produces it (EC_EPI_GELU_BWD16), LayerNorm
 //             backward recomputes its statistics from the saved input, attention backward recomputes the
 //             probabilities from the saved log-sum-exp (attention_bwd.hip);
@@ -50,8 +54,8 @@ __device__ __forceinline__ float quick_gelu_f(float x)
 
 // ------------------------------------------------------------------------------------------
 // Transposed 16-bit copies: dst_t[n][m] = f(src[row(m)][n]) for m < M, 0 for M <= m < Mp.
-// MODE 0: 16-bit source; 1: QuickGELU of a 16-bit source (u -> g: the c_proj input is recomputed, not
-// stored); 2: fp32 source, optionally also written row-major as 16 bit (the dX GEMM's operand).
+// MODE 0: 16-bit source; 1: QuickGELU of a 16-bit source; 2: fp32 source, optionally also written row-major
+// as 16 bit (the dX GEMM's operand).  (The blocks' weight gradients no longer need these copies: weight_grad_rows.)
 // Logical row m reads source row (m / seq_out) * seq_in + seq_off + m % seq_out (seq_out = 0: row m):
 // the patch rows of the embedding gradient skip every sequence's class-token row.
 // ------------------------------------------------------------------------------------------
