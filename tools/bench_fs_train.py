@@ -75,18 +75,24 @@ def main():
             for _ in range(5):
                 tr.step(feats, valid, labels)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                loss = tr.step(feats, valid, labels)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / a.steps
-            cases.append((kind, name, B, T, K, dt, float(loss), clf, feats, valid, labels))
-    for kind, name, B, T, K, dt, loss, clf, feats, valid, labels in cases:
+            # two timed passes, the faster one counts (a one-off stall of the host -- an allocator refill, a code
+            # object's first use -- would otherwise be most of a 50-step sum); the slowest single call is reported
+            dt, worst = float('inf'), 0.0
+            for _ in range(2):
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    t1 = time.perf_counter()
+                    loss = tr.step(feats, valid, labels)
+                    worst = max(worst, time.perf_counter() - t1)
+                torch.cuda.synchronize()
+                dt = min(dt, (time.perf_counter() - t0) / a.steps)
+            cases.append((kind, name, B, T, K, dt, float(loss), clf, feats, valid, labels, worst))
+    for kind, name, B, T, K, dt, loss, clf, feats, valid, labels, worst in cases:
         cb = cpu_step(kind, clf, feats, valid, labels)
         cb['speedup'] = round(cb['ms_per_step'] / (dt * 1e3), 1)
         print(json.dumps(dict(adapter_type=kind, geometry=name, batch=B, views=T, classes=K,
                               ms_per_step=round(dt * 1e3, 3), samples_per_s=round(B / dt, 1),
-                              loss=round(loss, 4), cpu_baseline=cb)), flush=True)
+                              loss=round(loss, 4), slowest_call_ms=round(worst * 1e3, 3), cpu_baseline=cb)), flush=True)
 
 
 if __name__ == '__main__':
