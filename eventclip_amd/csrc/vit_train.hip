@@ -933,10 +933,13 @@ inline int pick_splits(int n_out, int n_in, int mp, int cus)
 // the same for the row batches of a weight gradient taken straight from the row-major operands
 inline int pick_splits_rows(int n_out, int n_in, int rows, int cus)
 {
+    // any count (the row batches may be ragged: rows past the end read as zero): as many batches as fill one round
+    // of workgroups -- 48 tiles of a 3W x W gradient run as 5 batches on 240 of 256 CUs, not 4 on 192
     const int tiles = ((n_out + 255) / 256) * ((n_in + 255) / 256);
-    int s = 1;
-    while (s < 16 && tiles * s * 2 <= cus && rows / (s * 2) >= 256) s *= 2;
-    return s;
+    int s = cus / tiles;
+    s = s > 16 ? 16 : s;
+    while (s > 1 && rows / s < 256) s--;
+    return s < 1 ? 1 : s;
 }
 
 struct TrainBufs {
