@@ -1257,6 +1257,8 @@ int ln_backward(const float *x, long ldx, const float *dy, long ldy, const float
                                LN_EPS, dx, ldo, accumulate, want ? partials : (float *)nullptr, dx16);
     }
     EC_CHECK_HIP(hipGetLastError());
+    // (d gamma | d beta lie side by side in a partial row; side by side in the gradient buffer too -> one launch)
+    if (dg && db == dg + W) return reduce(partials, 2L * W, wgs, 2L * W, dg, s);
     if (dg) EC_TRY(reduce(partials, 2L * W, wgs, W, dg, s));
     if (db) EC_TRY(reduce(partials + W, 2L * W, wgs, W, db, s));
     return EC_OK;
