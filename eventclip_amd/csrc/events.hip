@@ -36,7 +36,7 @@ constexpr int EV_THREADS = 1024;
 constexpr int EV_WAVES = EV_THREADS / 64;
 constexpr int EV_BIN_BYTES = 156 * 1024;          // histogram band
 constexpr int EV_LUT_N = 16;                       // colour look-up table over counts 0..15 x 0..15
-constexpr int EV_REDUCE_BYTES = 8 * EV_WAVES * 2;  // block-reduction scratch (u64 per wave, 2 slots)
+constexpr int EV_REDUCE_BYTES = 8 * EV_WAVES * 4;  // block-reduction scratch (u64 per wave, up to 3 values at once)
 constexpr int EV_SCRATCH_BYTES = EV_REDUCE_BYTES + EV_LUT_N * EV_LUT_N * 4;   // + the LUT
 
 struct EvArgs {
@@ -225,17 +225,30 @@ __device__ void sort_by_band(const EV *ev, long long n, int H, int W, int flip_x
     const int entries = bands * EV_WAVES;
     for (int i = threadIdx.x; i < entries; i += EV_THREADS) cnt[i] = 0;
     __syncthreads();
-    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
-        int x, y, p;
-        parse(ev[i], W, flip_x, negate_p, x, y, p);
-        if (p == 0) continue;
-        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
-            dropped++;
-            continue;
+    // (both scans: eight loads in flight per thread -- one dependent load per iteration made each scan of a
+    // 70 000-event frame 68 memory latencies long)
+    unsigned out_of_sensor = 0;
+    for (long long i = threadIdx.x; i < n; i += 8 * EV_THREADS) {
+        EV e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long j = i + (long long)k * EV_THREADS;
+            e[k] = ev[j < n ? j : n - 1];
         }
-        const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
-        atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int x, y, p;
+            parse(e[k], W, flip_x, negate_p, x, y, p);
+            const bool there = i + (long long)k * EV_THREADS < n && p != 0;
+            const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+            out_of_sensor += there && !inside;
+            if (there && inside) {
+                const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
+                atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
+            }
+        }
     }
+    dropped += out_of_sensor;
     __syncthreads();
     // exclusive scan of the (band, wave) counts by the first wave: lane l owns a run of entries
     if (threadIdx.x < 64) {
@@ -259,13 +272,22 @@ __device__ void sort_by_band(const EV *ev, long long n, int H, int W, int flip_x
         if (threadIdx.x == 63) start[bands] = incl;
     }
     __syncthreads();
-    for (long long i = threadIdx.x; i < n; i += EV_THREADS) {
-        int x, y, p;
-        parse(ev[i], W, flip_x, negate_p, x, y, p);
-        if (p == 0 || (unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) continue;
-        const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
-        const unsigned slot = atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
-        ws[slot] = ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+    for (long long i = threadIdx.x; i < n; i += 8 * EV_THREADS) {
+        EV e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long j = i + (long long)k * EV_THREADS;
+            e[k] = ev[j < n ? j : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int x, y, p;
+            parse(e[k], W, flip_x, negate_p, x, y, p);
+            if (i + (long long)k * EV_THREADS >= n || p == 0 || (unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) continue;
+            const unsigned band = (unsigned)(((unsigned long long)(unsigned)y * magic) >> 32);
+            const unsigned slot = atomicAdd(&cnt[band * EV_WAVES + wave], 1u);
+            ws[slot] = ((unsigned)(y * W + x) << 1) | (p < 0 ? 1u : 0u);
+        }
     }
     __syncthreads();   // the stores are visible to the whole workgroup (one CU, one L1)
 }
@@ -277,7 +299,17 @@ __device__ void bin_band_sorted(const unsigned *ws, unsigned begin, unsigned end
     const unsigned lo = (unsigned)(y0 * W * 2);
     for (int i = threadIdx.x; i < nb; i += EV_THREADS) bins[i] = 0;
     __syncthreads();
-    for (unsigned i = begin + threadIdx.x; i < end; i += EV_THREADS) atomicAdd(&bins[ws[i] - lo], 1u);
+    for (unsigned i = begin + threadIdx.x; i < end; i += 4 * EV_THREADS) {      // four loads in flight
+        unsigned c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned j = i + k * EV_THREADS;
+            c[k] = ws[j < end ? j : end - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i + k * EV_THREADS < end) atomicAdd(&bins[c[k] - lo], 1u);
+    }
     __syncthreads();
 }
 
@@ -571,6 +603,31 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned P10_MASK = 1023u;
 
+// all five sums of pass 1 behind one pair of barriers (five block_sum_u64 calls were half of the pass)
+struct P10Sums {
+    unsigned long long s1, total, s2, nnz, dropped;
+};
+__device__ __forceinline__ P10Sums block_sums5(unsigned s1, unsigned total, unsigned long long s2, unsigned nnz,
+                                               unsigned dropped, unsigned long long *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // per-wave sums of the 32-bit partials fit 32 bits (<= 64 x 86 k); s2 needs 64
+    unsigned long long p01 = wave_sum_u64((unsigned long long)s1 | ((unsigned long long)total << 32));
+    unsigned long long p34 = wave_sum_u64((unsigned long long)nnz | ((unsigned long long)dropped << 32));
+    s2 = wave_sum_u64(s2);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = p01, scratch[EV_WAVES + wave] = s2, scratch[2 * EV_WAVES + wave] = p34;
+    __syncthreads();
+    P10Sums r = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < EV_WAVES; w++) {
+        const unsigned long long a01 = scratch[w], a34 = scratch[2 * EV_WAVES + w];
+        r.s1 += a01 & 0xffffffffull, r.total += a01 >> 32, r.s2 += scratch[EV_WAVES + w];
+        r.nnz += a34 & 0xffffffffull, r.dropped += a34 >> 32;
+    }
+    return r;
+}
+
 template <typename EV>
 __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs a)
 {
@@ -588,36 +645,40 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
 
     for (int i = threadIdx.x; i < words; i += EV_THREADS) bins[i] = 0;
     __syncthreads();
+    // (the tallies are additions of the lambda's return value, not increments inside its divergent branches)
     unsigned dropped = 0, binned = 0;
-    auto bin_one = [&](const EV e) {
+    auto bin_event = [&](const EV e) -> unsigned {          // 1: binned, 0x10000: dropped, 0: polarity 0
         int x, y, p;
         parse(e, W, a.flip_x, a.negate_p, x, y, p);
-        if (p == 0) return;
-        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) {
-            dropped++;
-            return;
+        const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+        if (p != 0 && inside) {
+            const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
+            const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
+            atomicAdd(&bins[w], 1u << sh);
         }
-        const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
-        const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
-        atomicAdd(&bins[w], 1u << sh);
-        binned++;
+        return p == 0 ? 0u : (inside ? 1u : 0x10000u);
     };
-    {   // the frame's only HBM read: eight 16-byte loads in flight per thread
-        long long i = threadIdx.x;
-        for (; i + 7 * EV_THREADS < n; i += 8 * EV_THREADS) {
+    {   // the frame's only HBM read: eight 16-byte loads in flight per thread; a frame's last partial round of
+        // eight (20 000 events = 2 rounds + 3 616) through clamped, masked loads instead of one load at a time
+        for (long long i = threadIdx.x; i < n; i += 8 * EV_THREADS) {
             EV e[8];
+            unsigned tally = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) e[k] = ev[i + k * EV_THREADS];
+            for (int k = 0; k < 8; k++) {
+                const long long j = i + (long long)k * EV_THREADS;
+                e[k] = ev[j < n ? j : n - 1];
+            }
 #pragma unroll
-            for (int k = 0; k < 8; k++) bin_one(e[k]);
+            for (int k = 0; k < 8; k++)
+                if (i + (long long)k * EV_THREADS < n) tally += bin_event(e[k]);
+            binned += tally & 0xffffu, dropped += tally >> 16;
         }
-        for (; i < n; i += EV_THREADS) bin_one(ev[i]);
     }
     __syncthreads();
 
     // ---- pass 1: sum, sum of squares, non-zero bins (fields past M2 in the last word are zero) ----
     // per-thread partial sums stay in 32 bits: at most ceil(58 000 / 1024) words x 3 counts <= 1023
-    unsigned s1t = 0, s2t = 0, nnz = 0;
+    unsigned s1t = 0, s2t = 0, nnzt = 0;
     for (int w = threadIdx.x; w < words; w += EV_THREADS) {
         const unsigned v = bins[w];
 #pragma unroll
@@ -625,18 +686,17 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
             const unsigned h = (v >> (10 * k)) & P10_MASK;
             s1t += h;
             s2t += h * h;
-            nnz += h > 0;
+            nnzt += h > 0;
         }
     }
-    unsigned long long s1 = block_sum_u64(s1t, scratch), s2 = s2t;
-    const unsigned long long total = block_sum_u64(binned, scratch);
-    if (s1 != total) {                               // a field overflowed: leave the frame to the 32-bit kernel
+    const P10Sums sums = block_sums5(s1t, binned, s2t, nnzt, dropped, scratch);
+    const unsigned long long s1 = sums.s1, s2 = sums.s2;
+    if (s1 != sums.total) {                          // a field overflowed: leave the frame to the 32-bit kernel
         if (threadIdx.x == 0) a.redo[f] = 1;
         return;
     }
-    s2 = block_sum_u64(s2, scratch);
-    nnz = (unsigned)block_sum_u64(nnz, scratch);
-    dropped = (unsigned)block_sum_u64(dropped, scratch);
+    const unsigned nnz = (unsigned)sums.nnz;
+    dropped = (unsigned)sums.dropped;
     const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
     const unsigned thr_hi = hp.thr_hi;
 
@@ -655,8 +715,22 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
             if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
         }
     }
-    mx = block_max_u32(mx, scratch);
-    amb = (unsigned)block_sum_u64(amb, scratch);
+    {   // max and the ambiguous-count tally behind one pair of barriers
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        mx = wave_max_u32(mx);
+        const unsigned long long ab = wave_sum_u64(amb);
+        __syncthreads();
+        if (lane == 0) scratch[wave] = (unsigned long long)mx | (ab << 32);
+        __syncthreads();
+        mx = 0, amb = 0;
+#pragma unroll
+        for (int w = 0; w < EV_WAVES; w++) {
+            const unsigned long long t = scratch[w];
+            const unsigned m = (unsigned)(t & 0xffffffffull);
+            mx = m > mx ? m : mx;
+            amb += (unsigned)(t >> 32);
+        }
+    }
     const double dmx = (double)mx;
     if (a.stats && threadIdx.x == 0) {
         ec_frame_stats st;
