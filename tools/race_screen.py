@@ -1,6 +1,8 @@
 """Race screen for the default GEMM (persistent, staggered, LDS-DMA, LDS-transposed epilogues): every shape /
 epilogue is run many times on the same inputs under memory load and must reproduce its first result bit for
-bit, which in turn is checked against torch.  Run on the GPU box: python tools/race_screen.py [repeats]"""
+bit, which in turn is checked against torch.  Also the modes added in round 2: transposed operands with row
+batches (weight gradients), the K-batched low-latency path with its fixup kernel, the QuickGELU pair and gradient
+epilogues.  Run on the GPU box: python tools/race_screen.py [repeats]"""
 import os
 import sys
 
@@ -42,5 +44,68 @@ for (M, N, K) in shapes:
                 print('NONDETERMINISTIC', (M, N, K), epi, 'run', r, n, 'elements differ', flush=True)
                 break
     print('ok', (M, N, K), flush=True)
+
+
+def repeat(label, fn, check):
+    """fn() -> tensor (or tuple of tensors); the first result is checked, the others must equal it bit for bit."""
+    global bad
+    first = None
+    for r in range(reps):
+        got = fn()
+        got = got if isinstance(got, tuple) else (got,)
+        if r % 3 == 0:
+            noise.add_(1.0)
+        if first is None:
+            first = tuple(g.clone() for g in got)
+            err = check(*first)
+            if err is not None:
+                bad += 1
+                print('MISMATCH vs torch', label, err)
+        elif not all(torch.equal(a, b) for a, b in zip(got, first)):
+            bad += 1
+            print('NONDETERMINISTIC', label, 'run', r, flush=True)
+            return
+    print('ok', label, flush=True)
+
+
+# transposed operands: C = A^T W over the rows, in row batches (ragged last K tile)
+for (rows, M, N, splits) in ((16448, 1024, 3072, 5), (16448, 1024, 1024, 16), (16448, 4096, 1024, 4), (70001, 768, 768, 8),
+                             (3001, 256, 512, 2), (16448, 1024, 4096, 4)):
+    g = torch.Generator(device='cuda').manual_seed(rows + M + N)
+    A = torch.randn(rows, M, device='cuda', generator=g).half()
+    W = (torch.randn(rows, N, device='cuda', generator=g) / rows ** 0.5).half()
+    want = A.float().t() @ W.float()
+
+    def check(out, want=want, splits=splits):
+        tot = out if splits == 1 else out.sum(0)
+        e = float((tot - want).abs().max() / want.abs().max())
+        return e if e > 2e-4 else None
+    repeat(('rows', rows, M, N, splits), lambda: ops.gemm_rows(A, W, splits), check)
+
+# a few frames: K-batched launches + fixup (ec_gemm_args.ws), every epilogue the fixup implements
+ws = torch.empty(80 << 20, dtype=torch.uint8, device='cuda')
+for (M, N, K) in ((257, 1024, 1024), (257, 3072, 1024), (514, 1024, 4096), (50, 768, 3072), (2570, 4096, 1024)):
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, device='cuda', generator=g).half()
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, device='cuda', generator=g)
+    resid = torch.randn(M, N, device='cuda', generator=g)
+    want = A.float() @ W.float().t() + bias
+    for epi in ('store16', 'gelu16', 'resid32', 'store32', 'gelu16_save'):
+        def run(epi=epi):
+            if epi == 'resid32':
+                return ops.gemm(A, W, bias, epi, resid=resid, ws=ws)
+            if epi == 'gelu16_save':
+                aux = torch.empty((M, N), dtype=A.dtype, device='cuda')
+                return ops.gemm(A, W, bias, epi, aux=aux, ws=ws), aux
+            return ops.gemm(A, W, bias, epi, ws=ws)
+
+        def check(out, *rest, epi=epi):
+            ref = want * torch.sigmoid(1.702 * want) if epi.startswith('gelu16') else (want + resid if epi == 'resid32' else want)
+            tol = 2e-3 if epi in ('store16', 'gelu16', 'gelu16_save') else 1e-4
+            e = float((out.float() - ref).abs().max() / ref.abs().max())
+            return e if e > tol else None
+        repeat(('ws', M, N, K, epi), run, check)
+
 print('race screen:', 'CLEAN' if bad == 0 else f'{bad} problems', f'({reps} repeats per case)')
 sys.exit(1 if bad else 0)
