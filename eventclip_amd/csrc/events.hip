@@ -215,7 +215,8 @@ __device__ void bin_band_cached(const unsigned *cache, int n, int y0, int y1, in
 // contiguous bucket.  Slots inside a bucket come from 16 sub-counters per band (one per wave), so
 // the LDS atomics that hand them out are spread like the binning atomics themselves.
 constexpr int EV_SORT_MAX_BANDS = 64;
-constexpr int EV_SORT_BYTES = (EV_SORT_MAX_BANDS * EV_WAVES + EV_SORT_MAX_BANDS + 1) * 4;
+constexpr int EV_CC_N = 1024;      // count-of-counts histogram (sorted mode): how many bins hold the count c < 1023
+constexpr int EV_SORT_BYTES = (EV_SORT_MAX_BANDS * EV_WAVES + EV_SORT_MAX_BANDS + 1 + EV_CC_N) * 4;
 
 template <typename EV>
 __device__ void sort_by_band(const EV *ev, long long n, int H, int W, int flip_x, int negate_p,
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     unsigned *cache = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_SCRATCH_BYTES);
     unsigned *sort_cnt = cache;                                   // sorted mode: no event cache
     unsigned *sort_start = cache + EV_SORT_MAX_BANDS * EV_WAVES;
+    unsigned *cc = sort_start + EV_SORT_MAX_BANDS + 1;            // sorted mode: EV_CC_N words
     unsigned *ws = a.sort_ws ? a.sort_ws + (size_t)blockIdx.x * a.sort_cap : nullptr;
 
   for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
@@ -442,6 +444,15 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     const bool sorted = !cached && ws != nullptr && bands > 1 && n <= (long long)a.sort_cap;
     unsigned long long s1 = 0, s2 = 0;
     unsigned nnz = 0, dropped = 0;
+    // Long frames re-bin every band for every pass; the second pass only wants the largest count that survives
+    // the hot-pixel threshold (and how many bins hold the one ambiguous count).  Both follow from how many bins
+    // hold each count, which pass 1 can tally on the side (non-zero bins only: ~ one LDS atomic per event): the
+    // frame then takes 2 x bands re-binnings instead of 3 x.  Counts of 1023 and more share the last slot; a
+    // frame that has one runs the real pass 2.
+    const bool use_cc = sorted && !a.kept;
+    if (use_cc) {
+        for (int i = threadIdx.x; i < EV_CC_N; i += EV_THREADS) cc[i] = 0;   // (visible after the first band's barriers)
+    }
     if (cached) {
         fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
         __syncthreads();
@@ -466,6 +477,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
             s1 += h;
             s2 += (unsigned long long)h * h;
             nnz += h > 0;
+            if (use_cc && h > 0) atomicAdd(&cc[h < EV_CC_N - 1 ? h : EV_CC_N - 1], 1u);
             if (a.raw) a.raw[f * M2 + (long long)y0 * W * 2 + i] = (int)h;
         }
     }
@@ -482,7 +494,16 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 
     // ---- pass 2: max of the counts that survive (vis.py:24,27) ----
     unsigned mx = 0, amb = 0;
-    for (int b = 0; b < bands; b++) {
+    const bool from_cc = use_cc && cc[EV_CC_N - 1] == 0;      // (workgroup-uniform: every thread reads the same word)
+    if (from_cc) {
+        for (int c = threadIdx.x; c < EV_CC_N - 1; c += EV_THREADS)
+            if (c > 0 && cc[c] > 0 && (unsigned)c <= thr_hi) mx = (unsigned)c > mx ? (unsigned)c : mx;
+        if (threadIdx.x == 0 && amb_h >= 0) {
+            if (amb_h == 0) amb = (unsigned)(M2 - (long long)nnz);
+            else if (amb_h < EV_CC_N - 1) amb = cc[amb_h];
+        }
+    }
+    for (int b = 0; b < bands && !from_cc; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
         if (bands > 1) {

@@ -221,6 +221,37 @@ def test_long_frames_band_sorted_path(shape, n, frames, packed, hip):
     np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
 
 
+@pytest.mark.parametrize('hot', [0, 700, 1022, 1023, 1500])
+def test_long_frames_skip_their_second_pass_through_the_count_of_counts(hot, hip):
+    """Band-sorted frames take the largest surviving count (and the ambiguous-count tally) from a histogram of
+    counts built in pass 1 instead of re-binning every band a second time; a frame with a count of 1023 or more
+    runs the real pass.  Frames and statistics equal the streaming path's (which always runs it) and the oracle's,
+    with hot pixels on both sides of the histogram's last slot and of the hot-pixel threshold."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import make_events
+    from oracle import events as oe
+    shape, n, frames = (480, 640), 70000, 3
+    ev = np.concatenate([make_events(n, shape, seed=90 + i) for i in range(frames)])
+    if hot:
+        for i in range(frames):                       # `hot` events of one polarity on one pixel, a second pixel half as hot
+            blk = ev[i * n:(i + 1) * n]
+            blk[:hot, 0], blk[:hot, 1], blk[:hot, 3] = 321, 123 + i, 1
+            blk[hot:hot + hot // 2, 0], blk[hot:hot + hot // 2, 1], blk[hot:hot + hot // 2, 3] = 17, 400, -1
+    rng = torch.tensor([[i * n, (i + 1) * n] for i in range(frames)], dtype=torch.int64).cuda()
+    e = torch.from_numpy(ev).cuda()
+    for kw in (dict(), dict(count_non_zero=True), dict(thresh=3.0), dict(thresh=0.0)):
+        a = vis.events_to_frames_device(e, rng, shape, grayscale=False, return_stats=True, max_frame_events=n, **kw)
+        b = vis.events_to_frames_device(e, rng, shape, grayscale=False, return_stats=True, max_frame_events=n,
+                                        sort_workspace=False, **kw)
+        assert torch.equal(a[0], b[0])
+        for k in ('sum', 'sumsq', 'nnz', 'max_kept', 'dropped', 'ambiguous'):
+            np.testing.assert_array_equal(a[1][k], b[1][k], err_msg=k)
+        want = oe.events2frames(ev[:n], 'event_count', 'event_histogram', shape=shape, N=n, grayscale=False,
+                                **{k: v for k, v in kw.items()})
+        np.testing.assert_array_equal(a[0][0].cpu().numpy(), want[0])
+
+
 def test_band_sorted_many_frames_reuse_slots(hip):
     """More frames than CUs: every workgroup walks several frames through its one scratch slot."""
     import torch
