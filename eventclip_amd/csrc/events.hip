@@ -315,6 +315,38 @@ __device__ void bin_band_sorted(const unsigned *ws, unsigned begin, unsigned end
     __syncthreads();
 }
 
+// Walks over a band's bucket of bin codes (four loads in flight), for the passes of long, sparse frames that
+// touch only the bins the events name instead of zeroing and scanning the whole band: OP 0 counts the events into
+// bins that are all zero, OP 1 reads every event's final count h back (the sum over EVENTS of h is the sum over
+// BINS of h^2; cc[h] grows by h per bin with that count), OP 2 puts the touched bins back to zero.
+template <int OP>
+__device__ __forceinline__ void walk_bucket(const unsigned *ws, unsigned begin, unsigned end, unsigned lo, unsigned *bins,
+                                            unsigned *cc, unsigned long long &s2)
+{
+    for (unsigned i = begin + threadIdx.x; i < end; i += 4 * EV_THREADS) {
+        unsigned c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned j = i + k * EV_THREADS;
+            c[k] = ws[j < end ? j : end - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k * EV_THREADS >= end) continue;
+            unsigned *bin = &bins[c[k] - lo];
+            if (OP == 0) {
+                atomicAdd(bin, 1u);
+            } else if (OP == 1) {
+                const unsigned h = *bin;
+                s2 += h;
+                atomicAdd(&cc[h < EV_CC_N - 1 ? h : EV_CC_N - 1], 1u);
+            } else {
+                *bin = 0;
+            }
+        }
+    }
+}
+
 // vis.py:27-39 for one pixel in float32: what the reference's pinned numpy 1.25 computes (value-based
 // casting keeps `float32 array / int64 scalar` and everything after it in float32; sgemm's K = 2
 // inner product is fmaf(q, blue, p * red), every ufunc after it rounds once).  FP contraction is off.
@@ -450,8 +482,18 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     // frame then takes 2 x bands re-binnings instead of 3 x.  Counts of 1023 and more share the last slot; a
     // frame that has one runs the real pass 2.
     const bool use_cc = sorted && !a.kept;
+    // ... and a long frame is sparse (70 000 events on 614 400 bins): with the bins all zero at the start of a
+    // band, pass 1 counts the bucket in, reads each event's count back and puts the touched bins back to zero --
+    // three walks of ~4 events per thread instead of zeroing and scanning 38 000 words; pass 3 likewise clears what
+    // it binned after colouring the band.  Not with the debug outputs, and not for a frame with a count >= 1023
+    // (its tallies by count cannot be divided back into bins): those take the dense passes.
+    bool lean = use_cc && !a.raw;
     if (use_cc) {
         for (int i = threadIdx.x; i < EV_CC_N; i += EV_THREADS) cc[i] = 0;   // (visible after the first band's barriers)
+    }
+    if (lean) {
+        const int nbw = rpb * W * 2;
+        for (int i = threadIdx.x; i < nbw; i += EV_THREADS) bins[i] = 0;
     }
     if (cached) {
         fill_cache(ev, n, H, W, a.flip_x, a.negate_p, cache, dropped);
@@ -460,8 +502,36 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         sort_by_band(ev, n, H, W, a.flip_x, a.negate_p, bands, a.band_magic, sort_cnt, sort_start, ws,
                      dropped);
     }
+    if (lean) {
+        for (int b = 0; b < bands; b++) {
+            const unsigned lo = (unsigned)(b * rpb * W * 2), begin = sort_start[b], end = sort_start[b + 1];
+            walk_bucket<0>(ws, begin, end, lo, bins, cc, s2);
+            __syncthreads();
+            walk_bucket<1>(ws, begin, end, lo, bins, cc, s2);
+            __syncthreads();
+            walk_bucket<2>(ws, begin, end, lo, bins, cc, s2);
+            __syncthreads();
+        }
+        if (cc[EV_CC_N - 1] != 0) {          // (uniform) a count of 1023 or more: start over with the dense passes
+            lean = false;
+            s2 = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < EV_CC_N; i += EV_THREADS) cc[i] = 0;
+            __syncthreads();
+        } else {
+            // cc[h] holds h per bin with count h: back to bins per count, whose sum is the non-zero bins
+            __syncthreads();
+            for (int h = threadIdx.x; h < EV_CC_N - 1; h += EV_THREADS)
+                if (h > 0) {
+                    const unsigned per = cc[h] / (unsigned)h;
+                    cc[h] = per;
+                    nnz += per;
+                }
+            if (threadIdx.x == 0) s1 = sort_start[bands];      // every event that was binned
+        }
+    }
     // ---- pass 1: counts -> sum, sum of squares, non-zero bins ----
-    for (int b = 0; b < bands; b++) {
+    for (int b = 0; b < bands && !lean; b++) {
         const int y0 = b * rpb, y1 = min(H, y0 + rpb);
         unsigned dr = 0;
         if (cached)
@@ -568,6 +638,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         if (bands > 1) {
             if (cached)
                 bin_band_cached(cache, (int)n, y0, y1, W, bins);
+            else if (sorted && lean)
+                walk_bucket<0>(ws, sort_start[b], sort_start[b + 1], (unsigned)(y0 * W * 2), bins, cc, s2);   // (bins all zero)
             else if (sorted)
                 bin_band_sorted(ws, sort_start[b], sort_start[b + 1], y0, y1, W, bins);
             else
@@ -603,6 +675,10 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
             }
         }
         __syncthreads();
+        if (lean) {                                   // leave the band's bins zero for the next one
+            walk_bucket<2>(ws, sort_start[b], sort_start[b + 1], (unsigned)(y0 * W * 2), bins, cc, s2);
+            __syncthreads();
+        }
     }
   }   // frames of this workgroup
 }
