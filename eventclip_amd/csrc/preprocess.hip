@@ -102,6 +102,7 @@ struct PreArgs {
     const int32_t *plan;
     void *out;
     int in_h, in_w, n_px, band_rows, bands, ks_h, ks_v, off_bh, off_kh, off_bv, off_kv, off_lut;
+    int tmp_bytes;      // LDS bytes of the horizontally resampled rows; the table and the band's coefficients follow
     int mode, patch, kpad, grid_w;
 };
 
@@ -116,14 +117,64 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a)
     const int oy1 = min(R, oy0 + a.band_rows);
     const int32_t *bh = a.plan + a.off_bh, *kh = a.plan + a.off_kh;
     const int32_t *bv = a.plan + a.off_bv, *kv = a.plan + a.off_kv;
-    const float *lut = reinterpret_cast<const float *>(a.plan + a.off_lut);
+    // the normalisation table and this band's vertical coefficients go to LDS once (three table look-ups and
+    // up to 11 coefficient loads per output pixel were texture-unit instructions)
+    float *lut = reinterpret_cast<float *>(tmp + a.tmp_bytes);
+    int32_t *kvs = reinterpret_cast<int32_t *>(tmp + a.tmp_bytes + 3 * 256 * 4);
+    {
+        const float *lut_g = reinterpret_cast<const float *>(a.plan + a.off_lut);
+        for (int i = threadIdx.x; i < 3 * 256; i += 256) lut[i] = lut_g[i];
+        const int nk = (oy1 - oy0) * a.ks_v;
+        for (int i = threadIdx.x; i < nk; i += 256) kvs[i] = kv[oy0 * a.ks_v + i];
+    }
     const int ymin = bv[2 * oy0];
     const int ymax = bv[2 * (oy1 - 1)] + bv[2 * (oy1 - 1) + 1];
     const int ny = ymax - ymin;
     const uint8_t *src = a.frames + (long)f * a.in_h * a.in_w * 3;
 
     // ---- horizontal pass into LDS ----
-    for (int it = threadIdx.x; it < ny * R; it += 256) {
+    // An item is an output column and every HG-th input row: its (at most 12) coefficients stay in registers, and
+    // a row's tap window -- 3 cnt contiguous bytes -- is read as unaligned dwords, not byte by byte.  (One output
+    // per item with byte loads issued 40 loads per output on N-ImageNet frames; the pass ran at the texture
+    // unit's instruction rate: 6.3 ms per 2560 frames.)
+    constexpr int HT = 12, HW = 3 * HT / 4, HG = 8;
+    const bool fast_h = a.ks_h <= HT;
+    for (int it = threadIdx.x; fast_h && it < R * HG; it += 256) {
+        const int ox = it % R, rg = it / R;
+        const int xmin = bh[2 * ox], cnt = bh[2 * ox + 1];
+        int coef[HT];
+#pragma unroll
+        for (int t = 0; t < HT; t++) coef[t] = t < cnt ? kh[ox * a.ks_h + t] : 0;
+        const int nbytes = 3 * cnt, ndw = nbytes >> 2;
+        for (int yy = rg; yy < ny; yy += HG) {
+            const uint8_t *row = src + ((long)(ymin + yy) * a.in_w + xmin) * 3;
+            unsigned w[HW];
+#pragma unroll
+            for (int j = 0; j < HW; j++) {
+                w[j] = 0;
+                if (j < ndw) {
+                    unsigned v;
+                    __builtin_memcpy(&v, row + 4 * j, 4);          // (unaligned global load)
+                    w[j] = v;
+                } else if (j == ndw) {                             // the window's last 1-3 bytes, one at a time
+                    for (int b = 0; b < (nbytes & 3); b++) w[j] |= (unsigned)row[4 * j + b] << (8 * b);
+                }
+            }
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                const int c = coef[t];
+                s0 += (int)((w[(3 * t) >> 2] >> (8 * ((3 * t) & 3))) & 255u) * c;
+                s1 += (int)((w[(3 * t + 1) >> 2] >> (8 * ((3 * t + 1) & 3))) & 255u) * c;
+                s2 += (int)((w[(3 * t + 2) >> 2] >> (8 * ((3 * t + 2) & 3))) & 255u) * c;
+            }
+            unsigned char *d = tmp + (yy * R + ox) * 3;
+            d[0] = (unsigned char)min(255, max(0, s0 >> PRECISION_BITS));
+            d[1] = (unsigned char)min(255, max(0, s1 >> PRECISION_BITS));
+            d[2] = (unsigned char)min(255, max(0, s2 >> PRECISION_BITS));
+        }
+    }
+    for (int it = threadIdx.x; !fast_h && it < ny * R; it += 256) {
         const int yy = it / R, ox = it - yy * R;
         const int xmin = bh[2 * ox], cnt = bh[2 * ox + 1];
         const uint8_t *row = src + ((long)(ymin + yy) * a.in_w + xmin) * 3;
@@ -142,46 +193,86 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a)
     }
     __syncthreads();
 
-    // ---- vertical pass, normalise, store ----
+    // ---- vertical pass, normalise, store: a thread takes two neighbouring pixels (their six bytes in one LDS
+    // read per tap, one coefficient read for both; in the patch layout the pair shares a patch row, so every
+    // value leaves as one 4-byte store of two 16-bit elements) ----
     const int p = a.patch, pp = p * p;
-    for (int it = threadIdx.x; it < (oy1 - oy0) * R; it += 256) {
-        const int oyl = it / R, ox = it - oyl * R;
+    const bool pairs = (R & 1) == 0 && (a.mode != EC_PRE_PATCHES16 || ((p & 1) == 0 && (a.kpad & 1) == 0));
+    const int RW = pairs ? R / 2 : R;                  // work items per output row
+    for (int it = threadIdx.x; it < (oy1 - oy0) * RW; it += 256) {
+        const int oyl = it / RW, ox = (it - oyl * RW) * (pairs ? 2 : 1);
         const int oy = oy0 + oyl;
         const int y0 = bv[2 * oy] - ymin, cnt = bv[2 * oy + 1];
-        const int32_t *k = kv + oy * a.ks_v;
-        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        const int32_t *k = kvs + oyl * a.ks_v;
+        int sa[3], sb[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) sa[c] = sb[c] = 1 << (PRECISION_BITS - 1);
         const unsigned char *col = tmp + (y0 * R + ox) * 3;
-        for (int t = 0; t < cnt; t++) {
-            const int c = k[t];
-            s0 += (int)col[0] * c;
-            s1 += (int)col[1] * c;
-            s2 += (int)col[2] * c;
-            col += R * 3;
+        if (pairs) {
+            for (int t = 0; t < cnt; t++) {
+                const int c = k[t];
+                unsigned long long v;
+                __builtin_memcpy(&v, col, 8);                 // two pixels' six bytes (+ two beyond, inside the carve)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    sa[ch] += (int)((v >> (8 * ch)) & 255u) * c;
+                    sb[ch] += (int)((v >> (8 * (3 + ch))) & 255u) * c;
+                }
+                col += R * 3;
+            }
+        } else {
+            for (int t = 0; t < cnt; t++) {
+                const int c = k[t];
+                unsigned v;
+                __builtin_memcpy(&v, col, 4);
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) sa[ch] += (int)((v >> (8 * ch)) & 255u) * c;
+                col += R * 3;
+            }
         }
-        const int u0 = min(255, max(0, s0 >> PRECISION_BITS));
-        const int u1 = min(255, max(0, s1 >> PRECISION_BITS));
-        const int u2 = min(255, max(0, s2 >> PRECISION_BITS));
-        const float v0 = lut[u0], v1 = lut[256 + u1], v2 = lut[512 + u2];
+        int ua[3], ub[3];
+        float va[3], vb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            ua[ch] = min(255, max(0, sa[ch] >> PRECISION_BITS));
+            ub[ch] = min(255, max(0, sb[ch] >> PRECISION_BITS));
+            va[ch] = lut[256 * ch + ua[ch]];
+            vb[ch] = lut[256 * ch + ub[ch]];
+        }
         if (a.mode == EC_PRE_CHW_F32) {
             float *o = (float *)a.out + (long)f * 3 * R * R + (long)oy * R + ox;
-            o[0] = v0;
-            o[(long)R * R] = v1;
-            o[2L * R * R] = v2;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (pairs) *reinterpret_cast<float2 *>(o + (long)ch * R * R) = make_float2(va[ch], vb[ch]);
+                else o[(long)ch * R * R] = va[ch];
+            }
         } else if (a.mode == EC_PRE_HWC_U8) {
             uint8_t *o = (uint8_t *)a.out + ((long)f * R * R + (long)oy * R + ox) * 3;
-            o[0] = (uint8_t)u0, o[1] = (uint8_t)u1, o[2] = (uint8_t)u2;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                o[ch] = (uint8_t)ua[ch];
+                if (pairs) o[3 + ch] = (uint8_t)ub[ch];
+            }
         } else {
             const int py = oy / p, i = oy - py * p, px = ox / p, j = ox - px * p;
             // a patch row carries every value as hi + lo 16-bit parts: [hi (c,i,j) | lo (c,i,j) | 0]
             elem *o = (elem *)a.out + ((long)f * a.grid_w * a.grid_w + py * a.grid_w + px) * a.kpad +
                       i * p + j;
-            const elem h0 = to16(v0, elem()), h1 = to16(v1, elem()), h2 = to16(v2, elem());
-            o[0] = h0;
-            o[pp] = h1;
-            o[2 * pp] = h2;
-            o[3 * pp] = to16(v0 - (float)h0, elem());
-            o[4 * pp] = to16(v1 - (float)h1, elem());
-            o[5 * pp] = to16(v2 - (float)h2, elem());
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const elem ha = to16(va[ch], elem()), la = to16(va[ch] - (float)ha, elem());
+                if (pairs) {
+                    typedef elem elem2 __attribute__((ext_vector_type(2)));
+                    const elem hb = to16(vb[ch], elem()), lb = to16(vb[ch] - (float)hb, elem());
+                    elem2 hi, lo;
+                    hi[0] = ha, hi[1] = hb, lo[0] = la, lo[1] = lb;
+                    *reinterpret_cast<elem2 *>(o + ch * pp) = hi;
+                    *reinterpret_cast<elem2 *>(o + (3 + ch) * pp) = lo;
+                } else {
+                    o[ch * pp] = ha;
+                    o[(3 + ch) * pp] = la;
+                }
+            }
         }
     }
     if (a.mode == EC_PRE_PATCHES16) {
@@ -311,7 +402,9 @@ EC_API int ec_preprocess(const uint8_t *frames, int F, const void *plan_host, co
         const int ny = bv[2 * o1] + bv[2 * o1 + 1] - bv[2 * o0];
         if (ny > max_ny) max_ny = ny;
     }
-    const int lds = ((max_ny * R * 3 + 15) / 16) * 16;
+    // ... then the normalisation table (3 x 256 floats) and the band's vertical coefficients
+    a.tmp_bytes = ((max_ny * R * 3 + 8 + 15) / 16) * 16;      // (+ 8: the vertical pass reads 6 bytes as a qword)
+    const int lds = a.tmp_bytes + 3 * 256 * 4 + ((a.band_rows * a.ks_v * 4 + 15) / 16) * 16;
     EC_REQUIRE(lds <= 160 * 1024, "ec_preprocess: band needs %d bytes of LDS", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto kern = dtype == EC_BF16 ? preprocess_kernel<EC_BF16> : preprocess_kernel<EC_F16>;
