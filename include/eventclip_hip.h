@@ -540,11 +540,13 @@ EC_API int ec_sgemm(const float *A, long sam, long sak, const float *B, long sbk
  * into whatever _build_clip (:44-80) left trainable (all of model.visual, sub-sets, or LoRA factors that act
  * through merged weights W + up @ down, models/lora.py:138-150) -> Adam (method.py:152-186).  Here:
  *   ec_vit_train_forward   encode_image keeping what the backward pass needs (per block: both residual
- *                          inputs, q | k | v, the attention output and its log-sum-exp, the MLP pre-activation);
+ *                          inputs, both LayerNorm outputs, q | k | v, the attention output and its log-sum-exp,
+ *                          the MLP pre-activation and its QuickGELU: 36 bytes per token and channel);
  *   ec_ft_loss_grad        the classifier head: loss and d loss / d image features, d loss / d text_feats;
  *   ec_vit_train_backward  d features -> gradients of every visual parameter asked for, in the layouts of
- *                          the state dict (fp32); LoRA and sub-set selection are the caller's (chain rule on
- *                          the merged-weight gradients with ec_sgemm; unused gradients: NULL pointers);
+ *                          the state dict (fp32; weight gradients dY^T X straight from the row-major
+ *                          activations: ec_gemm_args.transposed); unused gradients: NULL pointers; LoRA factor
+ *                          gradients through ec_vit_lora (rank-r products from the activations);
  *   ec_pack_weight16_batched  fp32 master weights -> the 16-bit operand copies the kernels read;
  *   ec_grad_unscale_check  the gradient-scaler step of mixed-precision training (`--fp16`, train.py:121).
  * Arithmetic: 16-bit MFMA operands (activations, weights, activation gradients), fp32 accumulation, fp32
