@@ -107,11 +107,12 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *i
     const int f = blockIdx.x / bands, band = blockIdx.x % bands;
     const ec_aug_op op = ops[(long)f * num_ops + step];
     const long npix = (long)H * W;
-    const long per = (npix + bands - 1) / bands;
-    const long p0 = band * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const long per = ((npix + bands - 1) / bands + 3) / 4 * 4;        // bands start on multiples of four pixels
+    const long p0 = band * per < npix ? band * per : npix, p1 = p0 + per < npix ? p0 + per : npix;
     const uint8_t *src = in + (long)f * npix * 3;
     uint8_t *dst = out + (long)f * npix * 3;
     const int kind = op.kind;
+    const bool quads = ((npix * 3) & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
 
     __shared__ uint8_t lut[3 * 256];
     __shared__ int mean_l;
@@ -179,9 +180,10 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *i
     const float alpha = op.alpha;
     const bool inside01 = alpha >= 0.f && alpha <= 1.f;
     const uint8_t fillc[3] = {fr, fg, fb};
-    for (long p = p0 + threadIdx.x; p < p1; p += AUG_THREADS) {
+    // One output pixel.  v: the pixel's own source bytes (the operators that are functions of them get them from
+    // the caller, who reads four pixels as three dwords).
+    auto pixel = [&](long p, const int (&v)[3], uint8_t (&o)[3]) {
         const int y = (int)(p / W), x = (int)(p - (long)y * W);
-        uint8_t o[3];
         switch (kind) {
         case EC_AUG_AFFINE: {
             const double xs = (double)x + 0.5, ys = (double)y + 0.5;
@@ -202,23 +204,38 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *i
                 const int xx = x0 + k;
                 xc[k] = xx < 0 ? 0 : (xx < W ? xx : W - 1);
             }
+            // the four taps of a row are 12 contiguous bytes away from the left / right borders: three unaligned
+            // dwords instead of twelve byte loads (the kernel ran at the texture unit's instruction rate)
+            const bool contiguous = x0 >= 0 && x0 + 3 < W;
+            double rows[3][4];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                double rows[4];
+            for (int k = 0; k < 4; k++) {
+                const int yy = y0 + k;
+                if (k == 0 || (yy >= 0 && yy < H)) {
+                    const int yr = yy < 0 ? 0 : (yy < H ? yy : H - 1);   // YCLIP (first row only)
+                    const uint8_t *r = src + ((long)yr * W) * 3;
+                    int t[4][3];
+                    if (contiguous) {
+                        unsigned w[3];
+                        __builtin_memcpy(w, r + (long)x0 * 3, 12);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int yy = y0 + k;
-                    if (k == 0 || (yy >= 0 && yy < H)) {
-                        const int yr = yy < 0 ? 0 : (yy < H ? yy : H - 1);   // YCLIP (first row only)
-                        const uint8_t *r = src + ((long)yr * W) * 3 + c;
-                        rows[k] = cubic((double)r[xc[0] * 3], (double)r[xc[1] * 3], (double)r[xc[2] * 3],
-                                        (double)r[xc[3] * 3], dx);
+                        for (int i = 0; i < 12; i++) t[i / 3][i % 3] = (int)((w[i >> 2] >> (8 * (i & 3))) & 255u);
                     } else {
-                        rows[k] = rows[k - 1];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+#pragma unroll
+                            for (int c = 0; c < 3; c++) t[i][c] = r[xc[i] * 3 + c];
                     }
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        rows[c][k] = cubic((double)t[0][c], (double)t[1][c], (double)t[2][c], (double)t[3][c], dx);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) rows[c][k] = rows[c][k - 1];
                 }
-                o[c] = clip8_trunc(cubic(rows[0], rows[1], rows[2], rows[3], dy));
             }
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[c] = clip8_trunc(cubic(rows[c][0], rows[c][1], rows[c][2], rows[c][3], dy));
             break;
         }
         case EC_AUG_ROT180: {
@@ -240,10 +257,8 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *i
         case EC_AUG_COLOR:
         case EC_AUG_CONTRAST:
         case EC_AUG_SHARPNESS: {
-            const uint8_t *s = src + p * 3;
-            const int v[3] = {s[0], s[1], s[2]};
             if (alpha == 1.f) {                      // Image.blend returns a copy of the image
-                o[0] = s[0], o[1] = s[1], o[2] = s[2];
+                o[0] = (uint8_t)v[0], o[1] = (uint8_t)v[1], o[2] = (uint8_t)v[2];
                 break;
             }
             int deg[3];
@@ -282,15 +297,47 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_apply_kernel(const uint8_t *i
         case EC_AUG_SOLARIZE:
         case EC_AUG_AUTOCONTRAST:
         case EC_AUG_EQUALIZE: {
-            const uint8_t *s = src + p * 3;
-            o[0] = lut[s[0]], o[1] = lut[256 + s[1]], o[2] = lut[512 + s[2]];
+            o[0] = lut[v[0]], o[1] = lut[256 + v[1]], o[2] = lut[512 + v[2]];
             break;
         }
         default: {   // EC_AUG_IDENTITY
-            const uint8_t *s = src + p * 3;
-            o[0] = s[0], o[1] = s[1], o[2] = s[2];
+            o[0] = (uint8_t)v[0], o[1] = (uint8_t)v[1], o[2] = (uint8_t)v[2];
         }
         }
+    };
+    const bool own_bytes = !(kind == EC_AUG_AFFINE || kind == EC_AUG_ROT180 || kind == EC_AUG_ROT90 || kind == EC_AUG_ROT270);
+    // four pixels = twelve bytes = three dwords per thread, in (the operators above that want them) and out; a
+    // band starts on a multiple of four pixels and a frame's byte size is a multiple of four when `quads`
+    long p_tail = p0;
+    if (quads) {
+        const long g1 = p1 / 4;
+        for (long g = p0 / 4 + threadIdx.x; g < g1; g += AUG_THREADS) {
+            unsigned in[3] = {0, 0, 0}, out3[3] = {0, 0, 0};
+            if (own_bytes) {
+                const unsigned *s4 = reinterpret_cast<const unsigned *>(src + g * 12);
+                in[0] = s4[0], in[1] = s4[1], in[2] = s4[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int v[3];
+                uint8_t o[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[c] = (int)((in[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3))) & 255u);
+                pixel(g * 4 + j, v, o);
+#pragma unroll
+                for (int c = 0; c < 3; c++) out3[(3 * j + c) >> 2] |= (unsigned)o[c] << (8 * ((3 * j + c) & 3));
+            }
+            unsigned *d4 = reinterpret_cast<unsigned *>(dst + g * 12);
+            d4[0] = out3[0], d4[1] = out3[1], d4[2] = out3[2];
+        }
+        p_tail = g1 * 4 > p0 ? g1 * 4 : p0;
+    }
+    for (long p = p_tail + threadIdx.x; p < p1; p += AUG_THREADS) {
+        const uint8_t *s = src + p * 3;
+        int v[3] = {0, 0, 0};
+        if (own_bytes) v[0] = s[0], v[1] = s[1], v[2] = s[2];
+        uint8_t o[3];
+        pixel(p, v, o);
         dst[p * 3] = o[0], dst[p * 3 + 1] = o[1], dst[p * 3 + 2] = o[2];
     }
 }

@@ -124,16 +124,23 @@ def apply_ops(frames, per_frame_ops, fill):
     if F == 0:
         return frames.clone()
     num_ops = len(per_frame_ops[0])
-    arr = (_lib.EcAugOp * (F * num_ops))()
-    cache = {}
-    for f, ops in enumerate(per_frame_ops):
-        assert len(ops) == num_ops
-        for k, (name, mag) in enumerate(ops):
-            key = (name, mag)
-            if key not in cache:
-                cache[key] = op_descriptor(name, mag, (H, W))
-            arr[f * num_ops + k] = cache[key]
-    host = np.frombuffer(arr, dtype=np.uint8).copy()
+    # one descriptor blob per distinct operator list (the views of a sample share theirs; filling a ctypes array
+    # element by element cost more host time than the kernels take)
+    cache, blobs = {}, {}
+
+    def blob(ops):
+        b = blobs.get(id(ops))
+        if b is None:
+            assert len(ops) == num_ops
+            arr = (_lib.EcAugOp * num_ops)()
+            for k, (name, mag) in enumerate(ops):
+                key = (name, mag)
+                if key not in cache:
+                    cache[key] = op_descriptor(name, mag, (H, W))
+                arr[k] = cache[key]
+            b = blobs[id(ops)] = bytes(arr)
+        return b
+    host = np.frombuffer(b''.join([blob(ops) for ops in per_frame_ops]), dtype=np.uint8).copy()
     ops_d = torch.from_numpy(host).to(dev)
     out = torch.empty_like(frames)
     need = int(_lib.lib().ec_randaugment_workspace_bytes(F, H, W, num_ops))
