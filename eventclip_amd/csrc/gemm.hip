@@ -1582,11 +1582,13 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
 {
     switch (variant) {
     case 0: return launch2pp<DT, EPI>(g, s);                     // default: persistent staggered 2-phase
+#ifdef EC_GEMM_DIAG
+    // the kernels the default one grew out of, kept for comparisons in the diagnostic build only: nothing in the
+    // product calls them, and the plain 128 x 128 one once returned five wrong elements in ~10^9 on one box
     case 1: return launch<DT, 256, 256, 2, 4, EPI>(g, s);        // plain two-barrier loop, 256 x 256
     case 2: return launch<DT, 128, 128, 2, 2, EPI>(g, s);
     case 3: return launch<DT, 128, 256, 1, 4, EPI>(g, s);
     case 5: return launch2p<DT, EPI>(g, s);                      // staggered 2-phase, one tile per workgroup
-#ifdef EC_GEMM_DIAG
     case 4: return launch4p<DT, EPI>(g, s);
     case 6: return launch2p<DT, EPI, 1>(g, s);   // timing experiment: no DMA in the loop (wrong results)
     case 7: return launch2p<DT, EPI, 2>(g, s);   // timing experiment: every WG streams tile (0,0)

@@ -240,8 +240,8 @@ typedef struct {
     int M, N, K;       /* K % 64 == 0, N % 16 == 0 */
     int dtype;         /* EC_F16 / EC_BF16: A, W and 16-bit outputs */
     int epilogue;      /* EC_EPI_* */
-    int variant;       /* 0 = default tiling; 1, 2, 3, 5 = other tilings with the same results (A/B
-                          runs and cross-checks); anything else is EC_ERR_INVALID */
+    int variant;       /* 0 = the kernel; anything else is EC_ERR_INVALID.  (The tilings it grew out of and the
+                          stamp / timeline variants exist in the -DEC_GEMM_DIAG build for tools/ only.) */
     const void *A;     /* [M, K] 16-bit, row stride lda elements (0 = K) */
     long lda;
     const void *W;     /* [N, K] 16-bit, dense (nn.Linear weight layout) */

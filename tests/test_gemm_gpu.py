@@ -16,7 +16,7 @@ def ref_gemm(A, W, bias, epilogue, resid=None):
     return y
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 5])
+@pytest.mark.parametrize('variant', [0])      # (the product library has the default kernel only)
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 3072, 1024), (513, 1024, 4096),
                                    (77, 768, 640), (5, 512, 64), (256, 256, 128), (300, 48, 64)])
@@ -41,7 +41,7 @@ def test_gemm_matches_torch(M, N, K, dt, epilogue, variant, hip):
     torch.testing.assert_close(got.float(), want, rtol=rtol, atol=rtol)
 
 
-@pytest.mark.parametrize('variant', [0, 5])
+@pytest.mark.parametrize('variant', [0])
 @pytest.mark.parametrize('epilogue', ['store16', 'gelu16', 'resid32', 'store32'])
 @pytest.mark.parametrize('M,N,K', [(70001, 512, 256), (66000, 1024, 64), (40000, 784, 192)])
 def test_gemm_many_tiles(M, N, K, epilogue, variant, hip):
@@ -124,3 +124,15 @@ def test_low_latency_k_batched_launch_matches_the_single_pass(hip, M, N, K, dtyp
     # a launch that fills the chip (tiles * 2 > 256 CUs for every N here) ignores the scratch: same bits
     big = torch.randn(256 * 96, K, device='cuda').to(dtype)
     assert torch.equal(ops.gemm(big, W, bias, 'store16', ws=ws), ops.gemm(big, W, bias, 'store16'))
+
+
+def test_only_the_default_kernel_is_in_the_product_library(hip):
+    """The comparison kernels (variants 1, 2, 3, 5) and the stamp / timeline variants live in the diagnostic
+    build; the product's ec_gemm refuses them instead of running code nothing else exercises."""
+    import torch
+    from eventclip_amd import ops
+    A = torch.randn(256, 64, device='cuda').half()
+    W = torch.randn(256, 64, device='cuda').half()
+    for v in (1, 2, 3, 5, 10, 16):
+        with pytest.raises(RuntimeError, match='unknown variant'):
+            ops.gemm(A, W, None, 'store16', variant=v)
