@@ -142,8 +142,235 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
     }
 }
 
-template <int DT, int AT_WAVES, bool LSE = false>
-__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnArgs a)
+// Version 2 of the block (the product path; `attn_block` above is kept for A/B in the diagnostic build).
+// The vector ALU is the saturated pipe of this kernel (profiles/r2_attention.md), so the block is
+// arranged to leave it only what no other unit can do -- one exp2, half a max3 and half a convert per score:
+//  * the query fragment arrives pre-multiplied by log2(e) / sqrt(64), so the MFMA result is already the
+//    exponent's argument up to the row offset;
+//  * the row offset is the MFMA's C operand: mneg = {-m, -m, -m, -m} for the lane's query (a lane's four
+//    accumulator rows belong to ONE query column), so the matrix pipe delivers s - m and no per-score
+//    subtract is left;
+//  * m is the running maximum as of the last time it MOVED, not of the block.  It starts at 0; a block whose
+//    scores stay below m + ATTN_THR (log2 units; and, for a tile's first block only, whose maximum is not
+//    below m - ATTN_LO) keeps m, O and the row sum as they are -- P <= 2^ATTN_THR is exact in either 16-bit
+//    type, and nothing is rescaled.  Only when some lane sees a larger score (a wave-uniform branch, seldom
+//    taken) are m, the scores of this block, O and the row sum moved to the new maximum, all of them
+//    exactly once, BEFORE this block's P is formed (cdna_hip_programming.md T13's safe order);
+//  * the row sum comes from the matrix pipe too: a fifth "V^T" tile of ones, so l = sum of the ROUNDED
+//    P the output was built from.
+// The pre-multiplied query is rounded to the operand type a second time.  f16: +20 % on the kernel's own
+// rounding error (6.3e-4 against 4.8e-4 on unit-variance data).  bf16's 8 bits would put 2e-2 on the log-sum-exp the
+// training forward saves, so bf16 keeps the scores in raw units and pays one multiply per score.
+__host__ __device__ constexpr bool attn_prescaled(int dt) { return dt == 0; }
+constexpr float ATTN_THR = 10.f;
+constexpr float ATTN_LO = 4.f;   // first block: P of the row maximum >= 2^-4, the rest of a 16-bit float's range below it
+
+// O += A . B IN PLACE (tied operand), one asm statement per MFMA.  Through the builtin hipcc lets the
+// loop-carried accumulators wander (D != C) and pays for it with a copy of all of O in every block once the
+// block has the seldom-taken branch below in it; an asm statement's "+v" operand cannot move (one statement
+// with all five accumulators tied brings the copies back: one each).  What hipcc does not pad for an asm
+// statement (cdna_hip_programming.md 5.7 item 2) is handled by hand:
+//  pad 1 = two wait states in front -- a just-written vector result needs them before an MFMA reads it (a
+//          step's first MFMA: the converted P);
+//  pad 2 = twelve behind -- a block's last MFMA: hipcc may read O right behind the block (copies at loop
+//          exits, spills, the epilogue) and pads nothing for a producer inside an asm string.
+// Elsewhere O arrives from the previous step's MFMAs (an accumulate chain on the whole of D needs none) and the
+// V^T fragments from ds_reads (the compiler's own s_waitcnt covers asm inputs).  tools/check_attn_isa.py
+// checks the compiled kernels for vector writes right in front of the unpadded statements.
+template <int pad> __device__ __forceinline__ void mfma16_acc(const f16x8 &a, const f16x8 &b, f32x4 &c)
+{
+    if (pad == 1)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else if (pad == 2)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 11" : "+v"(c) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int pad> __device__ __forceinline__ void mfma16_acc(const bf16x8 &a, const bf16x8 &b, f32x4 &c)
+{
+    if (pad == 1)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else if (pad == 2)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 11" : "+v"(c) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// The seldom-taken arm: move the lane's query to a new maximum.  d = how far in the units of the scores,
+// d_log2 = in log2 units (the same where the query arrives pre-scaled); everything still
+// at the old m moves with it exactly once: the caller's pending scores (by the caller), O and the row sum
+// (scaled by 2^-d; by 0 while they are still empty: `down`), and -m.  O and -m IN PLACE like the MFMAs'
+// accumulate; O was last written by the previous block's MFMAs, whose last statement waited for them.
+__device__ __forceinline__ void attn_move(float d, float d_log2, bool down, f32x4 &mneg, f32x4 (&o)[5])
+{
+    float alpha = __builtin_amdgcn_exp2f(-d_log2);
+    alpha = down ? 0.f : alpha;
+#pragma unroll
+    for (int dt = 0; dt < 5; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float t = o[dt][r];
+            asm volatile("s_nop 0\n\tv_mul_f32 %0, %0, %1" : "+v"(t) : "v"(alpha));   // s_nop: alpha is fresh from v_exp / v_cndmask
+            o[dt][r] = t;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float t = mneg[r];
+        asm volatile("v_sub_f32 %0, %0, %1" : "+v"(t) : "v"(d));
+        mneg[r] = t;
+    }
+}
+
+// One block of KSTEPS 32-key steps.  `down`: the tile has added nothing yet (m may move down too).
+template <int DT, int KSTEPS, bool MASK>
+__device__ __forceinline__ void attn_block2(const unsigned char *ldsK, const unsigned char *ldsV,
+                                            int key0, int klimit, const typename T16<DT>::v8 (&qf)[2],
+                                            const typename T16<DT>::v8 &ones, bool down, float c, f32x4 &mneg,
+                                            f32x4 (&o)[5], int g, int c16)
+{
+    constexpr bool PRE = attn_prescaled(DT);   // else: scores in raw units, c = log2(e) / sqrt(64) applied per score
+    const float thr = PRE ? ATTN_THR : ATTN_THR / c, lo = PRE ? ATTN_LO : ATTN_LO / c;
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    typedef typename T16<DT>::v4 v4;
+    constexpr int NT = 2 * KSTEPS;
+    // ---- acc[kt][r] = c <k[key0 + 16 kt + 4 g + r], q[c16]> - m[c16] ----
+    f32x4 acc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        const int row = key0 + kt * 16 + c16;
+        const v8 k0 = *reinterpret_cast<const v8 *>(ldsK + row * 128 + (((0 + g) ^ (row & 7)) << 4));
+        const v8 k1 = *reinterpret_cast<const v8 *>(ldsK + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+        acc[kt] = mfma16(k0, qf[0], mneg);
+        acc[kt] = mfma16(k1, qf[1], acc[kt]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (MASK) {   // only blocks that reach past klimit (padding, causal diagonal)
+                const int key = key0 + kt * 16 + 4 * g + r;
+                acc[kt][r] = key < klimit ? acc[kt][r] : -INFINITY;
+            }
+            mx = fmaxf(mx, acc[kt][r]);
+        }
+    if (__builtin_amdgcn_ballot_w64(mx > thr || (down && mx < -lo)) != 0) {
+        // the four lane groups hold different keys of the same query and all hold parts of its O column:
+        // one distance for all of them; up only, unless nothing has been added yet
+        const float mq = xor_max(mx);
+        const float d = down ? mq : fmaxf(mq, 0.f);
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) acc[kt] -= d;
+        attn_move(d, PRE ? d : d * c, down, mneg, o);
+    }
+    // ---- O^T += V^T . P^T, row sum += 1^T . P^T ----
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+        // the step's four V^T fragments are requested first: their LDS latency passes under the
+        // exponentials.  A operand row i <-> head dim (i >> 2) * 16 + 4 dt + (i & 3), key order as below
+        v8 vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int row = key0 + 32 * s + 16 * hh + 4 * g + (c16 >> 2);
+                const int u = ((c16 & 3) * 4 + dt) ^ ((row >> 1) & 3);
+                const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(ldsV + row * 128 + u * 8));
+                const v4 tv = __builtin_bit_cast(v4, t);
+                vf[dt][4 * hh] = tv[0], vf[dt][4 * hh + 1] = tv[1], vf[dt][4 * hh + 2] = tv[2],
+                            vf[dt][4 * hh + 3] = tv[3];
+            }
+        // B operand element j <-> key key0 + 32 s + 16 (j >> 2) + 4 g + (j & 3)
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            pf[r] = to16(__builtin_amdgcn_exp2f(PRE ? acc[2 * s][r] : acc[2 * s][r] * c), elem());
+            pf[4 + r] = to16(__builtin_amdgcn_exp2f(PRE ? acc[2 * s + 1][r] : acc[2 * s + 1][r] * c), elem());
+        }
+        mfma16_acc<1>(ones, pf, o[4]);
+#pragma unroll
+        for (int dt = 0; dt < 3; dt++) mfma16_acc<0>(vf[dt], pf, o[dt]);
+        if (s == KSTEPS - 1)
+            mfma16_acc<2>(vf[3], pf, o[3]);
+        else
+            mfma16_acc<0>(vf[3], pf, o[3]);
+    }
+}
+
+// A single key (the 257th / 577th token of the ViT sequences: S = 32 n + 1) as a rank-one update instead of
+// a masked 32-key step: two MFMAs for its 16 scores -- the LDS rows behind the last key are copies of it, so
+// every row of the key tile, hence every accumulator register of a lane, is the lane's query against THIS
+// key -- one exp2, and 16 multiply-adds of the key's V row (head dims 16 g .. 16 g + 15 for this lane, as the
+// epilogue stores them) instead of 8 masked scores, 5 MFMAs and 16 LDS reads.  P is rounded to 16 bit like
+// every other P.  Must follow the tile's last block (its last MFMA waited for O to settle).
+template <int DT>
+__device__ __forceinline__ void attn_odd_key(const unsigned char *ldsK, const unsigned char *ldsV, int key,
+                                             const typename T16<DT>::v8 (&qf)[2], bool down, float c, f32x4 &mneg,
+                                             f32x4 (&o)[5], int g, int c16)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    typedef typename T16<DT>::v4 v4;
+    constexpr bool PRE = attn_prescaled(DT);
+    const float thr = PRE ? ATTN_THR : ATTN_THR / c, lo = PRE ? ATTN_LO : ATTN_LO / c;
+    const int row = key + c16;
+    const v8 k0 = *reinterpret_cast<const v8 *>(ldsK + row * 128 + (((0 + g) ^ (row & 7)) << 4));
+    const v8 k1 = *reinterpret_cast<const v8 *>(ldsK + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+    v4 vv[4];
+    const int sw = (key >> 1) & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)   // logical 8-byte slot 4 g + dt of V's row, stored at slot ^ sw
+        vv[dt] = *reinterpret_cast<const v4 *>(ldsV + key * 128 + (4 * g + (dt ^ sw)) * 8);
+    f32x4 acc = mfma16(k0, qf[0], mneg);
+    acc = mfma16(k1, qf[1], acc);
+    float sc = acc[0];
+    if (__builtin_amdgcn_ballot_w64(sc > thr || (down && sc < -lo)) != 0) {
+        const float d = down ? sc : fmaxf(sc, 0.f);   // the same in the query's four lane groups
+        sc -= d;
+        attn_move(d, PRE ? d : d * c, down, mneg, o);
+    }
+    const float p = (float)to16(__builtin_amdgcn_exp2f(PRE ? sc : sc * c), elem());
+    o[4][0] += p;    // the epilogue reads register 0 of the row-sum tile
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[dt][r] = __builtin_fmaf(p, (float)vv[dt][r], o[dt][r]);
+}
+
+// Keys of one tile, not causal: the full 32-key steps [step0, step1) in blocks of two, then (`tail`) whatever
+// lies behind the last full step of the sequence: nothing, one key (rank-one update) or a masked step.
+template <int DT>
+__device__ __forceinline__ void attn_keys(const unsigned char *ldsK, const unsigned char *ldsV, int S, int step0,
+                                          int step1, bool tail, const typename T16<DT>::v8 (&qf)[2],
+                                          const typename T16<DT>::v8 &ones, float c, f32x4 &mneg, f32x4 (&o)[5],
+                                          int g, int c16)
+{
+    bool down = true;
+    int s = step0;
+    for (; s + 2 <= step1; s += 2) {
+        attn_block2<DT, 2, false>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
+        down = false;
+    }
+    if (s < step1) {
+        attn_block2<DT, 1, false>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
+        down = false;
+    }
+    if (tail) {
+        const int full = S >> 5, nt = S - 32 * full;
+        if (nt == 1)
+            attn_odd_key<DT>(ldsK, ldsV, S - 1, qf, down, c, mneg, o, g, c16);
+        else if (nt > 1)
+            attn_block2<DT, 1, true>(ldsK, ldsV, 32 * full, S, qf, ones, down, c, mneg, o, g, c16);
+    }
+}
+
+// Floats per wave in the merge area of a tile whose keys are split over the waves: O (64), m, l
+constexpr int ATTN_PART = 66;
+
+template <int DT, int AT_WAVES, bool LSE = false, bool V2 = true>
+__global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -158,14 +385,41 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, c16 = lane & 15;
+    const int g_lane = lane >> 4, c_lane = lane & 15;
     const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
     const long ld = 3L * W;
     const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
     attn_stamp(0);
 
-    // ---- stage K and V of this head: AT_THREADS / 8 rows x 8 chunks of 16 B per pass ----
-    {
+    // ---- stage K and V of this head: AT_THREADS / 8 rows x 8 chunks of 16 B per pass, at most five passes
+    // (S <= 320 on 8 waves, <= 640 on 16).  V2: every load of the head is requested before the first LDS
+    // write, so the staging costs one memory round trip instead of one per pass (a third of a workgroup's
+    // life at S = 257 otherwise) ----
+    if constexpr (V2) {
+        const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
+        u32x4 kv[5], vv[5];
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int row = r_in + p * (AT_THREADS / 8);
+            if (row < SP) {
+                const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
+                const elem *src = base + (long)srow * ld + ch * 8;
+                kv[p] = *reinterpret_cast<const u32x4 *>(src + W);
+                vv[p] = *reinterpret_cast<const u32x4 *>(src + 2 * W);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int row = r_in + p * (AT_THREADS / 8);
+            if (row < SP) {
+                *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kv[p];
+                // V: 8-byte slot u -> u ^ ((row>>1)&3): chunk moves by bit 1, halves swap by bit 0
+                u32x4 t = vv[p];
+                if ((row >> 1) & 1) t = u32x4{t[2], t[3], t[0], t[1]};
+                *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = t;
+            }
+        }
+    } else {
         const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
         for (int row = r_in; row < SP; row += AT_THREADS / 8) {
             const int srow = row < S ? row : S - 1;  // padded keys: finite data, masked below
@@ -178,52 +432,113 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
             *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = vv;
         }
     }
+    // Query tiles.  A sequence of 16 n + 1 tokens whose tile count leaves ONE tile over after whole rounds of
+    // the waves (S = 257 on 8 waves: 17 tiles) would keep seven waves idle for a third round that holds a
+    // single query row: that tile's KEYS are split over all waves instead and the partial (m, l, O) merged
+    // through LDS (V2 kernels, not causal).  Whether a tile is split depends on S alone, never on q_rows, so
+    // ec_attention_rows stays a bit-exact prefix of ec_attention.
+    const int n_qt_all = (S + 15) / 16;
+    const bool lone = V2 && !a.causal && (S & 15) == 1 && n_qt_all > AT_WAVES && n_qt_all % AT_WAVES == 1;
+    const int n_qt_req = (a.q_rows + 15) / 16;                           // tiles the caller asked for
+    const int n_qt = lone ? min(n_qt_req, n_qt_all - 1) : n_qt_req;      // ... that are walked tile by tile
+    const bool do_lone = lone && n_qt_req == n_qt_all;
     // first Q tile of this wave, issued before the barrier so its latency hides behind staging
-    const int n_qt = (a.q_rows + 15) / 16;
     v8 qf[2], qn[2];
     auto load_q = [&](int qt, v8(&dst)[2]) {
-        int qsrc = qt * 16 + c16;
+        int qsrc = qt * 16 + c_lane;
         qsrc = qsrc < S ? qsrc : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
-            dst[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 32 + g * 8);
+            dst[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 32 + g_lane * 8);
     };
-    if (wave < n_qt) load_q(wave, qn);
+    if (wave < n_qt)
+        load_q(wave, qn);
+    else if (do_lone)
+        load_q(n_qt_all - 1, qn);
     __syncthreads();
     attn_stamp(1);
 
+    v8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = to16(1.f, elem());
+    asm volatile("" : "+v"(ones));   // stays in four VGPRs (else rebuilt from SGPRs in every block)
+    // q <- q * log2(e) / sqrt(64), rounded to the operand type once per tile
+    auto scale_q = [&](v8(&q)[2]) {
+        if (!attn_prescaled(DT)) return;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[ks][j] = to16((float)q[ks][j] * a.scale_log2e, elem());
+    };
     for (int qt = wave; qt < n_qt; qt += AT_WAVES) {
         qf[0] = qn[0], qf[1] = qn[1];
-        if (qt + AT_WAVES < n_qt) load_q(qt + AT_WAVES, qn);   // prefetch the next tile's Q
-        const int qrow = qt * 16 + c16;
-        const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;  // keys < klimit are visible
-        // causal rows of this tile see no key beyond 16 qt + 15: skip the blocks past it
-        const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
-        float m_run = -1e30f, l_run = 0.f;
-        f32x4 o[4];
+        // prefetch the next tile's Q (after the last one: the split tile's)
+        if (qt + AT_WAVES < n_qt)
+            load_q(qt + AT_WAVES, qn);
+        else if (do_lone)
+            load_q(n_qt_all - 1, qn);
+        const int qrow = qt * 16 + c_lane;
+        // lane coordinates made opaque per tile: otherwise hipcc hoists the per-lane LDS addresses of EVERY
+        // block variant out of the tile loop, keeps them live across it and spills (scratch reloads in the
+        // tile path cost a memory round trip each)
+        int g = g_lane, c16 = c_lane;
+        asm volatile("" : "+v"(g), "+v"(c16));
+        float lsum, m_log2;   // softmax denominator and maximum (log2 domain, scaled scores)
+        f32x4 o[5];
 #pragma unroll
-        for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // blocks entirely below every lane's klimit need no masking: klimit >= kfree for all
-        // 16 queries of the tile (causal: 16 qt + 1 .. ; otherwise S)
-        const int kfree = a.causal ? qt * 16 + 1 : S;
-        int key0 = 0;
-        for (; key0 + 64 <= kend; key0 += 64) {
-            if (key0 + 64 <= kfree)
-                attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
-                                         g, c16);
-            else
-                attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o,
-                                        g, c16);
+        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (V2) {
+            f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
+            scale_q(qf);
+            if (!a.causal) {
+                attn_keys<DT>(ldsK, ldsV, S, 0, S >> 5, true, qf, ones, a.scale_log2e, mneg, o, g, c16);
+            } else {
+                const int klimit = qrow < S ? qrow + 1 : S;   // keys < klimit are visible
+                // rows of this tile see no key beyond 16 qt + 15: skip the blocks past it; blocks entirely
+                // below every lane's klimit (16 qt + 1 ..) need no masking
+                const int kend = min(SP, ((qt * 16 + 16 + 31) / 32) * 32);
+                const int kfree = min(qt * 16 + 1, kend);
+                bool down = true;
+                int key0 = 0;
+                for (; key0 + 64 <= kfree; key0 += 64, down = false)
+                    attn_block2<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+                for (; key0 + 64 <= kend; key0 += 64, down = false)
+                    attn_block2<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+                if (key0 < kend)
+                    attn_block2<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+            }
+            lsum = o[4][0];      // every row of the ones tile carries the query's row sum
+            m_log2 = attn_prescaled(DT) ? -mneg[0] : -mneg[0] * a.scale_log2e;
+        } else {
+            const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;
+            const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
+            const int kfree = a.causal ? qt * 16 + 1 : S;
+            float m_run = -1e30f, l_run = 0.f;
+            f32x4 o4[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o4[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int key0 = 0;
+            for (; key0 + 64 <= kend; key0 += 64) {
+                if (key0 + 64 <= kfree)
+                    attn_block<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o4,
+                                             g, c16);
+                else
+                    attn_block<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o4,
+                                            g, c16);
+            }
+            if (key0 < kend)
+                attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o4, g,
+                                        c16);
+            lsum = xor_sum(l_run);
+            m_log2 = m_run * a.scale_log2e;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o[dt] = o4[dt];
         }
-        if (key0 < kend)
-            attn_block<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, a.scale_log2e, m_run, l_run, o, g,
-                                    c16);
 
         // ---- normalise and store: lane owns query c16, head dims 16 g .. 16 g + 15 ----
-        const float lsum = xor_sum(l_run);
         const float inv = 1.f / lsum;
         if (LSE && qrow < a.q_rows && g == 0)
-            a.lse[((long)seq * a.heads + head) * S + qrow] = m_run * a.scale_log2e + __builtin_amdgcn_logf(lsum);
+            a.lse[((long)seq * a.heads + head) * S + qrow] = m_log2 + __builtin_amdgcn_logf(lsum);
         if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll
@@ -233,6 +548,52 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
             elem *dst = (elem *)a.out + ((long)seq * a.q_rows + qrow) * W + head * 64 + g * 16;
             *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&ov[0]);
             *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
+        }
+    }
+    if constexpr (V2) {
+        if (do_lone) {
+            // ---- the tile left over: this wave's share of its keys, then the merge ----
+            float *part = reinterpret_cast<float *>(smem + 2 * SP * 128);
+            const int steps = S >> 5;
+            const int s0 = wave * steps / AT_WAVES, s1 = (wave + 1) * steps / AT_WAVES;
+            const bool tail = wave == AT_WAVES - 1;
+            int g = g_lane, c16 = c_lane;
+            asm volatile("" : "+v"(g), "+v"(c16));
+            qf[0] = qn[0], qf[1] = qn[1];
+            scale_q(qf);
+            f32x4 o[5];
+#pragma unroll
+            for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
+            attn_keys<DT>(ldsK, ldsV, S, s0, s1, tail, qf, ones, a.scale_log2e, mneg, o, g, c16);
+            if (c16 == 0) {   // the tile's one valid query (row S - 1) lives in lanes 0, 16, 32, 48
+                float *dst = part + wave * ATTN_PART;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++)
+                    *reinterpret_cast<f32x4 *>(dst + 16 * g + 4 * dt) = o[dt];
+                if (g == 0) {
+                    const float mw = attn_prescaled(DT) ? -mneg[0] : -mneg[0] * a.scale_log2e;   // log2 units
+                    dst[64] = (s1 > s0 || tail) ? mw : -1e30f;   // a wave without keys: weight 0
+                    dst[65] = o[4][0];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {   // lane = head dim
+                float m = -1e30f;
+#pragma unroll
+                for (int w = 0; w < AT_WAVES; w++) m = fmaxf(m, part[w * ATTN_PART + 64]);
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int w = 0; w < AT_WAVES; w++) {
+                    const float f = __builtin_amdgcn_exp2f(part[w * ATTN_PART + 64] - m);
+                    num = __builtin_fmaf(f, part[w * ATTN_PART + lane], num);
+                    den = __builtin_fmaf(f, part[w * ATTN_PART + 65], den);
+                }
+                const int qrow = S - 1;
+                ((elem *)a.out)[((long)seq * a.q_rows + qrow) * W + head * 64 + lane] = to16(num / den, elem());
+                if (LSE && lane == 0)
+                    a.lse[((long)seq * a.heads + head) * S + qrow] = m + __builtin_amdgcn_logf(den);
+            }
         }
     }
     attn_stamp(2);
@@ -246,10 +607,15 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_kernel(const AttnA
 #endif
 }
 
+#ifdef EC_GEMM_DIAG
+int g_attn_variant = 0;
+#endif
+
 template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
 {
     const int n32 = (a.S + 31) / 32;
-    const int lds = 32 * n32 * 128 * 2;
+    // K and V images + the merge area of a tile whose keys are split over the waves (16 waves at most)
+    const int lds = 32 * n32 * 128 * 2 + 16 * ATTN_PART * 4;
     if (lds > 160 * 1024)
         return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d > 640", a.S);
     // Waves per workgroup: 16 when K + V leave room for one workgroup per CU only, else 8.  (9..12 waves,
@@ -258,6 +624,11 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const bool wide = lds > 80 * 1024;
     void (*kern)(const AttnArgs) = a.lse ? (wide ? attention_kernel<DT, 16, true> : attention_kernel<DT, 8, true>)
                                          : (wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>);
+#ifdef EC_GEMM_DIAG
+    if (g_attn_variant == 1)   // round 1 / 2 block (per-block maximum, vector-ALU row sum), for A/B
+        kern = a.lse ? (wide ? attention_kernel<DT, 16, true, false> : attention_kernel<DT, 8, true, false>)
+                     : (wide ? attention_kernel<DT, 16, false, false> : attention_kernel<DT, 8, false, false>);
+#endif
     const int nw = wide ? 16 : 8;
     // always the full carve (one attribute call per kernel and device, thread-safe)
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
@@ -355,6 +726,7 @@ extern "C" __attribute__((visibility("default"))) int ec_attn_stamps_read(unsign
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(ec_attn_stamps), (size_t)n * 8) == hipSuccess ? 0 : 1;
 }
+extern "C" __attribute__((visibility("default"))) void ec_attn_set_variant(int v) { g_attn_variant = v; }
 #endif
 
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,

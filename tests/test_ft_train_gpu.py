@@ -151,7 +151,11 @@ def test_attention_forward_saves_lse_and_backward_matches_autograd(hip, S, heads
     q, k, v = [t.view(n, S, heads, 64).transpose(1, 2) for t in x.view(n, S, 3 * W).split(W, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) * 0.125
     ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(n * S, W)
-    torch.testing.assert_close(l2, torch.logsumexp(sc.detach(), -1) * 1.4426950408889634, rtol=1e-4, atol=2e-3)
+    # the row sum is that of the ROUNDED probabilities the output was built from (matrix pipe); with the running
+    # maximum left where it is, a row's largest P is 2^x rounded to the operand type instead of exactly 1:
+    # up to 2^-9 relative = 2.8e-3 in log2 units for bf16 (f16: 3.5e-4)
+    torch.testing.assert_close(l2, torch.logsumexp(sc.detach(), -1) * 1.4426950408889634, rtol=1e-4,
+                               atol=2e-3 if dtype == torch.float16 else 4e-3)
     dout = (torch.randn(n * S, W, device='cuda') * 0.5).to(dtype)
     ref.backward(dout.float())
     got = _attention_bwd(qkv, out, l2, dout, n, S, W, heads)

@@ -90,6 +90,63 @@ def test_attention_exact_selector(hip):
     assert torch.equal(out.cpu(), want)
 
 
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('S,spike_keys', [(257, (70,)), (257, (5, 130, 256)), (577, (100, 300, 570)),
+                                          (197, (64, 128, 196)), (77, (40, 76))])
+def test_attention_running_maximum_moves(S, spike_keys, dt, hip):
+    """The kernel keeps a query's running maximum where it is while a block's scores stay within 2^10 of it and
+    only otherwise moves it (rescaling O and the row sum once).  Bounded random data never takes that branch
+    after a tile's first block, so force it: chosen keys, in chosen later blocks, score far above everything
+    before them for SOME queries (each spike larger than the last), and the whole output is checked against
+    fp32 -- rows that moved, rows that did not, and rows of the same 16-query tile as a row that moved."""
+    import torch
+    from eventclip_amd import _lib
+    dtype = getattr(torch, dt)
+    torch.manual_seed(S + len(spike_keys))
+    n_seq, heads = 2, 3
+    W = heads * 64
+    q = torch.randn(n_seq, S, heads, 64)
+    k = torch.randn(n_seq, S, heads, 64)
+    v = torch.randn(n_seq, S, heads, 64)
+    for i, key in enumerate(spike_keys):
+        # queries 3 (i + 1) j + 1 line up with key `key`: score ~ 8 * (4 + 3 i) * 64 / 8 natural units above the rest
+        rows = torch.arange(1, S, 3 * (i + 1))
+        direction = torch.sign(torch.randn(64))
+        k[:, key] = direction * (4.0 + 3 * i)
+        q[:, rows] = q[:, rows] * 0.25 + direction * 2.0
+    qkv = torch.cat([q.reshape(n_seq * S, W), k.reshape(n_seq * S, W), v.reshape(n_seq * S, W)], 1)
+    qkv = qkv.to(dtype).cuda()
+    out = torch.empty(n_seq * S, W, dtype=dtype, device='cuda')
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0,
+                                       _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16, _lib.stream_ptr()))
+    want = ref_attention(qkv, n_seq, S, W, heads, 0)
+    assert torch.isfinite(out.float()).all()
+    # bf16: the spiked scores are O(100) and carry the 2^-9 relative rounding of q, k AND of the pre-scaled q
+    tol = 4e-3 if dt == 'float16' else 4e-2
+    torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
+
+
+def test_attention_lse_matches_reference(hip):
+    """ec_attention_train's log-sum-exp (log2 domain, scaled scores) against fp32, incl. rows whose maximum moved."""
+    import torch
+    from eventclip_amd import _lib
+    torch.manual_seed(11)
+    n_seq, S, heads = 2, 257, 2
+    W = heads * 64
+    qkv = torch.randn(n_seq * S, 3 * W) * 1.5
+    qkv[130, W:W + 64] = 6.0           # key 130 of sequence 0, head 0: a late spike for positive-sum queries
+    qkv = qkv.half().cuda()
+    out = torch.empty(n_seq * S, W, dtype=torch.float16, device='cuda')
+    lse = torch.empty(n_seq, heads, S, dtype=torch.float32, device='cuda')
+    _lib.check(_lib.lib().ec_attention_train(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), n_seq, S, W, heads,
+                                             _lib.EC_F16, _lib.stream_ptr()))
+    q, k, v = qkv.float().view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q * 0.125) @ k.transpose(-1, -2)
+    want = torch.logsumexp(att, -1) * 1.4426950408889634
+    torch.testing.assert_close(lse, want, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(out.float(), ref_attention(qkv, n_seq, S, W, heads, 0), rtol=4e-3, atol=4e-3)
+
+
 def load_tiny():
     import torch
     from conftest import GOLDEN

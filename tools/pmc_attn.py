@@ -1,9 +1,18 @@
-"""Attention kernel alone (ViT-L/14 shape), target for rocprofv3 --pmc runs."""
+"""Attention kernel alone (ViT-L/14 shape), target for rocprofv3 --pmc runs.
+
+    python3 tools/pmc_attn.py [S] [variant]     # variant needs the diagnostic build (1 = the round-1/2 block)
+"""
+import ctypes
 import os
 import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 2:
+    os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', 'libeventclip_hip_diag.so'))
 from eventclip_amd import _lib  # noqa: E402
+if len(sys.argv) > 2:
+    ctypes.CDLL(os.environ['EVENTCLIP_HIP_LIB']).ec_attn_set_variant(int(sys.argv[2]))
 n_seq, S, heads = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 257, 16
 W = heads * 64
 qkv = (torch.randn(n_seq * S, 3 * W, device='cuda')).half()

@@ -19,6 +19,8 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 257
 n_seq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 heads = 16
 W = heads * 64
+if len(sys.argv) > 3:   # block variant of the diagnostic build (1 = round-1/2 block)
+    ctypes.CDLL(os.environ['EVENTCLIP_HIP_LIB']).ec_attn_set_variant(int(sys.argv[3]))
 qkv = torch.randn(n_seq * S, 3 * W, device='cuda').half()
 out = torch.empty(n_seq * S, W, dtype=torch.float16, device='cuda')
 for _ in range(3):
