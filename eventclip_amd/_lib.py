@@ -100,7 +100,7 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
-                ('low_latency', c_int)]
+                ('low_latency', c_int), ('q_scaled', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):
@@ -205,6 +205,8 @@ SIGNATURES = {
                               c_void_p]),
     'ec_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
+    'ec_attention_scaled_q': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
     'ec_attention_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p]),
     'ec_vit_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(EcVitWeights), c_int]),

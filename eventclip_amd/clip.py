@@ -68,9 +68,20 @@ def _block_keys(prefix, i):
                             'mlp.c_proj.bias')]
 
 
-def random_state_dict(cfg, seed=0):
+# log2(e) / sqrt(head dim 64): what ec_attention_scaled_q expects in the q columns (include/eventclip_hip.h)
+ATTN_Q_SCALE = 0.125 * 1.4426950408889634
+
+
+def random_state_dict(cfg, seed=0, qk_gain=1.0, branch_gain=1.0):
     """Seeded random weights with OpenAI CLIP's key names and init scales (fp32, CPU).
-    Biases and LayerNorm affine terms are perturbed too so every code path carries signal."""
+    Biases and LayerNorm affine terms are perturbed too so every code path carries signal.
+
+    At the plain init scales the image features of a random tower are ~98 % the same vector whatever the
+    input (uniform attention averages the tokens; the (2 L)^-1/2 branch scaling keeps the class token's
+    constant start dominant).  ``qk_gain`` scales the vision tower's query / key projections (sharper,
+    content-dependent attention) and ``branch_gain`` its out_proj / c_proj (the branches against the residual
+    stream): (6, 4) makes a third of the ViT-L/14 feature norm input-dependent -- the weights the logit-parity
+    tests use, so that their error is measured against a signal and not against a constant."""
     g = torch.Generator().manual_seed(seed)
 
     def rn(*shape, std=1.0):
@@ -105,6 +116,13 @@ def random_state_dict(cfg, seed=0):
     sd['visual.ln_pre.weight'] = 1 + rn(W, std=0.1)
     sd['visual.ln_pre.bias'] = rn(W, std=0.1)
     blocks('visual.transformer', W, cfg['layers'])
+    if qk_gain != 1.0 or branch_gain != 1.0:
+        for i in range(cfg['layers']):
+            p = f'visual.transformer.resblocks.{i}.'
+            sd[p + 'attn.in_proj_weight'][:2 * W] *= qk_gain
+            sd[p + 'attn.in_proj_bias'][:2 * W] *= qk_gain
+            sd[p + 'attn.out_proj.weight'] *= branch_gain
+            sd[p + 'mlp.c_proj.weight'] *= branch_gain
     sd['visual.ln_post.weight'] = 1 + rn(W, std=0.1)
     sd['visual.ln_post.bias'] = rn(W, std=0.1)
     sd['visual.proj'] = rn(W, cfg['embed_dim'], std=scale)
@@ -229,13 +247,21 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def blocks(prefix, layers, precise):
+        def blocks(prefix, layers, precise, q_scaled=False):
             arr = (_lib.EcBlockWeights * layers)()
             for i in range(layers):
                 ks = _block_keys(prefix, i)
                 b = arr[i]
                 b.ln1_g, b.ln1_b = dev32(sd[ks[0]]), dev32(sd[ks[1]])
-                b.qkv_w, b.qkv_b = dev16(sd[ks[2]]), dev32(sd[ks[3]])
+                wqkv, bqkv = sd[ks[2]], sd[ks[3]]
+                if q_scaled:
+                    # ec_vit_weights.q_scaled: softmax temperature and base change folded into the q rows in
+                    # fp32, before the one rounding to 16 bit
+                    width = wqkv.shape[1]
+                    wqkv, bqkv = wqkv.float().clone(), bqkv.float().clone()
+                    wqkv[:width] *= ATTN_Q_SCALE
+                    bqkv[:width] *= ATTN_Q_SCALE
+                b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
                 b.out_w, b.out_b = dev16(sd[ks[4]]), dev32(sd[ks[5]])
                 b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
                 b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
@@ -270,8 +296,9 @@ class CLIP(nn.Module):
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
         v.low_latency = int(self.low_latency)
+        v.q_scaled = 0 if self.image_precise else 1
         v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
-        vb = blocks('visual.transformer', c['layers'], self.image_precise)
+        vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled=bool(v.q_scaled))
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']

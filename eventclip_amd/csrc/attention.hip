@@ -56,6 +56,7 @@ struct AttnArgs {
     int q_rows;       // only the first q_rows query rows of every sequence are computed; out is
                       // [n_seq * q_rows, W] (q_rows = S: the whole sequence)
     float scale_log2e;
+    int q_scaled;     // the q columns already hold q * scale_log2e (QM_INPUT)
     float *lse;       // LSE kernels only: [n_seq, heads, S] fp32, log2 of the softmax denominator in the
                       // scaled-score domain (m * scale_log2e + log2 l), kept for ec_attention_backward
 };
@@ -158,10 +159,17 @@ __device__ __forceinline__ void attn_block(const unsigned char *ldsK, const unsi
 //    exactly once, BEFORE this block's P is formed (cdna_hip_programming.md T13's safe order);
 //  * the row sum comes from the matrix pipe too: a fifth "V^T" tile of ones, so l = sum of the ROUNDED
 //    P the output was built from.
-// The pre-multiplied query is rounded to the operand type a second time.  f16: +20 % on the kernel's own
-// rounding error (6.3e-4 against 4.8e-4 on unit-variance data).  bf16's 8 bits would put 2e-2 on the log-sum-exp the
-// training forward saves, so bf16 keeps the scores in raw units and pays one multiply per score.
-__host__ __device__ constexpr bool attn_prescaled(int dt) { return dt == 0; }
+// Where the factor c = log2(e) / sqrt(64) of the scores comes from (template parameter QM of the block):
+//  QM_INPUT  the q columns of qkv already hold c q: the image tower folds c into the q rows of in_proj_weight /
+//            in_proj_bias BEFORE they are rounded to 16 bit (ec_vit_weights.q_scaled), so the product is rounded
+//            once, like an unscaled q -- no work and no error in the kernel;
+//  QM_KERNEL the kernel multiplies its query fragment by c and rounds it to the operand type a second time: f16
+//            callers that pass a plain q (ec_attention, the training forward).  +20 % on the kernel's own
+//            rounding error on unit-variance data (6.3e-4 against 4.8e-4), +25 % on the logits of a tower with
+//            sharp attention (tests/test_configs_gpu.py configs[3]), which is why the tower uses QM_INPUT;
+//  QM_RAW    scores stay in raw units and every score is multiplied by c in fp32: bf16 callers with a plain q
+//            (8 bits of a twice-rounded q would put 2e-2 on the log-sum-exp the training forward saves).
+enum { QM_RAW = 0, QM_KERNEL = 1, QM_INPUT = 2 };
 constexpr float ATTN_THR = 10.f;
 constexpr float ATTN_LO = 4.f;   // first block: P of the row maximum >= 2^-4, the rest of a 16-bit float's range below it
 
@@ -222,13 +230,13 @@ __device__ __forceinline__ void attn_move(float d, float d_log2, bool down, f32x
 }
 
 // One block of KSTEPS 32-key steps.  `down`: the tile has added nothing yet (m may move down too).
-template <int DT, int KSTEPS, bool MASK>
+template <int DT, int KSTEPS, bool MASK, int QM>
 __device__ __forceinline__ void attn_block2(const unsigned char *ldsK, const unsigned char *ldsV,
                                             int key0, int klimit, const typename T16<DT>::v8 (&qf)[2],
                                             const typename T16<DT>::v8 &ones, bool down, float c, f32x4 &mneg,
                                             f32x4 (&o)[5], int g, int c16)
 {
-    constexpr bool PRE = attn_prescaled(DT);   // else: scores in raw units, c = log2(e) / sqrt(64) applied per score
+    constexpr bool PRE = QM != QM_RAW;   // else: scores in raw units, c = log2(e) / sqrt(64) applied per score
     const float thr = PRE ? ATTN_THR : ATTN_THR / c, lo = PRE ? ATTN_LO : ATTN_LO / c;
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -257,9 +265,12 @@ __device__ __forceinline__ void attn_block2(const unsigned char *ldsK, const uns
         }
     if (__builtin_amdgcn_ballot_w64(mx > thr || (down && mx < -lo)) != 0) {
         // the four lane groups hold different keys of the same query and all hold parts of its O column:
-        // one distance for all of them; up only, unless nothing has been added yet
+        // one distance for all of them; up only, unless nothing has been added yet.  Only the queries that
+        // need it move (d = 0, scale 1 for the others: bit for bit as if the branch had not been taken), so a
+        // query's result never depends on which other queries share its tile (ec_attention_rows computes a
+        // prefix of the rows next to whatever the caller left in the others)
         const float mq = xor_max(mx);
-        const float d = down ? mq : fmaxf(mq, 0.f);
+        const float d = (mq > thr || (down && mq < -lo)) ? mq : 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; kt++) acc[kt] -= d;
         attn_move(d, PRE ? d : d * c, down, mneg, o);
@@ -305,7 +316,7 @@ __device__ __forceinline__ void attn_block2(const unsigned char *ldsK, const uns
 // key -- one exp2, and 16 multiply-adds of the key's V row (head dims 16 g .. 16 g + 15 for this lane, as the
 // epilogue stores them) instead of 8 masked scores, 5 MFMAs and 16 LDS reads.  P is rounded to 16 bit like
 // every other P.  Must follow the tile's last block (its last MFMA waited for O to settle).
-template <int DT>
+template <int DT, int QM>
 __device__ __forceinline__ void attn_odd_key(const unsigned char *ldsK, const unsigned char *ldsV, int key,
                                              const typename T16<DT>::v8 (&qf)[2], bool down, float c, f32x4 &mneg,
                                              f32x4 (&o)[5], int g, int c16)
@@ -313,7 +324,7 @@ __device__ __forceinline__ void attn_odd_key(const unsigned char *ldsK, const un
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     typedef typename T16<DT>::v4 v4;
-    constexpr bool PRE = attn_prescaled(DT);
+    constexpr bool PRE = QM != QM_RAW;
     const float thr = PRE ? ATTN_THR : ATTN_THR / c, lo = PRE ? ATTN_LO : ATTN_LO / c;
     const int row = key + c16;
     const v8 k0 = *reinterpret_cast<const v8 *>(ldsK + row * 128 + (((0 + g) ^ (row & 7)) << 4));
@@ -327,7 +338,7 @@ __device__ __forceinline__ void attn_odd_key(const unsigned char *ldsK, const un
     acc = mfma16(k1, qf[1], acc);
     float sc = acc[0];
     if (__builtin_amdgcn_ballot_w64(sc > thr || (down && sc < -lo)) != 0) {
-        const float d = down ? sc : fmaxf(sc, 0.f);   // the same in the query's four lane groups
+        const float d = (sc > thr || (down && sc < -lo)) ? sc : 0.f;   // the same in the query's four lane groups
         sc -= d;
         attn_move(d, PRE ? d : d * c, down, mneg, o);
     }
@@ -341,7 +352,7 @@ __device__ __forceinline__ void attn_odd_key(const unsigned char *ldsK, const un
 
 // Keys of one tile, not causal: the full 32-key steps [step0, step1) in blocks of two, then (`tail`) whatever
 // lies behind the last full step of the sequence: nothing, one key (rank-one update) or a masked step.
-template <int DT>
+template <int DT, int QM>
 __device__ __forceinline__ void attn_keys(const unsigned char *ldsK, const unsigned char *ldsV, int S, int step0,
                                           int step1, bool tail, const typename T16<DT>::v8 (&qf)[2],
                                           const typename T16<DT>::v8 &ones, float c, f32x4 &mneg, f32x4 (&o)[5],
@@ -350,26 +361,26 @@ __device__ __forceinline__ void attn_keys(const unsigned char *ldsK, const unsig
     bool down = true;
     int s = step0;
     for (; s + 2 <= step1; s += 2) {
-        attn_block2<DT, 2, false>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
+        attn_block2<DT, 2, false, QM>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
         down = false;
     }
     if (s < step1) {
-        attn_block2<DT, 1, false>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
+        attn_block2<DT, 1, false, QM>(ldsK, ldsV, 32 * s, S, qf, ones, down, c, mneg, o, g, c16);
         down = false;
     }
     if (tail) {
         const int full = S >> 5, nt = S - 32 * full;
         if (nt == 1)
-            attn_odd_key<DT>(ldsK, ldsV, S - 1, qf, down, c, mneg, o, g, c16);
+            attn_odd_key<DT, QM>(ldsK, ldsV, S - 1, qf, down, c, mneg, o, g, c16);
         else if (nt > 1)
-            attn_block2<DT, 1, true>(ldsK, ldsV, 32 * full, S, qf, ones, down, c, mneg, o, g, c16);
+            attn_block2<DT, 1, true, QM>(ldsK, ldsV, 32 * full, S, qf, ones, down, c, mneg, o, g, c16);
     }
 }
 
 // Floats per wave in the merge area of a tile whose keys are split over the waves: O (64), m, l
 constexpr int ATTN_PART = 66;
 
-template <int DT, int AT_WAVES, bool LSE = false, bool V2 = true>
+template <int DT, int AT_WAVES, bool LSE = false, bool V2 = true, int QM = (DT == 0 ? QM_KERNEL : QM_RAW)>
 __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnArgs a)
 {
     typedef typename T16<DT>::elem elem;
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
     asm volatile("" : "+v"(ones));   // stays in four VGPRs (else rebuilt from SGPRs in every block)
     // q <- q * log2(e) / sqrt(64), rounded to the operand type once per tile
     auto scale_q = [&](v8(&q)[2]) {
-        if (!attn_prescaled(DT)) return;
+        if (QM != QM_KERNEL) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
             f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
             scale_q(qf);
             if (!a.causal) {
-                attn_keys<DT>(ldsK, ldsV, S, 0, S >> 5, true, qf, ones, a.scale_log2e, mneg, o, g, c16);
+                attn_keys<DT, QM>(ldsK, ldsV, S, 0, S >> 5, true, qf, ones, a.scale_log2e, mneg, o, g, c16);
             } else {
                 const int klimit = qrow < S ? qrow + 1 : S;   // keys < klimit are visible
                 // rows of this tile see no key beyond 16 qt + 15: skip the blocks past it; blocks entirely
@@ -501,14 +512,14 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
                 bool down = true;
                 int key0 = 0;
                 for (; key0 + 64 <= kfree; key0 += 64, down = false)
-                    attn_block2<DT, 2, false>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+                    attn_block2<DT, 2, false, QM>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
                 for (; key0 + 64 <= kend; key0 += 64, down = false)
-                    attn_block2<DT, 2, true>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+                    attn_block2<DT, 2, true, QM>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
                 if (key0 < kend)
-                    attn_block2<DT, 1, true>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
+                    attn_block2<DT, 1, true, QM>(ldsK, ldsV, key0, klimit, qf, ones, down, a.scale_log2e, mneg, o, g, c16);
             }
             lsum = o[4][0];      // every row of the ones tile carries the query's row sum
-            m_log2 = attn_prescaled(DT) ? -mneg[0] : -mneg[0] * a.scale_log2e;
+            m_log2 = QM != QM_RAW ? -mneg[0] : -mneg[0] * a.scale_log2e;
         } else {
             const int klimit = a.causal ? (qrow < S ? qrow + 1 : S) : S;
             const int kend = a.causal ? min(SP, ((qt * 16 + 16 + 31) / 32) * 32) : SP;
@@ -565,14 +576,14 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 #pragma unroll
             for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
-            attn_keys<DT>(ldsK, ldsV, S, s0, s1, tail, qf, ones, a.scale_log2e, mneg, o, g, c16);
+            attn_keys<DT, QM>(ldsK, ldsV, S, s0, s1, tail, qf, ones, a.scale_log2e, mneg, o, g, c16);
             if (c16 == 0) {   // the tile's one valid query (row S - 1) lives in lanes 0, 16, 32, 48
                 float *dst = part + wave * ATTN_PART;
 #pragma unroll
                 for (int dt = 0; dt < 4; dt++)
                     *reinterpret_cast<f32x4 *>(dst + 16 * g + 4 * dt) = o[dt];
                 if (g == 0) {
-                    const float mw = attn_prescaled(DT) ? -mneg[0] : -mneg[0] * a.scale_log2e;   // log2 units
+                    const float mw = QM != QM_RAW ? -mneg[0] : -mneg[0] * a.scale_log2e;   // log2 units
                     dst[64] = (s1 > s0 || tail) ? mw : -1e30f;   // a wave without keys: weight 0
                     dst[65] = o[4][0];
                 }
@@ -624,8 +635,10 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const bool wide = lds > 80 * 1024;
     void (*kern)(const AttnArgs) = a.lse ? (wide ? attention_kernel<DT, 16, true> : attention_kernel<DT, 8, true>)
                                          : (wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>);
+    if (a.q_scaled)   // the inference towers (never with a log-sum-exp)
+        kern = wide ? attention_kernel<DT, 16, false, true, QM_INPUT> : attention_kernel<DT, 8, false, true, QM_INPUT>;
 #ifdef EC_GEMM_DIAG
-    if (g_attn_variant == 1)   // round 1 / 2 block (per-block maximum, vector-ALU row sum), for A/B
+    if (g_attn_variant == 1 && !a.q_scaled)   // round 1 / 2 block (per-block maximum, vector-ALU row sum), for A/B
         kern = a.lse ? (wide ? attention_kernel<DT, 16, true, false> : attention_kernel<DT, 8, true, false>)
                      : (wide ? attention_kernel<DT, 16, false, false> : attention_kernel<DT, 8, false, false>);
 #endif
@@ -729,6 +742,21 @@ extern "C" __attribute__((visibility("default"))) int ec_attn_stamps_read(unsign
 extern "C" __attribute__((visibility("default"))) void ec_attn_set_variant(int v) { g_attn_variant = v; }
 #endif
 
+static int attention_rows(const void *qkv, void *out, int n_seq, int S, int width, int heads, int causal, int q_rows,
+                          int q_scaled, int dtype, ec_stream_t stream)
+{
+    AttnArgs a;
+    a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = causal;
+    a.q_rows = q_rows;
+    a.lse = nullptr;
+    a.scale_log2e = 0.125f * 1.4426950408889634f;
+    a.q_scaled = q_scaled;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
+    if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);
+    return ec::fail(EC_ERR_INVALID, "ec_attention: unknown dtype %d", dtype);
+}
+
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
                                    int heads, int causal, int dtype, ec_stream_t stream)
 {
@@ -745,15 +773,18 @@ extern "C" EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, i
                heads);
     if (n_seq == 0) return EC_OK;
     EC_REQUIRE(qkv && out, "ec_attention: null buffer");
-    AttnArgs a;
-    a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = causal;
-    a.q_rows = q_rows;
-    a.lse = nullptr;
-    a.scale_log2e = 0.125f * 1.4426950408889634f;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
-    if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);
-    return ec::fail(EC_ERR_INVALID, "ec_attention: unknown dtype %d", dtype);
+    return attention_rows(qkv, out, n_seq, S, width, heads, causal, q_rows, 0, dtype, stream);
+}
+
+extern "C" EC_API int ec_attention_scaled_q(const void *qkv, void *out, int n_seq, int S, int width, int heads,
+                                            int causal, int q_rows, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention_scaled_q: bad shape");
+    EC_REQUIRE(q_rows >= 1 && q_rows <= S, "ec_attention_scaled_q: q_rows=%d outside 1..%d", q_rows, S);
+    EC_REQUIRE(width == heads * 64, "ec_attention_scaled_q: head dim must be 64 (width %d, heads %d)", width, heads);
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv && out, "ec_attention_scaled_q: null buffer");
+    return attention_rows(qkv, out, n_seq, S, width, heads, causal, q_rows, 1, dtype, stream);
 }
 
 extern "C" EC_API int ec_attention_train(const void *qkv, void *out, float *lse, int n_seq, int S, int width,
@@ -768,6 +799,7 @@ extern "C" EC_API int ec_attention_train(const void *qkv, void *out, float *lse,
     a.q_rows = S;
     a.lse = lse;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
+    a.q_scaled = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == EC_F16) return dispatch<EC_F16>(a, n_seq, heads, s);
     if (dtype == EC_BF16) return dispatch<EC_BF16>(a, n_seq, heads, s);

@@ -28,7 +28,8 @@ struct BlockBufs {
 // same kernels with the residual stream addressed at row stride S * W.  Each output row of these
 // kernels depends on its own input row only, so the class-token features are bit-identical.
 int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
-               int causal, int dtype, const BlockBufs &b, ec_stream_t s, bool first_only = false)
+               int causal, int dtype, const BlockBufs &b, ec_stream_t s, bool first_only = false,
+               bool q_scaled = false)
 {
     const int rows = n_seq * S;
     for (int l = 0; l < layers; l++) {
@@ -44,7 +45,8 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
                         static_cast<unsigned char *>(b.qkv) + (size_t)W * esz, s, 3L * W));
             EC_TRY(gemm(n_seq, W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s, 3L * W * S,
                         (long)S * W));
-            EC_TRY(ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, causal, 1, dtype, s));
+            EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, causal, 1, dtype, s)
+                            : ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, causal, 1, dtype, s));
             EC_TRY(gemm(n_seq, W, W, dtype, EC_EPI_RESID32, b.h, w.out_w, w.out_b, b.x, s, ldx));
             EC_TRY(ec_layernorm(b.x, ldx, nullptr, w.ln2_g, w.ln2_b, n_seq, W, LN_EPS, b.h, W, dtype, s));
             EC_TRY(gemm(n_seq, 4 * W, W, dtype, EC_EPI_GELU16, b.h, w.fc1_w, w.fc1_b, b.mlp, s));
@@ -53,7 +55,8 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
         }
         EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, W, dtype, s));
         EC_TRY(gemm(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, w.qkv_w, w.qkv_b, b.qkv, s));
-        EC_TRY(ec_attention(b.qkv, b.h, n_seq, S, W, heads, causal, dtype, s));
+        EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, causal, S, dtype, s)
+                        : ec_attention(b.qkv, b.h, n_seq, S, W, heads, causal, dtype, s));
         EC_TRY(gemm(rows, W, W, dtype, EC_EPI_RESID32, b.h, w.out_w, w.out_b, b.x, s));
         EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, W, dtype, s));
         EC_TRY(gemm(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, w.fc1_w, w.fc1_b, b.mlp, s));
@@ -188,6 +191,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     EC_REQUIRE(w->conv_w && w->conv_w_lo && w->proj_w && w->proj_w_lo,
                "ec_vit_encode: conv / proj weights need their hi and lo parts");
     EC_REQUIRE(w->out_dim % 16 == 0, "ec_vit_encode: out_dim %d", w->out_dim);
+    EC_REQUIRE(!(w->precise && w->q_scaled), "ec_vit_encode: the split-precision tower takes a plain q (q_scaled = 0)");
     const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype;
     if (chunk > n_img) chunk = n_img;
     Scratch sc{(unsigned char *)workspace, 0, workspace_bytes};
@@ -237,7 +241,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, b.x,
                             stream));
         EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream,
-                          w->full_last_block == 0));
+                          w->full_last_block == 0, w->q_scaled != 0));
         // ln_post on the CLS rows (row stride S*W), then @ proj.  These n rows are the features
         // themselves: their 16-bit rounding is not averaged over anything downstream and was 45 % of the
         // logit error budget (tools/rounding_budget.py), so both operands keep their lo parts here

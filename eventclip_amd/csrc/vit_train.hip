@@ -1031,6 +1031,7 @@ int check_geometry(const ec_vit_weights *w, const char *who)
     EC_REQUIRE(w->conv_w && w->conv_w_lo && w->proj_w && w->proj_w_lo, "%s: conv / proj weights need hi and lo parts", who);
     EC_REQUIRE(w->out_dim % 16 == 0, "%s: out_dim %d", who, w->out_dim);
     EC_REQUIRE(!w->precise, "%s: the split-precision tower has no training form", who);
+    EC_REQUIRE(!w->q_scaled, "%s: the training form differentiates a plain q (ec_vit_weights.q_scaled must be 0)", who);
     return EC_OK;
 }
 

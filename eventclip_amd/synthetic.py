@@ -18,8 +18,8 @@ GEOMETRY = {
 
 
 def make_events(n_ev, resolution, seed=0, max_t=0.3, hot_pixels=4, hot_frac=0.005,
-                blob_frac=0.1, p_zero_frac=0.0):
-    """One sample's events: 90 % uniform, 10 % in a Gaussian blob (sigma = H/8),
+                blob_frac=0.1, p_zero_frac=0.0, blob_sigma=None):
+    """One sample's events: 90 % uniform, 10 % in a Gaussian blob (sigma = H/8 unless ``blob_sigma`` pixels),
     plus ``hot_pixels`` pixels that each receive ``hot_frac`` of all events so
     that the hot-pixel removal (vis.py:17-24) has something to remove."""
     H, W = resolution
@@ -28,8 +28,9 @@ def make_events(n_ev, resolution, seed=0, max_t=0.3, hot_pixels=4, hot_frac=0.00
     y = rng.integers(0, H, size=n_ev)
     blob = rng.random(n_ev) < blob_frac
     cx, cy = rng.uniform(0.25, 0.75) * W, rng.uniform(0.25, 0.75) * H
-    bx = np.clip(np.rint(rng.normal(cx, H / 8., size=n_ev)), 0, W - 1)
-    by = np.clip(np.rint(rng.normal(cy, H / 8., size=n_ev)), 0, H - 1)
+    sig = H / 8. if blob_sigma is None else float(blob_sigma)
+    bx = np.clip(np.rint(rng.normal(cx, sig, size=n_ev)), 0, W - 1)
+    by = np.clip(np.rint(rng.normal(cy, sig, size=n_ev)), 0, H - 1)
     x = np.where(blob, bx, x)
     y = np.where(blob, by, y)
     if hot_pixels:

@@ -321,6 +321,12 @@ EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
  * tower needs: encode_image reads nothing but the class token of its output. */
 EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, int S, int width, int heads,
                              int causal, int q_rows, int dtype, ec_stream_t stream);
+/* ec_attention_rows for a qkv buffer whose q columns already hold q * log2(e) / sqrt(64) (the softmax
+ * temperature and the base change folded into the q rows of in_proj before their rounding to 16 bit:
+ * ec_vit_weights.q_scaled): the kernel's scores are the exponent's arguments as they leave the MFMA.  What the
+ * image tower calls; the other entry points multiply a plain q themselves. */
+EC_API int ec_attention_scaled_q(const void *qkv, void *out, int n_seq, int S, int width, int heads,
+                                 int causal, int q_rows, int dtype, ec_stream_t stream);
 
 /* Training forms (fine-tuning the vision tower, models/clip_cls_ft.py:44-80): the same forward that also
  * keeps, per (sequence, head, query), the log2 of its softmax denominator in the scaled-score domain
@@ -380,6 +386,11 @@ typedef struct {
                                    (ec_gemm_args.ws): a single frame of ViT-L/14 in about half the time, at the
                                    price of results that differ from the large-batch ones in the last fp32 bits.
                                    0 (default): a frame's features do not depend on the batch it is in. */
+    int q_scaled;               /* != 0: the q rows of every block's qkv_w / qkv_b (rows 0 .. W-1 of in_proj) were
+                                   multiplied by log2(e) / sqrt(64) in fp32 BEFORE the rounding to 16 bit, and the
+                                   blocks call ec_attention_scaled_q: the attention kernel then has nothing to
+                                   scale -- the product is rounded once, like an unscaled q.  Inference only:
+                                   ec_vit_train_forward and precise towers take a plain q (0). */
 } ec_vit_weights;
 
 typedef struct {

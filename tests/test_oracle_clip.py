@@ -81,3 +81,85 @@ def test_full_size_oracle_outputs_agree_with_hf_transformers():
         a, b = z[name], z[name + '_hf']
         assert a.shape == b.shape
         assert np.abs(a - b).max() / np.abs(b).max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle/clip_ref.py emulate='fp16_reference': the yardstick of the logit-parity tests
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm16(torch.nn.LayerNorm):
+    """openai/CLIP's LayerNorm: fp32 compute on an fp16 tensor, result cast back."""
+
+    def forward(self, x):
+        return super().forward(x.type(torch.float32)).type(x.dtype)
+
+
+class _Block16(torch.nn.Module):
+    """ResidualAttentionBlock of the published clip/model.py over torch's own modules."""
+
+    def __init__(self, W, heads):
+        super().__init__()
+        self.attn = torch.nn.MultiheadAttention(W, heads)
+        self.ln_1, self.ln_2 = _LayerNorm16(W), _LayerNorm16(W)
+        self.c_fc, self.c_proj = torch.nn.Linear(W, 4 * W), torch.nn.Linear(4 * W, W)
+
+    def forward(self, x):                                     # [S, N, W] fp16
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False)[0]
+        h = self.c_fc(self.ln_2(x))
+        return x + self.c_proj(h * torch.sigmoid(1.702 * h))
+
+
+def test_fp16_reference_emulation_matches_torch_half_modules():
+    """The emulation (fp32 arithmetic + an explicit round to fp16 after every op) against torch's OWN fp16 kernels
+    (CPU half): nn.MultiheadAttention / nn.Linear / elementwise ops on half tensors, LayerNorm computed in fp32,
+    convert_weights' split of what is fp16 and what stays fp32.  Two blocks.  The two are independent fp16
+    realisations of the same arithmetic (sums associate differently, so roundings fall differently): what the
+    yardstick needs is that both sit at the SAME distance from fp32 (within 2x) and no further from each other
+    than two such realisations are (< 2x that distance)."""
+    from oracle import clip_ref
+    torch.manual_seed(3)
+    W, heads, S, N, L = 128, 2, 10, 4, 2
+    blocks = [_Block16(W, heads) for _ in range(L)]
+    sd = {}
+    for i, b in enumerate(blocks):
+        for p in b.parameters():
+            p.data.add_(torch.randn_like(p) * 0.05)
+        # convert_weights: Linear / MultiheadAttention to fp16, LayerNorm stays fp32
+        for mod in (b.attn, b.attn.out_proj, b.c_fc, b.c_proj):
+            mod.half()
+        pre = f'visual.transformer.resblocks.{i}.'
+        sd[pre + 'ln_1.weight'], sd[pre + 'ln_1.bias'] = b.ln_1.weight.data, b.ln_1.bias.data
+        sd[pre + 'ln_2.weight'], sd[pre + 'ln_2.bias'] = b.ln_2.weight.data, b.ln_2.bias.data
+        sd[pre + 'attn.in_proj_weight'], sd[pre + 'attn.in_proj_bias'] = b.attn.in_proj_weight.data.float(), b.attn.in_proj_bias.data.float()
+        sd[pre + 'attn.out_proj.weight'], sd[pre + 'attn.out_proj.bias'] = b.attn.out_proj.weight.data.float(), b.attn.out_proj.bias.data.float()
+        sd[pre + 'mlp.c_fc.weight'], sd[pre + 'mlp.c_fc.bias'] = b.c_fc.weight.data.float(), b.c_fc.bias.data.float()
+        sd[pre + 'mlp.c_proj.weight'], sd[pre + 'mlp.c_proj.bias'] = b.c_proj.weight.data.float(), b.c_proj.bias.data.float()
+    x = torch.randn(N, S, W)
+    with torch.no_grad():
+        y = x.half().transpose(0, 1)
+        for b in blocks:
+            y = b(y)
+        y = y.transpose(0, 1).float()
+        emu = clip_ref._blocks_h(clip_ref._h(x), clip_ref.fp16_reference_weights(sd), 'visual.transformer', L, heads)
+        exact = clip_ref._blocks(x, sd, 'visual.transformer', L, heads)
+    scale = float(exact.abs().max())
+    d_emu_torch = float((emu - y).abs().max()) / scale
+    d_torch_exact = float((y - exact).abs().max()) / scale
+    d_emu_exact = float((emu - exact).abs().max()) / scale
+    assert d_emu_torch < 2.0 * d_torch_exact, (d_emu_torch, d_torch_exact)
+    assert 0.5 < d_emu_exact / d_torch_exact < 2.0, (d_emu_exact, d_torch_exact)
+
+
+def test_fp16_reference_emulation_towers_run_and_differ_from_fp32_at_fp16_scale():
+    cfg, sd, z = load_tiny()
+    from oracle import clip_ref
+    img = torch.from_numpy(z['img'].astype(np.float32))
+    a = clip_ref.encode_image(sd, cfg, img)
+    b = clip_ref.encode_image(sd, cfg, img, emulate='fp16_reference')
+    e = float((a - b).abs().max() / a.abs().max())
+    assert 1e-5 < e < 2e-2, e
+    assert torch.equal(b, b.half().float())                   # an fp16 tensor's values
+    tok = torch.from_numpy(z['tok'])
+    a, b = clip_ref.encode_text(sd, cfg, tok), clip_ref.encode_text(sd, cfg, tok, emulate='fp16_reference')
+    e = float((a - b).abs().max() / a.abs().max())
+    assert 1e-5 < e < 2e-2, e

@@ -126,6 +126,32 @@ def test_attention_running_maximum_moves(S, spike_keys, dt, hip):
     torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('S,heads,q_rows', [(257, 16, 257), (257, 2, 1), (577, 3, 577), (50, 12, 50), (197, 2, 20)])
+def test_attention_scaled_q(S, heads, q_rows, dt, hip):
+    """ec_attention_scaled_q: the q columns hold q * log2(e) / sqrt(64) (what ec_vit_weights.q_scaled packs);
+    softmax(q k^T / 8) v must come out -- checked against fp32 on the rounded operands the kernel sees."""
+    import math
+    import torch
+    from eventclip_amd import _lib
+    dtype = getattr(torch, dt)
+    torch.manual_seed(S + q_rows)
+    n_seq, W = 3, heads * 64
+    c = 0.125 * 1.4426950408889634
+    qkv32 = torch.randn(n_seq * S, 3 * W, device='cuda') * 1.5
+    qkv32[:, :W] *= c
+    qkv = qkv32.to(dtype)
+    out = torch.empty(n_seq * q_rows, W, dtype=dtype, device='cuda')
+    _lib.check(_lib.lib().ec_attention_scaled_q(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0, q_rows,
+                                                _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16,
+                                                _lib.stream_ptr()))
+    q, k, v = qkv.float().view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * math.log(2.0)          # exp2(q' k) = exp(ln 2 q' k)
+    want = (att.softmax(-1) @ v).permute(0, 2, 1, 3)[:, :q_rows].reshape(n_seq * q_rows, W)
+    tol = 4e-3 if dt == 'float16' else 2.5e-2
+    torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
+
+
 def test_attention_lse_matches_reference(hip):
     """ec_attention_train's log-sum-exp (log2 domain, scaled scores) against fp32, incl. rows whose maximum moved."""
     import torch

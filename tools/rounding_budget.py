@@ -87,6 +87,9 @@ def main():
     ap.add_argument('--dtype', default='float16')
     ap.add_argument('--seed', type=int, default=5)
     ap.add_argument('--classes', type=int, default=101)
+    ap.add_argument('--qk', type=float, default=1.0, help='random_state_dict qk_gain (2.5: the parity tests)')
+    ap.add_argument('--branch', type=float, default=1.0, help='random_state_dict branch_gain (4: the parity tests)')
+    ap.add_argument('--blob', type=float, default=0.1, help='share of events in the Gaussian blob (0.7: the parity tests)')
     ap.add_argument('--mixes', default='', help='extra comma-separated mixes to evaluate, groups '
                     'joined by +, an optional @a:b restricts the rounding to blocks a..b-1; '
                     'each mix lists the groups that STAY rounded')
@@ -97,12 +100,12 @@ def main():
     from oracle import preprocess as op
     torch.manual_seed(0)
     cfg = eclip.arch_config(a.arch, layers=a.layers)
-    sd = {k: v.float() for k, v in eclip.random_state_dict(cfg, seed=a.seed).items()}
+    sd = {k: v.float() for k, v in eclip.random_state_dict(cfg, seed=a.seed, qk_gain=a.qk, branch_gain=a.branch).items()}
     g = GEOMETRY['n_caltech']
     frames = []
     i = 0
     while len(frames) < a.frames:
-        ev = make_events(2 * g['N'], g['resolution'], seed=300 + i)
+        ev = make_events(2 * g['N'], g['resolution'], seed=300 + i, blob_frac=a.blob)
         f = oe.events2frames(ev, 'event_count', 'event_histogram', shape=g['resolution'], N=g['N'],
                              grayscale=False, count_non_zero=False, background_mask=True)
         frames.extend(list(f))
