@@ -11,6 +11,13 @@ when N > 1).  Every sample has 10 x 20000 events, i.e. 10 valid views, so a step
 pushes 2560 frames per GPU; weak scaling (each rank gets its own 256 samples).
 Weights are seeded random (no checkpoints ship), data is synthetic.
 
+`--config 2|3|4` runs the other BASELINE.json configs through the same step (default 1 = the line above):
+2 = N-Cars few-shot adapter, ViT-L/14, 512 samples per GPU (weak scaling, like 1); 3 = N-ImageNet zero-shot,
+ViT-L/14@336px, GLOBAL batch 2048 x 2 views; 4 = N-ImageNet few-shot adapter, ViT-L/14, GLOBAL batch 4096 x 5
+views -- 3 and 4 split their global batch over the ranks (harness.shard_range: strong scaling, as BASELINE words
+them: "DP-sharded across 8").  The line also carries every rank's own ms per step and the time the all-gather
+of the logits took on rank 0's stream.
+
 Rank 0 prints one JSON line; `roofline` comes from HIP events the library records
 around its own launches during the timed steps, `cpu_baseline` is the CPU oracle
 (test infrastructure) timed on a bounded sample on the host.
@@ -35,29 +42,56 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md
 MFMA_KERNELS = ('gemm_kernel', 'attention_kernel')
 
 
+# BASELINE.json configs[1..4].  batch: samples per step -- per GPU where scaling is
+# 'weak', over the whole job where it is 'strong'; n_ev: events per sample (T views of N, or fewer than N)
+CONFIGS = {
+    1: dict(name='N-Caltech101 zero-shot, {arch}, RGB-polarity event2img', geo='n_caltech', arch='ViT-L/14',
+            batch=256, T=10, n_ev=200000, K=101, adapter=None, max_n=None, grayscale=False, scaling='weak'),
+    2: dict(name='N-Cars few-shot (text-trans adapter), {arch}, gray event2img', geo='n_cars', arch='ViT-L/14',
+            batch=512, T=1, n_ev=12500, K=2, adapter=0.8, max_n=None, grayscale=True, scaling='weak'),
+    3: dict(name='N-ImageNet zero-shot, {arch}, gray event2img', geo='n_imagenet', arch='ViT-L/14@336px',
+            batch=2048, T=2, n_ev=140000, K=1000, adapter=None, max_n=None, grayscale=True, scaling='strong'),
+    4: dict(name='N-ImageNet few-shot (text-trans adapter), {arch}, T=5 event frames', geo='n_imagenet',
+            arch='ViT-L/14', batch=4096, T=5, n_ev=350000, K=1000, adapter=0.95, max_n=350000, grayscale=True,
+            scaling='strong'),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS),
+                    help='BASELINE.json configs[i]; 1 (default) is the headline line')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
-    ap.add_argument('--arch', default='ViT-L/14')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='samples per step: per GPU for configs 1 / 2, over all GPUs for 3 / 4 (default: the config\'s)')
+    ap.add_argument('--arch', default=None, help='default: the config\'s')
     ap.add_argument('--dtype', default='float16', choices=['float16', 'bfloat16'])
     ap.add_argument('--chunk', type=int, default=2560, help='frames per pass through the tower')
-    ap.add_argument('--classes', type=int, default=101)
+    ap.add_argument('--classes', type=int, default=None, help='default: the config\'s')
+    ap.add_argument('--unique-samples', type=int, default=None,
+                    help='distinct synthetic event streams per rank, tiled to the batch (default: the batch for config 1, else 16)')
     ap.add_argument('--cpu-baseline-samples', type=int, default=3)
     ap.add_argument('--cpu-baseline-frames', type=int, default=10, help='views per baseline sample')
     ap.add_argument('--packed-events', action='store_true',
                     help='feed the 8-byte packed event form (SURVEY 8(f)) instead of float32 [n, 4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dvfs', action='store_true', help='skip the clock / power sampling steps')
-    return ap.parse_args()
+    a = ap.parse_args()
+    c = CONFIGS[a.config]
+    a.batch = a.batch or c['batch']
+    a.arch = a.arch or c['arch']
+    a.classes = a.classes or c['K']
+    return a
 
 
 def _cpu_event2img(args):
     """One sample through the CPU event2img stage (what a DataLoader worker of the reference does,
     datasets/event2img.py:114-128): events -> frames -> CLIP preprocess.  Returns the frame count."""
     ev, qa, n_px = args
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     from oracle import events as oe
     from oracle import preprocess as op
     frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
@@ -106,8 +140,9 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, 
            'sample': f'{n_samples} sample(s) cut to {n_frames} frames of the same workload through the '
                      f'CPU oracle (C events2frames + numpy Pillow-bicubic + torch fp32 '
                      f'{threads}-thread ViT), {dt:.1f} s'}
-    # event2img stage alone: one process, then a worker pool (fork: the parent holds a GPU context
-    # the children never touch; they only run numpy / the C oracle)
+    # event2img stage alone: one process, then a worker pool.  'spawn', not 'fork': the parent holds a HIP
+    # context, runtime threads and a 64-thread OpenMP pool, and a forked child can inherit a lock one of those
+    # threads held; every wait has a timeout, so a stuck worker costs the pool number, not the bench line
     jobs = [(np.ascontiguousarray(ev[:max_frames * qa['N']]), qa, cfg['image_size'])
             for ev in events[:max(n_samples, 2)]]
     t0 = time.perf_counter()
@@ -116,10 +151,10 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, 
     try:
         workers = min(workers, os.cpu_count() or 1)
         pool_jobs = [jobs[i % len(jobs)] for i in range(2 * workers)]
-        with mp.get_context('fork').Pool(workers) as pool:
-            pool.map(_cpu_event2img, pool_jobs[:workers])           # start the workers, build caches
+        with mp.get_context('spawn').Pool(workers) as pool:
+            pool.map_async(_cpu_event2img, pool_jobs[:workers]).get(timeout=180)   # start the workers, build caches
             t0 = time.perf_counter()
-            done = sum(pool.map(_cpu_event2img, pool_jobs))
+            done = sum(pool.map_async(_cpu_event2img, pool_jobs).get(timeout=180))
             res[f'event2img_frames_per_s_pool{workers}'] = done / (time.perf_counter() - t0)
     except Exception as e:   # noqa: BLE001 -- a baseline must never take the bench line down
         res['event2img_pool_error'] = repr(e)
@@ -259,50 +294,76 @@ def main():
 
     from eventclip_amd import _lib
     from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.clip_cls import FSCLIPClassifier, ZSCLIPClassifier
     from eventclip_amd.event2img import Event2ImagePipeline
-    from eventclip_amd.harness import all_gather_rows
+    from eventclip_amd.harness import all_gather_rows, shard_range
     from eventclip_amd.synthetic import GEOMETRY, make_events
 
-    geo = GEOMETRY['n_caltech']
-    T, N = 10, geo['N']
+    c = CONFIGS[a.config]
+    geo = GEOMETRY[c['geo']]
+    T, N = c['T'], geo['N']
     quantize_args = dict(max_imgs=T, N=N, split_method='event_count',
-                         convert_method='event_histogram', grayscale=False,
+                         convert_method='event_histogram', grayscale=c['grayscale'],
                          count_non_zero=geo['count_non_zero'],
                          background_mask=geo['background_mask'])
 
-    # ---- model: seeded random ViT-L/14 CLIP, text features cached once ----
+    # ---- model: seeded random CLIP, text features cached once ----
     cfg = eclip.arch_config(a.arch)
     sd = eclip.random_state_dict(cfg, seed=2)
     clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk).cuda().eval()
     tokens = eclip.synthetic_tokens(a.classes, seed=2)
-    model = ZSCLIPClassifier(clip_dict=dict(
-        clip_model=clip_model, prompt='a point cloud image of a {}',
-        class_names=[f'class {i}' for i in range(a.classes)], agg_func='mean',
-        class_tokens=tokens)).cuda().eval()
+    clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
+                     class_names=[f'class {i}' for i in range(a.classes)], agg_func='mean', class_tokens=tokens)
+    if c['adapter'] is None:
+        model = ZSCLIPClassifier(clip_dict=clip_dict)
+    else:
+        torch.manual_seed(2)
+        model = FSCLIPClassifier(adapter_dict=dict(adapter_type='text-trans', in_dim=cfg['embed_dim'], d_model=256,
+                                                   num_heads=4, ffn_dim=1024, norm_first=True, num_layers=2,
+                                                   residual=c['adapter']),
+                                 clip_dict=clip_dict, loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
+    model = model.cuda().eval()
     model.get_text_feats()
 
-    # ---- data: per-rank batch of event streams, resident in HBM ----
-    # every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
-    # then not flattered by an 8x reuse pattern)
-    evs = [make_events(T * N, geo['resolution'], seed=2 * 100003 + rank * 1000 + i)
-           for i in range(a.batch)]
-    n_events = [T * N] * a.batch
-    events = torch.from_numpy(np.concatenate(evs)).cuda()
+    # ---- data: this rank's share of the batch as event streams resident in HBM ----
+    if c['scaling'] == 'strong':       # a GLOBAL batch, contiguous shards (harness.shard_range)
+        shard_sizes = [shard_range(a.batch, r, world)[1] - shard_range(a.batch, r, world)[0] for r in range(world)]
+        local_batch, global_batch = shard_sizes[rank], a.batch
+    else:                              # the batch is per GPU
+        shard_sizes = [a.batch] * world
+        local_batch, global_batch = a.batch, a.batch * world
+    assert local_batch > 0, f'rank {rank} has no samples: batch {a.batch} over {world} ranks'
+    # config 1: every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
+    # then not flattered by a reuse pattern); the big configs tile a few distinct streams ON THE DEVICE
+    uniq_n = min(local_batch, a.unique_samples or (local_batch if a.config == 1 else 16))
+    evs = [make_events(c['n_ev'], geo['resolution'], seed=2 * 100003 + rank * 1000 + i) for i in range(uniq_n)]
+    if uniq_n == local_batch:
+        events = torch.from_numpy(np.concatenate(evs)).cuda()
+    else:
+        u = torch.from_numpy(np.stack(evs)).cuda()                                  # [uniq, n_ev, 4]
+        events = u[torch.arange(local_batch, device='cuda') % uniq_n].reshape(-1, 4).contiguous()
+        del u
+    n_events = [c['n_ev']] * local_batch
     if a.packed_events:
         from eventclip_amd.vis import pack_events_device
         events = pack_events_device(events)
-    pipe = Event2ImagePipeline(geo['resolution'], geo['max_n'], quantize_args,
+    pipe = Event2ImagePipeline(geo['resolution'], c['max_n'] or geo['max_n'], quantize_args,
                                n_px=cfg['image_size'], patch=cfg['patch'], kpad=clip_model.kpad,
                                dtype=clip_model.compute_dtype)
     pipe.strict = False   # no host sync inside the step (bounds are checked by the tests)
-    frames_per_step = a.batch * T
+    views = T if c['n_ev'] >= N else 1          # frames per sample (vis.py:55-72: fewer than N events = one chunk)
+    frames_per_step = local_batch * views       # this rank's
+    gather_events = []                          # HIP event pairs around the all-gather (rank-local stream)
 
     def step():
         batch = pipe(events, n_events)
         out = model(batch)
         if world > 1:
-            out['logits'] = all_gather_rows(out['logits'])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out['logits'] = all_gather_rows(out['logits'], shard_sizes)
+            e1.record()
+            gather_events.append((e0, e1))
         return out
 
     def fence():
@@ -314,21 +375,31 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    gather_events.clear()
     _lib.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0           # this rank's own time, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()
     assert int(out['valid_masks'].sum()) == frames_per_step
+    assert out['logits'].shape[0] == global_batch
+    rank_ms = [dt_own / a.steps * 1e3]
+    gather_ms = None
     if world > 1:
         t = torch.tensor([dt], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        rank_ms = [None] * world
+        dist.all_gather_object(rank_ms, dt_own / a.steps * 1e3)
+        gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in gather_events) / a.steps
+    total_frames = sum(shard_sizes) * views     # all ranks, one step
 
     if rank == 0:
-        value = world * frames_per_step * a.steps / dt
+        value = total_frames * a.steps / dt
         # ---- roofline of the dominant kernel, from the live HIP-event records ----
         dom = max(prof, key=lambda e: e['total_ms'])
         avg_ms = dom['total_ms'] / dom['launches']
@@ -364,18 +435,23 @@ def main():
                            'traffic': per_kernel.get('events_to_frames_kernel', {}).get('hbm_bytes_per_launch')}
         gpu_ms = sum(e['total_ms'] for e in prof) / a.steps
         breakdown = {e['name']: round(e['total_ms'] / a.steps, 3) for e in prof}
+        metric = 'event-frames/sec (whole node) ViT-L/14 zero-shot @224' if a.config == 1 else \
+            f'event-frames/sec (whole node), BASELINE configs[{a.config}]'
+        if c['scaling'] == 'weak':
+            batch_txt = f'batch={a.batch} samples x {views} view{"s" if views > 1 else ""} per GPU'
+        else:
+            batch_txt = f'global batch={a.batch} samples x {views} views, sharded over the GPUs'
         res = {
-            'metric': 'event-frames/sec (whole node) ViT-L/14 zero-shot @224',
+            'metric': metric,
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if a.dtype == 'float16' else 'bf16',
+            'scaling': c['scaling'], 'vs_baseline': None, 'dtype': 'f16' if a.dtype == 'float16' else 'bf16',
             'data': 'synthetic',
-            'config': {'workload': f'N-Caltech101 zero-shot, {a.arch}, RGB-polarity event2img, '
-                                   f'batch={a.batch} samples x {T} views per GPU (configs[1])',
+            'config': {'workload': f'{c["name"].format(arch=a.arch)}, {batch_txt} (configs[{a.config}])',
                        'frames_per_step_per_gpu': frames_per_step, 'classes': a.classes,
-                       'events_per_frame': N, 'resolution': list(geo['resolution']),
+                       'events_per_frame': min(N, c['n_ev']), 'resolution': list(geo['resolution']),
                        'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
-                       'unique_samples': a.batch,
+                       'unique_samples': uniq_n,
                        'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
                        'precision': ('16-bit MFMA operands, fp32 accumulate / residual stream / LayerNorm / '
                                      'softmax; patch embedding and ln_post @ proj with hi + lo operands; '
@@ -391,6 +467,13 @@ def main():
             'kernel_launches_per_step': {e['name']: e['launches'] / a.steps for e in prof},
             'kernel_algorithmic_bytes_per_launch': {e['name']: e['bytes'] / e['launches'] for e in prof},
         }
+        if a.config != 1 or world > 1:
+            res['config'].update(adapter=(None if c['adapter'] is None else f'text-trans, residual {c["adapter"]}'),
+                                 samples_per_rank=shard_sizes, frames_per_step_total=total_frames)
+            # each rank's own time per step (before it waits for the slowest) and what the all-gather of the
+            # logits cost on rank 0's stream: what a scaling run needs to attribute its loss
+            res['ms_per_step_per_rank'] = rank_ms
+            res['all_gather_ms_per_step'] = gather_ms
         if world == 1 and not a.no_dvfs:
             dv = sample_dvfs(step, fence, device=local)
             if dv:
@@ -398,8 +481,9 @@ def main():
                 if roof['bound'] == 'mfma':
                     roof['frac_of_peak_at_sclk'] = roof['achieved'] / dv['peak_at_sclk']
         if world == 1 and not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
-                                               a.cpu_baseline_samples, a.cpu_baseline_frames)
+            if a.config == 1:
+                res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
+                                                   a.cpu_baseline_samples, a.cpu_baseline_frames)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

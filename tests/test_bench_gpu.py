@@ -71,3 +71,41 @@ def test_gpus_2_launches_itself(hip):
     bad = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--arch', 'no-such-arch'] + SMALL[:4],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize('config,batch,expect', [
+    (2, 3, dict(scaling='weak', samples=[3, 3], views=1)),            # per-GPU batch, one short view per sample
+    (3, 5, dict(scaling='strong', samples=[3, 2], views=2)),          # GLOBAL batch over the ranks, uneven shards
+    (4, 3, dict(scaling='strong', samples=[2, 1], views=5)),
+])
+def test_other_baseline_configs_two_ranks_over_gloo(hip, config, batch, expect):
+    """bench.py --config 2 | 3 | 4 (BASELINE.json configs[2..4]) on two gloo ranks sharing the GPU: the geometry,
+    views and adapter of the config, weak (per-GPU batch) or strong (global batch split by harness.shard_range)
+    scaling, the whole-job value, every rank's own ms per step and the all-gather's time in the line."""
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--config', str(config), '--batch', str(batch), '--steps', '2',
+           '--warmup', '1', '--arch', 'ViT-B/32', '--classes', '11', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d) and d['n_gpus'] == 2 and d['scaling'] == expect['scaling']
+    cfg = d['config']
+    assert f'configs[{config}]' in cfg['workload'] and cfg['samples_per_rank'] == expect['samples']
+    frames = sum(expect['samples']) * expect['views']
+    assert cfg['frames_per_step_total'] == frames
+    assert abs(d['value'] - frames * 1e3 / d['ms_per_step']) < 1e-6 * d['value']      # whole-job aggregate
+    assert len(d['ms_per_step_per_rank']) == 2 and all(0 < t <= d['ms_per_step'] * 1.001 for t in d['ms_per_step_per_rank'])
+    assert d['all_gather_ms_per_step'] is not None and d['all_gather_ms_per_step'] >= 0
+    assert (cfg['adapter'] is None) == (config == 3)
+
+
+def test_config1_line_keeps_its_keys(hip):
+    """--config 1 is the default line: same metric string and config keys as before the other configs existed."""
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--config', '1', '--no-cpu-baseline', '--no-dvfs'] + SMALL,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['metric'] == 'event-frames/sec (whole node) ViT-L/14 zero-shot @224' and d['scaling'] == 'weak'
+    assert 'samples_per_rank' not in d['config'] and 'ms_per_step_per_rank' not in d
+    assert d['config']['workload'].endswith('batch=4 samples x 10 views per GPU (configs[1])')
