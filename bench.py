@@ -77,6 +77,9 @@ def parse():
     ap.add_argument('--packed-events', action='store_true',
                     help='feed the 8-byte packed event form (SURVEY 8(f)) instead of float32 [n, 4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--from-host', action='store_true',
+                    help='also time the step with every batch starting in HOST memory (pinned staging ring + copy '
+                         'stream, the upload of batch i + 1 under the tower of batch i): value_from_host')
     ap.add_argument('--no-dvfs', action='store_true', help='skip the clock / power sampling steps')
     a = ap.parse_args()
     c = CONFIGS[a.config]
@@ -398,6 +401,40 @@ def main():
         gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in gather_events) / a.steps
     total_frames = sum(shard_sizes) * views     # all ranks, one step
 
+    # ---- the same steps with every batch starting in host memory (never part of `value`) ----
+    host_line = None
+    if a.from_host:
+        host_samples = [evs[i % uniq_n] for i in range(local_batch)]      # numpy float32 [n_ev, 4] each
+        if a.packed_events:
+            from eventclip_amd.vis import pack_events
+            packed = [pack_events(e) for e in evs]
+            host_samples = [packed[i % uniq_n] for i in range(local_batch)]
+
+        def host_batches():
+            for _ in range(a.warmup + a.steps):
+                yield host_samples
+        t0h = None
+        for i, batch in enumerate(pipe.stream(host_batches(), depth=2)):
+            if i == a.warmup:
+                fence()
+                t0h = time.perf_counter()
+            out_h = model(batch)
+            if world > 1:
+                out_h['logits'] = all_gather_rows(out_h['logits'], shard_sizes)
+        fence()
+        dth = time.perf_counter() - t0h
+        if world > 1:
+            t = torch.tensor([dth], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        assert torch.equal(out_h['logits'], out['logits'])                 # same batch, same bits
+        host_bytes = sum(e.nbytes for e in host_samples)
+        host_line = {'value_from_host': total_frames * a.steps / dth, 'ms_per_step_from_host': dth / a.steps * 1e3,
+                     'from_host': {'bytes_per_step_per_gpu': host_bytes,
+                                   'path': 'per-sample copies into a pinned staging ring (8 threads), one async H2D '
+                                           'copy per batch on a copy stream, batch i + 1 uploaded under the GPU work of '
+                                           'batch i (eventclip_amd.event2img.HostFeeder)'}}
+
     if rank == 0:
         value = total_frames * a.steps / dt
         # ---- roofline of the dominant kernel, from the live HIP-event records ----
@@ -474,6 +511,8 @@ def main():
             # logits cost on rank 0's stream: what a scaling run needs to attribute its loss
             res['ms_per_step_per_rank'] = rank_ms
             res['all_gather_ms_per_step'] = gather_ms
+        if host_line is not None:
+            res.update(host_line)
         if world == 1 and not a.no_dvfs:
             dv = sample_dvfs(step, fence, device=local)
             if dv:

@@ -194,3 +194,143 @@ def build_event2img_pipeline(params, resolution, max_n, clip_model=None):
         n_px = c['image_size']
         kw = dict(patch=c['patch'], kpad=clip_model.kpad, dtype=clip_model.compute_dtype)
     return Event2ImagePipeline(resolution, max_n, params.quantize_args, n_px=n_px, **kw)
+
+
+class HostFeeder:
+    """Batches that start in HOST memory, overlapped with the GPU's work on the batch before.
+
+    The reference hides its CPU event -> image work behind the GPU with DataLoader worker processes
+    (/root/reference/test.py:36-38, ``num_workers`` 8 / 16 in configs/zsclip/*.py:15) and then uploads fp32 images
+    with a synchronous ``.cuda()`` (test.py:60).  Here the image work is on the GPU and what is left for the host
+    is moving the raw events; ``Event2ImagePipeline.__call__`` on a list of arrays does that with one
+    single-threaded ``np.concatenate`` and a pageable, synchronous copy.  This class does it the way a loader
+    would:
+
+      * a ring of ``depth`` pinned staging buffers and as many device buffers, all allocated once;
+      * a producer thread takes the next batch from the iterable, copies every sample into the staging buffer at
+        its offset with a small thread pool (torch's CPU copy releases the GIL), and issues ONE asynchronous
+        host-to-device copy on a copy stream, followed by an event;
+      * ``__next__`` makes the caller's stream wait for that event, runs the pipeline on the device buffer, and
+        records on the caller's stream the event after which the producer may overwrite the slot.
+
+    Samples: float32 [n_i, 4] rows (16 B per event, as the dataset readers store them) or packed uint64 [n_i]
+    (8 B per event, ``vis.pack_events``) -- whatever the batch holds is uploaded as it is.  The batches are
+    bit-identical to ``pipe(list_of_arrays)``.
+    """
+
+    def __init__(self, pipe, batches, depth=2, copy_threads=8, capacity_bytes=None, **call_kw):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.pipe, self.call_kw = pipe, call_kw
+        self.dev = _lib.require_gpu()
+        self.depth = max(2, int(depth))
+        self.capacity = capacity_bytes
+        self._slots = None
+        self._pool = ThreadPoolExecutor(max(1, int(copy_threads)))
+        self._copy_stream = torch.cuda.Stream(device=self.dev)
+        self._ready = queue.Queue(maxsize=self.depth - 1)     # the producer runs at most depth - 1 batches ahead
+        self._free = queue.Queue()
+        self._batches = iter(batches)
+        self._err = None
+        self._th = threading.Thread(target=self._produce, daemon=True)
+        self._th.start()
+
+    # ---- producer side -------------------------------------------------------------------------------
+    def _alloc(self, nbytes):
+        cap = max(int(nbytes), int(self.capacity or 0))
+        cap = (cap + (1 << 20) - 1) >> 20 << 20
+        self._slots = []
+        for i in range(self.depth):
+            host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            devb = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+            self._slots.append(dict(host=host, dev=devb, consumed=None))
+            self._free.put(i)
+        self.capacity = cap
+
+    def _stage(self, samples):
+        host = [e.cpu() if torch.is_tensor(e) else e for e in samples]
+        packed = all(not isinstance(e, dict) and vis.is_packed(e) for e in host)
+        if packed:
+            arrs = [np.ascontiguousarray(np.asarray(e).view(np.int64)) for e in host]
+        else:
+            arrs = [vis.parse_events(e) for e in host]          # float32 [n, 4], contiguous (no copy if it already is)
+        n_events = [int(a.shape[0]) for a in arrs]
+        esz = 8 if packed else 16
+        total = sum(n_events) * esz
+        if self._slots is None:
+            self._alloc(total)
+        if total > self.capacity:
+            # a batch larger than any before it (pass capacity_bytes= to avoid this): wait until no slot is in
+            # use any more, then allocate the ring again
+            held = [self._free.get() for _ in range(self.depth)]
+            for j in held:
+                if self._slots[j]['consumed'] is not None:
+                    self._slots[j]['consumed'].synchronize()
+            self._slots = None
+            self._alloc(total + total // 4)
+        i = self._free.get()
+        slot = self._slots[i]
+        if slot['consumed'] is not None:
+            slot['consumed'].synchronize()        # the kernels that read this slot's device buffer are done
+        offs = np.concatenate([[0], np.cumsum(n_events)]) * esz
+
+        def put(j):
+            src = torch.from_numpy(arrs[j].reshape(-1).view(np.uint8))
+            slot['host'][int(offs[j]):int(offs[j + 1])].copy_(src)
+        list(self._pool.map(put, range(len(arrs))))
+        with torch.cuda.stream(self._copy_stream):
+            slot['dev'][:total].copy_(slot['host'][:total], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return dict(slot=i, total=total, packed=packed, n_events=n_events, done=done)
+
+    def _produce(self):
+        try:
+            torch.cuda.set_device(self.dev)
+            for samples in self._batches:
+                extra = None
+                if isinstance(samples, dict):               # harness-style data_dict: events + anything else
+                    extra = {k: v for k, v in samples.items() if k != 'events'}
+                    samples = samples['events']
+                item = self._stage(samples)
+                item['extra'] = extra
+                self._ready.put(item)
+        except BaseException as e:   # noqa: BLE001 -- handed to the consumer
+            self._err = e
+        finally:
+            self._ready.put(None)
+
+    # ---- consumer side -------------------------------------------------------------------------------
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._ready.get()
+        if item is None:
+            self._pool.shutdown(wait=False)
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        slot = self._slots[item['slot']]
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(item['done'])
+        buf = slot['dev'][:item['total']]
+        events = buf.view(torch.int64) if item['packed'] else buf.view(torch.float32).view(-1, 4)
+        out = self.pipe(events, item['n_events'], **self.call_kw)
+        consumed = torch.cuda.Event()
+        consumed.record(cur)
+        slot['consumed'] = consumed
+        self._free.put(item['slot'])
+        if item['extra']:
+            out.update(item['extra'])
+        return out
+
+
+def _stream(self, batches, depth=2, copy_threads=8, capacity_bytes=None, **call_kw):
+    """Iterate over model-ready batches for an iterable of host-resident sample lists (or harness data_dicts
+    with an ``events`` entry), the upload of batch i + 1 overlapped with whatever the GPU does for batch i."""
+    return HostFeeder(self, batches, depth=depth, copy_threads=copy_threads, capacity_bytes=capacity_bytes, **call_kw)
+
+
+Event2ImagePipeline.stream = _stream

@@ -74,11 +74,16 @@ def batch_accuracies(out_dict, labels, top5=False):
 
 
 @torch.no_grad()
-def evaluate(model, batches, is_nin=False, pipeline=None):
+def evaluate(model, batches, is_nin=False, pipeline=None, prefetch=1):
     """test.py:55-93.  ``batches`` yields data_dicts with ``label`` and either the
     reference's ``img``/``valid_mask`` or raw ``events`` (list of arrays) when a
-    ``pipeline`` (Event2ImagePipeline) is given."""
+    ``pipeline`` (Event2ImagePipeline) is given; ``prefetch`` batches are then uploaded ahead of the one the
+    GPU is working on (0: the synchronous path)."""
     meters = {}
+    if pipeline is not None and prefetch:
+        # host-resident event batches: staged through pinned memory and uploaded on a copy stream while the GPU
+        # works on the batch before (event2img.HostFeeder) -- the reference's DataLoader prefetch, test.py:36-38
+        batches = pipeline.stream(batches, depth=1 + int(prefetch))
     for data_dict in batches:
         if pipeline is not None and 'events' in data_dict:
             data_dict = {**pipeline(data_dict['events']), 'label': data_dict['label']}

@@ -208,3 +208,35 @@ def test_classifier_forward_runs_through_the_registered_custom_ops(hip):
     full, logits, probs = ops.classify(feats, ri.cuda(), text.t().contiguous(), float(model.logit_scale), 1, False)
     assert torch.equal(full, out['full_logits']) and torch.equal(logits, out['logits'])
     assert torch.equal(probs, out['probs'])
+
+
+def test_host_feeder_is_bit_identical_to_the_synchronous_path(hip):
+    """Event2ImagePipeline.stream (pinned staging ring, copy stream, batch i + 1 uploaded while the GPU works on
+    batch i) against pipe(list_of_arrays) (np.concatenate + synchronous copy): the same patches, masks and view
+    order for every batch, float and packed events, ragged batch sizes, more batches than ring slots."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import GEOMETRY, make_events
+    g = GEOMETRY['n_caltech']
+    qa = dict(max_imgs=10, N=g['N'], split_method='event_count', convert_method='event_histogram', grayscale=False,
+              count_non_zero=False, background_mask=True)
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=32, kpad=6144)
+    sizes = [[50000, 20000, 93000], [200000], [7000, 41000], [120000, 60000, 20000, 20001], [30000]]
+    batches = [[make_events(n, g['resolution'], seed=10 * b + i) for i, n in enumerate(ns)] for b, ns in enumerate(sizes)]
+    for packed in (False, True):
+        bs = [[vis.pack_events(e) for e in b] for b in batches] if packed else batches
+        want = [pipe(b) for b in bs]
+        got = list(pipe.stream(iter(bs), depth=2, copy_threads=3))
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            for k in ('patches', 'valid_mask', 'row_idx'):
+                assert torch.equal(a[k], b[k]), (packed, k)
+    # harness-style dicts keep their other entries
+    dd = [dict(events=b, label=torch.tensor([1] * len(b))) for b in batches[:2]]
+    out = list(pipe.stream(iter(dd)))
+    assert all('label' in o and 'events' not in o for o in out)
+    # an exception in the producer thread reaches the caller
+    import pytest
+    with pytest.raises(IndexError):
+        list(pipe.stream(iter([[make_events(0, g['resolution'])]])))
