@@ -67,7 +67,12 @@ class FTCLIPClassifier(FSCLIPClassifier):
         sd = dict(state_dict)
         vis = {k[len('model.visual.'):]: v for k, v in sd.items() if k.startswith('model.visual.')}
         rest = {k: v for k, v in sd.items() if not k.startswith('model.')}
-        if vis:
+        if vis and self._trainer is not None:
+            # the resume flow (nerv builds the optimiser first, then loads the checkpoint): the weights go INTO the
+            # trainer -- masters in place, LoRA factors as factors (not folded into an already-merged base) --
+            # and its 16-bit operand copies are rebuilt
+            self._trainer.load_visual_state_dict(vis, strict=strict)
+        elif vis:
             merged = elora.merge_lora_visual(vis)        # plain checkpoints pass through unchanged
             clip_sd = self.model.state_dict()
             new = {k: v for k, v in clip_sd.items() if not k.startswith('visual.')}

@@ -567,6 +567,7 @@ class FTTrainer:
         if self.lora:
             for n, p in self.lora.params.items():
                 self.tensors['model.visual.' + n] = p
+        self._broadcast_initial_state()
         self.lr = float(lr)
         self.clip_lr = float(lr if clip_lr is None else clip_lr)
         self.total_steps = int(total_steps)
@@ -620,8 +621,81 @@ class FTTrainer:
         classifier._tower, classifier._trainer = self.tower, self
         self.last = {}
 
+    def _broadcast_initial_state(self):
+        """Under torch.distributed every rank starts from rank 0's tensors, as torch's DistributedDataParallel
+        does at construction (the reference wraps the model in it, nerv / train.py --ddp): the LoRA down factors
+        are drawn from each rank's own generator (lora.py:8-11), and ranks usually seed differently for their
+        data augmentation -- averaging gradients over replicas that started apart lets them drift apart for good.
+        Masters that do not train are broadcast too (a rank may have built them differently); the 16-bit operand
+        copies are rebuilt from what arrived."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        seen = set()
+        for t in list(self.tensors.values()) + list(self.tower.master.values()):
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            dist.broadcast(t, src=0)
+        self.tower.pack()
+
     def trainable_names(self):
         return sorted(self.tensors)
+
+    # ---- optimiser state: what a resumed run needs beyond the parameters (torch.optim.Adam.state_dict + the
+    # scheduler's step count + GradScaler.state_dict in the reference's checkpoints) ----
+    def state_dict(self):
+        self.resolve()
+        return {'exp_avg': {k: m.clone() for k, (m, _) in self.state.items()},
+                'exp_avg_sq': {k: v.clone() for k, (_, v) in self.state.items()},
+                'steps': self.steps, 'opt_steps': self.opt_steps,
+                'scaler': {'scale': self.scaler.scale, 'good_steps': self.scaler._good}}
+
+    def load_state_dict(self, sd):
+        self.resolve()
+        missing = set(self.state) ^ set(sd['exp_avg'])
+        if missing:
+            raise KeyError(f'optimiser state does not match the trainable tensors: {sorted(missing)[:3]} ...')
+        for k, (m, v) in self.state.items():          # in place: the Adam item table holds these addresses
+            m.copy_(sd['exp_avg'][k])
+            v.copy_(sd['exp_avg_sq'][k])
+        self.steps, self.opt_steps = int(sd['steps']), int(sd['opt_steps'])
+        self.scaler.scale, self.scaler._good = float(sd['scaler']['scale']), int(sd['scaler']['good_steps'])
+        self._graph = None                             # a captured step baked the old scalars' addresses' contents in
+
+    def load_visual_state_dict(self, vis, strict=True):
+        """``model.visual.*`` of a checkpoint (keys without that prefix) INTO the attached trainer: the masters in
+        place, the LoRA factors into ``lora.params`` (``merged_proj`` / ``linear.*`` are the FROZEN base weights
+        there, lora.py:138-150, and go to the masters unmerged), then the merge and the repack of the 16-bit
+        operand copies.  FTCLIPClassifier.load_state_dict routes here while a trainer is attached."""
+        self.resolve()
+        t = self.tower
+        vis = dict(vis)
+        src_of = {name: name for name in t.master}          # checkpoint key of every master
+        if self.lora:
+            for i in range(t.L):
+                pre = _block_name(i, 'attn')
+                src_of[pre + '.in_proj_weight'] = pre + '.in_proj_weight.merged_proj'
+                if self.lora.lora_o:
+                    src_of[pre + '.out_proj.weight'] = pre + '.out_proj.linear.weight'
+                    src_of[pre + '.out_proj.bias'] = pre + '.out_proj.linear.bias'
+        targets = [(m, src_of[name]) for name, m in t.master.items()]
+        if self.lora:
+            targets += [(p, k) for k, p in self.lora.params.items()]
+        for dst, key in targets:
+            if key in vis:
+                dst.copy_(torch.as_tensor(vis[key]).to(dst.device, dst.dtype))      # in place: addresses are baked in
+            elif strict:
+                raise KeyError(f'checkpoint lacks model.visual.{key}')
+        if self.lora and not self.lora.lora_k:    # the k rows carry no factors: their merged rows are the base rows
+            W = t.W
+            for i in range(t.L):
+                n = _block_name(i, 'attn.in_proj_weight')
+                t.effective[n][W:2 * W].copy_(t.master[n][W:2 * W])
+        t.pack()
+        if self.lora:
+            self.lora.merge()
+        t.clip._packed = None                          # the inference copies are rebuilt from the masters on demand
+        self._graph = None
 
     def _patches(self, data_dict):
         """-> patches [Nv, G, kpad] of the valid views, valid [B, T], row_idx [B, T] (no host synchronisation when

@@ -692,6 +692,62 @@ def test_eval_between_steps_uses_the_trained_weights(hip):
     torch.testing.assert_close(fresh(data)['logits'], after, rtol=2e-3, atol=2e-3 * float(after.abs().max()))
 
 
+@pytest.mark.parametrize('case', ['lora_qkvo', 'full'])
+def test_resume_from_a_checkpoint_reproduces_the_next_step(hip, case):
+    """The resume flow of the reference (nerv builds the optimiser, THEN loads the checkpoint): three steps, save
+    model + trainer state, build a fresh classifier + trainer (different LoRA draw), load both, and the next step
+    -- loss and every tensor after it -- equals the uninterrupted run's bit for bit.  With LoRA this only holds
+    if the factors come back as factors over the frozen base (not folded into it) and Adam's moments, step counts
+    and the loss scale travel too."""
+    from eventclip_amd import ft
+    z, c = _golden_case(case)
+    data = {'img': c['imgs'].cuda(), 'valid_mask': c['valid'].cuda(), 'label': c['labels'].cuda()}
+    kw = dict(lr=1e-2, clip_lr=5e-3, total_steps=20, warmup_steps_pct=0.2, init_scale=512.0, growth_interval=2)
+    clf = _classifier_for(c)
+    torch.manual_seed(21)
+    tr = ft.FTTrainer(clf, **kw)
+    for _ in range(3):
+        tr.step(data)
+    ckpt = {k: v.detach().cpu().clone() for k, v in clf.state_dict().items()}
+    opt = {k: ({kk: vv.cpu().clone() for kk, vv in v.items()} if k.startswith('exp_avg') else v)
+           for k, v in tr.state_dict().items()}
+    want_loss = float(tr.step(data))
+    tr.resolve()
+    want = {k: v.clone() for k, v in tr.tensors.items()}
+    clf.eval()
+    want_logits = clf(data)['logits'].clone()
+
+    clf2 = _classifier_for(c)
+    torch.manual_seed(99)                                   # another draw of the LoRA factors: must not matter
+    tr2 = ft.FTTrainer(clf2, **kw)
+    clf2.load_state_dict(ckpt)
+    tr2.load_state_dict(opt)
+    assert tr2.steps == 3 and tr2.opt_steps == 3 and tr2.scaler.scale == opt['scaler']['scale']
+    got_loss = float(tr2.step(data))
+    tr2.resolve()
+    assert got_loss == want_loss
+    for k in want:
+        assert torch.equal(tr2.tensors[k], want[k]), k
+    clf2.eval()
+    assert torch.equal(clf2(data)['logits'], want_logits)   # eval after the load runs on the trained weights
+
+
+def test_two_ranks_with_different_seeds_start_from_rank_zero(hip):
+    """FTTrainer under torch.distributed broadcasts rank 0's tensors at construction (DistributedDataParallel's
+    behaviour): two ranks that seed their LoRA draw differently hold identical factors before and after steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', FT_DDP_SEED_PER_RANK='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29549', 'tools/ft_ddp_check.py', 'lora']
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['seed_per_rank'] and d['params_equal_at_start'] and d['params_equal_after_steps'], d
+
+
 @pytest.mark.parametrize('mode', ['full', 'lora'])
 def test_two_ranks_average_their_gradients(hip, mode):
     """FTTrainer under torch.distributed (two gloo ranks sharing the GPU): one all-reduce of the flat gradient

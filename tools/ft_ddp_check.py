@@ -26,7 +26,10 @@ def build(mode):
               lora='qkvo-4' if mode == 'lora' else -1)
     clf = FTCLIPClassifier(adapter_dict=dict(adapter_type='text-identity', residual=True), clip_dict=cd,
                            loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda().train()
-    torch.manual_seed(5)                       # the LoRA factors' initial values: same on every rank
+    # the LoRA factors' initial values: the same seed on every rank -- or, with FT_DDP_SEED_PER_RANK=1, a
+    # different one per rank (the usual per-rank seed offset): FTTrainer then has to start everyone from rank 0's
+    per_rank = os.environ.get('FT_DDP_SEED_PER_RANK') == '1' and dist.is_initialized()
+    torch.manual_seed(5 + (dist.get_rank() if per_rank else 0))
     tr = ft.FTTrainer(clf, lr=1e-2, clip_lr=1e-3, total_steps=100, warmup_steps_pct=0.0, init_scale=256.0)
     if tr.lora:
         for k, p in tr.lora.params.items():
@@ -53,6 +56,15 @@ def main():
     imgs, valid, labels = batch(B)
     lo, hi = rank * 4, rank * 4 + 4
     clf, tr = build(mode)
+
+    def same_everywhere():
+        ok = True
+        for k in sorted(tr.tensors):
+            both = [torch.empty_like(tr.tensors[k]) for _ in range(world)]
+            dist.all_gather(both, tr.tensors[k].contiguous())
+            ok = ok and all(torch.equal(both[0], b) for b in both[1:])
+        return ok
+    equal_start = same_everywhere()
     loss = tr.step({'img': imgs[lo:hi].cuda(), 'valid_mask': valid[lo:hi].cuda(), 'label': labels[lo:hi].cuda()})
     tr.resolve()
     losses = [torch.zeros(1, device='cuda') for _ in range(world)]
@@ -76,10 +88,16 @@ def main():
             if k.endswith('attn.in_proj_bias'):
                 continue                       # its key third is zero in exact arithmetic: rounding noise only
             worst = max(worst, ((v - mine[k]).norm() / v.norm().clamp_min(1e-30)).item())
-        out = dict(mode=mode, world=world, loss_mean_of_ranks=float(torch.cat(losses).mean()), loss_whole=float(whole),
+        out = dict(seed_per_rank=os.environ.get('FT_DDP_SEED_PER_RANK') == '1', params_equal_at_start=equal_start,
+                   mode=mode, world=world, loss_mean_of_ranks=float(torch.cat(losses).mean()), loss_whole=float(whole),
                    worst_grad_rel_l2=worst, tensors=len(mine), skipped=bool(tr.last['skipped']))
+    for _ in range(2):
+        tr.step({'img': imgs[lo:hi].cuda(), 'valid_mask': valid[lo:hi].cuda(), 'label': labels[lo:hi].cuda()})
+    tr.resolve()
+    equal_end = same_everywhere()
     dist.barrier()
     if rank == 0:
+        out['params_equal_after_steps'] = equal_end
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 
