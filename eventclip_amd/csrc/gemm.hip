@@ -1674,16 +1674,18 @@ __global__ __launch_bounds__(256) void kbatch_fixup_kernel(const float *partial,
     }
 }
 
-// -> EC_OK after launching the K-batched form, or -1 when the launch does not qualify (the caller goes on as usual)
+// -> EC_OK after launching the K-batched form, KBATCH_NOT_APPLICABLE (a positive value: never an error code) when the
+// launch does not qualify and the caller goes on as usual, or the negative error code of a launch that failed
+constexpr int KBATCH_NOT_APPLICABLE = 1;
 template <int DT> int try_kbatched(const GemmArgs &g0, int epi, float *ws, size_t ws_bytes, hipStream_t stream)
 {
     const int cus = ec::cu_count();
     const int tiles = ec::ceil_div(g0.M, 256) * ec::ceil_div(g0.N, 256);
-    if (cus <= 0 || tiles * 2 > cus || g0.N % 4 != 0) return -1;
+    if (cus <= 0 || tiles * 2 > cus || g0.N % 4 != 0) return KBATCH_NOT_APPLICABLE;
     const int nk = g0.K / BK;
     int splits = 1;
     while (splits < 16 && tiles * splits * 2 <= cus && nk % (splits * 2) == 0 && nk / (splits * 2) >= 2) splits *= 2;
-    if (splits < 2 || (size_t)splits * g0.M * g0.N * 4 > ws_bytes) return -1;
+    if (splits < 2 || (size_t)splits * g0.M * g0.N * 4 > ws_bytes) return KBATCH_NOT_APPLICABLE;
     GemmArgs g = g0;
     g.K = g0.K / splits, g.splits = splits, g.split_stride = (long)g0.M * g0.N;
     g.C = ws, g.ldc = g0.N, g.bias = nullptr, g.resid = nullptr, g.aux = nullptr;
@@ -1750,10 +1752,14 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a->ws && a->variant == 0 && g.splits == 1 && a->epilogue >= EC_EPI_STORE16 && a->epilogue <= EC_EPI_GELU_BWD16) {
         EC_REQUIRE(((uintptr_t)a->ws & 15) == 0, "ec_gemm: ws must be 16-byte aligned");
-        int rc = -1;
+        // what dispatch_epi would check: the fixup kernel reads / writes through these on the device
+        EC_REQUIRE(!(a->epilogue == EC_EPI_GELU16_SAVE || a->epilogue == EC_EPI_GELU_BWD16) || a->aux != nullptr,
+                   "ec_gemm: epilogue %d needs aux", a->epilogue);
+        EC_REQUIRE(a->resid == nullptr || ((uintptr_t)a->resid & 15) == 0, "ec_gemm: resid must be 16-byte aligned");
+        int rc = KBATCH_NOT_APPLICABLE;
         if (a->dtype == EC_F16) rc = try_kbatched<EC_F16>(g, a->epilogue, static_cast<float *>(a->ws), a->ws_bytes, s);
         else if (a->dtype == EC_BF16) rc = try_kbatched<EC_BF16>(g, a->epilogue, static_cast<float *>(a->ws), a->ws_bytes, s);
-        if (rc >= 0) return rc;
+        if (rc != KBATCH_NOT_APPLICABLE) return rc;   // launched, or failed with a real error code
     }
     if (a->dtype == EC_F16) return dispatch_epi<EC_F16>(g, a->epilogue, a->variant, s);
     if (a->dtype == EC_BF16) return dispatch_epi<EC_BF16>(g, a->epilogue, a->variant, s);

@@ -48,7 +48,7 @@ class Event2ImagePipeline:
         self.count_non_zero = bool(qa.get('count_non_zero', False))
         self.background_mask = bool(qa.get('background_mask', True))
         # not a key of the reference's configs: which numpy the frames should agree with (vis.py:27)
-        self.float_stage = qa.get('float_stage', 'float64')
+        self.float_stage = qa.get('float_stage', vis.DEFAULT_FLOAT_STAGE)
         self.n_px, self.patch, self.kpad, self.dtype = int(n_px), patch, kpad, dtype
         self.generator = generator
         self.strict = True   # raise on events outside the sensor, as the reference does

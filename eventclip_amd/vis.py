@@ -17,6 +17,15 @@ import numpy as np
 from . import _lib
 
 
+# Which numpy the float stage of make_event_histogram (vis.py:27-39) agrees with when the caller does not say.
+# The reference pins numpy 1.25.2 (/root/reference/environment.yml:49), whose value-based casting keeps
+# `hist.astype(np.float32) / hist.max()` -- and everything after it -- in float32; under numpy >= 2 (NEP 50, this
+# image) the same line promotes to float64.  The two differ by 1 LSB at exact .5 ties only.  Default: the pinned
+# reference environment; quantize_args['float_stage'] = 'float64' gives what this image's numpy makes of the
+# reference (both are pinned by every events fixture).
+DEFAULT_FLOAT_STAGE = 'float32'
+
+
 def parse_events(events):
     """vis.py:44-52: accept an [n, 4] (x, y, t, p) array or a dict of columns.
     Returns one contiguous float32 [n, 4] array (the integer truncation of
@@ -65,7 +74,7 @@ def colour_map(grayscale=True):
 
 
 def make_params(shape, grayscale=True, thresh=10., count_non_zero=False, background_mask=True,
-                max_frame_events=0, flip_x=False, negate_p=False, float_stage='float64',
+                max_frame_events=0, flip_x=False, negate_p=False, float_stage=DEFAULT_FLOAT_STAGE,
                 total_events=0):
     H, W = shape
     red, blue = colour_map(grayscale)
@@ -172,15 +181,15 @@ def pack_events_device(events, return_bad=False):
 def events_to_frames_device(events, frame_range, shape, grayscale=True, thresh=10.,
                             count_non_zero=False, background_mask=True, return_counts=False,
                             return_stats=False, out=None, max_frame_events=0, flip_x=False,
-                            negate_p=False, sort_workspace=True, float_stage='float64',
+                            negate_p=False, sort_workspace=True, float_stage=DEFAULT_FLOAT_STAGE,
                             total_events=0):
     """Batched device entry.
 
     events:      float32 CUDA tensor [n_total, 4], or packed events: int64 CUDA tensor [n_total]
                  (pack_events / pack_events_device, layout in include/eventclip_hip.h).
     frame_range: int64 CUDA tensor [F, 2] of (begin, end) rows per frame.
-    float_stage: 'float64' runs vis.py:27-39 as numpy >= 2 does (the default, and what the
-                 fixtures of this image record), 'float32' as the reference's pinned numpy 1.25 did.
+    float_stage: 'float32' runs vis.py:27-39 as the reference's pinned numpy 1.25 does (the default,
+                 DEFAULT_FLOAT_STAGE), 'float64' as numpy >= 2 does.
     total_events: sum of the frame lengths when known (profiling: the launch's algorithmic bytes).
     Returns uint8 CUDA tensor [F, H, W, 3] (+ raw, kept int32 [F, H, W, 2] and a
     stats structured array when asked).
@@ -248,7 +257,7 @@ def events2frames(events, split_method, convert_method, shape=(180, 240), **kwar
         count_non_zero=kwargs.get('count_non_zero', False),
         background_mask=kwargs.get('background_mask', True), return_stats=True,
         max_frame_events=max(b - a for a, b in zip(idx0, idx1)),
-        float_stage=kwargs.get('float_stage', 'float64'),
+        float_stage=kwargs.get('float_stage', DEFAULT_FLOAT_STAGE),
         total_events=sum(b - a for a, b in zip(idx0, idx1)))
     if int(stats['dropped'].sum()) > 0:
         # the reference's bincount/reshape raises on such input (vis.py:11)

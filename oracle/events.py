@@ -84,9 +84,9 @@ def events2frames(events, split_method='event_count', convert_method='event_hist
         raise NotImplementedError(f'{convert_method} not implemented!')
     N = int(kwargs['N'])
     thresh = float(kwargs.get('thresh', 10.))
-    # float_stage='float32': the reference's pinned numpy 1.25 semantics of vis.py:27-39 (value-based
-    # casting keeps the stage in float32); default 'float64' = numpy >= 2, what the fixtures record
-    f32 = kwargs.get('float_stage', 'float64') == 'float32'
+    # float_stage='float32' (default): the reference's pinned numpy 1.25 semantics of vis.py:27-39 (value-based
+    # casting keeps the stage in float32); 'float64' = numpy >= 2, what importing vis.py in this image gives
+    f32 = kwargs.get('float_stage', 'float32') == 'float32'
     cnz = bool(kwargs.get('count_non_zero', False))
     bgm = bool(kwargs.get('background_mask', True))
     red, blue = colour_map(grayscale)

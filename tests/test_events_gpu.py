@@ -41,7 +41,7 @@ def test_hip_matches_reference_fixture(path, hip):
     np.testing.assert_array_equal(c_raw, raw)
     np.testing.assert_array_equal(c_kept, kept)
     o_frames, o_raw, o_kept = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape,
-                                               return_counts=True, **kw)
+                                               return_counts=True, float_stage='float64', **kw)
     assert frames.shape == o_frames.shape and frames.shape[0] == exp['n_frames']
     np.testing.assert_array_equal(raw, o_raw)             # bit-exact counts
     assert sha(raw.astype(np.int32)) == exp['raw_sha256']

@@ -16,8 +16,10 @@ def sha(a):
 @pytest.mark.parametrize('path', event_fixture_paths(), ids=os.path.basename)
 def test_oracle_matches_reference_fixture(path):
     ev, shape, kw, exp = load_event_fixture(path)
+    # the fixtures' main frames come from the reference's vis.py imported under THIS image's numpy (>= 2:
+    # float64 stage); the reference's pinned numpy 1.25 (the default, float32 stage) is the second hash below
     frames, raw, kept = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape,
-                                         return_counts=True, **kw)
+                                         return_counts=True, float_stage='float64', **kw)
     assert frames.shape[0] == exp['n_frames']
     assert frames.dtype == np.uint8 and frames.shape[1:] == (*shape, 3)
     assert sha(raw.astype(np.int32)) == exp['raw_sha256']
@@ -29,6 +31,7 @@ def test_oracle_matches_reference_fixture(path):
     # float32 stage: what the reference computes under its pinned numpy 1.25 (value-based casting)
     f32 = oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape, float_stage='float32', **kw)
     assert sha(f32) == exp['frames_f32_sha256']
+    np.testing.assert_array_equal(f32, oe.events2frames(ev, 'event_count', 'event_histogram', shape=shape, **kw))   # = default
     d = np.flatnonzero(f32.ravel() != frames.ravel())
     assert len(d) == exp['f32_differs']
     if len(d):                                   # 1 LSB apart, at exact .5 ties only
