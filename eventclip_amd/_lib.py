@@ -65,11 +65,13 @@ class EcGemmArgs(ctypes.Structure):
                 ('bias', c_void_p), ('C', c_void_p), ('ldc', c_long), ('diag', c_void_p),
                 ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
                 ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t),
-                ('transposed', c_int), ('k_rows', c_int)]
+                ('transposed', c_int), ('k_rows', c_int), ('row_stats', c_void_p), ('row_stats_stride', c_long),
+                ('col_sums', c_void_p)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
 EC_EPI_GELU16_SAVE, EC_EPI_GELU_BWD16 = 4, 5
+EC_EPI_RESID_HL, EC_EPI_STORE16_LN, EC_EPI_GELU16_LN = 6, 7, 8
 EC_STEP_LR0, EC_STEP_LR1, EC_STEP_BC1, EC_STEP_BC2_SQRT, EC_STEP_GRAD_SCALE, EC_STEP_INV_SCALE, EC_STEP_COUNT = 0, 1, 2, 3, 4, 5, 8
 EC_PRE_CHW_F32, EC_PRE_PATCHES16, EC_PRE_HWC_U8 = 0, 1, 2
 EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
@@ -78,7 +80,8 @@ EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
 class EcBlockWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
-        'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo')]
+        'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo', 'qkv_w_ln', 'qkv_cs', 'qkv_bf', 'fc1_w_ln',
+        'fc1_cs', 'fc1_bf')]
 
 
 class EcAdapterTrainLayer(ctypes.Structure):
@@ -100,7 +103,7 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
-                ('low_latency', c_int), ('q_scaled', c_int)]
+                ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):
@@ -205,6 +208,7 @@ SIGNATURES = {
                               c_void_p]),
     'ec_attention': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
+    'ec_row_stats': (c_int, [c_void_p, c_long, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
     'ec_attention_scaled_q': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     'ec_attention_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

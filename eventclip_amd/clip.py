@@ -172,7 +172,7 @@ class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
-                 image_precise=False, full_last_block=None, low_latency=False):
+                 image_precise=False, full_last_block=None, low_latency=False, ln_folded=None, q_scaled=True):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -196,6 +196,14 @@ class CLIP(nn.Module):
         # serving a few frames at a time: under-filled GEMM launches run K-batched (about half the latency of a
         # single frame); a frame's features then differ from its large-batch ones in the last fp32 bits
         self.low_latency = bool(low_latency)
+        # LayerNorm of the image tower's blocks folded into the GEMMs around it (include/eventclip_hip.h,
+        # ec_vit_weights.ln_folded); EVENTCLIP_LN_FOLDED=0 runs the plain LayerNorm launches
+        if ln_folded is None:
+            ln_folded = os.environ.get('EVENTCLIP_LN_FOLDED', '1') not in ('', '0')
+        self.ln_folded = bool(ln_folded)
+        # softmax scale folded into the q rows of in_proj before their rounding (ec_vit_weights.q_scaled); False packs
+        # the weights exactly as the training path holds them (plain q, plain LayerNorm with ln_folded=False too)
+        self.q_scaled = bool(q_scaled)
         self.workspace_budget = 24 << 30   # bytes of tower scratch at most
         self._packed = None
         self._ws = None
@@ -247,7 +255,7 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def blocks(prefix, layers, precise, q_scaled=False):
+        def blocks(prefix, layers, precise, q_scaled=False, ln_folded=False):
             arr = (_lib.EcBlockWeights * layers)()
             for i in range(layers):
                 ks = _block_keys(prefix, i)
@@ -262,6 +270,18 @@ class CLIP(nn.Module):
                     wqkv[:width] *= ATTN_Q_SCALE
                     bqkv[:width] *= ATTN_Q_SCALE
                 b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
+                if ln_folded:
+                    # ec_vit_weights.ln_folded: W' = W diag(gamma) rounded once, its row sums AS ROUNDED, b + W beta
+                    def fold(wt, bias, gamma, beta):
+                        wt, bias = wt.float().to(dev), bias.float().to(dev)
+                        wp = (wt * gamma.float().to(dev)[None, :]).to(cd).contiguous()
+                        keep.append(wp)
+                        cs = wp.float().sum(1).contiguous()
+                        bf = (bias + wt @ beta.float().to(dev)).contiguous()
+                        keep.extend([cs, bf])
+                        return wp.data_ptr(), cs.data_ptr(), bf.data_ptr()
+                    b.qkv_w_ln, b.qkv_cs, b.qkv_bf = fold(wqkv, bqkv, sd[ks[0]], sd[ks[1]])
+                    b.fc1_w_ln, b.fc1_cs, b.fc1_bf = fold(sd[ks[8]], sd[ks[9]], sd[ks[6]], sd[ks[7]])
                 b.out_w, b.out_b = dev16(sd[ks[4]]), dev32(sd[ks[5]])
                 b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
                 b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
@@ -296,9 +316,11 @@ class CLIP(nn.Module):
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
         v.low_latency = int(self.low_latency)
-        v.q_scaled = 0 if self.image_precise else 1
+        v.q_scaled = int(self.q_scaled and not self.image_precise)
+        v.ln_folded = int(self.ln_folded and not self.image_precise)
         v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
-        vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled=bool(v.q_scaled))
+        vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled=bool(v.q_scaled),
+                    ln_folded=bool(v.ln_folded))
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']

@@ -52,6 +52,10 @@ struct GemmArgs {
     // their ROW index; K = rows per batch (a multiple of 64), k_valid = rows that exist (the rest read as zero)
     int tn;
     int k_valid;
+    // LayerNorm folded into the GEMMs around it (EC_EPI_RESID_HL / EC_EPI_STORE16_LN / EC_EPI_GELU16_LN)
+    const float *rowstat;       // consumers: [M][2] (rstd, -rstd * mean) of the A rows, row m at rowstat + 2 m rowstat_stride
+    long rowstat_stride;
+    const float *colsum;        // consumers: [N] sum over k of the (gamma-scaled, rounded) weight row
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -78,8 +82,10 @@ __device__ __forceinline__ float quick_gelu_grad(float x)
 }
 constexpr bool epi_is16(int e)
 {
-    return e == EC_EPI_STORE16 || e == EC_EPI_GELU16 || e == EC_EPI_GELU16_SAVE || e == EC_EPI_GELU_BWD16;
+    return e == EC_EPI_STORE16 || e == EC_EPI_GELU16 || e == EC_EPI_GELU16_SAVE || e == EC_EPI_GELU_BWD16 ||
+           e == EC_EPI_STORE16_LN || e == EC_EPI_GELU16_LN;
 }
+constexpr bool epi_is_ln(int e) { return e == EC_EPI_STORE16_LN || e == EC_EPI_GELU16_LN; }
 
 // bijective XCD remap (blocks b and b+8 share an XCD): XCD x gets a contiguous id range
 __device__ __forceinline__ int xcd_remap(int bid, int nblk)
@@ -239,6 +245,75 @@ __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[T
     }
 }
 
+// Residual epilogue on a residual stream kept as two 16-bit planes, x = hi + lo (EC_EPI_RESID_HL): hi = x rounded to
+// the operand type IS the A operand of the GEMM that follows (its LayerNorm is folded into that GEMM's epilogue),
+// lo = fp16(x - hi) keeps the stream at ~2^-22 relative -- the same 4 bytes per element as the fp32 stream, and no
+// LayerNorm pass in between.  Same transpose through LDS as epilogue32_lds; afterwards a lane holds 8 consecutive
+// columns of two rows, so each plane is read and written with 16-byte accesses (8 lanes = one 128-byte line).
+template <int DT, int TM>
+__device__ __forceinline__ void epilogue_hl_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
+                                                int lane, float *scratch)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int PITCH = 68;
+    const int q = lane >> 4, lr = lane & 15;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nb = n_base + q * 16;
+    if (g.bias && nb < g.N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
+    }
+    const int c8 = lane & 7, r8 = lane >> 3;
+    const int col = n_base + c8 * 8;          // this lane's 8 output columns after the transpose
+    const bool col_ok = col < g.N;
+    constexpr int DEPTH = TM < 3 ? TM : 3;
+    v8 xh[DEPTH][2];
+    f16x8 xl[DEPTH][2];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            int m = m_base + i * 16 + r8 + 8 * p;
+            m = m < g.M ? m : g.M - 1;
+            const long off = (long)m * g.ldc + (col_ok ? col : 0);
+            xh[i % DEPTH][p] = *reinterpret_cast<const v8 *>((const elem *)g.C + off);
+            xl[i % DEPTH][p] = *reinterpret_cast<const f16x8 *>((const _Float16 *)g.aux + off);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) fetch(i);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        float *buf = scratch;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = r8 + 8 * p;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + row * PITCH + c8 * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(buf + row * PITCH + c8 * 8 + 4);
+            const int m = m_base + i * 16 + row;
+            v8 oh;
+            f16x8 ol;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float x = (float)xh[i % DEPTH][p][e] + (float)xl[i % DEPTH][p][e] + (e < 4 ? a[e] : b[e - 4]);
+                oh[e] = to16(x, elem());
+                ol[e] = (_Float16)(x - (float)oh[e]);
+            }
+            if (m < g.M && col_ok) {
+                const long off = (long)m * g.ldc + col;
+                *reinterpret_cast<v8 *>((elem *)g.C + off) = oh;
+                *reinterpret_cast<f16x8 *>((_Float16 *)g.aux + off) = ol;
+            }
+        }
+        if (i + DEPTH < TM) fetch(i + DEPTH);
+    }
+}
+
 // 16-bit counterpart: a 16 x 64 row group is 16 rows of 128 B (pitch 144 B); after the transpose
 // 8 consecutive lanes cover one full 128-B row and a store instruction writes 8 whole lines.
 // scratch: 2 x 16 x 144 bytes per wave.
@@ -261,17 +336,38 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
     }
     const int col = n_base + (lane & 7) * 8;   // this lane's 8 output columns after the transpose
     const bool col_ok = col < g.N;
+    // LayerNorm folded in (EC_EPI_*_LN): A held the RAW rows x and W the gamma-scaled weight, so
+    //   LN(x) . W^T + b = rstd (x . W'^T) - rstd mean colsum(W') + (b + W beta):
+    // per lane one row (rstd, -rstd mean) per 16-row group and the column sums next to the (folded) bias
+    f32x4 cs[4];
+    float rs0[TM], rs1[TM];
+    if constexpr (epi_is_ln(EPI)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            cs[j] = nb < g.N ? *reinterpret_cast<const f32x4 *>(g.colsum + nb + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            int m = m_base + i * 16 + lr;
+            m = m < g.M ? m : g.M - 1;
+            const float2 r = *reinterpret_cast<const float2 *>(g.rowstat + 2 * (long)m * g.rowstat_stride);
+            rs0[i] = r.x, rs1[i] = r.y;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         unsigned char *buf = scratch + (i & 1) * 16 * PITCH;
         elem o[16];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const f32x4 v = acc[i][j] + bias[j];
+            f32x4 v;
+            if constexpr (epi_is_ln(EPI))
+                v = acc[i][j] * rs0[i] + (cs[j] * rs1[i] + bias[j]);
+            else
+                v = acc[i][j] + bias[j];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float y = v[r];
-                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE) y = quick_gelu(y);
+                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU16_LN) y = quick_gelu(y);
                 o[4 * j + r] = to16(y, elem());
             }
         }
@@ -1241,7 +1337,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             issue(3, 0);
             issue(1, 0);
         }
-        if constexpr (!epi_is16(EPI))
+        if constexpr (EPI == EC_EPI_RESID_HL)
+            epilogue_hl_lds<DT, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                   reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+        else if constexpr (!epi_is16(EPI))
             epilogue32_lds<EPI, 8, 1, TN>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
                                           reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
         else
@@ -1280,12 +1379,12 @@ template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
     EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
-    constexpr int cls = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU_BWD16) ? ec::PROF_GEMM_STORE16
-                        : (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE) ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 ? 2.0
+    constexpr int cls = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU_BWD16 || EPI == EC_EPI_STORE16_LN) ? ec::PROF_GEMM_STORE16
+                        : (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU16_LN) ? ec::PROF_GEMM_GELU16
+                        : (EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI)) ? 2.0
                              : (EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU_BWD16) ? 4.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
+                             : ((EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? 8.0 : 4.0);
     ec::ProfScope prof(g.splits > 1 ? (int)ec::PROF_GEMM_DW : cls, stream, 2.0 * g.M * g.N * g.K * g.splits,
                        (2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N) * g.splits);
     const int tiles = g.tiles_m * g.tiles_n * g.splits;
@@ -1623,6 +1722,16 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_GELU_BWD16:
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_GELU_BWD16 needs variant 0 and args.aux");
         return launch2pp<DT, EC_EPI_GELU_BWD16>(g, s);
+    // LayerNorm folded into the GEMMs (default kernel only)
+    case EC_EPI_RESID_HL:
+        EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
+        return launch2pp<DT, EC_EPI_RESID_HL>(g, s);
+    case EC_EPI_STORE16_LN:
+        EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs variant 0, row_stats and col_sums");
+        return launch2pp<DT, EC_EPI_STORE16_LN>(g, s);
+    case EC_EPI_GELU16_LN:
+        EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs variant 0, row_stats and col_sums");
+        return launch2pp<DT, EC_EPI_GELU16_LN>(g, s);
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown epilogue %d", epi);
     }
 }
@@ -1719,6 +1828,7 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.ldw = a->ldw ? a->ldw : a->K, g.resid = a->resid, g.aux = a->aux;
     g.splits = a->splits > 1 ? a->splits : 1, g.split_stride = a->split_stride;
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
+    g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     if (g.tn) {
         g.lda = a->lda ? a->lda : a->M, g.ldw = a->ldw ? a->ldw : a->N;
         EC_REQUIRE(a->epilogue == EC_EPI_STORE32 && a->variant == 0 && !a->bias && !a->ws,
@@ -1750,6 +1860,8 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     }
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
+    EC_REQUIRE(a->epilogue < EC_EPI_RESID_HL || (g.splits == 1 && !a->ws && !a->resid),
+               "ec_gemm: the folded-LayerNorm epilogues take no splits / ws / resid");
     if (a->ws && a->variant == 0 && g.splits == 1 && a->epilogue >= EC_EPI_STORE16 && a->epilogue <= EC_EPI_GELU_BWD16) {
         EC_REQUIRE(((uintptr_t)a->ws & 15) == 0, "ec_gemm: ws must be 16-byte aligned");
         // what dispatch_epi would check: the fixup kernel reads / writes through these on the device

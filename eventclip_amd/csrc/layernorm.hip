@@ -12,6 +12,7 @@
 // shuffle reductions (mean, then centred variance), one write.
 #include "common.h"
 #include "mfma.h"
+#include "tower_ops.h"
 
 namespace {
 
@@ -96,6 +97,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx
         }
 }
 
+// LayerNorm statistics of 16-bit rows (the hi plane of the residual stream): one wave per row, the row in
+// registers as eight-element chunks, mean and centred variance like ln_row -> (rstd, -rstd * mean)
+template <int DT>
+__global__ __launch_bounds__(256) void row_stats_kernel(const void *x, long ldx, int rows, int width, float eps,
+                                                        float *stats)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const elem *xr = (const elem *)x + row * ldx;
+    constexpr int MAXC = LN_MAXV / 2;          // 8-element chunks per lane: width <= 2048
+    const int total = width / 8, nc = (total - lane + 63) / 64;
+    v8 v[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; i++)
+        if (i < nc) v[i] = *reinterpret_cast<const v8 *>(xr + (i * 64 + lane) * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++)
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += (float)v[i][e];
+        }
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++)
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float d = (float)v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = 1.f / __builtin_sqrtf(wave_sum(q) / (float)width + eps);
+    if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(rstd, -rstd * mean);
+}
+
 // fp32 [n] -> (optionally QuickGELU) -> 16-bit hi and lo parts
 template <int DT>
 __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, int gelu, void *hi,
@@ -121,10 +162,11 @@ __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, in
 
 // fp32 in -> fp32 out with an additive table (positional embedding) and a row
 // source that is either a broadcast vector (class token) or a GEMM output row.
+template <int DT = -1>   // DT >= 0: the residual stream goes out as hi (DT) + lo (fp16) planes (x = hi plane pointer)
 __global__ __launch_bounds__(256) void vit_embed_kernel(const float *patch, const float *cls,
                                                         const float *pos, const float *gamma,
                                                         const float *beta, int n_img, int seq,
-                                                        int width, float eps, float *x, float *pre)
+                                                        int width, float eps, float *x, float *pre, _Float16 *x_lo = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -145,10 +187,42 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const float *patch, cons
             if (pre) *reinterpret_cast<float4 *>(pre + row * width + c) = v[i];
         }
     ln_row(v, nv, width, lane, gamma, beta, eps);
+    if constexpr (DT >= 0) {
+        typedef typename T16<DT < 0 ? 0 : DT>::elem elem;
+        typedef typename T16<DT < 0 ? 0 : DT>::v4 v4;
+        elem *oh = reinterpret_cast<elem *>(x) + row * width;
+        _Float16 *ol = x_lo + row * width;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++)
+            if (i < nv) {
+                const v4 h = {to16(v[i].x, elem()), to16(v[i].y, elem()), to16(v[i].z, elem()), to16(v[i].w, elem())};
+                const f16x4 l = {(_Float16)(v[i].x - (float)h[0]), (_Float16)(v[i].y - (float)h[1]),
+                                 (_Float16)(v[i].z - (float)h[2]), (_Float16)(v[i].w - (float)h[3])};
+                *reinterpret_cast<v4 *>(oh + (i * 64 + lane) * 4) = h;
+                *reinterpret_cast<f16x4 *>(ol + (i * 64 + lane) * 4) = l;
+            }
+        return;
+    }
     float *o = x + row * width;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
         if (i < nv) *reinterpret_cast<float4 *>(o + (i * 64 + lane) * 4) = v[i];
+}
+
+// rows of a residual stream kept as hi + lo planes (row stride ld elements) -> fp32 [rows, width]
+template <int DT>
+__global__ __launch_bounds__(256) void join_hl_kernel(const void *x_hi, const _Float16 *x_lo, long ld, int rows, int width,
+                                                      float *out)
+{
+    typedef typename T16<DT>::elem elem;
+    const long n4 = (long)rows * (width / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (width / 4), c = (i % (width / 4)) * 4;
+        const elem *h = (const elem *)x_hi + r * ld + c;
+        const _Float16 *l = x_lo + r * ld + c;
+        *reinterpret_cast<float4 *>(out + r * width + c) = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1],
+                                                                       (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+    }
 }
 
 __global__ __launch_bounds__(256) void text_embed_kernel(const int *tokens, const float *table,
@@ -172,6 +246,49 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int *tokens, cons
 
 }  // namespace
 
+// ---- internal entry points of the folded-LayerNorm image tower (towers.hip; declared in tower_ops.h) ----
+namespace ec_tower {
+
+int vit_embed_hl(const float *patch, const float *cls, const float *pos, const float *gamma, const float *beta,
+                 int n_img, int seq, int width, float eps, void *x_hi, void *x_lo, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(width % 4 == 0 && width <= LN_MAXV * 256 && seq >= 2, "vit_embed_hl: bad shape");
+    if (n_img == 0) return EC_OK;
+    const long rows = (long)n_img * seq;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_EMBED, s, 0, (double)rows * width * 8.0);
+    const dim3 grid((unsigned)ec::ceil_div(rows, 4L));
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(vit_embed_kernel<EC_F16>, grid, dim3(256), 0, s, patch, cls, pos, gamma, beta, n_img, seq, width,
+                           eps, (float *)x_hi, (float *)nullptr, (_Float16 *)x_lo);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(vit_embed_kernel<EC_BF16>, grid, dim3(256), 0, s, patch, cls, pos, gamma, beta, n_img, seq, width,
+                           eps, (float *)x_hi, (float *)nullptr, (_Float16 *)x_lo);
+    else
+        return ec::fail(EC_ERR_INVALID, "vit_embed_hl: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int join_hl_rows(const void *x_hi, const void *x_lo, long ld, int rows, int width, float *out, int dtype, ec_stream_t stream)
+{
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(width % 4 == 0 && ld % 4 == 0, "join_hl_rows: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n4 = (long)rows * (width / 4);
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(join_hl_kernel<EC_F16>, dim3(grid), dim3(256), 0, s, x_hi, (const _Float16 *)x_lo, ld, rows, width, out);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(join_hl_kernel<EC_BF16>, dim3(grid), dim3(256), 0, s, x_hi, (const _Float16 *)x_lo, ld, rows, width, out);
+    else
+        return ec::fail(EC_ERR_INVALID, "join_hl_rows: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // namespace ec_tower
+
 extern "C" {
 
 EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
@@ -180,6 +297,25 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
 {
     return ec_layernorm_split(x, ldx, row_idx, gamma, beta, rows, width, eps, out16, nullptr, ldo,
                               dtype, stream);
+}
+
+EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
+                        ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && width > 0 && width % 8 == 0 && width <= LN_MAXV * 256,
+               "ec_row_stats: width=%d must be a multiple of 8 and <= %d", width, LN_MAXV * 256);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(x16 && stats && ldx % 8 == 0 && ((uintptr_t)x16 & 15) == 0, "ec_row_stats: null or misaligned buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 2.0);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(row_stats_kernel<EC_F16>, dim3(ec::ceil_div(rows, 4)), dim3(256), 0, s, x16, ldx, rows, width, eps, stats);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL(row_stats_kernel<EC_BF16>, dim3(ec::ceil_div(rows, 4)), dim3(256), 0, s, x16, ldx, rows, width, eps, stats);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_row_stats: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
 }
 
 EC_API int ec_split16(const float *x, long n, int gelu, void *hi16, void *lo16, int dtype,
@@ -241,9 +377,9 @@ EC_API int ec_vit_embed_train(const float *patch, const float *cls, const float 
     if (n_img == 0) return EC_OK;
     const long rows = (long)n_img * seq;
     ec::ProfScope prof(ec::PROF_EMBED, static_cast<hipStream_t>(stream), 0, (double)rows * width * 8.0);
-    hipLaunchKernelGGL(vit_embed_kernel, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
+    hipLaunchKernelGGL(vit_embed_kernel<-1>, dim3((unsigned)ec::ceil_div(rows, 4L)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), patch, cls, pos, gamma, beta, n_img, seq,
-                       width, eps, x, pre);
+                       width, eps, x, pre, (_Float16 *)nullptr);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

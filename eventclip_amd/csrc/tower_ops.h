@@ -43,6 +43,32 @@ inline int gemm(int M, int N, int K, int dtype, int epi, const void *A, const vo
     return ec_gemm(&g, s);
 }
 
+// the folded-LayerNorm forms (EC_EPI_RESID_HL: aux = lo plane; EC_EPI_*_LN: row statistics + column sums)
+inline int gemm_hl(int M, int N, int K, int dtype, const void *A, const void *W, const float *bias, void *x_hi,
+                   void *x_lo, ec_stream_t s, long ldc = 0)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = EC_EPI_RESID_HL, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = x_hi, g.ldc = ldc ? ldc : N, g.aux = x_lo;
+    return ec_gemm(&g, s);
+}
+inline int gemm_ln(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
+                   const float *row_stats, long row_stats_stride, const float *col_sums, void *C, ec_stream_t s,
+                   long ldc = 0, long lda = 0)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
+    g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
+    g.row_stats = row_stats, g.row_stats_stride = row_stats_stride, g.col_sums = col_sums;
+    return ec_gemm(&g, s);
+}
+
+// layernorm.hip: ln_pre'd embedding straight into the hi / lo planes; class rows of the planes back to fp32
+int vit_embed_hl(const float *patch, const float *cls, const float *pos, const float *gamma, const float *beta,
+                 int n_img, int seq, int width, float eps, void *x_hi, void *x_lo, int dtype, ec_stream_t stream);
+int join_hl_rows(const void *x_hi, const void *x_lo, long ld, int rows, int width, float *out, int dtype,
+                 ec_stream_t stream);
+
 #define EC_TRY(expr)                  \
     do {                              \
         int _rc = (expr);             \

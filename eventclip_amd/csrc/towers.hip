@@ -16,10 +16,11 @@ namespace {
 using namespace ec_tower;
 
 struct BlockBufs {
-    float *x;     // [rows, W] fp32 residual stream
+    float *x;     // [rows, W] fp32 residual stream (folded LayerNorm: the hi plane [rows, W] 16-bit, then the lo plane)
     void *h;      // [rows, W] 16-bit: LN output / attention output
     void *qkv;    // [rows, 3W] 16-bit
     void *mlp;    // [rows, 4W] 16-bit
+    float *stats; // [rows, 2] fp32: (rstd, -rstd mean) of the hi plane's rows (folded LayerNorm)
 };
 
 // first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
@@ -61,6 +62,51 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
         EC_TRY(ec_layernorm(b.x, W, nullptr, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, W, dtype, s));
         EC_TRY(gemm(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, w.fc1_w, w.fc1_b, b.mlp, s));
         EC_TRY(gemm(rows, W, 4 * W, dtype, EC_EPI_RESID32, b.mlp, w.fc2_w, w.fc2_b, b.x, s));
+    }
+    return EC_OK;
+}
+
+// The same blocks with LayerNorm folded into the GEMMs around it (ec_vit_weights.ln_folded): the residual
+// stream lives as hi + lo 16-bit planes, six launches per block,
+//   row stats(hi) -> GEMM(qkv on raw hi rows, LN in the epilogue) -> attention -> GEMM(out, (hi, lo) +=)
+//   -> row stats(hi) -> GEMM(fc1 on raw hi rows, LN + QuickGELU in the epilogue) -> GEMM(fc2, (hi, lo) +=)
+// and the LayerNorm passes (4 + 2 bytes per element each) are replaced by statistics passes over the hi plane
+// (2 bytes per element): 16.04 -> 15.62 ms per block at the bench shape (tools/bench_fold.py), same rounding points.
+int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads, int dtype,
+                      const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled)
+{
+    const int rows = n_seq * S;
+    void *x_hi = b.x;
+    void *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)rows * W * 2;
+    const size_t esz = 2;
+    for (int l = 0; l < layers; l++) {
+        const ec_block_weights &w = blocks[l];
+        EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+        if (first_only && l == layers - 1) {
+            // the class-token-only last block (see run_blocks): keys and values of every token, the rest for row 0
+            // of every sequence, the planes addressed at row stride S * W and the statistics at stride S
+            const long ldx = (long)S * W;
+            const unsigned char *wqkv = static_cast<const unsigned char *>(w.qkv_w_ln);
+            EC_TRY(gemm_ln(rows, 2 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, wqkv + (size_t)W * W * esz, w.qkv_bf + W,
+                           b.stats, 1, w.qkv_cs + W, static_cast<unsigned char *>(b.qkv) + (size_t)W * esz, s, 3L * W));
+            EC_TRY(gemm_ln(n_seq, W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, S, w.qkv_cs,
+                           b.qkv, s, 3L * W * S, ldx));
+            EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, 1, dtype, s)
+                            : ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, 0, 1, dtype, s));
+            EC_TRY(gemm_hl(n_seq, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, ldx));
+            EC_TRY(ec_row_stats(x_hi, ldx, n_seq, W, LN_EPS, b.stats, dtype, s));
+            EC_TRY(gemm_ln(n_seq, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs,
+                           b.mlp, s, 0, ldx));
+            EC_TRY(gemm_hl(n_seq, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, ldx));
+            break;
+        }
+        EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s));
+        EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
+                        : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
+        EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s));
+        EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+        EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s));
+        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s));
     }
     return EC_OK;
 }
@@ -125,6 +171,7 @@ size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs
     b.h = sc.take(rows * W * 2);
     b.qkv = sc.take(rows * 3 * W * 2);
     b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
+    b.stats = (float *)sc.take(rows * 8);
     *small16 = sc.take((size_t)chunk * W * 2);
     void *lo = sc.take((size_t)chunk * W * 2);
     if (small16_lo) *small16_lo = lo;
@@ -233,11 +280,32 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     if (need > workspace_bytes)
         return ec::fail(EC_ERR_WORKSPACE, "ec_vit_encode: workspace %zu < %zu bytes", workspace_bytes,
                         need);
+    const bool folded = w->ln_folded && !w->low_latency;
+    if (folded)
+        for (int l = 0; l < w->layers; l++)
+            EC_REQUIRE(w->blocks[l].qkv_w_ln && w->blocks[l].qkv_cs && w->blocks[l].qkv_bf && w->blocks[l].fc1_w_ln &&
+                           w->blocks[l].fc1_cs && w->blocks[l].fc1_bf,
+                       "ec_vit_encode: ln_folded but block %d lacks its folded weights", l);
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int n = (n_img - i0 < chunk) ? n_img - i0 : chunk;
         const unsigned char *p = (const unsigned char *)patches + (size_t)i0 * G * w->kpad * esz;
         float *patch_out = (float *)b.mlp;
         EC_TRY(patch_embed(w, p, n * G, patch_out, stream));
+        if (folded) {
+            // residual stream as hi + lo planes in the fp32 stream's 4 bytes per element
+            void *x_hi = b.x, *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)n * S * W * 2;
+            EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,
+                                stream));
+            EC_TRY(run_blocks_folded(w->blocks, w->layers, n, S, W, w->heads, dt, b, stream, w->full_last_block == 0,
+                                     w->q_scaled != 0));
+            // the class rows back to fp32 (x = hi + lo) for ln_post; patch_out (the mlp buffer) is free by now
+            EC_TRY(join_hl_rows(x_hi, x_lo, (long)S * W, n, W, patch_out, dt, stream));
+            EC_TRY(ec_layernorm_split(patch_out, W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16, cls16_lo, W,
+                                      dt, stream));
+            EC_TRY(gemm3(n, w->out_dim, W, dt, false, cls16, cls16_lo, w->proj_w, w->proj_w_lo, nullptr,
+                         feats + (size_t)i0 * w->out_dim, stream));
+            continue;
+        }
         EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, b.x,
                             stream));
         EC_TRY(run_blocks(w->blocks, w->layers, n, S, W, w->heads, 0, dt, b, stream,

@@ -234,6 +234,15 @@ enum {
     /* training (ec_vit_train_*; default variant only): */
     EC_EPI_GELU16_SAVE = 4, /* C16 = QuickGELU(acc + bias) and aux16 = acc + bias (kept for the backward pass) */
     EC_EPI_GELU_BWD16 = 5,  /* C16 = (acc + bias) * QuickGELU'(aux16): the gradient through the activation */
+    /* LayerNorm folded into the GEMMs around it (the image tower's blocks; default variant only):
+     * the residual stream is kept as two 16-bit planes x = hi + lo -- hi in `dtype`, lo in fp16, the same 4 bytes per
+     * element as fp32 and ~2^-22 relative -- and hi, the RAW row, is the A operand of the GEMM that follows.  That
+     * GEMM runs on the gamma-scaled weight W' = W diag(gamma) and finishes LayerNorm in its epilogue:
+     *   LN(x) W^T + b = rstd (x W'^T) - rstd mean colsum(W') + (b + W beta),
+     * with (rstd, -rstd mean) per row from ec_row_stats and colsum / the folded bias per column from the packer. */
+    EC_EPI_RESID_HL = 6,    /* C = hi plane, aux = lo plane (fp16), both [M, N] at stride ldc: (hi, lo) <- split(hi + lo + acc + bias) */
+    EC_EPI_STORE16_LN = 7,  /* C16 = row_stats[m][0] * acc + row_stats[m][1] * col_sums[n] + bias[n] */
+    EC_EPI_GELU16_LN = 8,   /* C16 = QuickGELU(the same) */
 };
 
 typedef struct {
@@ -270,6 +279,10 @@ typedef struct {
                           copies).  K = rows per batch (a multiple of 64), batch s reads rows s*K ..; EC_EPI_STORE32,
                           no bias, variant 0, M a multiple of 8. */
     int k_rows;        /* transposed: the rows that exist (<= splits * K); rows past it read as zero */
+    /* EC_EPI_STORE16_LN / EC_EPI_GELU16_LN: */
+    const float *row_stats;   /* fp32 pairs (rstd, -rstd * mean) of the A rows; row m at row_stats + 2 * m * row_stats_stride */
+    long row_stats_stride;    /* in rows (0 = 1): the class-token rows of a [n, S] statistics array are S apart */
+    const float *col_sums;    /* fp32 [N]: sum over k of W[n][k] as rounded to 16 bit */
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -280,6 +293,12 @@ EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
 EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
                         const float *beta, int rows, int width, float eps, void *out16, long ldo,
                         int dtype, ec_stream_t stream);
+
+/* (rstd, -rstd * mean) of `rows` 16-bit rows of `width` elements at row stride ldx -> stats fp32 [rows][2]: the
+ * LayerNorm statistics (eps inside the sqrt) of the hi plane of the residual stream, what EC_EPI_STORE16_LN /
+ * EC_EPI_GELU16_LN multiply and add.  Reads 2 bytes per element where ec_layernorm reads 4 and writes 2. */
+EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
+                        ec_stream_t stream);
 
 /* Split-precision helpers ("precise" towers): a value is carried as two 16-bit numbers
  * hi = round16(x), lo = round16(x - hi), and a product x.w as xh.wh + xh.wl + xl.wh with
@@ -358,6 +377,14 @@ typedef struct {
     const float *fc2_b;
     /* lo parts (w - round16(w)) of the four matrices; only read by precise towers, else NULL */
     const void *qkv_w_lo, *out_w_lo, *fc1_w_lo, *fc2_w_lo;
+    /* LayerNorm folded into the two GEMMs that consume it (ec_vit_weights.ln_folded; EC_EPI_*_LN): the weight
+     * with its columns scaled by the LayerNorm gain BEFORE the rounding to 16 bit, W' = W diag(gamma) [N, W]; the
+     * fp32 sum of every row of W' as rounded [N]; and the bias with the LayerNorm offset folded in, b + W beta [N]
+     * (ln_1 into in_proj, ln_2 into c_fc).  NULL otherwise. */
+    const void *qkv_w_ln;
+    const float *qkv_cs, *qkv_bf;
+    const void *fc1_w_ln;
+    const float *fc1_cs, *fc1_bf;
 } ec_block_weights;
 
 typedef struct {
@@ -391,6 +418,14 @@ typedef struct {
                                    blocks call ec_attention_scaled_q: the attention kernel then has nothing to
                                    scale -- the product is rounded once, like an unscaled q.  Inference only:
                                    ec_vit_train_forward and precise towers take a plain q (0). */
+    int ln_folded;              /* != 0: the blocks' LayerNorms run folded into the GEMMs around them (the *_ln / *_cs /
+                                   *_bf fields of every block are set): the residual stream is kept as hi + lo 16-bit
+                                   planes, the residual GEMMs update it in that form (EC_EPI_RESID_HL), ec_row_stats
+                                   reads the hi plane (2 bytes per element instead of LayerNorm's 4 + 2) and the QKV /
+                                   c_fc GEMMs take the raw hi rows and finish LayerNorm in their epilogues
+                                   (EC_EPI_STORE16_LN / EC_EPI_GELU16_LN).  Same rounding points as the plain chain
+                                   (the A operand is rounded once either way).  Ignored by precise / low_latency
+                                   towers and by the training entry points. */
 } ec_vit_weights;
 
 typedef struct {

@@ -306,7 +306,9 @@ CONFIGS = {
 def _tower(cfg, seed=0, dtype='float16'):
     from eventclip_amd import clip as eclip, ft
     sd = eclip.random_state_dict(cfg, seed=seed)
-    model = eclip.CLIP(cfg, sd, dtype=dtype, full_last_block=True).cuda()
+    # the inference tower packed the way the training path holds its weights (plain q, LayerNorm as its own launch):
+    # the two forwards are then the same kernels on the same operand copies
+    model = eclip.CLIP(cfg, sd, dtype=dtype, full_last_block=True, ln_folded=False, q_scaled=False).cuda()
     return model, ft.VisualTower(model), sd
 
 

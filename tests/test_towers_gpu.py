@@ -361,8 +361,36 @@ def test_low_latency_mode_gives_the_same_features(hip, arch, n):
     sd = eclip.random_state_dict(cfg, seed=3)
     torch.manual_seed(n)
     imgs = torch.randn(n, 3, cfg['image_size'], cfg['image_size'])
-    base = eclip.CLIP(cfg, sd).cuda().encode_image(imgs.cuda())
+    # the K-batched launches run the plain LayerNorm chain (their fix-up kernel has no folded epilogue): compare
+    # with the same chain in one pass, and with the default (folded) tower at the 16-bit operands' own tolerance
+    base = eclip.CLIP(cfg, sd, ln_folded=False).cuda().encode_image(imgs.cuda())
     fast = eclip.CLIP(cfg, sd, low_latency=True).cuda().encode_image(imgs.cuda())
     assert torch.isfinite(fast).all()
     assert float((fast - base).abs().max()) < 3e-4 * float(base.abs().max())
     assert not torch.equal(fast, base)          # the K-batched route really ran
+    folded = eclip.CLIP(cfg, sd).cuda().encode_image(imgs.cuda())
+    assert float((folded - base).abs().max()) < 1e-3 * float(base.abs().max())
+
+
+@pytest.mark.parametrize('arch', ['ViT-B/32', 'ViT-L/14'])
+def test_folded_layernorm_tower_matches_the_plain_chain_and_the_oracle(hip, arch):
+    """ec_vit_weights.ln_folded (the default): LayerNorm finished in the QKV / c_fc epilogues on the raw hi rows of
+    a residual stream kept as hi + lo planes, against the plain LayerNorm launches on an fp32 stream and against
+    the fp32 oracle: the same distance from the oracle (the A operand is rounded once either way), and the
+    class-token-only last block still bit-identical to computing every token."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config(arch)
+    sd = eclip.random_state_dict(cfg, seed=11)
+    torch.manual_seed(4)
+    imgs = torch.randn(6, 3, cfg['image_size'], cfg['image_size'])
+    want = clip_ref.encode_image(sd, cfg, imgs)
+    plain = eclip.CLIP(cfg, sd, ln_folded=False).cuda().encode_image(imgs.cuda()).cpu()
+    folded = eclip.CLIP(cfg, sd).cuda().encode_image(imgs.cuda()).cpu()
+    every = eclip.CLIP(cfg, sd, full_last_block=True).cuda().encode_image(imgs.cuda()).cpu()
+    mag = float(want.abs().max())
+    e_plain, e_fold = float((plain - want).abs().max()) / mag, float((folded - want).abs().max()) / mag
+    print(f'\n[{arch}] feature error vs the fp32 oracle: plain chain {e_plain:.2e}, folded {e_fold:.2e}')
+    assert e_fold < 1e-3 and e_fold < 1.5 * e_plain + 1e-4
+    assert torch.equal(folded, every)
