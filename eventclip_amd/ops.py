@@ -18,28 +18,34 @@ def dtype_code(t):
 
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
-         splits=1, K=None, ws=None):
+         splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
-    splits > 1: A [M, splits * K], W [N, splits * K] -> out [splits, M, N] partial products (fp32)."""
+    splits > 1: A [M, splits * K], W [N, splits * K] -> out [splits, M, N] partial products (fp32).
+    LayerNorm folded into the GEMM: resid_hl (``out`` = the hi plane in A's dtype, ``aux`` = the fp16 lo plane, both
+    updated in place: (hi, lo) <- split(hi + lo + acc + bias)); store16_ln / gelu16_ln (``row_stats`` fp32 [M, 2] =
+    (rstd, -rstd mean) of A's rows from ``row_stats``, ``col_sums`` fp32 [N] = row sums of W as rounded)."""
     import torch
     _lib.require_gpu()
     epi = {'store16': _lib.EC_EPI_STORE16, 'gelu16': _lib.EC_EPI_GELU16,
            'resid32': _lib.EC_EPI_RESID32, 'store32': _lib.EC_EPI_STORE32,
-           'gelu16_save': _lib.EC_EPI_GELU16_SAVE, 'gelu_bwd16': _lib.EC_EPI_GELU_BWD16}[epilogue]
+           'gelu16_save': _lib.EC_EPI_GELU16_SAVE, 'gelu_bwd16': _lib.EC_EPI_GELU_BWD16,
+           'resid_hl': _lib.EC_EPI_RESID_HL, 'store16_ln': _lib.EC_EPI_STORE16_LN, 'gelu16_ln': _lib.EC_EPI_GELU16_LN}[epilogue]
     M, KA = A.shape
     N = W.shape[0]
     if K is None:
         assert KA % splits == 0
         K = KA // splits
     assert W.shape[1] == KA and A.dtype == W.dtype and W.stride(1) == 1 and A.stride(1) == 1
-    out16 = epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16, _lib.EC_EPI_GELU16_SAVE, _lib.EC_EPI_GELU_BWD16)
+    out16 = epi in (_lib.EC_EPI_STORE16, _lib.EC_EPI_GELU16, _lib.EC_EPI_GELU16_SAVE, _lib.EC_EPI_GELU_BWD16,
+                    _lib.EC_EPI_RESID_HL, _lib.EC_EPI_STORE16_LN, _lib.EC_EPI_GELU16_LN)
     want = A.dtype if out16 else torch.float32
     shape = (M, N) if splits == 1 else (splits, M, N)
     if out is None:
         assert epilogue != 'resid32' or resid is not None, 'resid32 needs the fp32 residual tensor as out'
         out = torch.empty(shape, dtype=want, device=A.device)
+    assert (epilogue != 'resid_hl' or aux is not None) and (not epilogue.endswith('_ln') or row_stats is not None)
     assert out.dtype == want and tuple(out.shape) == shape and out.stride(-1) == 1, \
         f'{epilogue} writes a {want} {shape} tensor, got {out.dtype} {tuple(out.shape)}'
     a = _lib.EcGemmArgs()
@@ -54,8 +60,12 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
         assert resid.dtype == torch.float32 and tuple(resid.shape) == (M, N) and resid.stride(0) == out.stride(-2)
         a.resid = resid.data_ptr()
     if aux is not None:
-        assert aux.dtype == A.dtype and tuple(aux.shape) == (M, N) and aux.stride(0) == out.stride(-2)
+        want_aux = torch.float16 if epilogue == 'resid_hl' else A.dtype          # the lo plane is always fp16
+        assert aux.dtype == want_aux and tuple(aux.shape) == (M, N) and aux.stride(0) == out.stride(-2)
         a.aux = aux.data_ptr()
+    if row_stats is not None:
+        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and col_sums.dtype == torch.float32
+        a.row_stats, a.col_sums, a.row_stats_stride = row_stats.data_ptr(), col_sums.data_ptr(), row_stats_stride
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
@@ -89,4 +99,16 @@ def gemm_rows(A, W, splits=1, out=None):
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
+    return out
+
+
+def row_stats(x16, eps=1e-5):
+    """(rstd, -rstd * mean) of the rows of a 16-bit [rows, width] tensor -> fp32 [rows, 2] (ec_row_stats)."""
+    import torch
+    _lib.require_gpu()
+    rows, width = x16.shape
+    assert x16.stride(1) == 1
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x16.device)
+    _lib.check(_lib.lib().ec_row_stats(x16.data_ptr(), x16.stride(0), rows, width, float(eps), out.data_ptr(),
+                                       dtype_code(x16.dtype), _lib.stream_ptr()), 'ec_row_stats')
     return out

@@ -136,3 +136,100 @@ def test_only_the_default_kernel_is_in_the_product_library(hip):
     for v in (1, 2, 3, 5, 10, 16):
         with pytest.raises(RuntimeError, match='unknown variant'):
             ops.gemm(A, W, None, 'store16', variant=v)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMMs around it (EC_EPI_RESID_HL / ec_row_stats / EC_EPI_STORE16_LN / GELU16_LN)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 768, 3072), (77, 512, 64), (5, 256, 128), (300, 48, 64)])
+def test_residual_update_on_hi_lo_planes(M, N, K, dt, hip):
+    """(hi, lo) <- split(hi + lo + A W^T + b): the planes reproduce the fp32 residual update to ~2^-22 of the
+    stream's magnitude, hi is the stream rounded to the operand type (what the next GEMM reads)."""
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn(M, K, device='cuda', generator=g).to(dtype)
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g) * 4 + 0.5
+    hi = x.to(dtype)
+    lo = (x - hi.float()).half()
+    want = hi.float() + lo.float() + A.float() @ W.float().t() + bias
+    ops.gemm(A, W, bias, 'resid_hl', out=hi, aux=lo)
+    got = hi.float() + lo.float()
+    assert float((got - want).abs().max()) < 1e-6 * float(want.abs().max()) + 2e-5     # fp32 summation order + 2^-22
+    assert float((hi.float() - want).abs().max()) <= (2 ** -10 if dt == 'float16' else 2 ** -7) * float(want.abs().max())
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('rows,width,stride', [(301, 1024, 1024), (9, 768, 5 * 768), (64, 64, 64), (1000, 1280, 1280)])
+def test_row_stats(rows, width, stride, dt, hip):
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    buf = (torch.randn(rows, stride, device='cuda') * 3 + 0.7).to(dtype)
+    x = buf[:, :width]
+    st = ops.row_stats(x)
+    x32 = x.float()
+    rstd = (x32.var(1, unbiased=False) + 1e-5).rsqrt()
+    torch.testing.assert_close(st[:, 0], rstd, rtol=1e-5, atol=0)
+    torch.testing.assert_close(st[:, 1], -rstd * x32.mean(1), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('epilogue', ['store16_ln', 'gelu16_ln'])
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 3072, 1024), (1000, 4096, 1024), (77, 768, 640), (5, 512, 64), (300, 48, 128)])
+def test_layernorm_finished_in_the_gemm_epilogue(M, N, K, epilogue, dt, hip):
+    """LN(x) W^T + b from the RAW rows: A = x (16 bit), W' = W diag(gamma) (rounded once), and
+    rstd (x W'^T) - rstd mean colsum(W') + (b + W beta) in the epilogue -- against fp32 LayerNorm + linear on the
+    same x, and no further from it than LayerNorm -> 16 bit -> the plain GEMM."""
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device='cuda').manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, device='cuda', generator=g) * 2 + 0.4).to(dtype)
+    gamma = 1 + 0.2 * torch.randn(K, device='cuda', generator=g)
+    beta = 0.3 * torch.randn(K, device='cuda', generator=g)
+    Wt = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    bias = 0.1 * torch.randn(N, device='cuda', generator=g)
+    Wp = (Wt * gamma[None, :]).to(dtype)
+    cs, bf = Wp.float().sum(1).contiguous(), (bias + Wt @ beta).contiguous()
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ Wt.t() + bias
+    act = (lambda t: t * torch.sigmoid(1.702 * t)) if epilogue == 'gelu16_ln' else (lambda t: t)
+    got = ops.gemm(x, Wp, bf, epilogue, row_stats=ops.row_stats(x), col_sums=cs)
+    h = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5).to(dtype)
+    plain = ops.gemm(h, Wt.to(dtype), bias, 'gelu16' if epilogue == 'gelu16_ln' else 'store16')
+    mag = float(act(ref).abs().max())
+    e_fold, e_plain = float((got.float() - act(ref)).abs().max()) / mag, float((plain.float() - act(ref)).abs().max()) / mag
+    assert e_fold < (2e-3 if dt == 'float16' else 1.6e-2) and e_fold < 1.5 * e_plain + 1e-4, (e_fold, e_plain)
+
+
+def test_folded_epilogues_on_the_class_token_rows(hip):
+    """The strided forms the last block uses: A rows S * W apart, statistics S rows apart, planes updated in place
+    at row stride S * W -- the same values as the dense call on the gathered rows."""
+    import torch
+    from eventclip_amd import ops
+    torch.manual_seed(3)
+    n, S, W = 7, 5, 256
+    x = (torch.randn(n * S, W, device='cuda') * 2).half()
+    gamma, beta = 1 + 0.1 * torch.randn(W, device='cuda'), 0.1 * torch.randn(W, device='cuda')
+    Wt = torch.randn(3 * W, W, device='cuda') / W ** 0.5
+    Wp, bias = (Wt * gamma[None, :]).half(), 0.1 * torch.randn(3 * W, device='cuda')
+    cs, bf = Wp.float().sum(1).contiguous(), (bias + Wt @ beta).contiguous()
+    st_all = ops.row_stats(x)
+    cls_rows = x.view(n, S * W)[:, :W]                       # row stride S * W
+    got = ops.gemm(cls_rows, Wp, bf, 'store16_ln', row_stats=st_all, col_sums=cs, row_stats_stride=S)
+    dense = x.view(n, S, W)[:, 0].contiguous()
+    want = ops.gemm(dense, Wp, bf, 'store16_ln', row_stats=ops.row_stats(dense), col_sums=cs)
+    assert torch.equal(got, want)
+    # the residual update of the class rows only, in place in the planes
+    A = torch.randn(n, 128, device='cuda').half()
+    Wo, bo = (torch.randn(W, 128, device='cuda') * 0.1).half(), torch.randn(W, device='cuda')
+    hi, lo = x.clone(), torch.zeros_like(x)
+    ops.gemm(A, Wo, bo, 'resid_hl', out=hi.view(n, S * W)[:, :W], aux=lo.view(n, S * W)[:, :W])
+    want = x.view(n, S, W)[:, 0].float() + A.float() @ Wo.float().t() + bo
+    got = hi.view(n, S, W)[:, 0].float() + lo.view(n, S, W)[:, 0].float()
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert torch.equal(hi.view(n, S, W)[:, 1:], x.view(n, S, W)[:, 1:])      # the other tokens untouched

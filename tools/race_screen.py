@@ -26,7 +26,11 @@ for (M, N, K) in shapes:
     for epi in ('store16', 'gelu16', 'resid32', 'store32'):
         first = None
         for r in range(reps):
-            out = resid.clone() if epi == 'resid32' else None
+            if epi == 'resid32':
+                out = resid.clone()
+            else:   # a poisoned output buffer: a store the kernel misses cannot hide behind the previous repeat's value
+                out = torch.full((M, N), float('nan'), dtype=torch.float16 if epi in ('store16', 'gelu16') else torch.float32,
+                                 device='cuda')
             got = ops.gemm(A, W, bias, epi, out=out)
             if r % 3 == 0:
                 noise.add_(1.0)
@@ -35,7 +39,7 @@ for (M, N, K) in shapes:
                 ref = want * torch.sigmoid(1.702 * want) if epi == 'gelu16' else (want + resid if epi == 'resid32' else want)
                 tol = 2e-3 if epi in ('store16', 'gelu16') else 1e-4
                 err = float((got.float() - ref).abs().max() / ref.abs().max())
-                if err > tol:
+                if not err <= tol:
                     bad += 1
                     print('MISMATCH vs torch', (M, N, K), epi, err)
             elif not torch.equal(got, first):
@@ -106,6 +110,46 @@ for (M, N, K) in ((257, 1024, 1024), (257, 3072, 1024), (514, 1024, 4096), (50, 
             e = float((out.float() - ref).abs().max() / ref.abs().max())
             return e if e > tol else None
         repeat(('ws', M, N, K, epi), run, check)
+
+# LayerNorm folded into the GEMMs (round 3): hi / lo residual planes, row statistics, LN-finishing epilogues
+for (M, N, K) in ((65792, 1024, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
+    g = torch.Generator(device='cuda').manual_seed(M + N * 5 + K)
+    A = torch.randn(M, K, device='cuda', generator=g).half()
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g) * 3
+    hi0, lo0 = x.half(), (x - x.half().float()).half()
+    want = hi0.float() + lo0.float() + A.float() @ W.float().t() + bias
+
+    def run_hl():
+        hi, lo = hi0.clone(), lo0.clone()
+        ops.gemm(A, W, bias, 'resid_hl', out=hi, aux=lo)
+        return hi, lo
+
+    def check_hl(hi, lo):
+        e = float((hi.float() + lo.float() - want).abs().max() / want.abs().max())
+        return e if e > 2e-6 else None
+    repeat(('resid_hl', M, N, K), run_hl, check_hl)
+for (M, N, K) in ((65792, 3072, 1024), (65792, 4096, 1024), (70001, 768, 640), (514, 3072, 1024)):
+    g = torch.Generator(device='cuda').manual_seed(M + N * 3 + K * 7)
+    X = (torch.randn(M, K, device='cuda', generator=g) * 2 + 0.3).half()
+    gamma, beta = 1 + 0.2 * torch.randn(K, device='cuda', generator=g), 0.3 * torch.randn(K, device='cuda', generator=g)
+    Wt = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    bias = torch.randn(N, device='cuda', generator=g) * 0.1
+    Wp = (Wt * gamma[None, :]).half()
+    cs, bf = Wp.float().sum(1).contiguous(), (bias + Wt @ beta).contiguous()
+    ref = torch.nn.functional.layer_norm(X.float(), (K,), gamma, beta, 1e-5) @ Wt.t() + bias
+    for epi in ('store16_ln', 'gelu16_ln'):
+        def run_ln(epi=epi):
+            st = ops.row_stats(X)
+            out = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda')
+            return ops.gemm(X, Wp, bf, epi, out=out, row_stats=st, col_sums=cs), st
+
+        def check_ln(out, st, epi=epi):
+            w = ref * torch.sigmoid(1.702 * ref) if epi == 'gelu16_ln' else ref
+            e = float((out.float() - w).abs().max() / w.abs().max())
+            return e if not e <= 2e-3 else None
+        repeat((epi, M, N, K), run_ln, check_ln)
 
 print('race screen:', 'CLEAN' if bad == 0 else f'{bad} problems', f'({reps} repeats per case)')
 sys.exit(1 if bad else 0)

@@ -18,7 +18,8 @@ from eventclip_amd import ops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 variants = [int(v) for v in sys.argv[2:]] or [2, 1, 3, 0]
-shapes = [(1000, 3072, 1024), (3000, 1024, 1024), (777, 4096, 1024), (2570, 1024, 4096), (70001, 768, 640), (257 * 12, 1024, 64)]
+shapes = [(1000, 3072, 1024), (257 * 3, 1024, 1024), (513, 1024, 4096), (77, 768, 640), (5, 512, 64), (256, 256, 128), (300, 48, 64),
+          (70001, 768, 640)]
 side = torch.cuda.Stream()
 noise_a = torch.empty(96 << 20, device='cuda')
 noise_b = torch.empty(96 << 20, device='cuda')
@@ -31,19 +32,23 @@ for v in variants:
         bias = torch.randn(N, device='cuda', generator=g)
         resid = torch.randn(M, N, device='cuda', generator=g)
         want = A.float() @ W.float().t() + bias
-        for epi in ('store16', 'resid32'):
+        for epi in ('store16', 'resid32', 'gelu16', 'store32'):
             first, bad = None, 0
             for r in range(reps):
                 if r % 2 == 0:
                     with torch.cuda.stream(side):       # concurrent traffic, not between launches
                         noise_b.copy_(noise_a)
-                out = resid.clone() if epi == 'resid32' else None
+                if epi == 'resid32':
+                    out = resid.clone()
+                else:           # poisoned output: a store the kernel misses shows up (a reused buffer would hide it)
+                    out = torch.full((M, N), float('nan'), dtype=torch.float16 if epi in ('store16', 'gelu16') else torch.float32,
+                                     device='cuda')
                 got = ops.gemm(A, W, bias, epi, out=out, variant=v)
                 if first is None:
                     first = got.clone()
-                    ref = want + resid if epi == 'resid32' else want
+                    ref = want + resid if epi == 'resid32' else (want * torch.sigmoid(1.702 * want) if epi == 'gelu16' else want)
                     err = float((got.float() - ref).abs().max() / ref.abs().max())
-                    if err > (2e-3 if epi == 'store16' else 1e-4):
+                    if not err <= (2e-3 if epi in ('store16', 'gelu16') else 1e-4):
                         print('MISMATCH vs torch', v, (M, N, K), epi, err, flush=True)
                         bad += 1
                 elif not torch.equal(got, first):
