@@ -56,6 +56,8 @@ struct GemmArgs {
     const float *rowstat;       // consumers: [M][2] (rstd, -rstd * mean) of the A rows, row m at rowstat + 2 m rowstat_stride
     long rowstat_stride;
     const float *colsum;        // consumers: [N] sum over k of the (gamma-scaled, rounded) weight row
+    float *stat_out;            // RESID_HL: optional [M][stat_groups][2] (sum, sum of squares) of the new hi plane per 64 columns
+    int stat_groups;            // N / 64
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -67,6 +69,11 @@ __device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3)
 
 
 __device__ __forceinline__ int swz_key(int row) { return (row & 7) ^ ((row >> 3) & 6); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ float quick_gelu(float x)
 {
@@ -252,7 +259,7 @@ __device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[T
 // lo = fp16(x - hi) keeps the stream at ~2^-22 relative -- the same 4 bytes per element as the fp32 stream, and no
 // LayerNorm pass in between.  Same transpose through LDS as epilogue32_lds; afterwards a lane holds 8 consecutive
 // columns of two rows, so each plane is read and written with 16-byte accesses (8 lanes = one 128-byte line).
-template <int DT, int TM>
+template <int DT, int TM, bool STATS>
 __device__ __forceinline__ void epilogue_hl_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
                                                 int lane, float *scratch)
 {
@@ -300,16 +307,31 @@ __device__ __forceinline__ void epilogue_hl_lds(const GemmArgs &g, f32x4 (&acc)[
             const int m = m_base + i * 16 + row;
             v8 oh;
             f16x8 ol;
+            float ps = 0.f, pq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float x = (float)xh[i % DEPTH][p][e] + (float)xl[i % DEPTH][p][e] + (e < 4 ? a[e] : b[e - 4]);
                 oh[e] = to16(x, elem());
-                ol[e] = (_Float16)(x - (float)oh[e]);
+                const float h = (float)oh[e];
+                ol[e] = (_Float16)(x - h);
+                if (STATS) ps += h, pq = __builtin_fmaf(h, h, pq);
             }
             if (m < g.M && col_ok) {
                 const long off = (long)m * g.ldc + col;
                 *reinterpret_cast<v8 *>((elem *)g.C + off) = oh;
                 *reinterpret_cast<f16x8 *>((_Float16 *)g.aux + off) = ol;
+            }
+            if (STATS) {
+                // (sum, sum of squares) of the NEW hi values over this wave's 64 columns of the row: eight lanes
+                // hold one row; the LayerNorm statistics the next GEMM needs come out of the same pass
+                // (ec_row_stats_merge adds the N / 64 groups up), instead of a pass over the hi plane
+                // (DPP adds: lanes 1 and 2 apart inside a quad, then the other quad of the eight through
+                // row_half_mirror -- three vector instructions per value, no LDS round trip)
+                ps += dpp_f32<0xB1>(ps), pq += dpp_f32<0xB1>(pq);      // quad_perm [1, 0, 3, 2]
+                ps += dpp_f32<0x4E>(ps), pq += dpp_f32<0x4E>(pq);      // quad_perm [2, 3, 0, 1]
+                ps += dpp_f32<0x141>(ps), pq += dpp_f32<0x141>(pq);    // row_half_mirror
+                if (c8 == 0 && m < g.M && col_ok)
+                    *reinterpret_cast<float2 *>(g.stat_out + ((long)m * g.stat_groups + (n_base >> 6)) * 2) = make_float2(ps, pq);
             }
         }
         if (i + DEPTH < TM) fetch(i + DEPTH);
@@ -1340,9 +1362,14 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             issue(3, 0);
             issue(1, 0);
         }
-        if constexpr (EPI == EC_EPI_RESID_HL)
-            epilogue_hl_lds<DT, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                   reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+        if constexpr (EPI == EC_EPI_RESID_HL) {
+            if (ge.stat_out)
+                epilogue_hl_lds<DT, 8, true>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                             reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+            else
+                epilogue_hl_lds<DT, 8, false>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
+                                              reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
+        }
         else if constexpr (!epi_is16(EPI))
             epilogue32_lds<EPI, 8, 1, TN>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
                                           reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
@@ -1832,6 +1859,11 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.splits = a->splits > 1 ? a->splits : 1, g.split_stride = a->split_stride;
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
+    g.stat_out = nullptr, g.stat_groups = 0;
+    if (a->epilogue == EC_EPI_RESID_HL && a->row_sums) {
+        EC_REQUIRE(a->N % 64 == 0, "ec_gemm: row_sums needs N %% 64 == 0 (N = %d)", a->N);
+        g.stat_out = a->row_sums, g.stat_groups = a->N / 64;
+    }
     if (g.tn) {
         g.lda = a->lda ? a->lda : a->M, g.ldw = a->ldw ? a->ldw : a->N;
         EC_REQUIRE(a->epilogue == EC_EPI_STORE32 && a->variant == 0 && !a->bias && !a->ws,

@@ -137,6 +137,34 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *x, long ldx,
     if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(rstd, -rstd * mean);
 }
 
+// per-group (sum, sum of squares) of a row's hi values (EC_EPI_RESID_HL, ec_gemm_args.row_sums) -> (rstd, -rstd mean)
+__global__ __launch_bounds__(256) void row_stats_merge_kernel(const float *sums, int rows, int groups, int width, float eps,
+                                                              float *stats)
+{
+    // sixteen lanes per row: a row's groups are contiguous (128 B at 16 groups), one coalesced 8-byte load per lane
+    const int sub = threadIdx.x & 15;
+    const long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    float s = 0.f, q = 0.f;
+    if (row < rows) {
+        const float2 *p = reinterpret_cast<const float2 *>(sums) + row * groups;
+        for (int i = sub; i < groups; i += 16) {
+            const float2 v = p[i];
+            s += v.x, q += v.y;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        s += __shfl_xor(s, o, 16);
+        q += __shfl_xor(q, o, 16);
+    }
+    if (row < rows && sub == 0) {
+        const float mean = s / (float)width;
+        const float var = fmaxf(q / (float)width - mean * mean, 0.f);
+        const float rstd = 1.f / __builtin_sqrtf(var + eps);
+        *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(rstd, -rstd * mean);
+    }
+}
+
 // fp32 [n] -> (optionally QuickGELU) -> 16-bit hi and lo parts
 template <int DT>
 __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, int gelu, void *hi,
@@ -314,6 +342,20 @@ EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float ep
         hipLaunchKernelGGL(row_stats_kernel<EC_BF16>, dim3(ec::ceil_div(rows, 4)), dim3(256), 0, s, x16, ldx, rows, width, eps, stats);
     else
         return ec::fail(EC_ERR_INVALID, "ec_row_stats: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_row_stats_merge(const float *sums, int rows, int groups, int width, float eps, float *stats,
+                              ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && groups > 0 && width == groups * 64, "ec_row_stats_merge: width %d != 64 x %d groups", width, groups);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(sums && stats, "ec_row_stats_merge: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * (groups * 8.0 + 8.0));
+    hipLaunchKernelGGL(row_stats_merge_kernel, dim3(ec::ceil_div(rows, 16)), dim3(256), 0, s, sums, rows, groups, width, eps,
+                       stats);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -45,11 +45,12 @@ inline int gemm(int M, int N, int K, int dtype, int epi, const void *A, const vo
 
 // the folded-LayerNorm forms (EC_EPI_RESID_HL: aux = lo plane; EC_EPI_*_LN: row statistics + column sums)
 inline int gemm_hl(int M, int N, int K, int dtype, const void *A, const void *W, const float *bias, void *x_hi,
-                   void *x_lo, ec_stream_t s, long ldc = 0)
+                   void *x_lo, ec_stream_t s, long ldc = 0, float *row_sums = nullptr)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = EC_EPI_RESID_HL, g.variant = 0;
     g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = x_hi, g.ldc = ldc ? ldc : N, g.aux = x_lo;
+    g.row_sums = row_sums;
     return ec_gemm(&g, s);
 }
 inline int gemm_ln(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,

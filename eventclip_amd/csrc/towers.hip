@@ -21,6 +21,7 @@ struct BlockBufs {
     void *qkv;    // [rows, 3W] 16-bit
     void *mlp;    // [rows, 4W] 16-bit
     float *stats; // [rows, 2] fp32: (rstd, -rstd mean) of the hi plane's rows (folded LayerNorm)
+    float *sums;  // [rows, W / 64, 2] fp32: per-group (sum, sum of squares) out of the residual GEMMs' epilogues
 };
 
 // first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
@@ -68,10 +69,11 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
 
 // The same blocks with LayerNorm folded into the GEMMs around it (ec_vit_weights.ln_folded): the residual
 // stream lives as hi + lo 16-bit planes, six launches per block,
-//   row stats(hi) -> GEMM(qkv on raw hi rows, LN in the epilogue) -> attention -> GEMM(out, (hi, lo) +=)
-//   -> row stats(hi) -> GEMM(fc1 on raw hi rows, LN + QuickGELU in the epilogue) -> GEMM(fc2, (hi, lo) +=)
-// and the LayerNorm passes (4 + 2 bytes per element each) are replaced by statistics passes over the hi plane
-// (2 bytes per element): 16.04 -> 15.62 ms per block at the bench shape (tools/bench_fold.py), same rounding points.
+//   GEMM(qkv on raw hi rows, LN in the epilogue) -> attention -> GEMM(out, (hi, lo) +=, row sums) -> merge
+//   -> GEMM(fc1 on raw hi rows, LN + QuickGELU in the epilogue) -> GEMM(fc2, (hi, lo) +=, row sums) -> merge
+// and the LayerNorm passes (4 + 2 bytes per element each) are gone: 16.24 -> 15.48 ms per block at the bench shape
+// (tools/bench_fold.py; 15.87 with a statistics pass over the hi plane instead of the epilogue's sums), same
+// rounding points.
 int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads, int dtype,
                       const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled)
 {
@@ -79,9 +81,15 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
     void *x_hi = b.x;
     void *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)rows * W * 2;
     const size_t esz = 2;
+    // The statistics of a LayerNorm's input come out of the epilogue of the residual GEMM that wrote it (per-group
+    // sums of the new hi values, merged by a 40 us kernel); only the first block's ln_1 reads the plane itself
+    // (the embedding kernel wrote it).  Widths that are not a multiple of 64 keep the pass over the plane.
+    const bool fused = W % 64 == 0;
+    float *sums = fused ? b.sums : nullptr;
+    const int groups = W / 64;
+    EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
-        EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
         if (first_only && l == layers - 1) {
             // the class-token-only last block (see run_blocks): keys and values of every token, the rest for row 0
             // of every sequence, the planes addressed at row stride S * W and the statistics at stride S
@@ -93,8 +101,11 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
                            b.qkv, s, 3L * W * S, ldx));
             EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, 1, dtype, s)
                             : ec_attention_rows(b.qkv, b.h, n_seq, S, W, heads, 0, 1, dtype, s));
-            EC_TRY(gemm_hl(n_seq, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, ldx));
-            EC_TRY(ec_row_stats(x_hi, ldx, n_seq, W, LN_EPS, b.stats, dtype, s));
+            EC_TRY(gemm_hl(n_seq, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, ldx, sums));
+            if (fused)
+                EC_TRY(ec_row_stats_merge(sums, n_seq, groups, W, LN_EPS, b.stats, s));
+            else
+                EC_TRY(ec_row_stats(x_hi, ldx, n_seq, W, LN_EPS, b.stats, dtype, s));
             EC_TRY(gemm_ln(n_seq, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs,
                            b.mlp, s, 0, ldx));
             EC_TRY(gemm_hl(n_seq, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, ldx));
@@ -103,10 +114,19 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
         EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s));
         EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
                         : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
-        EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s));
-        EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+        EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums));
+        if (fused)
+            EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
+        else
+            EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
         EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s));
-        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s));
+        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, l + 1 < layers ? sums : nullptr));
+        if (l + 1 < layers) {
+            if (fused)
+                EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
+            else
+                EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+        }
     }
     return EC_OK;
 }
@@ -172,6 +192,7 @@ size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs
     b.qkv = sc.take(rows * 3 * W * 2);
     b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
     b.stats = (float *)sc.take(rows * 8);
+    b.sums = (float *)sc.take(rows * (size_t)(W / 64 + 1) * 8);
     *small16 = sc.take((size_t)chunk * W * 2);
     void *lo = sc.take((size_t)chunk * W * 2);
     if (small16_lo) *small16_lo = lo;

@@ -18,7 +18,7 @@ def dtype_code(t):
 
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
-         splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0):
+         splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
@@ -66,6 +66,9 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     if row_stats is not None:
         assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and col_sums.dtype == torch.float32
         a.row_stats, a.col_sums, a.row_stats_stride = row_stats.data_ptr(), col_sums.data_ptr(), row_stats_stride
+    if row_sums is not None:      # resid_hl: (sum, sum of squares) of the new hi plane per 64-column group
+        assert row_sums.dtype == torch.float32 and row_sums.is_contiguous() and row_sums.numel() == M * (N // 64) * 2
+        a.row_sums = row_sums.data_ptr()
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
@@ -96,6 +99,9 @@ def gemm_rows(A, W, splits=1, out=None):
     a.W, a.ldw = W.data_ptr(), W.stride(0)
     a.C, a.ldc = out.data_ptr(), out.stride(-2)
     a.transposed, a.k_rows = 1, rows
+    if row_sums is not None:      # resid_hl: (sum, sum of squares) of the new hi plane per 64-column group
+        assert row_sums.dtype == torch.float32 and row_sums.is_contiguous() and row_sums.numel() == M * (N // 64) * 2
+        a.row_sums = row_sums.data_ptr()
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
@@ -111,4 +117,14 @@ def row_stats(x16, eps=1e-5):
     out = torch.empty((rows, 2), dtype=torch.float32, device=x16.device)
     _lib.check(_lib.lib().ec_row_stats(x16.data_ptr(), x16.stride(0), rows, width, float(eps), out.data_ptr(),
                                        dtype_code(x16.dtype), _lib.stream_ptr()), 'ec_row_stats')
+    return out
+
+
+def row_stats_merge(row_sums, width, eps=1e-5):
+    """[rows, width / 64, 2] partial sums of resid_hl -> fp32 [rows, 2] (rstd, -rstd * mean) (ec_row_stats_merge)."""
+    import torch
+    rows, groups = row_sums.shape[0], row_sums.shape[1]
+    out = torch.empty((rows, 2), dtype=torch.float32, device=row_sums.device)
+    _lib.check(_lib.lib().ec_row_stats_merge(row_sums.data_ptr(), rows, groups, width, float(eps), out.data_ptr(),
+                                             _lib.stream_ptr()), 'ec_row_stats_merge')
     return out

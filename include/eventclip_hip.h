@@ -283,6 +283,10 @@ typedef struct {
     const float *row_stats;   /* fp32 pairs (rstd, -rstd * mean) of the A rows; row m at row_stats + 2 * m * row_stats_stride */
     long row_stats_stride;    /* in rows (0 = 1): the class-token rows of a [n, S] statistics array are S apart */
     const float *col_sums;    /* fp32 [N]: sum over k of W[n][k] as rounded to 16 bit */
+    /* EC_EPI_RESID_HL, optional (N % 64 == 0): */
+    float *row_sums;          /* fp32 [M][N / 64][2]: (sum, sum of squares) of the NEW hi plane over each 64-column group
+                                 of every row; ec_row_stats_merge turns them into the row statistics of the GEMM that
+                                 follows, so no pass over the hi plane is needed */
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -299,6 +303,13 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
  * EC_EPI_GELU16_LN multiply and add.  Reads 2 bytes per element where ec_layernorm reads 4 and writes 2. */
 EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
                         ec_stream_t stream);
+
+/* (sum, sum of squares) per 64-column group as EC_EPI_RESID_HL leaves them (ec_gemm_args.row_sums, `groups` = width / 64
+ * groups of row r at sums + 2 * r * groups * sums_stride ... in rows: row r at sums + 2 * groups * r) -> stats
+ * fp32 [rows][2] = (rstd, -rstd * mean) with variance = E[x^2] - mean^2 in fp32 (the hi values are 16-bit numbers:
+ * their sums over <= 2048 columns are exact to ~1e-7; relative error of the variance ~1e-7 (1 + mean^2 / variance)). */
+EC_API int ec_row_stats_merge(const float *sums, int rows, int groups, int width, float eps, float *stats,
+                              ec_stream_t stream);
 
 /* Split-precision helpers ("precise" towers): a value is carried as two 16-bit numbers
  * hi = round16(x), lo = round16(x - hi), and a product x.w as xh.wh + xh.wl + xl.wh with

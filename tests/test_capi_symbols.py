@@ -35,4 +35,4 @@ def test_version_and_error_string():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.EcFrameStats) == 40
     assert ctypes.sizeof(_lib.EcEventsParams) == 80
-    assert ctypes.sizeof(_lib.EcGemmArgs) == 168
+    assert ctypes.sizeof(_lib.EcGemmArgs) == 176

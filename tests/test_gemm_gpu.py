@@ -233,3 +233,30 @@ def test_folded_epilogues_on_the_class_token_rows(hip):
     got = hi.view(n, S, W)[:, 0].float() + lo.view(n, S, W)[:, 0].float()
     assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
     assert torch.equal(hi.view(n, S, W)[:, 1:], x.view(n, S, W)[:, 1:])      # the other tokens untouched
+
+
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (1000, 768, 3072), (77, 512, 64), (5, 256, 128), (300, 1280, 64)])
+def test_row_sums_out_of_the_residual_epilogue(M, N, K, dt, hip):
+    """EC_EPI_RESID_HL with row_sums: per 64-column group (sum, sum of squares) of the NEW hi plane; merged, they are
+    the LayerNorm statistics ec_row_stats reads off the plane."""
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device='cuda').manual_seed(M + 2 * N + K)
+    A = torch.randn(M, K, device='cuda', generator=g).to(dtype)
+    W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g) * 3 + 0.8
+    hi, lo = x.to(dtype), (x - x.to(dtype).float()).half()
+    hi_ref, lo_ref = hi.clone(), lo.clone()
+    ops.gemm(A, W, bias, 'resid_hl', out=hi_ref, aux=lo_ref)
+    sums = torch.full((M, N // 64, 2), float('nan'), device='cuda')
+    ops.gemm(A, W, bias, 'resid_hl', out=hi, aux=lo, row_sums=sums)
+    assert torch.equal(hi, hi_ref) and torch.equal(lo, lo_ref)                 # the planes do not depend on the option
+    h = hi.float().view(M, N // 64, 64)
+    torch.testing.assert_close(sums[..., 0], h.sum(-1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(sums[..., 1], (h * h).sum(-1), rtol=1e-5, atol=1e-3)
+    st, want = ops.row_stats_merge(sums, N), ops.row_stats(hi)
+    torch.testing.assert_close(st[:, 0], want[:, 0], rtol=2e-5, atol=0)
+    torch.testing.assert_close(st[:, 1], want[:, 1], rtol=1e-4, atol=2e-5)

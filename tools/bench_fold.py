@@ -17,13 +17,14 @@ sys.path.insert(0, ROOT)
 from eventclip_amd import _lib  # noqa: E402
 
 
-def gemm(M, N, K, A, W, bias, C, epi, ldc=0, aux=None, row_stats=None, col_sums=None, dtype=_lib.EC_F16):
+def gemm(M, N, K, A, W, bias, C, epi, ldc=0, aux=None, row_stats=None, col_sums=None, dtype=_lib.EC_F16, row_sums=None):
     a = _lib.EcGemmArgs()
     a.M, a.N, a.K, a.dtype, a.epilogue, a.variant = M, N, K, dtype, epi, 0
     a.A, a.W, a.bias, a.C, a.ldc = _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(C), ldc
     a.aux = _lib.ptr(aux) if aux is not None else None
     a.row_stats = _lib.ptr(row_stats) if row_stats is not None else None
     a.col_sums = _lib.ptr(col_sums) if col_sums is not None else None
+    a.row_sums = _lib.ptr(row_sums) if row_sums is not None else None
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
 
 
@@ -48,6 +49,16 @@ def check():
     got = hi.float() + lo.float()
     print('RESID_HL max rel err', float((got - want).abs().max() / want.abs().max()),
           ' hi == round(x):', bool(torch.equal(hi, want.half()) or (hi.float() - want).abs().max() < 2e-3 * want.abs().max()))
+    # statistics out of the producer's epilogue
+    x2 = torch.randn(M, Wd, device='cuda') * 3 + 0.5
+    hi2, lo2 = x2.half(), (x2 - x2.half().float()).half()
+    sums = torch.empty(M, Wd // 64, 2, device='cuda')
+    gemm(M, Wd, 128, A, Wo, bo, hi2, _lib.EC_EPI_RESID_HL, aux=lo2, row_sums=sums)
+    st2 = torch.empty(M, 2, device='cuda')
+    _lib.check(_lib.lib().ec_row_stats_merge(_lib.ptr(sums), M, Wd // 64, Wd, 1e-5, _lib.ptr(st2), _lib.stream_ptr()))
+    h2 = hi2.float()
+    r2 = (h2.var(1, unbiased=False) + 1e-5).rsqrt()
+    print('fused sums: rstd rel err', float(((st2[:, 0] - r2) / r2).abs().max()), ' -rstd*mean abs err', float((st2[:, 1] + r2 * h2.mean(1)).abs().max()))
     # statistics of the hi plane
     stats = torch.empty(M, 2, device='cuda')
     _lib.check(_lib.lib().ec_row_stats(_lib.ptr(hi), Wd, M, Wd, 1e-5, _lib.ptr(stats), _lib.EC_F16, _lib.stream_ptr()))
@@ -116,13 +127,26 @@ def bench(frames, rounds):
         gemm(M, 4 * Wd, Wd, hi, Wfc1, bf1, mlp, _lib.EC_EPI_GELU16_LN, row_stats=stats, col_sums=cs1)
         gemm(M, Wd, 4 * Wd, mlp, Wfc2, bf2, hi, _lib.EC_EPI_RESID_HL, aux=lo)
 
-    res = {'plain': [], 'folded': []}
-    for fn in (plain, folded):
+    sums = torch.empty(M, Wd // 64, 2, device=dev)
+
+    def merge():
+        _lib.check(L.ec_row_stats_merge(_lib.ptr(sums), M, Wd // 64, Wd, 1e-5, _lib.ptr(stats), _lib.stream_ptr()))
+
+    def folded_sums():      # the statistics come out of the residual GEMMs' epilogues (previous block's c_proj feeds ln_1)
+        merge()
+        gemm(M, 3 * Wd, Wd, hi, Wqkv, bq, qkv, _lib.EC_EPI_STORE16_LN, row_stats=stats, col_sums=csq)
+        gemm(M, Wd, Wd, att, Wout, bo, hi, _lib.EC_EPI_RESID_HL, aux=lo, row_sums=sums)
+        merge()
+        gemm(M, 4 * Wd, Wd, hi, Wfc1, bf1, mlp, _lib.EC_EPI_GELU16_LN, row_stats=stats, col_sums=cs1)
+        gemm(M, Wd, 4 * Wd, mlp, Wfc2, bf2, hi, _lib.EC_EPI_RESID_HL, aux=lo, row_sums=sums)
+
+    res = {'plain': [], 'folded': [], 'folded_sums': []}
+    for fn in (plain, folded, folded_sums):
         for _ in range(2):
             fn()
     torch.cuda.synchronize()
     for _ in range(rounds):
-        for name, fn in (('plain', plain), ('folded', folded)):
+        for name, fn in (('plain', plain), ('folded', folded), ('folded_sums', folded_sums)):
             _lib.profile_begin()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
