@@ -343,7 +343,8 @@ __device__ __forceinline__ void epilogue_hl_lds(const GemmArgs &g, f32x4 (&acc)[
 // scratch: 2 x 16 x 144 bytes per wave.
 template <int DT, int EPI, int TM>
 __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
-                                               int n_base, int lane, unsigned char *scratch)
+                                               int n_base, int lane, unsigned char *scratch,
+                                               const float *lds_rowstat = nullptr)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -369,12 +370,23 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
 #pragma unroll
         for (int j = 0; j < 4; j++)
             cs[j] = nb < g.N ? *reinterpret_cast<const f32x4 *>(g.colsum + nb + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lds_rowstat) {
+            // the persistent kernel had this wave row's 128 pairs brought into LDS by DMA while the main loop ran
+            // (the statistics were written by another kernel a moment ago: a cold read, ~1 k cycles per tile if
+            // it were issued here)
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            int m = m_base + i * 16 + lr;
-            m = m < g.M ? m : g.M - 1;
-            const float2 r = *reinterpret_cast<const float2 *>(g.rowstat + 2 * (long)m * g.rowstat_stride);
-            rs0[i] = r.x, rs1[i] = r.y;
+            for (int i = 0; i < TM; i++) {
+                const float2 r = *reinterpret_cast<const float2 *>(lds_rowstat + 2 * (i * 16 + lr));
+                rs0[i] = r.x, rs1[i] = r.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                int m = m_base + i * 16 + lr;
+                m = m < g.M ? m : g.M - 1;
+                const float2 r = *reinterpret_cast<const float2 *>(g.rowstat + 2 * (long)m * g.rowstat_stride);
+                rs0[i] = r.x, rs1[i] = r.y;
+            }
         }
     }
 #pragma unroll
@@ -1292,10 +1304,31 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     };
     GemmArgs ge = g;
 
+    // EC_EPI_*_LN: the tile's 256 row-statistics pairs (2 KiB) travel into an LDS side area behind the staging
+    // buffers by DMA, two slots used alternately (the epilogue of tile T reads slot T & 1 while the pairs of tile
+    // T + 1 land in the other).  Waves 0 and 1 issue one piece each, BEFORE the tile's first staging piece: an
+    // older request can only retire earlier, so every counted wait below keeps its meaning.  Rows past M read a
+    // clamped pair (never used); the caller keeps the array readable up to an even row count.
+    constexpr bool LNS = epi_is_ln(EPI);
+    const bool lds_stats = LNS && g.rowstat_stride == 1;
+    float *side = reinterpret_cast<float *>(smem + 2 * KT);
+    int slot = 0;
+    auto issue_stats = [&](int sl) {
+        if constexpr (LNS) {
+            if (lds_stats && wave < 2) {
+                long row = (long)m0 + wave * 128 + 2 * lane;
+                const long last = ((long)g.M - 1) & ~1L;
+                row = row < last ? row : last;
+                glds16(g.rowstat + 2 * row, reinterpret_cast<unsigned char *>(side) + sl * 2048 + wave * 1024);
+            }
+        }
+    };
+
     int id = blockIdx.x;
     tl_open(id);
     tstamp(1);
     setup(id);
+    issue_stats(0);
     issue(0, 0);
     issue(2, 0);
     issue(3, 0);
@@ -1357,6 +1390,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         tstamp(3);
         if (more) {
             setup(next);
+            issue_stats(slot ^ 1);
             issue(0, 0);
             issue(2, 0);
             issue(3, 0);
@@ -1375,7 +1409,9 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                                           reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
         else
             epilogue16_lds<DT, EPI, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                       smem + KT + wave * (2 * 16 * 144));
+                                       smem + KT + wave * (2 * 16 * 144),
+                                       lds_stats ? side + slot * 512 + wm * 256 : nullptr);
+        slot ^= 1;
         tstamp(4);
         if (!more) break;
         // K tile 0 of the next output tile has landed, the stores are acknowledged (loads and
@@ -1404,7 +1440,7 @@ template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const
     GemmArgs g = g0;
     g.tiles_m = ec::ceil_div(g.M, 256);
     g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 2 * 4 * 128 * 128;
+    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0);   // + the row-statistics side area
     auto kern = gemm2pp_kernel<DT, EPI, TL, TN>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();

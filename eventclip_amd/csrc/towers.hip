@@ -191,7 +191,7 @@ size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs
     b.h = sc.take(rows * W * 2);
     b.qkv = sc.take(rows * 3 * W * 2);
     b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
-    b.stats = (float *)sc.take(rows * 8);
+    b.stats = (float *)sc.take(rows * 8 + 16);   // (+ one pair: the LN epilogues fetch the pairs two at a time)
     b.sums = (float *)sc.take(rows * (size_t)(W / 64 + 1) * 8);
     *small16 = sc.take((size_t)chunk * W * 2);
     void *lo = sc.take((size_t)chunk * W * 2);

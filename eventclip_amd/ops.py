@@ -99,9 +99,6 @@ def gemm_rows(A, W, splits=1, out=None):
     a.W, a.ldw = W.data_ptr(), W.stride(0)
     a.C, a.ldc = out.data_ptr(), out.stride(-2)
     a.transposed, a.k_rows = 1, rows
-    if row_sums is not None:      # resid_hl: (sum, sum of squares) of the new hi plane per 64-column group
-        assert row_sums.dtype == torch.float32 and row_sums.is_contiguous() and row_sums.numel() == M * (N // 64) * 2
-        a.row_sums = row_sums.data_ptr()
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
@@ -114,7 +111,7 @@ def row_stats(x16, eps=1e-5):
     _lib.require_gpu()
     rows, width = x16.shape
     assert x16.stride(1) == 1
-    out = torch.empty((rows, 2), dtype=torch.float32, device=x16.device)
+    out = torch.zeros((rows + 1, 2), dtype=torch.float32, device=x16.device)[:rows]   # readable to an even row count
     _lib.check(_lib.lib().ec_row_stats(x16.data_ptr(), x16.stride(0), rows, width, float(eps), out.data_ptr(),
                                        dtype_code(x16.dtype), _lib.stream_ptr()), 'ec_row_stats')
     return out
@@ -124,7 +121,7 @@ def row_stats_merge(row_sums, width, eps=1e-5):
     """[rows, width / 64, 2] partial sums of resid_hl -> fp32 [rows, 2] (rstd, -rstd * mean) (ec_row_stats_merge)."""
     import torch
     rows, groups = row_sums.shape[0], row_sums.shape[1]
-    out = torch.empty((rows, 2), dtype=torch.float32, device=row_sums.device)
+    out = torch.zeros((rows + 1, 2), dtype=torch.float32, device=row_sums.device)[:rows]   # readable to an even row count
     _lib.check(_lib.lib().ec_row_stats_merge(row_sums.data_ptr(), rows, groups, width, float(eps), out.data_ptr(),
                                              _lib.stream_ptr()), 'ec_row_stats_merge')
     return out
