@@ -11,7 +11,7 @@ import re
 import sys
 from collections import defaultdict
 
-EPI = {0: 'STORE16', 1: 'GELU16', 2: 'RESID32', 3: 'STORE32'}
+EPI = {0: 'STORE16', 1: 'GELU16', 2: 'RESID32', 3: 'STORE32', 4: 'GELU16', 5: 'STORE16', 6: 'RESID32', 7: 'STORE16', 8: 'GELU16'}   # 6-8: the folded-LayerNorm forms of the same classes
 
 
 def classify(name):
