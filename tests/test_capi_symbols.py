@@ -36,3 +36,20 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.EcFrameStats) == 40
     assert ctypes.sizeof(_lib.EcEventsParams) == 80
     assert ctypes.sizeof(_lib.EcGemmArgs) == 176
+
+
+def test_attention_kernels_have_no_unpadded_asm_hazards():
+    """csrc/attention.hip updates its accumulators with inline-asm MFMAs, whose hazards hipcc does not pad
+    (cdna_hip_programming.md 5.7): tools/check_attn_isa.py compiles the file and scans every product kernel for a
+    vector write right in front of an unpadded asm MFMA and for accumulator copies in the key-block loops."""
+    import os
+    import shutil
+    import sys
+    import pytest
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import check_attn_isa
+    assert check_attn_isa.main() == 0
