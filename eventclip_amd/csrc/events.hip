@@ -81,6 +81,27 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     return v;
 }
 
+// 32-bit sums / maxima over a wave without LDS traffic: four DPP steps leave every lane with its row's (16 lanes)
+// value, the four rows meet on the scalar unit.  (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror)
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    v += dpp_u32<0xB1>(v), v += dpp_u32<0x4E>(v), v += dpp_u32<0x141>(v), v += dpp_u32<0x140>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned wave_max_dpp(unsigned v)
+{
+    auto mx = [](unsigned x, unsigned y) { return x > y ? x : y; };
+    v = mx(v, dpp_u32<0xB1>(v)), v = mx(v, dpp_u32<0x4E>(v)), v = mx(v, dpp_u32<0x141>(v)), v = mx(v, dpp_u32<0x140>(v));
+    return mx(mx((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+              mx((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 // Sum over the workgroup, result in every thread.  scratch: EV_WAVES u64.
 __device__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *scratch)
 {
@@ -701,27 +722,41 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned P10_MASK = 1023u;
 
-// all five sums of pass 1 behind one pair of barriers (five block_sum_u64 calls were half of the pass)
-struct P10Sums {
-    unsigned long long s1, total, s2, nnz, dropped;
+#ifdef EC_GEMM_DIAG
+// phase stamps of the first 4096 frames of a launch (diagnostic build only; tools/events_phases.py)
+__device__ unsigned long long g_ev_phase[4096 * 8];
+#define EV_STAMP(k)                                                                   \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_ev_phase[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define EV_STAMP(k)
+#endif
+
+// the frame's statistics (four sums and a max of per-thread tallies) behind one pair of barriers
+struct P10Stats {
+    unsigned long long total, s2, nnz, dropped;
+    unsigned max;
 };
-__device__ __forceinline__ P10Sums block_sums5(unsigned s1, unsigned total, unsigned long long s2, unsigned nnz,
-                                               unsigned dropped, unsigned long long *scratch)
+__device__ __forceinline__ P10Stats block_stats(unsigned hmax, unsigned total, unsigned s2, unsigned nnz, unsigned dropped,
+                                                unsigned long long *scratch)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // per-wave sums of the 32-bit partials fit 32 bits (<= 64 x 86 k); s2 needs 64
-    unsigned long long p01 = wave_sum_u64((unsigned long long)s1 | ((unsigned long long)total << 32));
-    unsigned long long p34 = wave_sum_u64((unsigned long long)nnz | ((unsigned long long)dropped << 32));
-    s2 = wave_sum_u64(s2);
+    // per-wave sums of the 32-bit partials fit 32 bits (s2: <= 64 threads x 20 events x 2047)
+    const unsigned long long p01 = (unsigned long long)wave_sum_u32(total) | ((unsigned long long)wave_sum_u32(nnz) << 32);
+    const unsigned long long p2 = wave_sum_u32(s2);
+    const unsigned long long p3 = (unsigned long long)wave_sum_u32(dropped) | ((unsigned long long)wave_max_dpp(hmax) << 32);
     __syncthreads();
-    if (lane == 0) scratch[wave] = p01, scratch[EV_WAVES + wave] = s2, scratch[2 * EV_WAVES + wave] = p34;
+    if (lane == 0) scratch[wave] = p01, scratch[EV_WAVES + wave] = p2, scratch[2 * EV_WAVES + wave] = p3;
     __syncthreads();
-    P10Sums r = {0, 0, 0, 0, 0};
+    P10Stats r = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int w = 0; w < EV_WAVES; w++) {
-        const unsigned long long a01 = scratch[w], a34 = scratch[2 * EV_WAVES + w];
-        r.s1 += a01 & 0xffffffffull, r.total += a01 >> 32, r.s2 += scratch[EV_WAVES + w];
-        r.nnz += a34 & 0xffffffffull, r.dropped += a34 >> 32;
+        const unsigned long long a01 = scratch[w], a3 = scratch[2 * EV_WAVES + w];
+        r.total += a01 & 0xffffffffull, r.nnz += a01 >> 32, r.s2 += scratch[EV_WAVES + w];
+        r.dropped += a3 & 0xffffffffull;
+        const unsigned m = (unsigned)(a3 >> 32);
+        r.max = m > r.max ? m : r.max;
     }
     return r;
 }
@@ -742,6 +777,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
         const int slot = f % a.stagger;
         for (int t = 0; t < slot * a.stagger_sleeps; t++) __builtin_amdgcn_s_sleep(127);
     }
+    EV_STAMP(0);
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
     const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
     const long long n = e1 - e0;
@@ -749,84 +785,100 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
     const int M2 = H * W * 2;
     const int words = (M2 + 2) / 3;
 
-    for (int i = threadIdx.x; i < words; i += EV_THREADS) bins[i] = 0;
+    if (n > (1ll << 24)) {                               // the 32-bit per-wave tallies below are sized for less
+        if (threadIdx.x == 0) a.redo[f] = 1;
+        return;
+    }
+    uint4 *bins4 = reinterpret_cast<uint4 *>(smem);
+    const int words4 = (words + 3) / 4;                  // (a.bin_bytes is a multiple of 16)
+    for (int i = threadIdx.x; i < words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    // (the tallies are additions of the lambda's return value, not increments inside its divergent branches)
-    unsigned dropped = 0, binned = 0;
-    auto bin_event = [&](const EV e) -> unsigned {          // 1: binned, 0x10000: dropped, 0: polarity 0
+    EV_STAMP(1);
+    // The statistics the reference takes from the finished histogram (vis.py:17-24: sum, sum of squares, non-zero
+    // bins; vis.py:27: max) come out of the binning itself: the atomic returns the word as it was, h = the field's
+    // count before this event, and over the events of a frame  sum of (2 h + 1) = sum over bins of count^2,
+    // number of h == 0 = non-zero bins, max of h + 1 = largest count -- no pass over the 28 800 words (it was 5.7 us
+    // of the frame's 36).  An event that finds h == 1023 overflows its 10-bit field: the first overflow of a word
+    // sees the true 1023 (fields are only ever wrong after one), so `some event saw 1023` == `some field overflowed`.
+    // (the tallies are selects on the lambda's return value, not increments inside its divergent branches)
+    unsigned dropped = 0, binned = 0, s2t = 0, nnzt = 0, hmax = 0;
+    constexpr unsigned EV_NOT_BINNED = 0xFFFFFFFFu, EV_DROPPED = 0xFFFFFFFEu;
+    auto bin_event = [&](const EV e) -> unsigned {          // previous count of the event's bin, or one of the codes
         int x, y, p;
         parse(e, W, a.flip_x, a.negate_p, x, y, p);
         const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+        unsigned h = p == 0 || inside ? EV_NOT_BINNED : EV_DROPPED;
         if (p != 0 && inside) {
             const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
             const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
-            atomicAdd(&bins[w], 1u << sh);
+            h = (atomicAdd(&bins[w], 1u << sh) >> sh) & P10_MASK;
         }
-        return p == 0 ? 0u : (inside ? 1u : 0x10000u);
+        return h;
     };
     {   // the frame's only HBM read: eight 16-byte loads in flight per thread; a frame's last partial round of
         // eight (20 000 events = 2 rounds + 3 616) through clamped, masked loads instead of one load at a time
         for (long long i = threadIdx.x; i < n; i += 8 * EV_THREADS) {
             EV e[8];
-            unsigned tally = 0;
+            unsigned h[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const long long j = i + (long long)k * EV_THREADS;
                 e[k] = ev[j < n ? j : n - 1];
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (i + (long long)k * EV_THREADS < n) tally += bin_event(e[k]);
-            binned += tally & 0xffffu, dropped += tally >> 16;
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 1: sum, sum of squares, non-zero bins (fields past M2 in the last word are zero) ----
-    // per-thread partial sums stay in 32 bits: at most ceil(58 000 / 1024) words x 3 counts <= 1023
-    unsigned s1t = 0, s2t = 0, nnzt = 0;
-    for (int w = threadIdx.x; w < words; w += EV_THREADS) {
-        const unsigned v = bins[w];
+            for (int k = 0; k < 8; k++) h[k] = i + (long long)k * EV_THREADS < n ? bin_event(e[k]) : EV_NOT_BINNED;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const unsigned h = (v >> (10 * k)) & P10_MASK;
-            s1t += h;
-            s2t += h * h;
-            nnzt += h > 0;
+            for (int k = 0; k < 8; k++) {
+                const bool there = h[k] < EV_DROPPED;
+                binned += there ? 1u : 0u;
+                dropped += h[k] == EV_DROPPED ? 1u : 0u;
+                s2t += there ? 2u * h[k] + 1u : 0u;            // <= 20 events x 2047 per thread
+                nnzt += h[k] == 0u ? 1u : 0u;
+                const unsigned now = there ? h[k] + 1u : 0u;   // 1024 = this event overflowed its field
+                hmax = now > hmax ? now : hmax;
+            }
         }
     }
-    const P10Sums sums = block_sums5(s1t, binned, s2t, nnzt, dropped, scratch);
-    const unsigned long long s1 = sums.s1, s2 = sums.s2;
-    if (s1 != sums.total) {                          // a field overflowed: leave the frame to the 32-bit kernel
+    EV_STAMP(2);
+    const P10Stats sums = block_stats(hmax, binned, s2t, nnzt, dropped, scratch);   // (its first barrier ends the binning)
+    if (sums.max > P10_MASK) {                       // a field overflowed: leave the frame to the 32-bit kernel
         if (threadIdx.x == 0) a.redo[f] = 1;
         return;
     }
+    const unsigned gmax = sums.max;
+    const unsigned long long s1 = sums.total, s2 = sums.s2;
     const unsigned nnz = (unsigned)sums.nnz;
     dropped = (unsigned)sums.dropped;
     const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
     const unsigned thr_hi = hp.thr_hi;
+    EV_STAMP(3);
 
     // ---- pass 2: max of the counts that survive; debug outputs ----
-    unsigned mx = 0, amb = 0;
-    for (int w = threadIdx.x; w < words; w += EV_THREADS) {
-        const unsigned v = bins[w];
+    // Only when the answer is not known already: the largest count survives the threshold in an ordinary frame
+    // (then it is the max of what is left, vis.py:27), and no count sits within 1e-9 of the threshold.
+    unsigned mx = gmax, amb = 0;
+    const bool amb_possible = hp.amb_h >= 0 && hp.amb_h <= (long long)gmax;
+    if (a.raw || a.kept || amb_possible) {               // debug outputs, or a count within 1e-9 of the threshold
+        mx = 0;
+        for (int w = threadIdx.x; w < words; w += EV_THREADS) {
+            const unsigned v = bins[w];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int idx = 3 * w + k;
-            unsigned h = (v >> (10 * k)) & P10_MASK;
-            if (a.raw && idx < M2) a.raw[(long long)f * M2 + idx] = (int)h;
-            amb += (long long)h == hp.amb_h;
-            if (h > thr_hi) h = 0;
-            mx = h > mx ? h : mx;
-            if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
+            for (int k = 0; k < 3; k++) {
+                const int idx = 3 * w + k;
+                unsigned h = (v >> (10 * k)) & P10_MASK;
+                if (a.raw && idx < M2) a.raw[(long long)f * M2 + idx] = (int)h;
+                amb += (long long)h == hp.amb_h;
+                if (h > thr_hi) h = 0;
+                mx = h > mx ? h : mx;
+                if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
+            }
         }
-    }
-    {   // max and the ambiguous-count tally behind one pair of barriers
+        // max and the ambiguous-count tally behind one pair of barriers
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        mx = wave_max_u32(mx);
-        const unsigned long long ab = wave_sum_u64(amb);
+        mx = wave_max_dpp(mx);
+        amb = wave_sum_u32(amb);
         __syncthreads();
-        if (lane == 0) scratch[wave] = (unsigned long long)mx | (ab << 32);
+        if (lane == 0) scratch[wave] = (unsigned long long)mx | ((unsigned long long)amb << 32);
         __syncthreads();
         mx = 0, amb = 0;
 #pragma unroll
@@ -836,6 +888,31 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
             mx = m > mx ? m : mx;
             amb += (unsigned)(t >> 32);
         }
+    } else if (gmax > thr_hi) {
+        // hot pixels were removed: the largest count that is left.  t = h - (thr_hi + 1) wraps to the top of the
+        // unsigned range exactly for the survivors, in their order, so one unsigned max per field finds it
+        // (thr_hi < gmax <= 1023 here)
+        const unsigned off = thr_hi + 1u;
+        unsigned t = 0;
+        for (int i = threadIdx.x; i < words4; i += EV_THREADS) {
+            const uint4 q = bins4[i];
+            const unsigned v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned t0 = (v[j] & P10_MASK) - off, t1 = ((v[j] >> 10) & P10_MASK) - off, t2 = ((v[j] >> 20) & P10_MASK) - off;
+                const unsigned m01 = t0 > t1 ? t0 : t1, m2 = t2 > t ? t2 : t;
+                t = m01 > m2 ? m01 : m2;
+            }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        t = wave_max_dpp(t);
+        __syncthreads();
+        if (lane == 0) scratch[wave] = t;
+        __syncthreads();
+        t = 0;
+#pragma unroll
+        for (int w = 0; w < EV_WAVES; w++) t = (unsigned)scratch[w] > t ? (unsigned)scratch[w] : t;
+        mx = t >= 0x80000000u ? t + off : 0u;
     }
     const double dmx = (double)mx;
     if (a.stats && threadIdx.x == 0) {
@@ -851,51 +928,68 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
     }
 
     // ---- pass 3: colour through the per-frame look-up table for small counts ----
+    // lut[h0 | h1 << 4] = the pixel of the counts (h0, h1) < 16 AFTER the threshold (a count above it is 0), so the
+    // look-up path does not compare against the threshold at all
+    EV_STAMP(4);
     if (threadIdx.x < EV_LUT_N * EV_LUT_N) {
         uint8_t px[4] = {0, 0, 0, 0};
-        colour_pixel(threadIdx.x / EV_LUT_N, threadIdx.x % EV_LUT_N, dmx, a, px);
+        const unsigned h0 = threadIdx.x % EV_LUT_N, h1 = threadIdx.x / EV_LUT_N;
+        colour_pixel(h0 > thr_hi ? 0u : h0, h1 > thr_hi ? 0u : h1, dmx, a, px);
         lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
     }
     __syncthreads();
+    EV_STAMP(5);
     auto colour = [&](unsigned h0, unsigned h1) -> unsigned {      // 0x00BBGGRR
+        if (h0 < EV_LUT_N && h1 < EV_LUT_N) return lut[h0 | (h1 << 4)];
         if (h0 > thr_hi) h0 = 0;
         if (h1 > thr_hi) h1 = 0;
-        if (h0 < EV_LUT_N && h1 < EV_LUT_N) return lut[h0 * EV_LUT_N + h1];
         uint8_t px[3];
         colour_pixel(h0, h1, dmx, a, px);
         return (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
     };
     uint8_t *out = a.frames + (long long)f * H * W * 3;
     const int npix = H * W;
-    // 4 pixels = 8 counts out of up to 4 consecutive words (the group's first count is field (8 g) % 3
-    // of word (8 g) / 3), 12 bytes = three dwords out; frames whose byte size is not a multiple of 4 take
-    // the byte path
-    const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 4 : 0;
+    // 12 pixels = 24 counts = exactly 8 words (two 16-byte LDS reads, every field at a fixed place), 36 bytes = nine
+    // dwords out; frames whose byte size is not a multiple of 4 take the byte path.  A group whose 24 counts are all
+    // below 16 (bits 4..9 of every field clear) is nine look-ups with the index cut straight out of the words.
+    const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 12 : 0;
     for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
-        const unsigned first = 8u * g, w0 = first / 3u, k0 = first - 3u * w0;
-        // fields k0 .. k0 + 7 of the 12 in words w0 .. w0 + 3 (120 bits; k0 <= 2)
-        unsigned __int128 bits = 0;
+        const uint4 qa = bins4[2 * g], qb = bins4[2 * g + 1];
+        const unsigned w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        unsigned c[12];
+        const unsigned any = (w[0] | w[1]) | (w[2] | w[3]) | (w[4] | w[5]) | (w[6] | w[7]);
+        if ((any & 0x3F0FC3F0u) == 0) {
 #pragma unroll
-        for (int j = 3; j >= 0; j--) {
-            const unsigned v = w0 + j < (unsigned)words ? (bins[w0 + j] & 0x3FFFFFFFu) : 0u;
-            bits = (bits << 30) | v;
+            for (int k = 0; k < 12; k++) {
+                const int fa = 2 * k, wa = fa / 3, pa = fa % 3;      // pixel k: fields 2 k and 2 k + 1
+                unsigned idx;
+                if (pa == 0) idx = (w[wa] & 0xFu) | ((w[wa] >> 6) & 0xF0u);
+                else if (pa == 1) idx = ((w[wa] >> 10) & 0xFu) | ((w[wa] >> 16) & 0xF0u);
+                else idx = ((w[wa] >> 20) & 0xFu) | ((w[wa + 1] & 0xFu) << 4);
+                c[k] = lut[idx];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int fa = 2 * k, fb = 2 * k + 1;
+                c[k] = colour((w[fa / 3] >> (10 * (fa % 3))) & P10_MASK, (w[fb / 3] >> (10 * (fb % 3))) & P10_MASK);
+            }
         }
-        bits >>= 10 * k0;
-        unsigned c[4];
+        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            c[k] = colour((unsigned)(bits >> (20 * k)) & P10_MASK, (unsigned)(bits >> (20 * k + 10)) & P10_MASK);
-        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 12);
-        dst[0] = c[0] | (c[1] << 24);
-        dst[1] = (c[1] >> 8) | (c[2] << 16);
-        dst[2] = (c[2] >> 16) | (c[3] << 8);
+        for (int k = 0; k < 3; k++) {
+            dst[3 * k] = c[4 * k] | (c[4 * k + 1] << 24);
+            dst[3 * k + 1] = (c[4 * k + 1] >> 8) | (c[4 * k + 2] << 16);
+            dst[3 * k + 2] = (c[4 * k + 2] >> 16) | (c[4 * k + 3] << 8);
+        }
     }
-    for (int q = groups * 4 + threadIdx.x; q < npix; q += EV_THREADS) {
+    for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) {
         const unsigned b0 = 2u * q, wa = b0 / 3u, wb = (b0 + 1u) / 3u;
         const unsigned v = colour((bins[wa] >> (10u * (b0 - 3u * wa))) & P10_MASK,
                                   (bins[wb] >> (10u * (b0 + 1u - 3u * wb))) & P10_MASK);
         out[3 * q] = (uint8_t)v, out[3 * q + 1] = (uint8_t)(v >> 8), out[3 * q + 2] = (uint8_t)(v >> 16);
     }
+    EV_STAMP(6);
 }
 
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
@@ -1224,6 +1318,15 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
 }
 
 }  // namespace
+
+#ifdef EC_GEMM_DIAG
+extern "C" EC_API int ec_events_phase_times(unsigned long long *host, int frames)
+{
+    EC_REQUIRE(host && frames > 0 && frames <= 4096, "ec_events_phase_times: bad arguments");
+    EC_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ev_phase), (size_t)frames * 8 * sizeof(unsigned long long)));
+    return EC_OK;
+}
+#endif
 
 extern "C" EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *prm)
 {
