@@ -59,9 +59,8 @@ struct EvArgs {
     unsigned *sort_ws;   // band-sorted bin indices, sort_cap per workgroup (long frames), or null
     int sort_cap;
     unsigned band_magic; // ceil(2^32 / rows_per_band): y / rows_per_band == (y * magic) >> 32 for y < 2^16
-    uint8_t *redo;       // per-frame flags shared with events_pack10_kernel: that kernel sets redo[f] for
-                         // a frame it could not finish, this one then processes ONLY those frames
-    int stagger, stagger_wgs, stagger_sleeps;   // events_pack10_kernel: start offsets of the first round's workgroups
+    uint8_t *redo;       // per-frame flags shared with events_pack10_kernel: that kernel sets redo[f] to 1 for
+                         // a frame it could not finish (0 otherwise), this one then processes ONLY those frames
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -482,6 +481,18 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
     unsigned *cc = sort_start + EV_SORT_MAX_BANDS + 1;            // sorted mode: EV_CC_N words
     unsigned *ws = a.sort_ws ? a.sort_ws + (size_t)blockIdx.x * a.sort_cap : nullptr;
 
+    if (a.redo) {       // behind events_pack10_kernel: ordinarily none of this workgroup's frames is flagged -- one look, together
+        int any = 0;
+        for (int f = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; f < a.F; f += EV_THREADS * (int)gridDim.x) any |= a.redo[f];
+        // (through the dynamic LDS the kernel owns: __syncthreads_or takes static LDS on top of the CU's 160 KB)
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = __ballot(any != 0);
+        __syncthreads();
+        unsigned long long all = 0;
+#pragma unroll
+        for (int w = 0; w < EV_WAVES; w++) all |= scratch[w];
+        if (all == 0) return;
+        __syncthreads();
+    }
   for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
     if (a.redo && !a.redo[f]) continue;   // finished by events_pack10_kernel (workgroup-uniform)
     const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
@@ -708,15 +719,16 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 // Whole frame in LDS: three 10-bit counts per 32-bit word.
 //
 // A sensor of up to ~59 000 pixels (N-Caltech: 180 x 240 x 2 bins -> 113 KiB) holds its complete
-// histogram on chip in this form: the events are read from HBM ONCE and binned ONCE with
-// fire-and-forget LDS atomics (no event cache, no bands), and the three frame-wide passes the
-// reference needs (sum / sum of squares, max of what survives the hot-pixel threshold, colour) walk
-// 28 800 words of LDS instead of re-binning 20 000 events for each of 3 passes x 5 bands.
-// An overflow of a 10-bit field (a pixel with more than 1023 events of one polarity) carries into its
-// neighbour and lowers the sum of all fields by 1022 or 1023, never raises it, so `sum of the fields ==
-// events binned` -- the first pass computes that sum anyway -- holds exactly when no count passed
-// 1023.  A frame that fails the check writes nothing and sets redo[f]; events_to_frames_kernel,
-// launched behind this kernel over the same frames, processes exactly those with 32-bit bins.
+// histogram on chip in this form: the events are read from HBM ONCE and binned ONCE with LDS atomics
+// (no event cache, no bands).  The atomics RETURN the word as it was, and the statistics the reference
+// takes from the finished histogram (sum, sum of squares, non-zero bins, max) are tallied from those
+// previous counts event by event, so no pass walks the histogram for them; a pass for the max of what
+// survives the hot-pixel threshold runs only in frames that lose a pixel to it, and the colour pass
+// reads 12 pixels = 8 words at a time through a 256-entry table of the float stage.
+// An event that finds its 10-bit field at 1023 overflows it (a pixel with more than 1023 events of one
+// polarity): such a frame writes no pixels and sets redo[f] (every frame writes its flag, 0 or 1);
+// events_to_frames_kernel, launched behind this kernel over the same frames, processes exactly those
+// with 32-bit bins.
 // Its own kernel rather than a mode of the one above so that its registers are its own (as a mode it
 // pushed both paths into scratch spills).
 // ---------------------------------------------------------------------------------------------
@@ -727,7 +739,7 @@ constexpr unsigned P10_MASK = 1023u;
 __device__ unsigned long long g_ev_phase[4096 * 8];
 #define EV_STAMP(k)                                                                   \
     do {                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_ev_phase[blockIdx.x * 8 + (k)] = wall_clock64(); \
+        if (threadIdx.x == 0 && f >= 0 && f < 4096) g_ev_phase[f * 8 + (k)] = wall_clock64(); \
     } while (0)
 #else
 #define EV_STAMP(k)
@@ -766,230 +778,279 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *bins = reinterpret_cast<unsigned *>(smem);
+    uint4 *bins4 = reinterpret_cast<uint4 *>(smem);
     unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + a.bin_bytes);
     unsigned *lut = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES);
-    const int f = blockIdx.x;
-    // Workgroups of one launch run in step: every CU reads its frame's events at the same time (measured: that
-    // phase runs at the chip's HBM rate, 3.9 TB/s) and then walks LDS with the memory idle.  The first round's
-    // workgroups (one per CU) start in a.stagger groups a fraction of a frame apart, and the rounds behind them
-    // inherit the offset, so that one group's reads overlap the others' passes.
-    if (a.stagger > 1 && f < a.stagger_wgs) {
-        const int slot = f % a.stagger;
-        for (int t = 0; t < slot * a.stagger_sleeps; t++) __builtin_amdgcn_s_sleep(127);
-    }
-    EV_STAMP(0);
-    const long long e0 = a.range[2 * f], e1 = a.range[2 * f + 1];
-    const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
-    const long long n = e1 - e0;
     const int H = a.H, W = a.W;
     const int M2 = H * W * 2;
     const int words = (M2 + 2) / 3;
-
-    if (n > (1ll << 24)) {                               // the 32-bit per-wave tallies below are sized for less
-        if (threadIdx.x == 0) a.redo[f] = 1;
-        return;
-    }
-    uint4 *bins4 = reinterpret_cast<uint4 *>(smem);
     const int words4 = (words + 3) / 4;                  // (a.bin_bytes is a multiple of 16)
-    for (int i = threadIdx.x; i < words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    EV_STAMP(1);
-    // The statistics the reference takes from the finished histogram (vis.py:17-24: sum, sum of squares, non-zero
-    // bins; vis.py:27: max) come out of the binning itself: the atomic returns the word as it was, h = the field's
-    // count before this event, and over the events of a frame  sum of (2 h + 1) = sum over bins of count^2,
-    // number of h == 0 = non-zero bins, max of h + 1 = largest count -- no pass over the 28 800 words (it was 5.7 us
-    // of the frame's 36).  An event that finds h == 1023 overflows its 10-bit field: the first overflow of a word
-    // sees the true 1023 (fields are only ever wrong after one), so `some event saw 1023` == `some field overflowed`.
-    // (the tallies are selects on the lambda's return value, not increments inside its divergent branches)
-    unsigned dropped = 0, binned = 0, s2t = 0, nnzt = 0, hmax = 0;
+    constexpr int PF = 4;                                // events per thread per round; two rounds in flight
+    constexpr int ROUND = PF * EV_THREADS;
     constexpr unsigned EV_NOT_BINNED = 0xFFFFFFFFu, EV_DROPPED = 0xFFFFFFFEu;
-    auto bin_event = [&](const EV e) -> unsigned {          // previous count of the event's bin, or one of the codes
-        int x, y, p;
-        parse(e, W, a.flip_x, a.negate_p, x, y, p);
-        const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
-        unsigned h = p == 0 || inside ? EV_NOT_BINNED : EV_DROPPED;
-        if (p != 0 && inside) {
-            const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
-            const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
-            h = (atomicAdd(&bins[w], 1u << sh) >> sh) & P10_MASK;
+
+    // One workgroup per CU (the histogram takes the CU's LDS) walks frames blockIdx.x, + gridDim.x, ...  A frame's
+    // events come in rounds of 4 096 through two register buffers: while one round is binned the next is in flight,
+    // and behind a frame's last rounds the buffers are refilled with the first two rounds of the NEXT frame, which
+    // land behind the statistics, the threshold and the LDS passes.  The workgroups of a launch drift apart on their
+    // own, so the memory system sees reads all the time instead of in bursts.
+    EV ea[PF], eb[PF];
+    auto request = [&](EV (&e)[PF], const EV *ev, long long n, long long i) {   // clamped: a masked slot re-reads the last event
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const long long j = i + (long long)k * EV_THREADS;
+            e[k] = ev[j < n ? j : n - 1];
         }
-        return h;
     };
-    {   // the frame's only HBM read: eight 16-byte loads in flight per thread; a frame's last partial round of
-        // eight (20 000 events = 2 rounds + 3 616) through clamped, masked loads instead of one load at a time
-        for (long long i = threadIdx.x; i < n; i += 8 * EV_THREADS) {
-            EV e[8];
-            unsigned h[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const long long j = i + (long long)k * EV_THREADS;
-                e[k] = ev[j < n ? j : n - 1];
+    // (the frame ranges through the constant address space: scalar loads.  As ordinary global memory -- the kernel
+    // stores to other global memory -- they were vector loads behind an s_waitcnt vmcnt(0) at the top of every
+    // frame, which also waited for the previous frame's pixel stores)
+    typedef const __attribute__((address_space(4))) long long *range_ptr;
+    const range_ptr range = (range_ptr)(a.range);
+    // events of a frame that this kernel bins: a frame of more than 2^24 events is left to the 32-bit kernel (the
+    // per-wave tallies are sized for less)
+    auto binnable = [](long long n) { return n > (1ll << 24) ? 0ll : n; };
+    // (the walk starts one frame early with an empty frame of no output, whose only effect is the request for the
+    // first real frame's rounds: one place per buffer that loads events -- with more, the compiler kept copies of the
+    // buffers alive and spilled)
+    long long e0 = 0, n = 0;
+    bool dirty = true;                                   // the histogram is not all zero
+    for (int f = (int)blockIdx.x - (int)gridDim.x; f < a.F; f += gridDim.x) {
+        const bool real = f >= 0;
+        EV_STAMP(0);
+        const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
+        const int fn = f + (int)gridDim.x;               // the frame after this one
+        long long e0n = 0, nn = 0;
+        if (fn < a.F) e0n = range[2 * fn], nn = range[2 * fn + 1] - e0n;
+        const EV *evn = reinterpret_cast<const EV *>(a.events) + e0n;
+
+        if (dirty) {                                     // (ordinarily the colour pass leaves it zero, below)
+            for (int i = threadIdx.x; i < words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+        dirty = real;
+        EV_STAMP(1);
+        // The statistics the reference takes from the finished histogram (vis.py:17-24: sum, sum of squares,
+        // non-zero bins; vis.py:27: max) come out of the binning itself: the atomic returns the word as it was, h =
+        // the field's count before this event, and over the events of a frame  sum of (2 h + 1) = sum over bins of
+        // count^2, number of h == 0 = non-zero bins, max of h + 1 = largest count -- no pass over the 28 800 words.
+        // An event that finds h == 1023 overflows its 10-bit field: the first overflow of a word sees the true 1023
+        // (fields are only ever wrong after one), so `some event saw 1023` == `some field overflowed`.
+        // (the tallies are selects on the lambda's return value, not increments inside its divergent branches)
+        unsigned dropped = 0, binned = 0, s2t = 0, nnzt = 0, hmax = 0;
+        auto bin_event = [&](const EV ek) -> unsigned {     // previous count of the event's bin, or one of the codes
+            int x, y, p;
+            parse(ek, W, a.flip_x, a.negate_p, x, y, p);
+            const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+            unsigned h = p == 0 || inside ? EV_NOT_BINNED : EV_DROPPED;
+            if (p != 0 && inside) {
+                const unsigned bin = (unsigned)(y * W + x) * 2u + (p < 0 ? 1u : 0u);
+                const unsigned w = bin / 3u, sh = 10u * (bin - 3u * w);
+                h = (atomicAdd(&bins[w], 1u << sh) >> sh) & P10_MASK;
             }
+            return h;
+        };
+        const bool too_long = n > (1ll << 24);
+        const long long nb = binnable(n), nnb = binnable(nn);
+        // Every thread runs the same number of rounds, two per iteration (slots past the frame's end are masked, a
+        // round past it is skipped): the frame's only HBM read.
+        const int pairs = nb > 0 ? (int)((nb + 2 * ROUND - 1) / (2 * ROUND)) : 1;
+        auto bin_round = [&](const EV (&e)[PF], int r) {
+            const long long i = threadIdx.x + (long long)r * ROUND;
+            unsigned h[PF];
 #pragma unroll
-            for (int k = 0; k < 8; k++) h[k] = i + (long long)k * EV_THREADS < n ? bin_event(e[k]) : EV_NOT_BINNED;
+            for (int k = 0; k < PF; k++) h[k] = i + (long long)k * EV_THREADS < nb ? bin_event(e[k]) : EV_NOT_BINNED;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < PF; k++) {
                 const bool there = h[k] < EV_DROPPED;
                 binned += there ? 1u : 0u;
                 dropped += h[k] == EV_DROPPED ? 1u : 0u;
-                s2t += there ? 2u * h[k] + 1u : 0u;            // <= 20 events x 2047 per thread
+                s2t += there ? 2u * h[k] + 1u : 0u;
                 nnzt += h[k] == 0u ? 1u : 0u;
                 const unsigned now = there ? h[k] + 1u : 0u;   // 1024 = this event overflowed its field
                 hmax = now > hmax ? now : hmax;
             }
+        };
+        // round g of this frame into a buffer, or -- past this frame's iterations -- round g - 2 pairs of the next
+        auto refill = [&](EV (&e)[PF], int g) {
+            const bool mine = g < 2 * pairs;
+            const long long first = (long long)(mine ? g : g - 2 * pairs) * ROUND;
+            const EV *src = mine ? ev : evn;
+            const long long ns = mine ? nb : nnb;
+            if (first < ns) request(e, src, ns, first + threadIdx.x);
+        };
+        for (int t = 0; t < pairs; t++) {
+            bin_round(ea, 2 * t);
+            refill(ea, 2 * t + 2);
+            bin_round(eb, 2 * t + 1);
+            refill(eb, 2 * t + 3);
         }
-    }
-    EV_STAMP(2);
-    const P10Stats sums = block_stats(hmax, binned, s2t, nnzt, dropped, scratch);   // (its first barrier ends the binning)
-    if (sums.max > P10_MASK) {                       // a field overflowed: leave the frame to the 32-bit kernel
-        if (threadIdx.x == 0) a.redo[f] = 1;
-        return;
-    }
-    const unsigned gmax = sums.max;
-    const unsigned long long s1 = sums.total, s2 = sums.s2;
-    const unsigned nnz = (unsigned)sums.nnz;
-    dropped = (unsigned)sums.dropped;
-    const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
-    const unsigned thr_hi = hp.thr_hi;
-    EV_STAMP(3);
+        EV_STAMP(2);
+        if (!real) {                                     // the lead-in frame: nothing but the requests above
+            e0 = e0n, n = nn;
+            continue;
+        }
+        const P10Stats sums = block_stats(hmax, binned, s2t, nnzt, dropped, scratch);   // (its first barrier ends the binning)
+        const bool overflow = too_long || sums.max > P10_MASK;   // a field overflowed: the 32-bit kernel takes the frame
+        if (threadIdx.x == 0) a.redo[f] = overflow ? 1 : 0;
+        const unsigned gmax = sums.max;
+        const unsigned long long s1 = sums.total, s2 = sums.s2;
+        const unsigned nnz = (unsigned)sums.nnz;
+        dropped = (unsigned)sums.dropped;
+        const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
+        const unsigned thr_hi = hp.thr_hi;
+        EV_STAMP(3);
 
-    // ---- pass 2: max of the counts that survive; debug outputs ----
-    // Only when the answer is not known already: the largest count survives the threshold in an ordinary frame
-    // (then it is the max of what is left, vis.py:27), and no count sits within 1e-9 of the threshold.
-    unsigned mx = gmax, amb = 0;
-    const bool amb_possible = hp.amb_h >= 0 && hp.amb_h <= (long long)gmax;
-    if (a.raw || a.kept || amb_possible) {               // debug outputs, or a count within 1e-9 of the threshold
-        mx = 0;
-        for (int w = threadIdx.x; w < words; w += EV_THREADS) {
-            const unsigned v = bins[w];
+        if (!overflow) {
+        // ---- pass 2: max of the counts that survive; debug outputs ----
+        // Only when the answer is not known already: the largest count survives the threshold in an ordinary frame
+        // (then it is the max of what is left, vis.py:27), and no count sits within 1e-9 of the threshold.
+        unsigned mx = gmax, amb = 0;
+        const bool amb_possible = hp.amb_h >= 0 && hp.amb_h <= (long long)gmax;
+        if (a.raw || a.kept || amb_possible) {               // debug outputs, or a count within 1e-9 of the threshold
+            mx = 0;
+            for (int w = threadIdx.x; w < words; w += EV_THREADS) {
+                const unsigned v = bins[w];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int idx = 3 * w + k;
-                unsigned h = (v >> (10 * k)) & P10_MASK;
-                if (a.raw && idx < M2) a.raw[(long long)f * M2 + idx] = (int)h;
-                amb += (long long)h == hp.amb_h;
-                if (h > thr_hi) h = 0;
-                mx = h > mx ? h : mx;
-                if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
+                for (int k = 0; k < 3; k++) {
+                    const int idx = 3 * w + k;
+                    unsigned h = (v >> (10 * k)) & P10_MASK;
+                    if (a.raw && idx < M2) a.raw[(long long)f * M2 + idx] = (int)h;
+                    amb += (long long)h == hp.amb_h;
+                    if (h > thr_hi) h = 0;
+                    mx = h > mx ? h : mx;
+                    if (a.kept && idx < M2) a.kept[(long long)f * M2 + idx] = (int)h;
+                }
             }
-        }
-        // max and the ambiguous-count tally behind one pair of barriers
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        mx = wave_max_dpp(mx);
-        amb = wave_sum_u32(amb);
-        __syncthreads();
-        if (lane == 0) scratch[wave] = (unsigned long long)mx | ((unsigned long long)amb << 32);
-        __syncthreads();
-        mx = 0, amb = 0;
+            // max and the ambiguous-count tally behind one pair of barriers
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            mx = wave_max_dpp(mx);
+            amb = wave_sum_u32(amb);
+            __syncthreads();
+            if (lane == 0) scratch[wave] = (unsigned long long)mx | ((unsigned long long)amb << 32);
+            __syncthreads();
+            mx = 0, amb = 0;
 #pragma unroll
-        for (int w = 0; w < EV_WAVES; w++) {
-            const unsigned long long t = scratch[w];
-            const unsigned m = (unsigned)(t & 0xffffffffull);
-            mx = m > mx ? m : mx;
-            amb += (unsigned)(t >> 32);
-        }
-    } else if (gmax > thr_hi) {
-        // hot pixels were removed: the largest count that is left.  t = h - (thr_hi + 1) wraps to the top of the
-        // unsigned range exactly for the survivors, in their order, so one unsigned max per field finds it
-        // (thr_hi < gmax <= 1023 here)
-        const unsigned off = thr_hi + 1u;
-        unsigned t = 0;
-        for (int i = threadIdx.x; i < words4; i += EV_THREADS) {
-            const uint4 q = bins4[i];
-            const unsigned v[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned t0 = (v[j] & P10_MASK) - off, t1 = ((v[j] >> 10) & P10_MASK) - off, t2 = ((v[j] >> 20) & P10_MASK) - off;
-                const unsigned m01 = t0 > t1 ? t0 : t1, m2 = t2 > t ? t2 : t;
-                t = m01 > m2 ? m01 : m2;
+            for (int w = 0; w < EV_WAVES; w++) {
+                const unsigned long long t = scratch[w];
+                const unsigned m = (unsigned)(t & 0xffffffffull);
+                mx = m > mx ? m : mx;
+                amb += (unsigned)(t >> 32);
             }
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        t = wave_max_dpp(t);
-        __syncthreads();
-        if (lane == 0) scratch[wave] = t;
-        __syncthreads();
-        t = 0;
+        } else if (gmax > thr_hi) {
+            // hot pixels were removed: the largest count that is left.  t = h - (thr_hi + 1) wraps to the top of the
+            // unsigned range exactly for the survivors, in their order, so one unsigned max per field finds it
+            // (thr_hi < gmax <= 1023 here)
+            const unsigned off = thr_hi + 1u;
+            unsigned t = 0;
+            for (int i = threadIdx.x; i < words4; i += EV_THREADS) {
+                const uint4 q = bins4[i];
+                const unsigned v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int w = 0; w < EV_WAVES; w++) t = (unsigned)scratch[w] > t ? (unsigned)scratch[w] : t;
-        mx = t >= 0x80000000u ? t + off : 0u;
-    }
-    const double dmx = (double)mx;
-    if (a.stats && threadIdx.x == 0) {
-        ec_frame_stats st;
-        st.sum = s1;
-        st.sumsq = s2;
-        st.nnz = nnz;
-        st.max_kept = mx;
-        st.dropped = dropped;
-        st.ambiguous = amb;
-        st.thr = hp.use_thr ? hp.thr : __builtin_nan("");
-        a.stats[f] = st;
-    }
+                for (int j = 0; j < 4; j++) {
+                    const unsigned t0 = (v[j] & P10_MASK) - off, t1 = ((v[j] >> 10) & P10_MASK) - off,
+                                   t2 = ((v[j] >> 20) & P10_MASK) - off;
+                    const unsigned m01 = t0 > t1 ? t0 : t1, m2 = t2 > t ? t2 : t;
+                    t = m01 > m2 ? m01 : m2;
+                }
+            }
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            t = wave_max_dpp(t);
+            __syncthreads();
+            if (lane == 0) scratch[wave] = t;
+            __syncthreads();
+            t = 0;
+#pragma unroll
+            for (int w = 0; w < EV_WAVES; w++) t = (unsigned)scratch[w] > t ? (unsigned)scratch[w] : t;
+            mx = t >= 0x80000000u ? t + off : 0u;
+        }
+        const double dmx = (double)mx;
+        if (a.stats && threadIdx.x == 0) {
+            ec_frame_stats st;
+            st.sum = s1;
+            st.sumsq = s2;
+            st.nnz = nnz;
+            st.max_kept = mx;
+            st.dropped = dropped;
+            st.ambiguous = amb;
+            st.thr = hp.use_thr ? hp.thr : __builtin_nan("");
+            a.stats[f] = st;
+        }
 
-    // ---- pass 3: colour through the per-frame look-up table for small counts ----
-    // lut[h0 | h1 << 4] = the pixel of the counts (h0, h1) < 16 AFTER the threshold (a count above it is 0), so the
-    // look-up path does not compare against the threshold at all
-    EV_STAMP(4);
-    if (threadIdx.x < EV_LUT_N * EV_LUT_N) {
-        uint8_t px[4] = {0, 0, 0, 0};
-        const unsigned h0 = threadIdx.x % EV_LUT_N, h1 = threadIdx.x / EV_LUT_N;
-        colour_pixel(h0 > thr_hi ? 0u : h0, h1 > thr_hi ? 0u : h1, dmx, a, px);
-        lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
-    }
-    __syncthreads();
-    EV_STAMP(5);
-    auto colour = [&](unsigned h0, unsigned h1) -> unsigned {      // 0x00BBGGRR
-        if (h0 < EV_LUT_N && h1 < EV_LUT_N) return lut[h0 | (h1 << 4)];
-        if (h0 > thr_hi) h0 = 0;
-        if (h1 > thr_hi) h1 = 0;
-        uint8_t px[3];
-        colour_pixel(h0, h1, dmx, a, px);
-        return (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
-    };
-    uint8_t *out = a.frames + (long long)f * H * W * 3;
-    const int npix = H * W;
-    // 12 pixels = 24 counts = exactly 8 words (two 16-byte LDS reads, every field at a fixed place), 36 bytes = nine
-    // dwords out; frames whose byte size is not a multiple of 4 take the byte path.  A group whose 24 counts are all
-    // below 16 (bits 4..9 of every field clear) is nine look-ups with the index cut straight out of the words.
-    const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 12 : 0;
-    for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
-        const uint4 qa = bins4[2 * g], qb = bins4[2 * g + 1];
-        const unsigned w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        unsigned c[12];
-        const unsigned any = (w[0] | w[1]) | (w[2] | w[3]) | (w[4] | w[5]) | (w[6] | w[7]);
-        if ((any & 0x3F0FC3F0u) == 0) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int fa = 2 * k, wa = fa / 3, pa = fa % 3;      // pixel k: fields 2 k and 2 k + 1
-                unsigned idx;
-                if (pa == 0) idx = (w[wa] & 0xFu) | ((w[wa] >> 6) & 0xF0u);
-                else if (pa == 1) idx = ((w[wa] >> 10) & 0xFu) | ((w[wa] >> 16) & 0xF0u);
-                else idx = ((w[wa] >> 20) & 0xFu) | ((w[wa + 1] & 0xFu) << 4);
-                c[k] = lut[idx];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int fa = 2 * k, fb = 2 * k + 1;
-                c[k] = colour((w[fa / 3] >> (10 * (fa % 3))) & P10_MASK, (w[fb / 3] >> (10 * (fb % 3))) & P10_MASK);
-            }
+        // ---- pass 3: colour through the per-frame look-up table for small counts ----
+        // lut[h0 | h1 << 4] = the pixel of the counts (h0, h1) < 16 AFTER the threshold (a count above it is 0), so
+        // the look-up path does not compare against the threshold at all
+        EV_STAMP(4);
+        if (threadIdx.x < EV_LUT_N * EV_LUT_N) {
+            uint8_t px[4] = {0, 0, 0, 0};
+            const unsigned h0 = threadIdx.x % EV_LUT_N, h1 = threadIdx.x / EV_LUT_N;
+            colour_pixel(h0 > thr_hi ? 0u : h0, h1 > thr_hi ? 0u : h1, dmx, a, px);
+            lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
         }
-        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
+        __syncthreads();
+        EV_STAMP(5);
+        uint8_t *out = a.frames + (long long)f * H * W * 3;
+        const int npix = H * W;
+        // one pixel the long way: counts cut out of the words wherever they lie, threshold, table or float stage,
+        // three byte stores.  (One copy of the float stage in the loop: unrolled into the group loop below it took
+        // the kernel past 128 registers, and a spill next to the prefetch waits for the prefetch.)
+        auto pixel = [&](int q) {
+            const unsigned b0 = 2u * q, wa = b0 / 3u, wb = (b0 + 1u) / 3u;
+            unsigned h0 = (bins[wa] >> (10u * (b0 - 3u * wa))) & P10_MASK, h1 = (bins[wb] >> (10u * (b0 + 1u - 3u * wb))) & P10_MASK;
+            unsigned v;
+            if (h0 < EV_LUT_N && h1 < EV_LUT_N) {
+                v = lut[h0 | (h1 << 4)];
+            } else {
+                if (h0 > thr_hi) h0 = 0;
+                if (h1 > thr_hi) h1 = 0;
+                uint8_t px[3];
+                colour_pixel(h0, h1, dmx, a, px);
+                v = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+            }
+            out[3 * q] = (uint8_t)v, out[3 * q + 1] = (uint8_t)(v >> 8), out[3 * q + 2] = (uint8_t)(v >> 16);
+        };
+        // 12 pixels = 24 counts = exactly 8 words (two 16-byte LDS reads, every field at a fixed place), 36 bytes =
+        // nine dwords out; frames whose byte size is not a multiple of 4 take the byte path.  A group whose 24 counts
+        // are all below 16 (bits 4..9 of every field clear) is twelve look-ups with the index cut straight out of
+        // the words; any other group goes pixel by pixel.
+        // A frame that is all groups leaves its histogram zero for the next frame: each group clears the words it read.
+        const int groups = (((long long)npix * 3) & 3) == 0 ? npix / 12 : 0;
+        const bool clears = groups * 12 == npix;
+        dirty = !clears;
+        for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
+            const uint4 qa = bins4[2 * g], qb = bins4[2 * g + 1];
+            const unsigned w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const unsigned any = (w[0] | w[1]) | (w[2] | w[3]) | (w[4] | w[5]) | (w[6] | w[7]);
+            if ((any & 0x3F0FC3F0u) == 0) {
+                unsigned c[12];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            dst[3 * k] = c[4 * k] | (c[4 * k + 1] << 24);
-            dst[3 * k + 1] = (c[4 * k + 1] >> 8) | (c[4 * k + 2] << 16);
-            dst[3 * k + 2] = (c[4 * k + 2] >> 16) | (c[4 * k + 3] << 8);
+                for (int k = 0; k < 12; k++) {
+                    const int fa = 2 * k, wa = fa / 3, pa = fa % 3;      // pixel k: fields 2 k and 2 k + 1
+                    unsigned idx;
+                    if (pa == 0) idx = (w[wa] & 0xFu) | ((w[wa] >> 6) & 0xF0u);
+                    else if (pa == 1) idx = ((w[wa] >> 10) & 0xFu) | ((w[wa] >> 16) & 0xF0u);
+                    else idx = ((w[wa] >> 20) & 0xFu) | ((w[wa + 1] & 0xFu) << 4);
+                    c[k] = lut[idx];
+                }
+                unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    dst[3 * k] = c[4 * k] | (c[4 * k + 1] << 24);
+                    dst[3 * k + 1] = (c[4 * k + 1] >> 8) | (c[4 * k + 2] << 16);
+                    dst[3 * k + 2] = (c[4 * k + 2] >> 16) | (c[4 * k + 3] << 8);
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 12; k++) pixel(12 * g + k);
+            }
+            if (clears) bins4[2 * g] = make_uint4(0, 0, 0, 0), bins4[2 * g + 1] = make_uint4(0, 0, 0, 0);
         }
+        for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) pixel(q);
+        }   // !overflow
+        EV_STAMP(6);
+        __syncthreads();                                 // the passes are done with the histogram and the table
+        e0 = e0n, n = nn;
     }
-    for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) {
-        const unsigned b0 = 2u * q, wa = b0 / 3u, wb = (b0 + 1u) / 3u;
-        const unsigned v = colour((bins[wa] >> (10u * (b0 - 3u * wa))) & P10_MASK,
-                                  (bins[wb] >> (10u * (b0 + 1u - 3u * wb))) & P10_MASK);
-        out[3 * q] = (uint8_t)v, out[3 * q + 1] = (uint8_t)(v >> 8), out[3 * q + 2] = (uint8_t)(v >> 16);
-    }
-    EV_STAMP(6);
 }
 
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
@@ -1170,13 +1231,12 @@ extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_rang
 
 namespace {
 
-// LDS bytes of the whole-frame 10-bit histogram, and whether that path applies: the frame does not fit
-// one band of 32-bit bins but does as packed counts (next to the reduction scratch and the LUT)
+// LDS bytes of the whole-frame 10-bit histogram, and whether that path applies: the frame fits as packed
+// counts next to the reduction scratch and the LUT.  (Also for sensors whose 32-bit histogram would fit:
+// the packed kernel takes its statistics from the binning and keeps the next frame's events in flight,
+// and two of its workgroups share a CU when the histogram is small, N-Cars: 32 KB.)
 inline long pack10_bytes(int H, int W) { return (((long)H * W * 2 + 2) / 3 * 4 + 15) / 16 * 16; }
-inline bool pack10_fits(int H, int W)
-{
-    return (long)W * 2 * 4 * H > EV_BIN_BYTES && pack10_bytes(H, W) + EV_SCRATCH_BYTES <= 160 * 1024;
-}
+inline bool pack10_fits(int H, int W) { return pack10_bytes(H, W) + EV_SCRATCH_BYTES <= 160 * 1024; }
 
 template <typename EV>
 int launch_events(const void *events, const int64_t *frame_range, int F, const ec_events_params *prm,
@@ -1277,6 +1337,8 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
         // ordinary data: its workgroups return at once).  The caller's workspace holds the flags.
         if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_pack10_kernel<EV>), lds))
             return rc;
+        const int p10_lds = (int)pack10_bytes(prm->H, prm->W) + EV_SCRATCH_BYTES;
+        const int p10_per_cu = 2 * p10_lds <= LDS_TOTAL ? 2 : 1;     // 1024 threads each: at most two fit a CU
         uint8_t *flags = static_cast<uint8_t *>(prm->sort_workspace);
         const long cap = (long)prm->sort_workspace_bytes;
         const long M2 = (long)prm->H * prm->W * 2;
@@ -1297,17 +1359,13 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
             g.redo = flags;
             EvArgs p = g;
             p.bin_bytes = (int)pack10_bytes(prm->H, prm->W);
-            {
-                const int p10_cus = ec::cu_count() > 0 ? ec::cu_count() : 256;
-                // three groups, 3 x s_sleep(127) (~10 us) apart; measured over 2560 N-Caltech frames: 0.469 ms
-                // without, 0.436-0.438 ms with 2-4 groups of 2-5 sleeps (only launches of several rounds)
-                p.stagger = fc > 2 * p10_cus ? 3 : 1;
-                p.stagger_wgs = p10_cus;
-                p.stagger_sleeps = 3;
-            }
-            EC_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)fc, hs));
-            hipLaunchKernelGGL(events_pack10_kernel<EV>, dim3(fc), dim3(EV_THREADS), lds, hs, p);
-            hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(fc < grid ? fc : grid), dim3(EV_THREADS), lds, hs, g);
+            // one persistent workgroup per CU for the 10-bit kernel (it writes every frame's flag); the 32-bit kernel
+            // behind it walks the flags with one workgroup per CU as well and touches only the flagged frames
+            const int p10_cus = ec::cu_count() > 0 ? ec::cu_count() : 256;
+            const int wgs = fc < p10_cus ? fc : p10_cus;
+            const int p10_wgs = fc < p10_cus * p10_per_cu ? fc : p10_cus * p10_per_cu;
+            hipLaunchKernelGGL(events_pack10_kernel<EV>, dim3(p10_wgs), dim3(EV_THREADS), p10_lds, hs, p);
+            hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(wgs), dim3(EV_THREADS), lds, hs, g);
             EC_CHECK_HIP(hipGetLastError());
         }
         return EC_OK;
