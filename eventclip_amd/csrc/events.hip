@@ -59,6 +59,8 @@ struct EvArgs {
     unsigned *sort_ws;   // band-sorted bin indices, sort_cap per workgroup (long frames), or null
     int sort_cap;
     unsigned band_magic; // ceil(2^32 / rows_per_band): y / rows_per_band == (y * magic) >> 32 for y < 2^16
+    unsigned *b10_ws;    // events_band10_kernel: [workgroup][band][wave][b10_cap] band-local bin codes
+    int b10_rows, b10_bands, b10_cap, b10_events;   // rows per band, bands, region capacity, most events per frame
     uint8_t *redo;       // per-frame flags shared with events_pack10_kernel: that kernel sets redo[f] to 1 for
                          // a frame it could not finish (0 otherwise), this one then processes ONLY those frames
 };
@@ -1053,6 +1055,307 @@ __global__ __launch_bounds__(EV_THREADS) void events_pack10_kernel(const EvArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large sensors (N-ImageNet: 480 x 640, 70 000 events per frame): row bands of 10-bit counts.
+//
+// The frame's histogram (614 400 counts) does not fit a CU, so the frame is walked in row bands of packed 10-bit
+// counts (81 rows = 135 KiB: 6 bands, where 32-bit bins take 17) and its events are routed to their bands ONCE, in the
+// scan that reads them from HBM: each wave appends the band-local bin codes (4 B) of its events to a region of its own
+// per band in the caller's workspace ([band][wave][cap] per workgroup -- sized for the worst case, every event in one
+// band, so there is no counting scan and no prefix sum; the lanes of a wave that meet in a band find their slots
+// from one ballot per band and one LDS add by the band's first lane).  Every later walk of a band is each wave
+// reading its own region back, coalesced, from L2.
+// As in the whole-frame kernel the statistics come from the binning (returning atomics); the max of what survives the
+// hot-pixel threshold and the tally of the one ambiguous count follow from how many events found their bin at count
+// v - 1 (= bins with a final count >= v), counted per value v on the side (v <= 4 with ballots, the rare rest with an
+// LDS add), so there is no pass over the bands for them.  The colour pass re-bins a band (fire-and-forget atomics),
+// colours 12 pixels = 8 words at a time and leaves the band zero.  An overflowing 10-bit field, or a frame with more
+// events than the regions were sized for, flags the frame for events_to_frames_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int B10_MAX_BANDS = 16;
+constexpr int B10_CNT_BYTES = EV_WAVES * B10_MAX_BANDS * 4;
+constexpr int B10_CC_BYTES = (EV_CC_N + 4) * 4;          // events per count value 0 .. 1024
+constexpr int B10_SIDE_BYTES = EV_SCRATCH_BYTES + B10_CNT_BYTES + B10_CC_BYTES;
+
+template <typename EV>
+__global__ __launch_bounds__(EV_THREADS) void events_band10_kernel(const EvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *bins = reinterpret_cast<unsigned *>(smem);
+    uint4 *bins4 = reinterpret_cast<uint4 *>(smem);
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem + a.bin_bytes);
+    unsigned *lut = reinterpret_cast<unsigned *>(smem + a.bin_bytes + EV_REDUCE_BYTES);
+    unsigned *cnt = lut + EV_LUT_N * EV_LUT_N;           // [wave][band]: codes in the wave's region of the band
+    unsigned *cc = cnt + EV_WAVES * B10_MAX_BANDS;       // [v]: events that brought their bin to the count v
+    const int H = a.H, W = a.W;
+    const long long M2 = (long long)H * W * 2;
+    const int rpb = a.b10_rows, bands = a.b10_bands, cap = a.b10_cap;
+    const int band_words4 = (int)(((long long)rpb * W * 2 + 2) / 3 + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned *region = a.b10_ws + ((size_t)blockIdx.x * bands * EV_WAVES + wave) * cap;   // + band * EV_WAVES * cap
+    const size_t band_stride = (size_t)EV_WAVES * cap;
+    constexpr int PF = 4;
+    constexpr int ROUND = PF * EV_THREADS;
+    constexpr unsigned NO_BAND = 0xFFu;
+
+    EV ea[PF], eb[PF];                                   // (the two-buffer scheme of events_pack10_kernel)
+    auto request = [&](EV (&e)[PF], const EV *ev, long long n, long long i) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const long long j = i + (long long)k * EV_THREADS;
+            e[k] = ev[j < n ? j : n - 1];
+        }
+    };
+    typedef const __attribute__((address_space(4))) long long *range_ptr;
+    const range_ptr range = (range_ptr)(a.range);
+    const long long most = a.b10_events < (1 << 24) ? a.b10_events : (1 << 24);
+    auto routable = [&](long long n) { return n > most ? 0ll : n; };
+    long long e0 = 0, n = 0;
+    bool dirty = true;
+    for (int f = (int)blockIdx.x - (int)gridDim.x; f < a.F; f += gridDim.x) {
+        const bool real = f >= 0;
+        const EV *ev = reinterpret_cast<const EV *>(a.events) + e0;
+        const int fn = f + (int)gridDim.x;
+        long long e0n = 0, nn = 0;
+        if (fn < a.F) e0n = range[2 * fn], nn = range[2 * fn + 1] - e0n;
+        const EV *evn = reinterpret_cast<const EV *>(a.events) + e0n;
+        const bool too_long = n > most;
+        const long long nb = routable(n), nnb = routable(nn);
+
+        if (dirty) {
+            for (int i = threadIdx.x; i < band_words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
+            dirty = false;
+        }
+        for (int i = threadIdx.x; i < EV_CC_N + 4; i += EV_THREADS) cc[i] = 0;
+        if (lane < B10_MAX_BANDS) cnt[wave * B10_MAX_BANDS + lane] = 0;       // (only this wave touches them)
+
+        // ---- the scan: the frame's only HBM read; every event to its band's region of this wave ----
+        unsigned dropped = 0;
+        auto place = [&](const EV ek, bool there) {
+            int x, y, p;
+            parse(ek, W, a.flip_x, a.negate_p, x, y, p);
+            const bool inside = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+            const bool ok = there && p != 0 && inside;
+            dropped += there && p != 0 && !inside ? 1u : 0u;
+            const unsigned band = ok ? (unsigned)(((unsigned long long)(unsigned)y * a.band_magic) >> 32) : NO_BAND;
+            unsigned long long mine = 0;                 // the lanes whose event falls in this lane's band
+            for (int b = 0; b < bands; b++) {
+                const unsigned long long m = __ballot(band == (unsigned)b);
+                if (band == (unsigned)b) mine = m;
+            }
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            unsigned base = 0;
+            if (ok && rank == 0) base = atomicAdd(&cnt[wave * B10_MAX_BANDS + band], (unsigned)__popcll(mine));
+            base = __shfl(base, ok ? __ffsll((long long)mine) - 1 : lane, 64);
+            if (ok) {
+                const unsigned local = (unsigned)((y - (int)band * rpb) * W + x) * 2u + (p < 0 ? 1u : 0u);
+                region[band * band_stride + base + rank] = local;
+            }
+        };
+        const int pairs = nb > 0 ? (int)((nb + 2 * ROUND - 1) / (2 * ROUND)) : 1;
+        auto place_round = [&](const EV (&e)[PF], int r) {
+            const long long i = threadIdx.x + (long long)r * ROUND;
+#pragma unroll
+            for (int k = 0; k < PF; k++) place(e[k], i + (long long)k * EV_THREADS < nb);
+        };
+        auto refill = [&](EV (&e)[PF], int g) {
+            const bool mine = g < 2 * pairs;
+            const long long first = (long long)(mine ? g : g - 2 * pairs) * ROUND;
+            const EV *src = mine ? ev : evn;
+            const long long ns = mine ? nb : nnb;
+            if (first < ns) request(e, src, ns, first + threadIdx.x);
+        };
+        for (int t = 0; t < pairs; t++) {
+            place_round(ea, 2 * t);
+            refill(ea, 2 * t + 2);
+            place_round(eb, 2 * t + 1);
+            refill(eb, 2 * t + 3);
+        }
+        if (!real) {                                     // the lead-in frame: nothing but the requests above
+            e0 = e0n, n = nn;
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();                                 // codes stored, bins / cc zero
+
+        // ---- pass 1: every band binned once for the statistics ----
+        unsigned binned = 0, s2t = 0, nnzt = 0, hmax = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        for (int b = 0; b < bands; b++) {
+            const unsigned count = cnt[wave * B10_MAX_BANDS + b];
+            const unsigned *codes = region + b * band_stride;
+            for (unsigned i0 = 0; i0 < count; i0 += 4 * 64) {          // four loads in flight; wave-uniform trips
+                const unsigned i = i0 + lane;
+                unsigned c[4], h[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned j = i + k * 64;
+                    c[k] = codes[j < count ? j : count - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool there = i + k * 64 < count;
+                    h[k] = 0xFFFFFFFFu;
+                    if (there) {
+                        const unsigned w = c[k] / 3u, sh = 10u * (c[k] - 3u * w);
+                        h[k] = (atomicAdd(&bins[w], 1u << sh) >> sh) & P10_MASK;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool there = h[k] != 0xFFFFFFFFu;
+                    const unsigned now = there ? h[k] + 1u : 0u;       // 1024 = this event overflowed its field
+                    binned += there ? 1u : 0u;
+                    s2t += there ? 2u * h[k] + 1u : 0u;
+                    nnzt += h[k] == 0u ? 1u : 0u;
+                    hmax = now > hmax ? now : hmax;
+                    // events per value of `now`: the common small values by ballot (a wave's lanes would all hit the
+                    // same LDS word), the rest by an LDS add
+                    c1 += (unsigned)__popcll(__ballot(now == 1u)), c2 += (unsigned)__popcll(__ballot(now == 2u));
+                    c3 += (unsigned)__popcll(__ballot(now == 3u)), c4 += (unsigned)__popcll(__ballot(now == 4u));
+                    if (now >= 5u) atomicAdd(&cc[now], 1u);
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < band_words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+        if (lane == 0) atomicAdd(&cc[1], c1), atomicAdd(&cc[2], c2), atomicAdd(&cc[3], c3), atomicAdd(&cc[4], c4);
+        const P10Stats sums = block_stats(hmax, binned, s2t, nnzt, dropped, scratch);   // (its barriers publish cc)
+        const bool overflow = too_long || sums.max > P10_MASK;
+        if (threadIdx.x == 0) a.redo[f] = overflow ? 1 : 0;
+        if (!overflow) {
+            const unsigned gmax = sums.max;
+            const unsigned long long s1 = sums.total, s2 = sums.s2;
+            const unsigned nnz = (unsigned)sums.nnz;
+            const HotPixel hp = hot_pixel_threshold(a, s1, s2, nnz, M2);
+            const unsigned thr_hi = hp.thr_hi;
+            // cc[v] events brought a bin to v = bins whose final count is >= v, so cc[v] - cc[v + 1] bins end at v
+            unsigned mx = gmax, amb = 0;
+            if (gmax > thr_hi) {
+                const unsigned v = threadIdx.x;            // 1024 threads: one count value each
+                unsigned cand = v >= 1u && v <= thr_hi && cc[v] > cc[v + 1] ? v : 0u;
+                cand = wave_max_dpp(cand);
+                __syncthreads();
+                if (lane == 0) scratch[wave] = cand;
+                __syncthreads();
+                mx = 0;
+#pragma unroll
+                for (int w = 0; w < EV_WAVES; w++) mx = (unsigned)scratch[w] > mx ? (unsigned)scratch[w] : mx;
+            }
+            if (hp.amb_h == 0) amb = (unsigned)(M2 - (long long)nnz);
+            else if (hp.amb_h > 0 && hp.amb_h <= (long long)P10_MASK) amb = cc[hp.amb_h] - cc[hp.amb_h + 1];
+            const double dmx = (double)mx;
+            if (a.stats && threadIdx.x == 0) {
+                ec_frame_stats st;
+                st.sum = s1;
+                st.sumsq = s2;
+                st.nnz = nnz;
+                st.max_kept = mx;
+                st.dropped = (unsigned)sums.dropped;
+                st.ambiguous = amb;
+                st.thr = hp.use_thr ? hp.thr : __builtin_nan("");
+                a.stats[f] = st;
+            }
+            if (threadIdx.x < EV_LUT_N * EV_LUT_N) {     // the table of events_pack10_kernel: lut[h0 | h1 << 4], thresholded
+                uint8_t px[4] = {0, 0, 0, 0};
+                const unsigned h0 = threadIdx.x % EV_LUT_N, h1 = threadIdx.x / EV_LUT_N;
+                colour_pixel(h0 > thr_hi ? 0u : h0, h1 > thr_hi ? 0u : h1, dmx, a, px);
+                lut[threadIdx.x] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+            }
+            // ---- pass 3: every band binned again and coloured ----
+            const bool aligned = (((long long)H * W * 3) & 3) == 0;        // every frame starts on a dword
+            for (int b = 0; b < bands; b++) {
+                const unsigned count = cnt[wave * B10_MAX_BANDS + b];
+                const unsigned *codes = region + b * band_stride;
+                for (unsigned i0 = 0; i0 < count; i0 += 4 * 64) {
+                    const unsigned i = i0 + lane;
+                    unsigned c[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned j = i + k * 64;
+                        c[k] = codes[j < count ? j : count - 1];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (i + k * 64 < count) {
+                            const unsigned w = c[k] / 3u, sh = 10u * (c[k] - 3u * w);
+                            atomicAdd(&bins[w], 1u << sh);
+                        }
+                }
+                __syncthreads();                         // (also: the table is written)
+                const int y0 = b * rpb, rows = min(H - y0, rpb);
+                const int npix = rows * W;
+                uint8_t *out = a.frames + ((long long)f * H + y0) * W * 3;
+                auto pixel = [&](int q) {                // (events_pack10_kernel's: one pixel the long way)
+                    const unsigned b0 = 2u * q, wa = b0 / 3u, wb = (b0 + 1u) / 3u;
+                    unsigned h0 = (bins[wa] >> (10u * (b0 - 3u * wa))) & P10_MASK, h1 = (bins[wb] >> (10u * (b0 + 1u - 3u * wb))) & P10_MASK;
+                    unsigned v;
+                    if (h0 < EV_LUT_N && h1 < EV_LUT_N) {
+                        v = lut[h0 | (h1 << 4)];
+                    } else {
+                        if (h0 > thr_hi) h0 = 0;
+                        if (h1 > thr_hi) h1 = 0;
+                        uint8_t px[3];
+                        colour_pixel(h0, h1, dmx, a, px);
+                        v = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+                    }
+                    out[3 * q] = (uint8_t)v, out[3 * q + 1] = (uint8_t)(v >> 8), out[3 * q + 2] = (uint8_t)(v >> 16);
+                };
+                // (a band of rpb rows starts on a multiple of 36 bytes: rpb * W is a multiple of 12 by the host's plan)
+                const int groups = aligned && (((long long)y0 * W * 3) & 3) == 0 ? npix / 12 : 0;
+                const bool clears = groups * 12 == npix;
+                for (int g = threadIdx.x; g < groups; g += EV_THREADS) {
+                    const uint4 qa = bins4[2 * g], qb = bins4[2 * g + 1];
+                    const unsigned w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+                    const unsigned any = (w[0] | w[1]) | (w[2] | w[3]) | (w[4] | w[5]) | (w[6] | w[7]);
+                    if (any == 0) {                      // a long frame is sparse: mostly this
+                        const unsigned z = lut[0];
+                        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            dst[3 * k] = z | (z << 24);
+                            dst[3 * k + 1] = (z >> 8) | (z << 16);
+                            dst[3 * k + 2] = (z >> 16) | (z << 8);
+                        }
+                        continue;
+                    }
+                    if ((any & 0x3F0FC3F0u) == 0) {
+                        unsigned c[12];
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            const int fa = 2 * k, wa = fa / 3, pa = fa % 3;
+                            unsigned idx;
+                            if (pa == 0) idx = (w[wa] & 0xFu) | ((w[wa] >> 6) & 0xF0u);
+                            else if (pa == 1) idx = ((w[wa] >> 10) & 0xFu) | ((w[wa] >> 16) & 0xF0u);
+                            else idx = ((w[wa] >> 20) & 0xFu) | ((w[wa + 1] & 0xFu) << 4);
+                            c[k] = lut[idx];
+                        }
+                        unsigned *dst = reinterpret_cast<unsigned *>(out + (long long)g * 36);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            dst[3 * k] = c[4 * k] | (c[4 * k + 1] << 24);
+                            dst[3 * k + 1] = (c[4 * k + 1] >> 8) | (c[4 * k + 2] << 16);
+                            dst[3 * k + 2] = (c[4 * k + 2] >> 16) | (c[4 * k + 3] << 8);
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int k = 0; k < 12; k++) pixel(12 * g + k);
+                    }
+                    if (clears) bins4[2 * g] = make_uint4(0, 0, 0, 0), bins4[2 * g + 1] = make_uint4(0, 0, 0, 0);
+                }
+                for (int q = groups * 12 + threadIdx.x; q < npix; q += EV_THREADS) pixel(q);
+                __syncthreads();
+                if (!clears) {
+                    for (int i = threadIdx.x; i < band_words4; i += EV_THREADS) bins4[i] = make_uint4(0, 0, 0, 0);
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        e0 = e0n, n = nn;
+    }
+}
+
 // center_events, datasets/utils.py:38-57, one workgroup per sample, in place:
 // t -= min t; x -= ((x_max + x_min + 1) - W) // 2; y likewise (float32 arithmetic).
 // (1024 threads, four events in flight per thread per pass: one workgroup per sample has to keep a CU's share of
@@ -1238,6 +1541,37 @@ namespace {
 inline long pack10_bytes(int H, int W) { return (((long)H * W * 2 + 2) / 3 * 4 + 15) / 16 * 16; }
 inline bool pack10_fits(int H, int W) { return pack10_bytes(H, W) + EV_SCRATCH_BYTES <= 160 * 1024; }
 
+// Row bands of 10-bit counts for sensors whose whole histogram does not fit (events_band10_kernel): rows per band a
+// multiple of 12 / gcd(W, 12) so that every band is whole groups of 12 pixels, as many as fit the LDS next to the
+// side arrays, then evened out over the bands.
+constexpr long B10_FLAG_BYTES = 65536;
+struct B10Plan {
+    bool ok;
+    int rows, bands, cap;
+    long bin_bytes;
+    size_t region_bytes;     // per workgroup
+};
+inline B10Plan b10_plan(int H, int W, int max_frame_events)
+{
+    B10Plan p = {false, 0, 0, 0, 0, 0};
+    if (max_frame_events <= 0 || pack10_fits(H, W)) return p;
+    int gcd = W % 12, t = 12;
+    while (gcd) { const int r = t % gcd; t = gcd; gcd = r; }          // t = gcd(W, 12)
+    const int unit = 12 / t;
+    const long budget_fields = ((long)160 * 1024 - B10_SIDE_BYTES) / 16 * 16 / 4 * 3;
+    int rows = (int)(budget_fields / ((long)W * 2)) / unit * unit;
+    if (rows < unit) return p;
+    const int bands = ec::ceil_div(H, rows);
+    if (bands > B10_MAX_BANDS) return p;
+    rows = ec::ceil_div(ec::ceil_div(H, bands), unit) * unit;
+    p.rows = rows, p.bands = ec::ceil_div(H, rows);
+    p.bin_bytes = (((long)rows * W * 2 + 2) / 3 * 4 + 15) / 16 * 16;
+    p.cap = 64 * ec::ceil_div(max_frame_events, EV_THREADS);
+    p.region_bytes = (size_t)p.bands * EV_WAVES * p.cap * 4;
+    p.ok = p.bin_bytes + B10_SIDE_BYTES <= (long)160 * 1024;
+    return p;
+}
+
 template <typename EV>
 int launch_events(const void *events, const int64_t *frame_range, int F, const ec_events_params *prm,
                   uint8_t *frames, int32_t *raw_counts, int32_t *kept_counts, ec_frame_stats *stats,
@@ -1292,17 +1626,25 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     int grid = F;
     a.sort_ws = nullptr;
     a.sort_cap = 0;
+    // banded 10-bit path (events_band10_kernel): the workspace is [frame flags | code regions, one per CU]; what the
+    // 32-bit kernel behind it uses as sort slots for the frames it is left with is the region area
+    const B10Plan b10 = b10_plan(prm->H, prm->W, prm->max_frame_events);
+    const int cus_now = ec::cu_count() > 0 ? ec::cu_count() : 256;
+    const bool use_b10 = b10.ok && !raw_counts && !kept_counts && prm->sort_workspace &&
+                         prm->sort_workspace_bytes >= (size_t)B10_FLAG_BYTES + b10.region_bytes && !getenv("EC_EVENTS_NO_BAND10");
+    unsigned char *sort_base = static_cast<unsigned char *>(prm->sort_workspace) + (use_b10 ? B10_FLAG_BYTES : 0);
+    const size_t sort_bytes = prm->sort_workspace ? prm->sort_workspace_bytes - (use_b10 ? B10_FLAG_BYTES : 0) : 0;
     if (cache_events == 0 && prm->max_frame_events > 0 && prm->sort_workspace) {
         const int sort_budget = (LDS_TOTAL - EV_SCRATCH_BYTES - EV_SORT_BYTES) / 16 * 16;
         const int budget = sort_budget < EV_BIN_BYTES ? sort_budget : EV_BIN_BYTES;
         const int rows = budget / row_bytes;
         const size_t slot = (size_t)prm->max_frame_events * 4;
-        const size_t slots = prm->sort_workspace_bytes / slot;
+        const size_t slots = sort_bytes / slot;
         if (rows >= 1 && ec::ceil_div(prm->H, rows) > 1 && ec::ceil_div(prm->H, rows) <= EV_SORT_MAX_BANDS &&
             slots >= 1) {
             EC_REQUIRE(((uintptr_t)prm->sort_workspace & 3) == 0, "ec_events_to_frames: sort workspace alignment");
             bin_budget = budget;
-            a.sort_ws = static_cast<unsigned *>(prm->sort_workspace);
+            a.sort_ws = reinterpret_cast<unsigned *>(sort_base);
             a.sort_cap = prm->max_frame_events;
             int cus = 256;
             int dev = 0;
@@ -1331,6 +1673,33 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
                        (double)F * prm->H * prm->W * 3.0 +
                            (double)(prm->total_events > 0 ? prm->total_events : 0) * sizeof(EV));
     a.redo = nullptr;
+    if (use_b10) {
+        // banded 10-bit path first, then the 32-bit kernel for the frames it flagged (none, for ordinary data)
+        const int b10_lds = (int)b10.bin_bytes + B10_SIDE_BYTES;
+        if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_band10_kernel<EV>), lds)) return rc;
+        uint8_t *flags = static_cast<uint8_t *>(prm->sort_workspace);
+        size_t wgs_fit = (prm->sort_workspace_bytes - B10_FLAG_BYTES) / b10.region_bytes;
+        if (wgs_fit > (size_t)cus_now) wgs_fit = (size_t)cus_now;
+        for (long f0 = 0; f0 < F; f0 += B10_FLAG_BYTES) {
+            const int fc = (int)(F - f0 < B10_FLAG_BYTES ? F - f0 : B10_FLAG_BYTES);
+            EvArgs g = a;
+            g.range = a.range + 2 * f0;
+            g.frames = a.frames + f0 * prm->H * prm->W * 3;
+            g.stats = a.stats ? a.stats + f0 : nullptr;
+            g.F = fc;
+            g.redo = flags;
+            EvArgs p = g;
+            p.bin_bytes = (int)b10.bin_bytes;
+            p.b10_ws = reinterpret_cast<unsigned *>(sort_base);
+            p.b10_rows = b10.rows, p.b10_bands = b10.bands, p.b10_cap = b10.cap, p.b10_events = prm->max_frame_events;
+            p.band_magic = (unsigned)((0x100000000ull + (unsigned)b10.rows - 1) / (unsigned)b10.rows);
+            const int wgs = fc < (int)wgs_fit ? fc : (int)wgs_fit;
+            hipLaunchKernelGGL(events_band10_kernel<EV>, dim3(wgs), dim3(EV_THREADS), b10_lds, hs, p);
+            hipLaunchKernelGGL(events_to_frames_kernel<EV>, dim3(fc < grid ? fc : grid), dim3(EV_THREADS), lds, hs, g);
+            EC_CHECK_HIP(hipGetLastError());
+        }
+        return EC_OK;
+    }
     if (pack10_fits(prm->H, prm->W) && prm->sort_workspace && prm->sort_workspace_bytes >= 256 &&
         !getenv("EC_EVENTS_NO_PACK10")) {
         // whole-frame 10-bit path first, then the 32-bit kernel for the frames it flagged (none, for
@@ -1391,6 +1760,11 @@ extern "C" EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *
     if (!prm || prm->H <= 0 || prm->W <= 0) return 0;
     if (pack10_fits(prm->H, prm->W)) return 65536;    // per-frame redo flags of the 10-bit path
     if (prm->max_frame_events <= 0) return 0;
+    {   // banded 10-bit path: the flags, then every CU's code regions
+        const B10Plan b10 = b10_plan(prm->H, prm->W, prm->max_frame_events);
+        const int cus_now = ec::cu_count() > 0 ? ec::cu_count() : 256;
+        if (b10.ok) return (size_t)B10_FLAG_BYTES + (size_t)cus_now * b10.region_bytes;
+    }
     const long row_bytes = (long)prm->W * 2 * 4;
     const long cache_bytes = ((long)prm->max_frame_events * 4 + 15) / 16 * 16;
     const long left = (long)EV_BIN_BYTES - cache_bytes;

@@ -299,3 +299,11 @@ def test_randomised_geometries_against_oracle(seed, hip):
         if int(stats['ambiguous'].sum()) == 0:       # a count exactly at the float64 threshold: order of summation decides
             np.testing.assert_array_equal(kept.cpu().numpy(), wkept)
             np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # the frames-only product call (no debug outputs): the 10-bit kernels -- whole frame or row bands -- where the
+    # geometry allows them, statistics from the binning; same frames, same statistics as the debug path above
+    got2, stats2 = vis.events_to_frames_device(
+        e, r, (H, W), grayscale=gray, thresh=kw['thresh'], count_non_zero=kw['count_non_zero'],
+        background_mask=kw['background_mask'], return_stats=True, max_frame_events=nmax, sort_workspace=True)
+    assert torch.equal(got2, got)
+    for k in ('sum', 'sumsq', 'nnz', 'max_kept', 'dropped', 'ambiguous'):
+        np.testing.assert_array_equal(stats2[k], stats[k], err_msg=k)

@@ -10,7 +10,7 @@ from eventclip_amd import vis  # noqa: E402
 from eventclip_amd.synthetic import make_events  # noqa: E402
 
 for name, shape, n, frames in (('n_caltech', (180, 240), 20000, 2560), ('n_cars', (100, 120), 12500, 512),
-                               ('n_imagenet', (480, 640), 70000, 512)):
+                               ('n_imagenet', (480, 640), 70000, 512), ('n_imagenet', (480, 640), 70000, 2560)):
     uniq = 8
     ev = np.concatenate([make_events(n, shape, seed=i) for i in range(uniq)] * (frames // uniq))
     rng = torch.tensor([[i * n, (i + 1) * n] for i in range(frames)], dtype=torch.int64).cuda()
