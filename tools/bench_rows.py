@@ -97,6 +97,24 @@ def main():
         line(name, timed(lambda: vis.events_to_frames_device(events, fr, (H, W), grayscale=False, out=out,
                                                              max_frame_events=20000, **kw)), F * (16 * 20000 + 3 * H * W), frames=F,
              cpu_baseline=cb)
+    # the other two dataset geometries (and the packed 8-byte events of all three)
+    pk = vis.pack_events_device(events)
+    line('events -> frames, packed events', timed(lambda: vis.events_to_frames_device(pk, fr, (H, W), grayscale=False, out=out,
+                                                                                     max_frame_events=20000)),
+         F * (8 * 20000 + 3 * H * W), frames=F)
+    for gname, gshape, gn, gframes in (('N-Cars 100x120, 12 500 events', (100, 120), 12500, 2560),
+                                       ('N-ImageNet 480x640, 70 000 events', (480, 640), 70000, 512),
+                                       ('N-ImageNet 480x640, 70 000 events', (480, 640), 70000, 2560)):
+        gev = np.concatenate([make_events(gn, gshape, seed=i) for i in range(8)] * (gframes // 8))
+        gfr = torch.tensor([[i * gn, (i + 1) * gn] for i in range(gframes)], dtype=torch.int64).cuda()
+        gout = torch.empty((gframes, *gshape, 3), dtype=torch.uint8, device='cuda')
+        for packed in (False, True):
+            ge = torch.from_numpy(vis.pack_events(gev).view(np.int64) if packed else gev).cuda()
+            line(f'events -> frames, {gname}{", packed" if packed else ""}',
+                 timed(lambda: vis.events_to_frames_device(ge, gfr, gshape, grayscale=False, out=gout, max_frame_events=gn)),
+                 gframes * ((8 if packed else 16) * gn + 3 * gshape[0] * gshape[1]), frames=gframes)
+            del ge
+        del gev, gfr, gout
     # RandAugment: two operators per frame, the same pair for the 10 views of a sample
     frames = out.clone()
     for pair in ((('Rotate', 17.6), ('Contrast', 0.34)), (('ShearX', 0.2), ('Equalize', 0.0)), (('TranslateY', 40.0), ('Sharpness', 0.5)),
