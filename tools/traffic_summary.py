@@ -21,7 +21,7 @@ def classify(name):
     m = re.search(r'gemm_kernel<(\d+), \d+, \d+, \d+, \d+, (\d+)', name)
     if m:
         return f'gemm_kernel<{EPI[int(m.group(2))]}>'
-    if 'events_pack10_kernel' in name:      # same launch site as the 32-bit kernel behind it (one class in bench.py)
+    if 'events_pack10_kernel' in name or 'events_band10_kernel' in name:      # same launch site as the 32-bit kernel behind them (one class in bench.py)
         return 'events_to_frames_kernel'
     m = re.search(r'::(\w+_kernel)', name)
     return m.group(1) if m else name.split('(')[0]
