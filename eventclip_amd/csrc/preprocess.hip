@@ -18,6 +18,7 @@
 #include "mfma.h"
 
 #include <cmath>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -137,43 +138,51 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a)
     // a row's tap window -- 3 cnt contiguous bytes -- is read as unaligned dwords, not byte by byte.  (One output
     // per item with byte loads issued 40 loads per output on N-ImageNet frames; the pass ran at the texture
     // unit's instruction rate: 6.3 ms per 2560 frames.)
-    constexpr int HT = 12, HW = 3 * HT / 4, HG = 8;
-    const bool fast_h = a.ks_h <= HT;
-    for (int it = threadIdx.x; fast_h && it < R * HG; it += 256) {
-        const int ox = it % R, rg = it / R;
-        const int xmin = bh[2 * ox], cnt = bh[2 * ox + 1];
-        int coef[HT];
+    // (The tap count is a compile-time bound of the item's loop: 6 covers every upscale -- a bicubic window is 4 or 5
+    // input pixels wide there, N-Caltech's 180 x 240 and N-Cars' frames -- and 12 the downscales to 2.75 x, N-ImageNet;
+    // with one bound of 12 an upscale multiplied seven zero coefficients per output.)
+    constexpr int HG = 8;
+    const bool fast_h = a.ks_h <= 12;
+    auto horizontal = [&](auto taps) {
+        constexpr int HT = decltype(taps)::value, HW = (3 * HT + 3) / 4;
+        for (int it = threadIdx.x; it < R * HG; it += 256) {
+            const int ox = it % R, rg = it / R;
+            const int xmin = bh[2 * ox], cnt = bh[2 * ox + 1];
+            int coef[HT];
 #pragma unroll
-        for (int t = 0; t < HT; t++) coef[t] = t < cnt ? kh[ox * a.ks_h + t] : 0;
-        const int nbytes = 3 * cnt, ndw = nbytes >> 2;
-        for (int yy = rg; yy < ny; yy += HG) {
-            const uint8_t *row = src + ((long)(ymin + yy) * a.in_w + xmin) * 3;
-            unsigned w[HW];
+            for (int t = 0; t < HT; t++) coef[t] = t < cnt ? kh[ox * a.ks_h + t] : 0;
+            const int nbytes = 3 * cnt, ndw = nbytes >> 2;
+            for (int yy = rg; yy < ny; yy += HG) {
+                const uint8_t *row = src + ((long)(ymin + yy) * a.in_w + xmin) * 3;
+                unsigned w[HW];
 #pragma unroll
-            for (int j = 0; j < HW; j++) {
-                w[j] = 0;
-                if (j < ndw) {
-                    unsigned v;
-                    __builtin_memcpy(&v, row + 4 * j, 4);          // (unaligned global load)
-                    w[j] = v;
-                } else if (j == ndw) {                             // the window's last 1-3 bytes, one at a time
-                    for (int b = 0; b < (nbytes & 3); b++) w[j] |= (unsigned)row[4 * j + b] << (8 * b);
+                for (int j = 0; j < HW; j++) {
+                    w[j] = 0;
+                    if (j < ndw) {
+                        unsigned v;
+                        __builtin_memcpy(&v, row + 4 * j, 4);          // (unaligned global load)
+                        w[j] = v;
+                    } else if (j == ndw) {                             // the window's last 1-3 bytes, one at a time
+                        for (int b = 0; b < (nbytes & 3); b++) w[j] |= (unsigned)row[4 * j + b] << (8 * b);
+                    }
                 }
-            }
-            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+                int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
 #pragma unroll
-            for (int t = 0; t < HT; t++) {
-                const int c = coef[t];
-                s0 += (int)((w[(3 * t) >> 2] >> (8 * ((3 * t) & 3))) & 255u) * c;
-                s1 += (int)((w[(3 * t + 1) >> 2] >> (8 * ((3 * t + 1) & 3))) & 255u) * c;
-                s2 += (int)((w[(3 * t + 2) >> 2] >> (8 * ((3 * t + 2) & 3))) & 255u) * c;
+                for (int t = 0; t < HT; t++) {
+                    const int c = coef[t];
+                    s0 += (int)((w[(3 * t) >> 2] >> (8 * ((3 * t) & 3))) & 255u) * c;
+                    s1 += (int)((w[(3 * t + 1) >> 2] >> (8 * ((3 * t + 1) & 3))) & 255u) * c;
+                    s2 += (int)((w[(3 * t + 2) >> 2] >> (8 * ((3 * t + 2) & 3))) & 255u) * c;
+                }
+                unsigned char *d = tmp + (yy * R + ox) * 3;
+                d[0] = (unsigned char)min(255, max(0, s0 >> PRECISION_BITS));
+                d[1] = (unsigned char)min(255, max(0, s1 >> PRECISION_BITS));
+                d[2] = (unsigned char)min(255, max(0, s2 >> PRECISION_BITS));
             }
-            unsigned char *d = tmp + (yy * R + ox) * 3;
-            d[0] = (unsigned char)min(255, max(0, s0 >> PRECISION_BITS));
-            d[1] = (unsigned char)min(255, max(0, s1 >> PRECISION_BITS));
-            d[2] = (unsigned char)min(255, max(0, s2 >> PRECISION_BITS));
         }
-    }
+    };
+    if (a.ks_h <= 6) horizontal(std::integral_constant<int, 6>());
+    else if (fast_h) horizontal(std::integral_constant<int, 12>());
     for (int it = threadIdx.x; !fast_h && it < ny * R; it += 256) {
         const int yy = it / R, ox = it - yy * R;
         const int xmin = bh[2 * ox], cnt = bh[2 * ox + 1];
@@ -199,8 +208,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a)
     const int p = a.patch, pp = p * p;
     const bool pairs = (R & 1) == 0 && (a.mode != EC_PRE_PATCHES16 || ((p & 1) == 0 && (a.kpad & 1) == 0));
     const int RW = pairs ? R / 2 : R;                  // work items per output row
+    // Item order: in the patch layout the 14 x 14 values of one patch and channel are contiguous in the output row
+    // (kpad elements per patch), so consecutive items walk (row in patch, pixel pair) INSIDE a patch and a wave's
+    // 4-byte stores fall into 256 contiguous bytes; row-major over the band they fell into runs of 28 bytes, one per
+    // patch, ten cache lines per store instruction.
+    const bool by_patch = pairs && a.mode == EC_PRE_PATCHES16 && (oy1 - oy0) % p == 0;
+    const int per_patch = p * (p / 2);
     for (int it = threadIdx.x; it < (oy1 - oy0) * RW; it += 256) {
-        const int oyl = it / RW, ox = (it - oyl * RW) * (pairs ? 2 : 1);
+        int oyl, ox;
+        if (by_patch) {
+            const int q = it / per_patch, r = it - q * per_patch;
+            const int pyl = q / a.grid_w, pxl = q - pyl * a.grid_w;
+            const int i = r / (p / 2), jp = r - i * (p / 2);
+            oyl = pyl * p + i, ox = pxl * p + 2 * jp;
+        } else {
+            oyl = it / RW, ox = (it - oyl * RW) * (pairs ? 2 : 1);
+        }
         const int oy = oy0 + oyl;
         const int y0 = bv[2 * oy] - ymin, cnt = bv[2 * oy + 1];
         const int32_t *k = kvs + oyl * a.ks_v;
