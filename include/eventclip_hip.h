@@ -91,9 +91,15 @@ typedef struct {
     int flip_x;               /* test-time augmentation: x -> W - 1 - x (datasets/utils.py:18-23) */
     int negate_p;             /* test-time augmentation: p -> -p; together with frame ranges taken on
                                  the reversed event order this is the time flip of utils.py:26-35 */
-    void *sort_workspace;     /* optional device scratch of ec_events_sort_workspace_bytes(): frames with
-                                 more events than the on-chip cache holds (N-ImageNet) are bucketed by row
-                                 band there once instead of being re-read for every band pass */
+    void *sort_workspace;     /* optional device scratch of ec_events_sort_workspace_bytes().  Sensors whose
+                                 histogram fits a CU as 10-bit counts (up to ~59 000 pixels: N-Caltech, N-Cars):
+                                 64 KiB of per-frame flags for the whole-frame kernel.  Larger sensors
+                                 (N-ImageNet) with max_frame_events set: the flags plus, per CU, a region of
+                                 band-local bin codes per (row band, wave) sized for the worst case -- every
+                                 event in one band -- so that the one scan that reads the events from HBM also
+                                 routes them to their bands (480 x 640, 70 000 events: 440 MB for 256 CUs).
+                                 Without it (or with raw / kept counts requested) the 32-bit band kernel of
+                                 rounds 1-2 runs: same results, more passes */
     size_t sort_workspace_bytes;
     int float32_stage;        /* 0: the float stage of vis.py:27-39 in float64, as numpy >= 2 runs the
                                  reference (NEP 50); != 0: in float32, as the reference's pinned numpy
@@ -103,7 +109,7 @@ typedef struct {
                                  only states the launch's algorithmic bytes to ec_profile_end */
 } ec_events_params;
 
-/* bytes of sort_workspace that pay off for this geometry / max_frame_events (0: not needed) */
+/* bytes of sort_workspace that pay off for this geometry / max_frame_events on the current device (0: not needed) */
 EC_API size_t ec_events_sort_workspace_bytes(const ec_events_params *prm);
 
 /*
