@@ -487,7 +487,8 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
         int any = 0;
         for (int f = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; f < a.F; f += EV_THREADS * (int)gridDim.x) any |= a.redo[f];
         // (through the dynamic LDS the kernel owns: __syncthreads_or takes static LDS on top of the CU's 160 KB)
-        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = __ballot(any != 0);
+        const unsigned long long flagged = __ballot(any != 0);        // (every lane's frames: taken outside the branch)
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = flagged;
         __syncthreads();
         unsigned long long all = 0;
 #pragma unroll

@@ -307,3 +307,45 @@ def test_randomised_geometries_against_oracle(seed, hip):
     assert torch.equal(got2, got)
     for k in ('sum', 'sumsq', 'nnz', 'max_kept', 'dropped', 'ambiguous'):
         np.testing.assert_array_equal(stats2[k], stats[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,hint', [((480, 640), 70000), ((180, 240), 20000), ((100, 120), 12500)])
+def test_ragged_batches_through_the_persistent_kernels(shape, hint, hip):
+    """The persistent 10-bit kernels (whole frame / row bands) walk several frames per workgroup with the next
+    frame's events in flight: empty frames, one-event frames, frames longer than the caller's max_frame_events
+    hint (left to the 32-bit kernel) and ordinary ones in one launch, more frames than workgroups, against the
+    streaming path (no workspace: the round-1 kernel) and, frame by frame, the C oracle."""
+    import torch
+    from eventclip_amd import vis
+    from eventclip_amd.synthetic import make_events
+    from oracle import events as oe
+    rng = np.random.default_rng(5)
+    lengths = [0, 1, 5, hint, hint + hint // 3, 300, hint - 1, 0, 4097, 8192, 8193, hint // 2] * 30
+    rng.shuffle(lengths)
+    evs = [make_events(max(n, 1), shape, seed=300 + i, hot_pixels=i % 3, p_zero_frac=0.01 * (i % 2))[:n] for i, n in enumerate(lengths)]
+    # a pixel past the 10-bit fields' 1023 in frames of both rounds of the workgroups' walks (256 CUs): flagged, redone
+    # by the 32-bit kernel
+    long_enough = [i for i, n in enumerate(lengths) if 4097 <= n <= hint]
+    overflowing = [i for i in long_enough if i < 256][:2] + [i for i in long_enough if i >= 256][:3]
+    for i in overflowing:
+        evs[i][:1100, 0], evs[i][:1100, 1], evs[i][:1100, 3] = 7, 9, 1
+    assert any(i >= 256 for i in overflowing)
+    ev = np.concatenate(evs)
+    ends = np.cumsum(lengths)
+    r = torch.tensor(np.stack([ends - np.array(lengths), ends], 1), dtype=torch.int64).cuda()
+    e = torch.from_numpy(ev).cuda()
+    for packed in (False, True):
+        src = torch.from_numpy(vis.pack_events(ev).view(np.int64)).cuda() if packed else e
+        a, sa = vis.events_to_frames_device(src, r, shape, grayscale=False, return_stats=True, max_frame_events=hint)
+        b, sb = vis.events_to_frames_device(src, r, shape, grayscale=False, return_stats=True, max_frame_events=hint,
+                                            sort_workspace=False)
+        assert torch.equal(a, b)
+        for k in ('sum', 'sumsq', 'nnz', 'max_kept', 'dropped', 'ambiguous'):
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    got = a.cpu().numpy()
+    for i in [0, 3, 7, 11, 100, len(lengths) - 1] + overflowing:
+        if lengths[i] == 0:
+            continue
+        want = oe.events2frames(evs[i], 'event_count', 'event_histogram', shape=shape, N=max(lengths[i], 1), grayscale=False)
+        np.testing.assert_array_equal(got[i], want[0])
