@@ -1462,6 +1462,123 @@ template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const
 
 #ifdef EC_GEMM_DIAG
 // ---------------------------------------------------------------------------------------
+// Probe (diagnostic build, variant 20): the vendor kernel's layout -- 256 x 256 x 64 tiles over FOUR waves, one per
+// SIMD, 128 x 128 and 256 accumulators each (the whole 512-entry register file), two K tiles of LDS, ONE barrier per K
+// tile: the ds_reads of the next half K tile ride under the MFMAs of the present one.  16-bit store only, M and N
+// multiples of 256, one tile per workgroup, plain (untransposed) stores: a measurement of the main loop, not a product
+// path (profiles/r3_gemm.md 7).
+// ---------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int STAGE = 512 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    raster(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = g.K / BK;
+    const int r8 = lane >> 3, c = lane & 7;
+    const unsigned off_a = (unsigned)r8 * (unsigned)g.lda * 2u + (unsigned)((c ^ r8) << 4);
+    const unsigned off_w = (unsigned)r8 * (unsigned)g.ldw * 2u + (unsigned)((c ^ r8) << 4);
+    auto issue = [&](int buf, int kt) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int p = wave + 4 * i;                 // 1-KiB piece: LDS rows 8 p .. 8 p + 7 (i < 8: activation rows)
+            const unsigned char *base = i < 8 ? (const unsigned char *)g.A + ((long)(m0 + 8 * p) * g.lda + (long)kt * BK) * 2
+                                              : (const unsigned char *)g.W + ((long)(n0 + 8 * (p - 32)) * g.ldw + (long)kt * BK) * 2;
+            glds16(base + (i < 8 ? off_a : off_w), smem + buf * STAGE + p * 1024);
+        }
+    };
+    int offB[8], offA[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int rb = wm * 128 + i * 16 + (lane & 15), ra = 256 + wn * 128 + i * 16 + (lane & 15);
+        offB[i] = rb * 128 + (((lane >> 4) ^ (rb & 7)) << 4);
+        offA[i] = ra * 128 + (((lane >> 4) ^ (ra & 7)) << 4);
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8 fb0[8], fa0[8], fb1[8], fa1[8];
+    auto load = [&](v8(&fb)[8], v8(&fa)[8], int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            fb[i] = *reinterpret_cast<const v8 *>(smem + buf * STAGE + (offB[i] ^ (ks << 6)));
+            fa[i] = *reinterpret_cast<const v8 *>(smem + buf * STAGE + (offA[i] ^ (ks << 6)));
+        }
+    };
+    // (accumulators pinned to the accumulation half of the register file with a tied asm operand: through the builtin
+    // hipcc kept them in VGPRs and moved ~8 registers across per MFMA)
+    auto mma = [&](v8(&fb)[8], v8(&fa)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (DT == 0)
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
+                else
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
+            }
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load(fb0, fa0, 0, 0);
+    for (int t = 0; t < nk; t++) {
+        const int buf = t & 1;
+        load(fb1, fa1, buf, 1);
+        mma(fb0, fa0);
+        // this wave has read all it needs of `buf`; its share of the next K tile has landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue(buf, t + 2);
+        if (t + 1 < nk) load(fb0, fa0, buf ^ 1, 0);
+        mma(fb1, fa1);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMAs' results, read by vector instructions below
+    // D rows <-> weight rows (output columns 16 j + 4 q + r), D columns <-> activation rows (16 i + lane & 15)
+    const int q = lane >> 4, lr = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int n = n0 + wn * 128 + 16 * j + 4 * q;
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b = *reinterpret_cast<const f32x4 *>(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = m0 + wm * 128 + 16 * i + lr;
+            typedef elem elem4 __attribute__((ext_vector_type(4)));
+            elem4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = to16(acc[i][j][r] + b[r], elem());
+            *reinterpret_cast<elem4 *>((elem *)g.C + (long)m * g.ldc + n) = o;
+        }
+    }
+}
+
+template <int DT> int launch4w(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    EC_REQUIRE(g.M % 256 == 0 && g.N % 256 == 0 && g.K % BK == 0 && g.splits <= 1, "ec_gemm variant 20: M, N multiples of 256");
+    g.tiles_m = g.M / 256, g.tiles_n = g.N / 256;
+    constexpr int lds = 2 * 512 * 128;
+    auto kern = gemm4w_kernel<DT>;
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+    ec::ProfScope prof(ec::PROF_GEMM_STORE16, stream, 2.0 * g.M * g.N * g.K, 2.0 * g.M * g.K + 2.0 * g.N * g.K + 2.0 * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Two workgroups per CU: 128 x 256 x 32 tiles, 4 waves (one per SIMD), each wave 128 x 64.
 // A 3-stage LDS-DMA ring of 24-KiB K tiles (72 KiB per workgroup, so two workgroups share a
 // CU's LDS and registers).  The SIMD partner of every wave belongs to the OTHER workgroup:
@@ -1767,6 +1884,9 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
     case 16: return launch2p<DT, EPI, 9>(g, s);   // per-workgroup timeline -> args.diag
     case 18: return launch2pp<DT, EPI, true>(g, s);  // persistent, with timeline records -> args.diag
+    case 20:                                         // probe: four waves x 128 x 128, 16-bit store only
+        if constexpr (EPI == EC_EPI_STORE16) return launch4w<DT>(g, s);
+        return ec::fail(EC_ERR_INVALID, "ec_gemm variant 20: store16 only");
 #endif
     default:
         return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d (diagnostic variants need an "
