@@ -1564,6 +1564,205 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmArgs g)
     }
 }
 
+// Variant 21: the four-wave layout with what tools/mfma_probe.py showed one wave per SIMD needs: the staging as a ring
+// of FOUR quarter tiles (K = 32; a quarter's DMA goes out three quarters before its first read), and the next
+// quarter's 16 fragment reads and this wave's 8 DMA requests SPREAD through the block of 64 MFMAs (two reads and one
+// request per eight MFMAs, pinned with sched_barriers) instead of bunched behind the barrier, where the four waves'
+// bursts fill the LDS queue and hold their own MFMAs back.  64-byte LDS rows, chunk ^ ((row >> 2) & 3).
+template <int DT>
+__global__ __launch_bounds__(256, 1) void gemm4i_kernel(const GemmArgs g)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int QK = 32, QUARTER = 512 * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    raster(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nq = g.K / QK;
+    const unsigned key = (unsigned)((lane >> 4) & 3);
+    const unsigned off_a = (unsigned)(lane >> 2) * (unsigned)g.lda * 2u + (((unsigned)(lane & 3) ^ key) << 4);
+    const unsigned off_w = (unsigned)(lane >> 2) * (unsigned)g.ldw * 2u + (((unsigned)(lane & 3) ^ key) << 4);
+    // piece i (0 .. 7) of this wave for quarter q: 16 rows x 64 bytes; i < 4 activation rows, else weight rows
+    auto issue1 = [&](int q, int i) {
+        const int p = wave + 4 * i;
+        const unsigned char *base = i < 4 ? (const unsigned char *)g.A + ((long)(m0 + 16 * p) * g.lda + (long)q * QK) * 2
+                                          : (const unsigned char *)g.W + ((long)(n0 + 16 * (p - 16)) * g.ldw + (long)q * QK) * 2;
+        glds16(base + (i < 4 ? off_a : off_w), smem + (q & 3) * QUARTER + p * 1024);
+    };
+    int offB[8], offA[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int rb = wm * 128 + i * 16 + (lane & 15), ra = 256 + wn * 128 + i * 16 + (lane & 15);
+        offB[i] = rb * 64 + (((lane >> 4) ^ ((rb >> 2) & 3)) << 4);
+        offA[i] = ra * 64 + (((lane >> 4) ^ ((ra >> 2) & 3)) << 4);
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8 fb0[8], fa0[8], fb1[8], fa1[8];
+    auto mfma1 = [&](f32x4 &c, const v8 &a, const v8 &b) {
+        if (DT == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    };
+    // one block: the MFMAs of the quarter held in (FB, FA); group i also fetches fragment pair i of quarter QN into
+    // (FBN, FAN) when LOAD, and requests piece i of quarter QI when ISSUE
+#define EC_G4I_BLOCK(FB, FA, FBN, FAN, LOAD, QN, ISSUE, QI)                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) {                                               \
+        if (LOAD) FBN[i] = *reinterpret_cast<const v8 *>(smem + ((QN) & 3) * QUARTER + offB[i]);  \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (LOAD) FAN[i] = *reinterpret_cast<const v8 *>(smem + ((QN) & 3) * QUARTER + offA[i]);  \
+        if (ISSUE) issue1(QI, i);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _Pragma("unroll") for (int j = 4; j < 8; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    }
+#define EC_G4I_SYNC(N)                                                    \
+    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    // quarters 0 .. 3 requested, quarter 0 waited for and fetched
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) issue1(q, i);
+    EC_G4I_SYNC(24)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        fb0[i] = *reinterpret_cast<const v8 *>(smem + offB[i]);
+        fa0[i] = *reinterpret_cast<const v8 *>(smem + offA[i]);
+    }
+    int q = 0;
+    for (; q + 4 < nq; q += 2) {
+        // quarter q + 1 landed (q + 2, q + 3 may still fly), everyone holds quarter q's fragments: its buffer takes q + 4
+        EC_G4I_SYNC(16)
+        EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, true, q + 4)
+        EC_G4I_SYNC(16)
+        EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, true, q + 5)
+    }
+    EC_G4I_SYNC(16)
+    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, false, 0)
+    EC_G4I_SYNC(8)
+    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, false, 0)
+    EC_G4I_SYNC(0)
+    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 3, false, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, false, 0, false, 0)
+#undef EC_G4I_BLOCK
+#undef EC_G4I_SYNC
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const int qq = lane >> 4, lr = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int n = n0 + wn * 128 + 16 * j + 4 * qq;
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b = *reinterpret_cast<const f32x4 *>(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = m0 + wm * 128 + 16 * i + lr;
+            typedef elem elem4 __attribute__((ext_vector_type(4)));
+            elem4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = to16(acc[i][j][r] + b[r], elem());
+            *reinterpret_cast<elem4 *>((elem *)g.C + (long)m * g.ldc + n) = o;
+        }
+    }
+}
+
+template <int DT> int launch4i(const GemmArgs &g0, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    EC_REQUIRE(g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 256 && g.splits <= 1, "ec_gemm variant 21: M, N multiples of 256, K of 64");
+    g.tiles_m = g.M / 256, g.tiles_n = g.N / 256;
+    constexpr int lds = 4 * 512 * 64;
+    auto kern = gemm4i_kernel<DT>;
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+    ec::ProfScope prof(ec::PROF_GEMM_STORE16, stream, 2.0 * g.M * g.N * g.K, 2.0 * g.M * g.K + 2.0 * g.N * g.K + 2.0 * g.M * g.N);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Probe (diagnostic build): what one wave per SIMD can issue.  256 threads per CU; a block = 64 independent
+// v_mfma_f32_16x16x32_f16 on AGPR accumulators (the four-wave layout's quarter tile), optionally with what the GEMM
+// loop puts between blocks: bit 0 = 16 ds_read_b128 of fresh fragments, bit 1 = a workgroup barrier, bit 2 = 8 LDS-DMA
+// requests (waited for two blocks later).  tools/mfma_probe.py turns the launch time into cycles per block.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const unsigned char *src, float *out, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 32768; i += 256) reinterpret_cast<unsigned *>(smem)[i] = 0x3c003c00u;   // f16 1.0
+    __syncthreads();
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 fa[8], fb[8];
+    int off[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) off[i] = (wave * 128 + i * 16 + (lane & 15)) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        fa[i] = *reinterpret_cast<const f16x8 *>(smem + off[i]);
+        fb[i] = *reinterpret_cast<const f16x8 *>(smem + 65536 + off[i]);
+    }
+    const unsigned char *gsrc = src + ((size_t)blockIdx.x * 4 + wave) * 8192 + lane * 16;
+    for (int it = 0; it < iters; it++) {
+        if (MODE & 4) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < 8; p++) glds16(gsrc + p * 1024, smem + 98304 + (it & 1) * 16384 + wave * 8192 + p * 1024 - (wave * 8192 / 2));
+        }
+        if (MODE & 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        f16x8 na[8], nb[8];
+        if ((MODE & 1) && !(MODE & 8)) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                na[i] = *reinterpret_cast<const f16x8 *>(smem + ((it & 1) << 15) + off[i]);
+                nb[i] = *reinterpret_cast<const f16x8 *>(smem + 65536 + ((it & 1) << 14) + off[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if ((MODE & 1) && (MODE & 8)) {        // bit 3: the reads spread through the block, one pair per eight MFMAs
+                const unsigned a0 = (unsigned)(((it & 1) << 15) + off[i]), a1 = (unsigned)(65536 + ((it & 1) << 14) + off[i]);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(na[i]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(nb[i]) : "v"(a1));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
+        }
+        if (MODE & 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; i++) fa[i] = na[i], fb[i] = nb[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.f) out[threadIdx.x] = s;            // (keeps the accumulators alive)
+}
+
 template <int DT> int launch4w(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
@@ -1887,6 +2086,9 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 20:                                         // probe: four waves x 128 x 128, 16-bit store only
         if constexpr (EPI == EC_EPI_STORE16) return launch4w<DT>(g, s);
         return ec::fail(EC_ERR_INVALID, "ec_gemm variant 20: store16 only");
+    case 21:                                         // ... ring of four quarter tiles, reads and DMA spread through the MFMAs
+        if constexpr (EPI == EC_EPI_STORE16) return launch4i<DT>(g, s);
+        return ec::fail(EC_ERR_INVALID, "ec_gemm variant 21: store16 only");
 #endif
     default:
         return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d (diagnostic variants need an "
@@ -2068,3 +2270,19 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     if (a->dtype == EC_BF16) return dispatch_epi<EC_BF16>(g, a->epilogue, a->variant, s);
     return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown dtype %d", a->dtype);
 }
+
+#ifdef EC_GEMM_DIAG
+extern "C" EC_API int ec_mfma_probe(int mode, int iters, int workgroups, const void *src, float *out, ec_stream_t stream)
+{
+    EC_REQUIRE(mode >= 0 && mode < 16 && iters > 0 && workgroups > 0 && src && out, "ec_mfma_probe: bad arguments");
+    void (*k[16])(const unsigned char *, float *, int) = {mfma_probe_kernel<0>, mfma_probe_kernel<1>, mfma_probe_kernel<2>, mfma_probe_kernel<3>,
+                                                          mfma_probe_kernel<4>, mfma_probe_kernel<5>, mfma_probe_kernel<6>, mfma_probe_kernel<7>,
+                                                          mfma_probe_kernel<8>, mfma_probe_kernel<9>, mfma_probe_kernel<10>, mfma_probe_kernel<11>,
+                                                          mfma_probe_kernel<12>, mfma_probe_kernel<13>, mfma_probe_kernel<14>, mfma_probe_kernel<15>};
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(k[mode]), 160 * 1024)) return rc;
+    hipLaunchKernelGGL(k[mode], dim3(workgroups), dim3(256), 160 * 1024, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char *>(src), out, iters);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+#endif
