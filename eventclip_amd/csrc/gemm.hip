@@ -1676,134 +1676,6 @@ __global__ __launch_bounds__(256, 1) void gemm4i_kernel(const GemmArgs g)
     }
 }
 
-// Variant 22 = variant 21 with the WEIGHT fragments fetched straight from L2 into registers (a GEMM's weights are 2 - 8 MB
-// and hot in the XCD's L2), one block ahead: only the activations go through LDS -- 48 KB of LDS traffic per quarter
-// instead of 96.  (Comment of variant 21:) the four-wave layout with what tools/mfma_probe.py showed one wave per SIMD needs: the staging as a ring
-// of FOUR quarter tiles (K = 32; a quarter's DMA goes out three quarters before its first read), and the next
-// quarter's 16 fragment reads and this wave's 8 DMA requests SPREAD through the block of 64 MFMAs (two reads and one
-// request per eight MFMAs, pinned with sched_barriers) instead of bunched behind the barrier, where the four waves'
-// bursts fill the LDS queue and hold their own MFMAs back.  64-byte LDS rows, chunk ^ ((row >> 2) & 3).
-template <int DT>
-__global__ __launch_bounds__(256, 1) void gemm4g_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::elem elem;
-    typedef typename T16<DT>::v8 v8;
-    constexpr int QK = 32, QUARTER = 512 * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    raster(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nq = g.K / QK;
-    const unsigned key = (unsigned)((lane >> 4) & 3);
-    const unsigned off_a = (unsigned)(lane >> 2) * (unsigned)g.lda * 2u + (((unsigned)(lane & 3) ^ key) << 4);
-    const unsigned off_w = (unsigned)(lane >> 2) * (unsigned)g.ldw * 2u + (((unsigned)(lane & 3) ^ key) << 4);
-    // piece i (0 .. 7) of this wave for quarter q: 16 rows x 64 bytes; i < 4 activation rows, else weight rows
-    auto issue1 = [&](int q, int i) {
-        const int p = wave + 4 * i;
-        const unsigned char *base = i < 4 ? (const unsigned char *)g.A + ((long)(m0 + 16 * p) * g.lda + (long)q * QK) * 2
-                                          : (const unsigned char *)g.W + ((long)(n0 + 16 * (p - 16)) * g.ldw + (long)q * QK) * 2;
-        glds16(base + (i < 4 ? off_a : off_w), smem + (q & 3) * QUARTER + p * 1024);
-    };
-    int offB[8];
-    const unsigned char *wrow[8];                        // this lane's 16 bytes of weight row tile j, quarter 0
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int rb = wm * 128 + i * 16 + (lane & 15);
-        offB[i] = rb * 64 + (((lane >> 4) ^ ((rb >> 2) & 3)) << 4);
-        wrow[i] = (const unsigned char *)g.W + ((long)(n0 + wn * 128 + i * 16 + (lane & 15)) * g.ldw + (lane >> 4) * 8) * 2;
-    }
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v8 fb0[8], fa0[8], fb1[8], fa1[8];
-    auto mfma1 = [&](f32x4 &c, const v8 &a, const v8 &b) {
-        if (DT == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    };
-    // one block: the MFMAs of the quarter held in (FB, FA); group i also fetches fragment pair i of quarter QN into
-    // (FBN, FAN) when LOAD, and requests piece i of quarter QI when ISSUE
-#define EC_G4I_BLOCK(FB, FA, FBN, FAN, LOAD, QN, ISSUE, QI)                                       \
-    _Pragma("unroll") for (int i = 0; i < 8; i++) {                                               \
-        if (LOAD) FBN[i] = *reinterpret_cast<const v8 *>(smem + ((QN) & 3) * QUARTER + offB[i]);  \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (LOAD) FAN[i] = *reinterpret_cast<const v8 *>(wrow[i] + (long)(QN) * (QK * 2));        \
-        if (ISSUE && i < 4) issue1(QI, i);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        _Pragma("unroll") for (int j = 4; j < 8; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    }
-#define EC_G4I_SYNC(N)                                                    \
-    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");      \
-    __builtin_amdgcn_s_barrier();                                         \
-    __builtin_amdgcn_sched_barrier(0);
-    // quarters 0 .. 3 requested, quarter 0 waited for and fetched
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) issue1(q, i);
-#pragma unroll
-    for (int i = 0; i < 8; i++) fa0[i] = *reinterpret_cast<const v8 *>(wrow[i]);
-    EC_G4I_SYNC(0)
-#pragma unroll
-    for (int i = 0; i < 8; i++) fb0[i] = *reinterpret_cast<const v8 *>(smem + offB[i]);
-    int q = 0;
-    for (; q + 4 < nq; q += 2) {
-        // quarter q + 1 landed (q + 2, q + 3 may still fly), everyone holds quarter q's fragments: its buffer takes q + 4
-        EC_G4I_SYNC(0)
-        EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, true, q + 4)
-        EC_G4I_SYNC(0)
-        EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, true, q + 5)
-    }
-    EC_G4I_SYNC(0)
-    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, false, 0)
-    EC_G4I_SYNC(0)
-    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, false, 0)
-    EC_G4I_SYNC(0)
-    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 3, false, 0)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, false, 0, false, 0)
-#undef EC_G4I_BLOCK
-#undef EC_G4I_SYNC
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    const int qq = lane >> 4, lr = lane & 15;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n = n0 + wn * 128 + 16 * j + 4 * qq;
-        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (g.bias) b = *reinterpret_cast<const f32x4 *>(g.bias + n);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int m = m0 + wm * 128 + 16 * i + lr;
-            typedef elem elem4 __attribute__((ext_vector_type(4)));
-            elem4 o;
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = to16(acc[i][j][r] + b[r], elem());
-            *reinterpret_cast<elem4 *>((elem *)g.C + (long)m * g.ldc + n) = o;
-        }
-    }
-}
-
-template <int DT> int launch4g(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    EC_REQUIRE(g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 256 && g.splits <= 1, "ec_gemm variant 22: M, N multiples of 256, K of 64");
-    g.tiles_m = g.M / 256, g.tiles_n = g.N / 256;
-    constexpr int lds = 4 * 512 * 64;
-    auto kern = gemm4g_kernel<DT>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    ec::ProfScope prof(ec::PROF_GEMM_STORE16, stream, 2.0 * g.M * g.N * g.K, 2.0 * g.M * g.K + 2.0 * g.N * g.K + 2.0 * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
 template <int DT> int launch4i(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
@@ -2217,9 +2089,6 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 21:                                         // ... ring of four quarter tiles, reads and DMA spread through the MFMAs
         if constexpr (EPI == EC_EPI_STORE16) return launch4i<DT>(g, s);
         return ec::fail(EC_ERR_INVALID, "ec_gemm variant 21: store16 only");
-    case 22:                                         // ... and the weight fragments straight from L2
-        if constexpr (EPI == EC_EPI_STORE16) return launch4g<DT>(g, s);
-        return ec::fail(EC_ERR_INVALID, "ec_gemm variant 22: store16 only");
 #endif
     default:
         return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown variant %d (diagnostic variants need an "
