@@ -81,6 +81,9 @@ def parse():
                     help='also time the step with every batch starting in HOST memory (pinned staging ring + copy '
                          'stream, the upload of batch i + 1 under the tower of batch i): value_from_host')
     ap.add_argument('--no-dvfs', action='store_true', help='skip the clock / power sampling steps')
+    ap.add_argument('--precise', action='store_true',
+                    help='image tower with hi + lo operands in every GEMM (ec_vit_weights.precise, 3 x the MFMA work): '
+                         'the mode that meets 1e-3 on input-dependent weights; a line of its own, never the headline')
     a = ap.parse_args()
     c = CONFIGS[a.config]
     a.batch = a.batch or c['batch']
@@ -313,7 +316,7 @@ def main():
     # ---- model: seeded random CLIP, text features cached once ----
     cfg = eclip.arch_config(a.arch)
     sd = eclip.random_state_dict(cfg, seed=2)
-    clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk).cuda().eval()
+    clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk, image_precise=a.precise).cuda().eval()
     tokens = eclip.synthetic_tokens(a.classes, seed=2)
     clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
                      class_names=[f'class {i}' for i in range(a.classes)], agg_func='mean', class_tokens=tokens)
@@ -339,7 +342,12 @@ def main():
     # config 1: every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
     # then not flattered by a reuse pattern); the big configs tile a few distinct streams ON THE DEVICE
     uniq_n = min(local_batch, a.unique_samples or (local_batch if a.config == 1 else 16))
-    evs = [make_events(c['n_ev'], geo['resolution'], seed=2 * 100003 + rank * 1000 + i) for i in range(uniq_n)]
+    # (generated on a few threads -- numpy releases the GIL in the generator and the sort: 256 streams of 200 000
+    # events are ~8 s of single-threaded host work per rank otherwise, and the ranks of a node do this at once)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(8, (os.cpu_count() or 8) // max(1, world)))) as ex:
+        evs = list(ex.map(lambda i: make_events(c['n_ev'], geo['resolution'], seed=2 * 100003 + rank * 1000 + i),
+                          range(uniq_n)))
     if uniq_n == local_batch:
         events = torch.from_numpy(np.concatenate(evs)).cuda()
     else:
@@ -474,6 +482,8 @@ def main():
         breakdown = {e['name']: round(e['total_ms'] / a.steps, 3) for e in prof}
         metric = 'event-frames/sec (whole node) ViT-L/14 zero-shot @224' if a.config == 1 else \
             f'event-frames/sec (whole node), BASELINE configs[{a.config}]'
+        if a.precise:
+            metric += ' -- split-precision image tower (validation mode, not the headline)'
         if c['scaling'] == 'weak':
             batch_txt = f'batch={a.batch} samples x {views} view{"s" if views > 1 else ""} per GPU'
         else:
@@ -490,9 +500,13 @@ def main():
                        'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
                        'unique_samples': uniq_n,
                        'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
-                       'precision': ('16-bit MFMA operands, fp32 accumulate / residual stream / LayerNorm / '
-                                     'softmax; patch embedding and ln_post @ proj with hi + lo operands; '
-                                     'text tower split-precision (cached)'),
+                       'precision': (('split precision: hi + lo 16-bit operands in every GEMM of the image tower '
+                                      '(ec_vit_weights.precise, 3 x the MFMA work), fp32 residual stream and LayerNorm'
+                                      if a.precise else
+                                      '16-bit MFMA operands, fp32 accumulate / softmax; residual stream as hi + lo '
+                                      '16-bit planes (~2^-22), LayerNorm folded into the QKV / c_fc GEMMs (statistics '
+                                      'of the 16-bit hi plane); patch embedding and ln_post @ proj with hi + lo operands')
+                                     + '; text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else
                                       'keys/values for every token; query projection, attention, out_proj, '
                                       'MLP for the class token only (bit-identical encode_image output)'),

@@ -5,7 +5,8 @@
 Every ``csrc/*.hip`` is compiled to an object next to it (cached by mtime) and
 linked into ``eventclip_amd/libeventclip_hip.so``.  The .so is git-ignored but
 travels with the tree to the GPU box.  ``--diag`` builds ``libeventclip_hip_diag.so`` with
--DEC_GEMM_DIAG instead: the same library plus ec_gemm's timing / stamp / timeline variants, for
+-DEC_GEMM_DIAG -DEC_ATTN_DIAG -DEC_EVENTS_DIAG instead: the same library plus ec_gemm's timing / stamp /
+timeline variants (csrc/gemm_diag.inc) and the attention / events phase stamps, for
 tools/ only (the product never loads it).
 """
 import argparse
@@ -24,9 +25,12 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-I', INCLUDE]
 
+# the diagnostic build: each translation unit keys its own extras on its own macro
+DIAG_FLAGS = ['-DEC_GEMM_DIAG', '-DEC_ATTN_DIAG', '-DEC_EVENTS_DIAG']
+
 
 def _newest_header():
-    hs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+    hs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + glob.glob(os.path.join(INCLUDE, '*.h'))
     return max(os.path.getmtime(h) for h in hs)
 
 
@@ -35,7 +39,7 @@ def _compile(src, force, diag=False):
     stamp = max(os.path.getmtime(src), _newest_header())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
         return obj, False
-    cmd = [HIPCC] + FLAGS + (['-DEC_GEMM_DIAG'] if diag else []) + ['-c', src, '-o', obj]
+    cmd = [HIPCC] + FLAGS + (DIAG_FLAGS if diag else []) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}')

@@ -266,6 +266,9 @@ class CLIP(nn.Module):
                     # ec_vit_weights.q_scaled: softmax temperature and base change folded into the q rows in
                     # fp32, before the one rounding to 16 bit
                     width = wqkv.shape[1]
+                    heads = c.get('heads', width // 64) if prefix.startswith('visual') else c.get('text_heads', width // 64)
+                    assert width == 64 * heads, \
+                        'q_scaled folds log2(e) / sqrt(64) into in_proj: the attention kernels are built for head dim 64'
                     wqkv, bqkv = wqkv.float().clone(), bqkv.float().clone()
                     wqkv[:width] *= ATTN_Q_SCALE
                     bqkv[:width] *= ATTN_Q_SCALE

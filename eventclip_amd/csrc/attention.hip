@@ -23,7 +23,7 @@
 #include "common.h"
 #include "mfma.h"
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
 // diagnostic build only (python -m eventclip_amd.build --diag, tools/timeline_attn.py): s_memtime at
 // workgroup start / K and V staged / done, and the CU the workgroup ran on
 __device__ unsigned long long ec_attn_stamps[4 * 65536];
@@ -33,7 +33,7 @@ namespace {
 
 using namespace ec;
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
 __device__ __forceinline__ void attn_stamp(int i)
 {
     unsigned long long now;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
         }
     }
     attn_stamp(2);
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
     if (threadIdx.x == 0 && blockIdx.x < 65536) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -618,26 +618,34 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 #endif
 }
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
 int g_attn_variant = 0;
 #endif
 
 template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStream_t s)
 {
     const int n32 = (a.S + 31) / 32;
-    // K and V images + the merge area of a tile whose keys are split over the waves (16 waves at most)
-    const int lds = 32 * n32 * 128 * 2 + 16 * ATTN_PART * 4;
+    // K and V images, plus the merge area of a tile whose keys are split over the waves -- reserved only where the
+    // kernel can take that path for this S (its `lone` condition: not causal, S = 16 n + 1, the tile count one more
+    // than a multiple of the wave count), so that S = 609 .. 640 (n32 = 20: exactly 160 KiB of K and V) still fits
+    const int kv = 32 * n32 * 128 * 2;
+    const int n_qt_all = (a.S + 15) / 16;
+    const int waves_if = kv + 16 * ATTN_PART * 4 > 80 * 1024 ? 16 : 8;      // the wave count the full carve would pick
+    const bool may_split = !a.causal && (a.S & 15) == 1 && n_qt_all > waves_if && n_qt_all % waves_if == 1;
+    const int lds = kv + (may_split ? 16 * ATTN_PART * 4 : 0);
     if (lds > 160 * 1024)
-        return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d > 640", a.S);
+        return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d needs %d bytes of LDS (K and V images%s), "
+                        "the CU has 163840: S <= 640%s", a.S, lds, may_split ? " + the split-tile merge area" : "",
+                        may_split ? " (608 for this S, whose last query tile is split over the waves)" : "");
     // Waves per workgroup: 16 when K + V leave room for one workgroup per CU only, else 8.  (9..12 waves,
     // which would spread the 17 query tiles of S = 257 over two even passes, measure 0.22 ms against
     // 0.17 ms for 8: the second workgroup no longer co-resides.)
-    const bool wide = lds > 80 * 1024;
+    const bool wide = kv + 16 * ATTN_PART * 4 > 80 * 1024;
     void (*kern)(const AttnArgs) = a.lse ? (wide ? attention_kernel<DT, 16, true> : attention_kernel<DT, 8, true>)
                                          : (wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>);
     if (a.q_scaled)   // the inference towers (never with a log-sum-exp)
         kern = wide ? attention_kernel<DT, 16, false, true, QM_INPUT> : attention_kernel<DT, 8, false, true, QM_INPUT>;
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
     if (g_attn_variant == 1 && !a.q_scaled)   // round 1 / 2 block (per-block maximum, vector-ALU row sum), for A/B
         kern = a.lse ? (wide ? attention_kernel<DT, 16, true, false> : attention_kernel<DT, 8, true, false>)
                      : (wide ? attention_kernel<DT, 16, false, false> : attention_kernel<DT, 8, false, false>);
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, vo
 
 }  // namespace
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_ATTN_DIAG
 // diagnostic build only (not part of the public header): copy the stamp records to the host
 extern "C" __attribute__((visibility("default"))) int ec_attn_stamps_read(unsigned long long *host, int n)
 {

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(EV_THREADS) void events_to_frames_kernel(const EvAr
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned P10_MASK = 1023u;
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_EVENTS_DIAG
 // phase stamps of the first 4096 frames of a launch (diagnostic build only; tools/events_phases.py)
 __device__ unsigned long long g_ev_phase[4096 * 8];
 #define EV_STAMP(k)                                                                   \
@@ -1747,7 +1747,7 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
 
 }  // namespace
 
-#ifdef EC_GEMM_DIAG
+#ifdef EC_EVENTS_DIAG
 extern "C" EC_API int ec_events_phase_times(unsigned long long *host, int frames)
 {
     EC_REQUIRE(host && frames > 0 && frames <= 4096, "ec_events_phase_times: bad arguments");

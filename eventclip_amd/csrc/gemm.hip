@@ -454,6 +454,351 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Buffer-addressed forms of the three LDS-transposed epilogues (round 4): what the persistent kernel runs.
+//  * A wave tile's global accesses go through a wave-uniform buffer descriptor of the tile (scalar registers) whose
+//    range ends at the last row that exists, plus ONE per-lane 32-bit byte offset (parked out of range for the
+//    lanes whose columns do not exist) plus a 32-bit add per row group: `buffer_* v, v_off, s[rsrc], 0 offen`.
+//    The hardware's range check drops the stores and zeroes the loads of rows >= M and columns >= N, so edge
+//    tiles and interior tiles run the SAME predicate-free code (a row's result cannot depend on which of the two
+//    its tile is in this launch: batch invariance), and every store instruction is always issued, which is what
+//    the counted hand-over wait of the tile loop needs.  (The offset that is range-checked is the vector one;
+//    a scalar offset would bypass the check.)
+//  * The general forms above spend 64 - 80 quarter-rate v_mul_lo_u32 / v_mad_u64_u32 and ~100 64-bit vector adds
+//    per wave tile on `(long)m * ldc + col` -- more vector-ALU time than the arithmetic of the epilogue itself
+//    (tile timelines: profiles/r4_gemm.md).  They stay for the diagnostic kernels and the training epilogues.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *origin, long bytes)
+{
+    // raw buffer (stride 0), dword3 = 0x00020000 (gfx9 / CDNA: 32-bit data format, no swizzle).  Every component goes
+    // through readfirstlane: the values ARE wave-uniform, but where one of them was computed on the vector ALU (64-bit
+    // products) a loop-carried descriptor lands in vector registers and every buffer instruction is wrapped in a
+    // waterfall loop
+    const unsigned long a = reinterpret_cast<unsigned long>(origin);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0 ? bytes : 0));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long)hi << 32) | lo), 0, n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, int voff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+}
+__device__ __forceinline__ void bstore16(u32x4 v, __amdgpu_buffer_rsrc_t r, int voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+constexpr int BUF_OOB = 0x7ffffff0;     // a vector offset no tile's range reaches: loads give 0, stores are dropped
+// rows of a TMx16-row wave tile at m_base that exist, as a byte range of `pitch`-byte rows
+__device__ __forceinline__ long tile_span(int M, int m_base, int rows, long pitch)
+{
+    const int left = M - m_base;
+    return (long)(left < rows ? (left > 0 ? left : 0) : rows) * pitch;
+}
+
+// v_fma_mix_f32 reads fp16 halves of a packed register in place (no convert instruction): the arithmetic of the
+// fp16 residual planes in 5.5 instructions per element instead of 9.5.  H = which half of the 32-bit register.
+// Every form is ONE correctly rounded fp32 operation, the same value the separate convert + add / fma gives.
+template <int H> __device__ __forceinline__ float mix_add16(unsigned a, unsigned b)     // (float)a.H + (float)b.H
+{
+    float d;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int H> __device__ __forceinline__ float mix_sub16(float x, unsigned h)        // x - (float)h.H
+{
+    float d;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(x), "v"(h));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(x), "v"(h));
+    return d;
+}
+template <int H> __device__ __forceinline__ float mix_acc16(unsigned h, float c)        // c + (float)h.H
+{
+    float d;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(c));
+    return d;
+}
+template <int H> __device__ __forceinline__ float mix_sq16(unsigned h, float c)         // fma(h.H, h.H, c)
+{
+    float d;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(h), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(h), "v"(c));
+    return d;
+}
+
+// bias of this lane's 16 accumulator columns (zero where there is no bias / the columns do not exist)
+__device__ __forceinline__ void load_bias(const GemmArgs &g, int nb, f32x4 (&bias)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias && nb < g.N) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
+    }
+}
+
+// (hi, lo) <- split(hi + lo + acc + bias), optional (sum, sum of squares) of the new hi values per 64 columns.
+// The residual loads of row group i + DEPTH are issued BEFORE the stores of group i: vmcnt retires in issue order,
+// so a load issued behind a store cannot deliver before that store is acknowledged -- with the stores first every
+// row group waited for a write acknowledgement (30 k cycles per out_proj tile, 38 % of it).
+// `between` runs once the epilogue's first loads (bias, the first residual row groups) are issued: the kernel puts the
+// DMA requests of the next tile's first K tile there, so that they are YOUNGER than those loads -- the epilogue's first
+// wait then is for its own data only (in-order vmcnt: waiting for a load also waits for everything issued before it).
+// MODE (A / B switch, diagnostic build variants 30 .. 33): bit 0 = two scratch buffers, row group i + 1 written while
+// the transposed reads of group i are in flight; bit 1 = the residual prefetch grows from DEPTH to the whole tile.
+constexpr int HL_MODE_DEFAULT = 1;
+template <int DT, int TM, int MODE, typename F>
+__device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
+                                                int lane, float *scratch, F &&between)
+{
+    constexpr bool PIPE = (MODE & 1) != 0, GROW = (MODE & 2) != 0;
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int PITCH = 68;
+    const int q = lane >> 4, lr = lane & 15;
+    f32x4 bias[4];
+    load_bias(g, n_base + q * 16, bias);
+    const int c8 = lane & 7, r8 = lane >> 3;
+    const long org = ((long)m_base * g.ldc + n_base) * 2;                  // wave-uniform byte offset of the tile
+    const long span = tile_span(g.M, m_base, TM * 16, g.ldc * 2);
+    const __amdgpu_buffer_rsrc_t rh = tile_rsrc(reinterpret_cast<const char *>(g.C) + org, span);
+    const __amdgpu_buffer_rsrc_t rl = tile_rsrc(reinterpret_cast<const char *>(g.aux) + org, span);
+    const bool col_ok = n_base + c8 * 8 < g.N;
+    const int voff = col_ok ? (r8 * (int)g.ldc + c8 * 8) * 2 : BUF_OOB;    // this lane's bytes inside the tile
+    const int step8 = (int)g.ldc * 16;                                     // bytes per 8 rows (scalar)
+    const bool stats = g.stat_out != nullptr;
+    float *st0 = g.stat_out + ((long)m_base * g.stat_groups + (n_base >> 6)) * 2;
+    const int svoff = r8 * g.stat_groups * 2;                              // floats
+    const int sstep8 = g.stat_groups * 16;
+    const int rows_left = g.M - m_base - r8;                               // row 16 i + 8 p + r8 exists iff 16 i + 8 p < rows_left
+    // Residual loads run DEPTH row groups ahead; the registers a finished row group frees (its 16 accumulators and
+    // its 16 loaded values) take the loads of TWO later groups, so the whole tile's planes are in flight from the
+    // second row group on (the epilogue is bound by the latency of these HBM reads, not by their bandwidth).
+    constexpr int DEPTH = TM < 3 ? TM : 3;
+    u32x4 xh[TM][2], xl[TM][2];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            xh[i][p] = bload16(rh, voff + (2 * i + p) * step8);
+            xl[i][p] = bload16(rl, voff + (2 * i + p) * step8);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) fetch(i);
+    between();
+    // two scratch buffers per wave: row group i + 1 is written while the transposed reads of group i are in flight
+    auto produce = [&](int i) {
+        float *buf = scratch + (PIPE ? (i & 1) * 16 * PITCH : 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
+    };
+    if (PIPE) produce(0);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const float *buf = scratch + (PIPE ? (i & 1) * 16 * PITCH : 0);
+        if (!PIPE) produce(i);
+        f32x4 ta[2], tb[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            ta[p] = *reinterpret_cast<const f32x4 *>(buf + (r8 + 8 * p) * PITCH + c8 * 8);
+            tb[p] = *reinterpret_cast<const f32x4 *>(buf + (r8 + 8 * p) * PITCH + c8 * 8 + 4);
+        }
+        if (PIPE && i + 1 < TM) produce(i + 1);
+        u32x4 oh[2], ol[2];
+        float ps[2], pq[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const f32x4 a = ta[p], b = tb[p];
+            ps[p] = 0.f, pq[p] = 0.f;
+            if constexpr (DT == EC_F16) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned h2 = xh[i][p][k], l2 = xl[i][p][k];
+                    const float a0 = k < 2 ? a[2 * k] : b[2 * k - 4], a1 = k < 2 ? a[2 * k + 1] : b[2 * k - 3];
+                    const float x0 = mix_add16<0>(h2, l2) + a0, x1 = mix_add16<1>(h2, l2) + a1;
+                    const f16x2 o = {(_Float16)x0, (_Float16)x1};
+                    const unsigned o2 = __builtin_bit_cast(unsigned, o);
+                    const f16x2 d = {(_Float16)mix_sub16<0>(x0, o2), (_Float16)mix_sub16<1>(x1, o2)};
+                    oh[p][k] = o2, ol[p][k] = __builtin_bit_cast(unsigned, d);
+                    ps[p] = mix_acc16<0>(o2, ps[p]), pq[p] = mix_sq16<0>(o2, pq[p]);
+                    ps[p] = mix_acc16<1>(o2, ps[p]), pq[p] = mix_sq16<1>(o2, pq[p]);
+                }
+            } else {
+                const v8 vh = __builtin_bit_cast(v8, xh[i][p]);
+                const f16x8 vl = __builtin_bit_cast(f16x8, xl[i][p]);
+                v8 wh;
+                f16x8 wl;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float x = (float)vh[e] + (float)vl[e] + (e < 4 ? a[e] : b[e - 4]);
+                    wh[e] = to16(x, elem());
+                    const float h = (float)wh[e];
+                    wl[e] = (_Float16)(x - h);
+                    ps[p] += h, pq[p] = __builtin_fmaf(h, h, pq[p]);
+                }
+                oh[p] = __builtin_bit_cast(u32x4, wh), ol[p] = __builtin_bit_cast(u32x4, wl);
+            }
+        }
+        // before the stores (see above); two groups per finished group until everything is requested
+        if constexpr (GROW) {
+            if (DEPTH + 2 * i < TM) fetch(DEPTH + 2 * i);
+            if (DEPTH + 2 * i + 1 < TM) fetch(DEPTH + 2 * i + 1);
+        } else {
+            if (i + DEPTH < TM) fetch(i + DEPTH);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            bstore16(oh[p], rh, voff + (2 * i + p) * step8);
+            bstore16(ol[p], rl, voff + (2 * i + p) * step8);
+        }
+        if (stats) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                float s = ps[p], qq = pq[p];
+                s += dpp_f32<0xB1>(s), qq += dpp_f32<0xB1>(qq);      // quad_perm [1, 0, 3, 2]
+                s += dpp_f32<0x4E>(s), qq += dpp_f32<0x4E>(qq);      // quad_perm [2, 3, 0, 1]
+                s += dpp_f32<0x141>(s), qq += dpp_f32<0x141>(qq);    // row_half_mirror
+                if (c8 == 0 && col_ok && 16 * i + 8 * p < rows_left)     // (a wave tile beyond N has no column group)
+                    *reinterpret_cast<float2 *>(st0 + (2 * i + p) * sstep8 + svoff) = make_float2(s, qq);
+            }
+        }
+    }
+}
+
+// 16-bit outputs (STORE16 / GELU16 and their folded-LayerNorm forms).  lds_rowstat: the wave row's 128 statistics
+// pairs in LDS (has_lds; always a pointer INTO the shared array, so that the reads compile to ds_read and not to
+// flat loads, whose s_waitcnt vmcnt(0) lgkmcnt(0) also waited for the next tile's first K tile), else g.rowstat
+template <int DT, int EPI, int TM, bool HAS_LDS, typename F>
+__device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
+                                               int lane, unsigned char *scratch, const float *lds_rowstat, F &&between)
+{
+    typedef typename T16<DT>::elem elem;
+    static_assert(EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI), "inference epilogues only");
+    constexpr int PITCH = 144;
+    const int q = lane >> 4, lr = lane & 15;
+    const int nb = n_base + q * 16;
+    f32x4 bias[4];
+    load_bias(g, nb, bias);
+    f32x4 cs[4];
+    float rs0[TM], rs1[TM];
+    if constexpr (epi_is_ln(EPI)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            cs[j] = nb < g.N ? *reinterpret_cast<const f32x4 *>(g.colsum + nb + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_LDS) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const float2 r = *reinterpret_cast<const float2 *>(lds_rowstat + 2 * (i * 16 + lr));
+                rs0[i] = r.x, rs1[i] = r.y;
+            }
+        } else {
+            // pairs [M][2] at a stride of rowstat_stride pairs (the class-token rows of the last block: a handful of
+            // rows per launch), rows past M read the last pair.  (Plain global loads: hipcc 7.2 lowers
+            // __builtin_amdgcn_raw_buffer_load_b64 to ONE dword here.)
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                int m = m_base + i * 16 + lr;
+                m = m < g.M ? m : g.M - 1;
+                const float2 r = *reinterpret_cast<const float2 *>(g.rowstat + 2 * (long)m * g.rowstat_stride);
+                rs0[i] = r.x, rs1[i] = r.y;
+            }
+        }
+    }
+    between();       // bias, column sums and (global) row statistics are requested: now the next tile's DMA
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(reinterpret_cast<char *>(g.C) + ((long)m_base * g.ldc + n_base) * 2,
+                                                tile_span(g.M, m_base, TM * 16, g.ldc * 2));
+    const bool col_ok = n_base + (lane & 7) * 8 < g.N;
+    const int voff = col_ok ? ((lane >> 3) * (int)g.ldc + (lane & 7) * 8) * 2 : BUF_OOB;
+    const int step8 = (int)g.ldc * 16;
+    // Row group i + 1 is converted and written to its scratch buffer while the transposed reads of row group i
+    // (other buffer) are in flight: one LDS round trip per row group is hidden behind the next group's arithmetic
+    auto produce = [&](int i) {
+        unsigned char *buf = scratch + (i & 1) * 16 * PITCH;
+        elem o[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 v;
+            if constexpr (epi_is_ln(EPI))
+                v = acc[i][j] * rs0[i] + (cs[j] * rs1[i] + bias[j]);
+            else
+                v = acc[i][j] + bias[j];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float y = v[r];
+                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_LN) y = quick_gelu(y);
+                o[4 * j + r] = to16(y, elem());
+            }
+        }
+        *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
+        *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
+    };
+    produce(0);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const unsigned char *buf = scratch + (i & 1) * 16 * PITCH;
+        u32x4 t[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            t[p] = *reinterpret_cast<const u32x4 *>(buf + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
+        if (i + 1 < TM) produce(i + 1);
+#pragma unroll
+        for (int p = 0; p < 2; p++) bstore16(t[p], rc, voff + (2 * i + p) * step8);
+    }
+}
+
+// fp32 outputs (STORE32 / RESID32); residual loads ahead of the stores as in epilogue_hl_buf
+template <int EPI, int TM, bool NAT, typename F>
+__device__ __forceinline__ void epilogue32_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
+                                               int lane, float *scratch, F &&between)
+{
+    static_assert(EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32, "fp32 outputs only");
+    constexpr int PITCH = 68;
+    const int q = lane >> 4, lr = lane & 15;
+    f32x4 bias[4];
+    load_bias(g, n_base + q * 16, bias);
+    const long org = ((long)m_base * g.ldc + n_base) * 4, span = tile_span(g.M, m_base, TM * 16, g.ldc * 4);
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(reinterpret_cast<char *>(g.C) + org, span);
+    const __amdgpu_buffer_rsrc_t rr = g.resid ? tile_rsrc(reinterpret_cast<const char *>(g.resid) + org, span) : rc;
+    const bool col_ok = n_base + lr * 4 < g.N;
+    const int voff = col_ok ? (q * (int)g.ldc + lr * 4) * 4 : BUF_OOB;
+    const int step4 = (int)g.ldc * 16;                                     // bytes per 4 rows
+    constexpr int DEPTH = EPI == EC_EPI_RESID32 ? (TM < 3 ? TM : 3) : 1;
+    f32x4 x[DEPTH][4];
+    auto fetch = [&](int i) {
+        if constexpr (EPI == EC_EPI_RESID32) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) x[i % DEPTH][p] = __builtin_bit_cast(f32x4, bload16(rr, voff + (4 * i + p) * step4));
+        }
+    };
+    if constexpr (EPI == EC_EPI_RESID32) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) fetch(i);
+    }
+    between();
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        float *buf = scratch;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + (NAT ? j * 16 + q * 4 : q * 16 + j * 4)) = acc[i][j] + bias[j];
+        f32x4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            v[p] = *reinterpret_cast<const f32x4 *>(buf + (q + 4 * p) * PITCH + lr * 4);
+            if constexpr (EPI == EC_EPI_RESID32) v[p] += x[i % DEPTH][p];
+        }
+        if constexpr (EPI == EC_EPI_RESID32) {
+            if (i + DEPTH < TM) fetch(i + DEPTH);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) bstore16(__builtin_bit_cast(u32x4, v[p]), rc, voff + (4 * i + p) * step4);
+    }
+}
+
+#define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
 // Tile raster inside an XCD's contiguous id range: 8 row panels x 4 column tiles per group of
 // 32 ids (one per CU of the XCD), so the 32 workgroups an XCD runs at a time stream 8 + 4
 // distinct operand panels through its L2 instead of 2-3 + tiles_n.  Rows beyond the last full
@@ -474,619 +819,6 @@ __device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm
     }
 }
 
-template <int DT, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::v8 v8;
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM / 16;  // 16-row activation tiles per wave
-    constexpr int TN = BN / WN / 16;  // 16-row weight tiles per wave
-    static_assert(TN == 4, "epilogue assumes 64 output columns per wave");
-    constexpr int PIECES = (BM + BN) / 8;  // 1-KiB DMA pieces (8 rows x 128 B) per stage
-    constexpr int PPW = PIECES / NW;       // pieces per wave
-    static_assert(PIECES % NW == 0, "stage must divide evenly over the waves");
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * BM;
-    const int n0 = (tile % g.tiles_n) * BN;
-
-    // ---- per-lane DMA source pointers: piece p covers stage rows 8p .. 8p+7 ----
-    const unsigned char *src[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; i++) {
-        const int piece = i * NW + wave;
-        const int row = piece * 8 + (lane >> 3);  // row within the stage (A rows, then W rows)
-        const int chunk = (lane & 7) ^ swz_key(row);
-        if (piece < BM / 8) {
-            int m = m0 + row;
-            m = m < g.M ? m : g.M - 1;
-            src[i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
-        } else {
-            int n = n0 + (row - BM);
-            n = n < g.N ? n : g.N - 1;
-            src[i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
-        }
-    }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PPW; i++) {
-            glds16(src[i], smem + buf * STAGE_BYTES + (i * NW + wave) * 1024);
-            src[i] += BK * 2;
-        }
-    };
-
-    // ---- per-lane fragment read offsets within a stage (k-substep 0) ----
-    // activation rows (MFMA B operand): natural order
-    int offB[TM];
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int row = wm * (BM / WM) + i * 16 + (lane & 15);
-        offB[i] = row * 128 + (((lane >> 4) ^ swz_key(row)) << 4);
-    }
-    // weight rows (MFMA A operand): row i of tile j is output column
-    // (i>>2)*16 + j*4 + (i&3) of this wave's 64, so that lane group g = lane>>4
-    // owns columns 16g .. 16g+15 after the MFMAs.
-    int offA[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int i = lane & 15;
-        const int row = BM + wn * 64 + (i >> 2) * 16 + j * 4 + (i & 3);
-        offA[j] = row * 128 + (((lane >> 4) ^ swz_key(row)) << 4);
-    }
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK;
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) stage(cur ^ 1);
-        const unsigned char *sb = smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            v8 fa[TN], fb[TM];
-            // k-substep ks selects chunks 4ks..4ks+3: XOR bit 2 of the chunk = byte 64
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                fa[j] = *reinterpret_cast<const v8 *>(sb + (offA[j] ^ (ks << 6)));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-                fb[i] = *reinterpret_cast<const v8 *>(sb + (offB[i] ^ (ks << 6)));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = mfma16(fa[j], fb[i], acc[i][j]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    epilogue<DT, EPI, TM>(g, acc, m0 + wm * (BM / WM), n0 + wn * 64, lane);
-}
-
-template <int DT, int BM, int BN, int WM, int WN, int EPI>
-int launch(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    g.tiles_m = ec::ceil_div(g.M, BM);
-    g.tiles_n = ec::ceil_div(g.N, BN);
-    constexpr int lds = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<DT, BM, BN, WM, WN, EPI>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-
-#define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-#ifdef EC_GEMM_DIAG
-// ---------------------------------------------------------------------------------------
-// 256 x 256 x 64 tile, 8 waves, four phases per K tile, LDS-DMA kept in flight across raw
-// barriers, the two wave groups staggered by one barrier interval.
-//
-// Per wave the 128 x 64 output splits into 2 x 2 quadrants of 64 rows x 32 columns; one
-// phase = one quadrant x the whole K tile = 16 MFMAs, quadrant order (m0,n0) (m0,n1)
-// (m1,n1) (m1,n0) so each phase needs at most one new operand set (12 / 4 / 8 / 0
-// ds_read_b128).  A K tile sits in LDS as four 16-KiB regions laid out by what a phase
-// reads -- Am0, Am1 (rows of quadrant row 0 / 1 of both wave rows), Bn0, Bn1 (the weight
-// rows of quadrant column 0 / 1 of all four wave columns) -- two K tiles deep (128 KiB).
-// Every phase has a load segment (ds_reads for this phase, one region of DMA for three
-// phases ahead = 2 global_load_lds_dwordx4 per lane, a counted s_waitcnt that retires only
-// the region the NEXT phase reads) and a compute segment (16 MFMAs), each closed by a raw
-// s_barrier.  Waves 4-7 (the second wave row; they share SIMDs with waves 0-3) run one
-// interval behind, so on every SIMD one wave computes while its partner loads.
-//
-// Hazards (intervals between barriers, group 0 loads phase p in interval 2p, group 1 in
-// 2p+1): a region read in phase q is waited for by every wave in its load segment of phase
-// q-1 (intervals 2q-2 and 2q-1), i.e. behind at least one barrier before the first read
-// (interval 2q); it is overwritten again 8 phases after it was staged, 5 phases after its
-// last read.
-// ---------------------------------------------------------------------------------------
-template <int DT, int EPI>
-__global__ __launch_bounds__(512) void gemm4p_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::v8 v8;
-    constexpr int BM = 256, BN = 256;
-    constexpr int REGION = 128 * 128;     // 128 rows x 128 B
-    constexpr int KT = 4 * REGION;        // one K tile: Am0 | Am1 | Bn0 | Bn1
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * BM;
-    const int n0 = (tile % g.tiles_n) * BN;
-
-    auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
-
-    // ---- DMA sources: region r (0 Am0, 1 Am1, 2 Bn0, 3 Bn1), instruction i (0, 1) ----
-    // piece = 8 i + wave covers region rows 8 piece .. 8 piece + 7
-    const unsigned char *src[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rr = (i * 8 + wave) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ key(rr);
-            if (r < 2) {
-                // region row rr = (wave row) * 64 + row within the 64-row quadrant
-                int m = m0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
-                m = m < g.M ? m : g.M - 1;
-                src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
-            } else {
-                // region row rr = (wave column) * 32 + p; output column c of the wave's 64 with
-                // bit 3 = quadrant column: c = (p >> 3) * 16 + nq * 8 + (p & 7)
-                const int p = rr & 31;
-                int n = n0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
-                n = n < g.N ? n : g.N - 1;
-                src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
-            }
-        }
-    auto issue = [&](int r, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
-            src[r][i] += BK * 2;
-        }
-    };
-
-    // ---- fragment read offsets inside a region (k-substep 0) ----
-    int offM[4], offN[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        const int row = wm * 64 + mt * 16 + (lane & 15);
-        offM[mt] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-        // MFMA A row i of tile j = 2 nq + jj is wave column (i >> 2) * 16 + 4 j + (i & 3)
-        const int i = lane & 15;
-        const int row = wn * 32 + ((i >> 2) << 3) + (jj << 2) + (i & 3);
-        offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    v8 fm[4][2], fn0[2][2], fn1[2][2];
-    auto load_m = [&](int buf, int mq) {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
-                                                           (offM[mt] ^ (ks << 6)));
-    };
-    auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
-                                                           (offN[jj] ^ (ks << 6)));
-    };
-    auto mma = [&](int mq, int nq, v8(&fn)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    acc[mq * 4 + mt][nq * 2 + jj] =
-                        mfma16(fn[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nq * 2 + jj]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto bar = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    const int nk = g.K / BK;
-    // prologue: the four regions of K tile 0; Am0 and Bn0 must have landed before phase 1
-    issue(0, 0);
-    issue(2, 0);
-    issue(3, 0);
-    issue(1, 0);
-    EC_VMCNT(4);
-    bar();
-    if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
-
-    for (int t = 0; t < nk; t++) {
-        const int buf = t & 1, nxt = buf ^ 1;
-        const bool more = t + 1 < nk;
-        // ---- phase 1: quadrant (m0, n0) ----
-        load_m(buf, 0);
-        load_n(fn0, buf, 0);
-        if (more) {
-            issue(0, nxt);      // Am0 of the next K tile
-            EC_VMCNT(4);        // retires Bn1 of this tile (phase 2)
-        } else {
-            EC_VMCNT(2);
-        }
-        bar();
-        mma(0, 0, fn0);
-        bar();
-        // ---- phase 2: quadrant (m0, n1) ----
-        load_n(fn1, buf, 1);
-        if (more) {
-            issue(2, nxt);      // Bn0 of the next K tile
-            EC_VMCNT(4);        // retires Am1 of this tile (phase 3)
-        } else {
-            EC_VMCNT(0);
-        }
-        bar();
-        mma(0, 1, fn1);
-        bar();
-        // ---- phase 3: quadrant (m1, n1) ----
-        load_m(buf, 1);
-        if (more) issue(3, nxt);   // Bn1 of the next K tile; nothing new is read in phase 4
-        bar();
-        mma(1, 1, fn1);
-        bar();
-        // ---- phase 4: quadrant (m1, n0), operands already in registers ----
-        if (more) {
-            issue(1, nxt);      // Am1 of the next K tile
-            EC_VMCNT(4);        // retires Am0 and Bn0 of the next tile (its phase 1)
-        }
-        bar();
-        mma(1, 0, fn0);
-        bar();
-    }
-    if (wm == 0) bar();   // balance the stagger barrier
-
-    epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
-}
-
-template <int DT, int EPI> int launch4p(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    g.tiles_m = ec::ceil_div(g.M, 256);
-    g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 2 * 4 * 128 * 128;
-    auto kern = gemm4p_kernel<DT, EPI>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-#endif  // EC_GEMM_DIAG
-
-template <int DT, int EPI, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm2p_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::v8 v8;
-    constexpr int BM = 256, BN = 256;
-    constexpr int REGION = 128 * 128;     // 128 rows x 128 B
-    constexpr int KT = 4 * REGION;        // one K tile: Am0 | Am1 | Bn0 | Bn1
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    int tm, tn;
-    raster(tile, g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lm0 = DBG == 2 ? 0 : m0, ln0 = DBG == 2 ? 0 : n0;   // timing experiments only
-
-    auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
-
-    // ---- DMA sources: region r (0 Am0, 1 Am1, 2 Bn0, 3 Bn1), instruction i (0, 1) ----
-    // piece = 8 i + wave covers region rows 8 piece .. 8 piece + 7
-    const unsigned char *src[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rr = (i * 8 + wave) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ key(rr);
-            if (r < 2) {
-                // region row rr = (wave row) * 64 + row within the 64-row quadrant
-                int m = lm0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
-                m = m < g.M ? m : g.M - 1;
-                src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
-            } else {
-                // region row rr = (wave column) * 32 + p; output column c of the wave's 64 with
-                // bit 3 = quadrant column: c = (p >> 3) * 16 + nq * 8 + (p & 7)
-                const int p = rr & 31;
-                int n = ln0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
-                n = n < g.N ? n : g.N - 1;
-                src[r][i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
-            }
-        }
-    auto issue = [&](int r, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
-            src[r][i] += BK * 2;
-        }
-    };
-
-    // ---- fragment read offsets inside a region (k-substep 0) ----
-    int offM[4], offN[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        const int row = wm * 64 + mt * 16 + (lane & 15);
-        offM[mt] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-        // MFMA A row i of tile j = 2 nq + jj is wave column (i >> 2) * 16 + 4 j + (i & 3)
-        const int i = lane & 15;
-        const int row = wn * 32 + ((i >> 2) << 3) + (jj << 2) + (i & 3);
-        offN[jj] = row * 128 + (((lane >> 4) ^ key(row)) << 4);
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    v8 fm[4][2], fn0[2][2], fn1[2][2];
-    auto load_m = [&](int buf, int mq) {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
-                                                           (offM[mt] ^ (ks << 6)));
-    };
-    auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                fn[jj][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + (2 + nq) * REGION +
-                                                           (offN[jj] ^ (ks << 6)));
-    };
-    auto bar = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    auto mma2 = [&](int mq, int nqa, v8(&fa)[2][2], int nqb, v8(&fb)[2][2]) {
-        if (DBG != 3 && DBG != 4) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    acc[mq * 4 + mt][nqa * 2 + jj] =
-                        mfma16(fa[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqa * 2 + jj]);
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    acc[mq * 4 + mt][nqb * 2 + jj] =
-                        mfma16(fb[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqb * 2 + jj]);
-            }
-        if (DBG != 3 && DBG != 4) __builtin_amdgcn_s_setprio(0);
-        if (DBG == 4) __builtin_amdgcn_s_setprio(1);   // the load segment that follows runs at priority
-    };
-    // end of a load segment: this wave's LDS reads have returned (the regions they came
-    // from may be re-staged by the other wave group in the very next interval)
-    auto bar_l = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (DBG == 4) __builtin_amdgcn_s_setprio(0);
-        bar();
-    };
-
-    // Two phases per K tile (32 MFMAs each): A = quadrants (m0,n0) (m0,n1), B = (m1,n1)
-    // (m1,n0).  Phase A reads Am0, Bn0, Bn1 of the tile, phase B reads Am1.  DMA runs a
-    // whole tile ahead: load segment B(t) stages {Am0, Bn0, Bn1} of tile t+2 into the
-    // regions phase A(t) has just drained, load segment A(t) stages Am1 of tile t+1.
-    // DBG == 5 (diagnostic build only): s_memtime stamps of waves 0 and 4 of workgroup 300 go to
-    // g.diag; layout [wave>>2][t][8 stamps]
-    unsigned long long *stamps = nullptr;
-    if (DBG == 5 && blockIdx.x == 300 && (wave & 3) == 0 && lane == 0)
-        stamps = g.diag + (wave >> 2) * 64 * 8;
-    auto stamp = [&](int t, int i) {
-        if (DBG == 5) {
-            unsigned long long now;
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (stamps && t < 64) stamps[t * 8 + i] = now;
-        }
-    };
-    // DBG == 9 (diagnostic build only): one record per workgroup in g.diag: {HW_ID, start,
-    // prologue landed, loop done, epilogue issued, stores acknowledged, XCC_ID}, for the per-CU
-    // timeline of tools/timeline_gemm.py
-    unsigned long long *tl = nullptr;
-    auto tstamp = [&](int i) {
-        if (DBG == 9) {
-            unsigned long long now;
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (tl) tl[i] = now;
-        }
-    };
-    if (DBG == 9 && threadIdx.x == 0) {
-        tl = g.diag + (long)blockIdx.x * 8;
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        tl[0] = hw;
-        tl[6] = xcc;
-    }
-    tstamp(1);
-    const int nk = g.K / BK;
-    if ((DBG == 7 || DBG == 8) && gridDim.x > 512 && blockIdx.x < 256) {
-        // The first workgroup of every CU starts at a different point of one tile period, so
-        // the CUs' epilogues (HBM-bound bursts) land on other CUs' MFMA phases instead of
-        // all 256 alternating between a compute-only and a memory-only phase in lockstep.
-        const int slot = (blockIdx.x >> 3) & 31;
-        const int period = nk * 3200 + 8192;                    // cycles, measured (stamps)
-        const int n = (slot * period / 32) >> (DBG == 8 ? 11 : 10);
-        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(16);   // 1024 cycles each
-    }
-    issue(0, 0);
-    issue(2, 0);
-    issue(3, 0);
-    issue(1, 0);
-    if (nk > 1) {
-        issue(0, 1);
-        issue(2, 1);
-        issue(3, 1);
-        EC_VMCNT(8);      // {Am0, Bn0, Bn1}(0) landed; Am1(0) and the three of tile 1 in flight
-    } else {
-        EC_VMCNT(2);
-    }
-    bar();
-    tstamp(2);
-    if (wm == 1) bar();   // stagger: the second wave row runs one interval behind
-
-    for (int t = 0; t < nk; t++) {
-        const int buf = t & 1, nxt = buf ^ 1;
-        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-        // ---- phase A ----
-        stamp(t, 0);
-        if (DBG != 6 || t == 0) {
-            load_m(buf, 0);
-            load_n(fn0, buf, 0);
-            load_n(fn1, buf, 1);
-        }
-        stamp(t, 1);
-        if (has1) {
-            if (DBG != 1 && DBG != 6) issue(1, nxt);      // Am1 of tile t+1
-            if (DBG != 1 && DBG != 6) EC_VMCNT(8);        // retires Am1 of this tile (phase B)
-        } else {
-            EC_VMCNT(0);
-        }
-        stamp(t, 2);
-        bar_l();
-        stamp(t, 3);
-        mma2(0, 0, fn0, 1, fn1);
-        stamp(t, 4);
-        bar();
-        // ---- phase B ----
-        stamp(t, 5);
-        if (DBG != 6 || t == 0) load_m(buf, 1);
-        if (has2) {
-            if (DBG != 1 && DBG != 6) {
-                issue(0, buf);      // {Am0, Bn0, Bn1} of tile t+2 replace what phase A consumed
-                issue(2, buf);
-                issue(3, buf);
-                EC_VMCNT(8);        // retires {Am0, Bn0, Bn1} of tile t+1
-            }
-        } else if (has1) {
-            EC_VMCNT(2);
-        }
-        stamp(t, 6);
-        bar_l();
-        mma2(1, 1, fn1, 0, fn0);
-        stamp(t, 7);
-        bar();
-    }
-    if (wm == 0) bar();   // balance the stagger barrier
-
-    if (DBG == 5 || DBG == 9) {
-        tstamp(3);
-        if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32)
-            epilogue32_lds<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane,
-                                   reinterpret_cast<float *>(smem) + wave * (2 * 16 * 68));
-        else if constexpr (DBG == 9)
-            epilogue16_lds<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
-        else
-            epilogue<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
-        tstamp(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tstamp(5);
-        return;
-    }
-    if constexpr (EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32) {
-        // every wave is past the closing barrier of the last K tile: the staging buffers are free
-        epilogue32_lds<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane,
-                               reinterpret_cast<float *>(smem) + wave * (2 * 16 * 68));
-    } else {
-        epilogue16_lds<DT, EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (2 * 16 * 144));
-    }
-}
-
-template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    g.tiles_m = ec::ceil_div(g.M, 256);
-    g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 2 * 4 * 128 * 128;
-    auto kern = gemm2p_kernel<DT, EPI, DBG>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
 
 // ---------------------------------------------------------------------------------------
 // Persistent form of the staggered two-phase kernel: one workgroup per CU walks tiles
@@ -1097,7 +829,7 @@ template <int DT, int EPI, int DBG = 0> int launch2p(const GemmArgs &g0, hipStre
 // prologue's HBM latency (~2.9 k cycles of a 48 k-cycle tile at K = 1024) is exposed.
 // TL: per-tile timeline records as in gemm2p_kernel<DBG = 9>.
 // ---------------------------------------------------------------------------------------
-template <int DT, int EPI, bool TL = false, bool TN = false>
+template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT>
 __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 {
     typedef typename T16<DT>::v8 v8;
@@ -1119,13 +851,40 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
 
     int m0 = 0, n0 = 0, sp0 = 0;
-    const unsigned char *src[4][2];
+    const unsigned char *src[4][2];     // transposed operands only (the row-major form addresses through descriptors)
+    // Row-major operands (round 4): the staging DMA is buffer-addressed.  Per tile two descriptors (scalar registers:
+    // the tile's A rows / W rows from this batch's first column, ranges ending at the last row that exists -- rows
+    // past M or N read as zeros), per lane ONE 32-bit byte offset per operand that never changes (row lane >> 3 of a
+    // piece, swizzled 16-byte chunk), per piece a scalar row offset, per region the bytes advanced along K: a request
+    // costs one 32-bit add.  The pointer form kept sixteen 64-bit pointers (32 registers of the main loop's 249),
+    // advanced each with a 64-bit add per K tile and rebuilt with 48 quarter-rate multiplies per tile; and as a
+    // FLAT-encoded instruction that also touches LDS, global_load_lds makes hipcc's wait-count pass treat vmcnt as
+    // unordered (every wait of its own behind one becomes vmcnt(0)).
+    __amdgpu_buffer_rsrc_t rsA = tile_rsrc(g.A, 0), rsW = tile_rsrc(g.W, 0);
+    int vbA = 0, vbW = 0, srow[4][2] = {}, kk[4] = {0, 0, 0, 0};
+    if constexpr (!TN) {
+        const int l3 = lane >> 3;
+        // key(rr) of piece row rr = (8 i + wave) 8 + l3:  rr & 7 = l3,  bit 4 of rr = bit 1 of wave
+        const int chunk = (lane & 7) ^ l3 ^ (((wave >> 1) & 1) << 2);
+        vbA = (l3 * (int)g.lda + chunk * 8) * 2;
+        vbW = (l3 * (int)g.ldw + chunk * 8) * 2;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                srow[r][i] = r < 2 ? (i * 128 + r * 64 + wave * 8) * (int)g.lda * 2
+                                   : ((i * 2 + (wave >> 2)) * 64 + (wave & 3) * 16 + (r - 2) * 8) * (int)g.ldw * 2;
+    }
     // transposed operands: reduction rows of this batch still to be issued per region (rows past k_valid read
     // tn_zero16), and the bytes one K tile advances an operand's pointer by
     int rem[4] = {0, 0, 0, 0};
     const long adv_a = TN ? (long)g.lda * BK * 2 : BK * 2, adv_w = TN ? (long)g.ldw * BK * 2 : BK * 2;
     auto setup = [&](int id) {
         int tm, tn;
+        // lane id re-derived per tile, opaque to the optimiser: the per-lane row / chunk constants below are cheap to
+        // recompute and must not live (= spill) across the main loop; a scratch reload sits behind s_waitcnt vmcnt
+        int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));
         int rid = xcd_remap(id, ntiles);
         sp0 = 0;
         if (g.splits > 1) {
@@ -1159,23 +918,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             }
             return;
         }
+        rsA = tile_rsrc(static_cast<const unsigned char *>(g.A) + ((long)m0 * g.lda + koff) * 2, tile_span(g.M, m0, BM, g.lda * 2));
+        rsW = tile_rsrc(static_cast<const unsigned char *>(g.W) + ((long)n0 * g.ldw + koff) * 2, tile_span(g.N, n0, BN, g.ldw * 2));
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int rr = (i * 8 + wave) * 8 + (lane >> 3);
-                const int chunk = (lane & 7) ^ key(rr);
-                if (r < 2) {
-                    int m = m0 + (rr >> 6) * 128 + r * 64 + (rr & 63);
-                    m = m < g.M ? m : g.M - 1;
-                    src[r][i] = (const unsigned char *)g.A + ((long)m * g.lda + koff + chunk * 8) * 2;
-                } else {
-                    const int p = rr & 31;
-                    int n = n0 + (rr >> 5) * 64 + ((p >> 3) << 4) + ((r - 2) << 3) + (p & 7);
-                    n = n < g.N ? n : g.N - 1;
-                    src[r][i] = (const unsigned char *)g.W + ((long)n * g.ldw + koff + chunk * 8) * 2;
-                }
-            }
+        for (int r = 0; r < 4; r++) kk[r] = 0;
     };
     auto issue = [&](int r, int buf) {
         if (TN && rem[r] < BK) {       // the batch's last K tile runs past the rows that exist
@@ -1185,13 +931,22 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 const unsigned char *p = krow < rem[r] ? src[r][i] : reinterpret_cast<const unsigned char *>(tn_zero16);
                 glds16(p, smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
             }
-        } else {
+        } else if constexpr (TN) {
 #pragma unroll
             for (int i = 0; i < 2; i++) glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; i++) src[r][i] += r < 2 ? adv_a : adv_w;
-        if (TN) rem[r] -= BK;
+            for (int i = 0; i < 2; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r < 2 ? rsA : rsW,
+                                                         (__attribute__((address_space(3))) void *)(smem + buf * KT + r * REGION + (i * 8 + wave) * 1024),
+                                                         16, (r < 2 ? vbA : vbW) + (srow[r][i] + kk[r]), 0, 0, 0);
+            kk[r] += BK * 2;
+        }
+        if constexpr (TN) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) src[r][i] += r < 2 ? adv_a : adv_w;
+            rem[r] -= BK;
+        }
     };
 
     int offM[4], offN[2];
@@ -1324,6 +1079,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         }
     };
 
+    bool carried = false;     // this tile's K tile 0 was waited for at the hand-over from the tile before
     int id = blockIdx.x;
     tl_open(id);
     tstamp(1);
@@ -1359,9 +1115,15 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             load_n(fn1, buf, 1);
             if (has1) {
                 issue(1, nxt);
-                EC_VMCNT(8);
+                // behind a tile hand-over every piece of K tile 0 has landed already (waited for before the hand-over
+                // barrier), and what is in flight besides K tile 1 are the last epilogue stores: no wait here, the
+                // counted wait of phase B (which K tile 1 needs anyway) is the first one they are older than
+                if (t > 0 || !carried) EC_VMCNT(8);
             } else {
                 EC_VMCNT(0);
+                // (satisfied already; tells hipcc's wait-count pass that no staging DMA is pending behind the main
+                // loop, so that it does not put a vmcnt(0) of its own in front of the epilogue's first LDS read)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
             }
             bar_l();
             mma2(0, 0, fn0, 1, fn1);
@@ -1388,36 +1150,59 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         const int next = id + gridDim.x;
         const bool more = next < ntiles;
         tstamp(3);
-        if (more) {
-            setup(next);
-            issue_stats(slot ^ 1);
-            issue(0, 0);
-            issue(2, 0);
-            issue(3, 0);
-            issue(1, 0);
-        }
-        if constexpr (EPI == EC_EPI_RESID_HL) {
-            if (ge.stat_out)
-                epilogue_hl_lds<DT, 8, true>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                             reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
-            else
-                epilogue_hl_lds<DT, 8, false>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                              reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
-        }
+        // the next tile's first K tile is requested from INSIDE the epilogue, behind its first loads (epilogue_*_buf)
+        auto next_tile = [&]() {
+            if (more) {
+                setup(next);
+                issue_stats(slot ^ 1);
+                issue(0, 0);
+                issue(2, 0);
+                issue(3, 0);
+                issue(1, 0);
+            }
+        };
+        const int wm0 = cm0 + wm * 128, wn0 = cn0 + wn * 64;
+        // the lane id as the epilogues see it is re-derived per tile and opaque to the optimiser: otherwise every
+        // per-lane constant of the epilogue's addressing is hoisted above the tile loop, does not fit beside the main
+        // loop's 249 registers and comes back from scratch -- behind an s_waitcnt vmcnt(0) that also waits for the
+        // next tile's first K tile, issued a moment ago
+        int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(elane));
+        // Hand-over wait.  vmcnt retires in issue order (loads, stores and LDS-DMA alike) and the DMA of the next
+        // tile's K tile 0 is OLDER than everything the epilogue issued, so waiting for all but the epilogue's last TAIL
+        // operations is waiting for it -- without waiting for the acknowledgement of the last stores (0.3 - 1.5 k
+        // cycles per tile).  TAIL <= the number of operations the buffer-addressed epilogues issue, whatever the
+        // tile (their stores are never predicated: the range check drops what does not exist).  The asm form is the
+        // scheduling fence; the builtin right behind it costs nothing (it is satisfied already) and tells hipcc's
+        // wait-count pass what has completed.
+        constexpr bool BUF_EPI = EPI == EC_EPI_RESID_HL || EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI) ||
+                                 EPI == EC_EPI_STORE32 || EPI == EC_EPI_RESID32;
+        constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? 48 : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : 16;
+        constexpr int enc_tail = (TAIL & 15) | (7 << 4) | (15 << 8) | ((TAIL >> 4) << 14);
+        if constexpr (EPI == EC_EPI_RESID_HL)
+            epilogue_hl_buf<DT, 8, HLM>(ge, acc, wm0, wn0, elane,
+                                        reinterpret_cast<float *>(smem + KT) + wave * ((HLM & 1) ? 2 * 16 * 68 : 16 * 68), next_tile);
         else if constexpr (!epi_is16(EPI))
-            epilogue32_lds<EPI, 8, 1, TN>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                          reinterpret_cast<float *>(smem + KT) + wave * (16 * 68));
-        else
-            epilogue16_lds<DT, EPI, 8>(ge, acc, cm0 + wm * 128, cn0 + wn * 64, lane,
-                                       smem + KT + wave * (2 * 16 * 144),
-                                       lds_stats ? side + slot * 512 + wm * 256 : nullptr);
-        slot ^= 1;
+            epilogue32_buf<EPI, 8, TN>(ge, acc, wm0, wn0, elane, reinterpret_cast<float *>(smem + KT) + wave * (16 * 68), next_tile);
+        else if constexpr (BUF_EPI) {
+            if (lds_stats)
+                epilogue16_buf<DT, EPI, 8, true>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
+                                                 side + slot * 512 + wm * 256, next_tile);
+            else
+                epilogue16_buf<DT, EPI, 8, false>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
+        }
+        else {    // the training epilogues (second output / second input): the general form
+            next_tile();
+            epilogue16_lds<DT, EPI, 8>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr);
+        }
         tstamp(4);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TAIL) : "memory");
+            __builtin_amdgcn_s_waitcnt(enc_tail);
+        }
+        slot ^= 1;
         if (!more) break;
-        // K tile 0 of the next output tile has landed, the stores are acknowledged (loads and
-        // stores share vmcnt and retire out of order with each other: only 0 is exact), and after
-        // the barrier no wave reads the scratch area any more
-        EC_VMCNT(0);
+        carried = nk > 1;
         tstamp(5);
         bar();
         if (nk > 1) {
@@ -1435,13 +1220,15 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     }
 }
 
-template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const GemmArgs &g0, hipStream_t stream)
+template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT> int launch2pp(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
     g.tiles_m = ec::ceil_div(g.M, 256);
     g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0);   // + the row-statistics side area
-    auto kern = gemm2pp_kernel<DT, EPI, TL, TN>;
+    // two staging buffers + the row-statistics side area (LN epilogues) / the tail of the hi-lo epilogue's double
+    // scratch (8 waves x 2 x 16 rows x 68 floats = 68 KiB from the second staging buffer on)
+    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 : 0);
+    auto kern = gemm2pp_kernel<DT, EPI, TL, TN, HLM>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
     EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
@@ -1459,600 +1246,10 @@ template <int DT, int EPI, bool TL = false, bool TN = false> int launch2pp(const
     return EC_OK;
 }
 
-
 #ifdef EC_GEMM_DIAG
-// ---------------------------------------------------------------------------------------
-// Probe (diagnostic build, variant 20): the vendor kernel's layout -- 256 x 256 x 64 tiles over FOUR waves, one per
-// SIMD, 128 x 128 and 256 accumulators each (the whole 512-entry register file), two K tiles of LDS, ONE barrier per K
-// tile: the ds_reads of the next half K tile ride under the MFMAs of the present one.  16-bit store only, M and N
-// multiples of 256, one tile per workgroup, plain (untransposed) stores: a measurement of the main loop, not a product
-// path (profiles/r3_gemm.md 7).
-// ---------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::elem elem;
-    typedef typename T16<DT>::v8 v8;
-    constexpr int STAGE = 512 * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    raster(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nk = g.K / BK;
-    const int r8 = lane >> 3, c = lane & 7;
-    const unsigned off_a = (unsigned)r8 * (unsigned)g.lda * 2u + (unsigned)((c ^ r8) << 4);
-    const unsigned off_w = (unsigned)r8 * (unsigned)g.ldw * 2u + (unsigned)((c ^ r8) << 4);
-    auto issue = [&](int buf, int kt) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int p = wave + 4 * i;                 // 1-KiB piece: LDS rows 8 p .. 8 p + 7 (i < 8: activation rows)
-            const unsigned char *base = i < 8 ? (const unsigned char *)g.A + ((long)(m0 + 8 * p) * g.lda + (long)kt * BK) * 2
-                                              : (const unsigned char *)g.W + ((long)(n0 + 8 * (p - 32)) * g.ldw + (long)kt * BK) * 2;
-            glds16(base + (i < 8 ? off_a : off_w), smem + buf * STAGE + p * 1024);
-        }
-    };
-    int offB[8], offA[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int rb = wm * 128 + i * 16 + (lane & 15), ra = 256 + wn * 128 + i * 16 + (lane & 15);
-        offB[i] = rb * 128 + (((lane >> 4) ^ (rb & 7)) << 4);
-        offA[i] = ra * 128 + (((lane >> 4) ^ (ra & 7)) << 4);
-    }
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v8 fb0[8], fa0[8], fb1[8], fa1[8];
-    auto load = [&](v8(&fb)[8], v8(&fa)[8], int buf, int ks) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            fb[i] = *reinterpret_cast<const v8 *>(smem + buf * STAGE + (offB[i] ^ (ks << 6)));
-            fa[i] = *reinterpret_cast<const v8 *>(smem + buf * STAGE + (offA[i] ^ (ks << 6)));
-        }
-    };
-    // (accumulators pinned to the accumulation half of the register file with a tied asm operand: through the builtin
-    // hipcc kept them in VGPRs and moved ~8 registers across per MFMA)
-    auto mma = [&](v8(&fb)[8], v8(&fa)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (DT == 0)
-                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
-                else
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
-            }
-    };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    load(fb0, fa0, 0, 0);
-    for (int t = 0; t < nk; t++) {
-        const int buf = t & 1;
-        load(fb1, fa1, buf, 1);
-        mma(fb0, fa0);
-        // this wave has read all it needs of `buf`; its share of the next K tile has landed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nk) issue(buf, t + 2);
-        if (t + 1 < nk) load(fb0, fa0, buf ^ 1, 0);
-        mma(fb1, fa1);
-    }
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMAs' results, read by vector instructions below
-    // D rows <-> weight rows (output columns 16 j + 4 q + r), D columns <-> activation rows (16 i + lane & 15)
-    const int q = lane >> 4, lr = lane & 15;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n = n0 + wn * 128 + 16 * j + 4 * q;
-        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (g.bias) b = *reinterpret_cast<const f32x4 *>(g.bias + n);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int m = m0 + wm * 128 + 16 * i + lr;
-            typedef elem elem4 __attribute__((ext_vector_type(4)));
-            elem4 o;
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = to16(acc[i][j][r] + b[r], elem());
-            *reinterpret_cast<elem4 *>((elem *)g.C + (long)m * g.ldc + n) = o;
-        }
-    }
-}
+#include "gemm_diag.inc"
+#endif
 
-// Variant 21: the four-wave layout with what tools/mfma_probe.py showed one wave per SIMD needs: the staging as a ring
-// of FOUR quarter tiles (K = 32; a quarter's DMA goes out three quarters before its first read), and the next
-// quarter's 16 fragment reads and this wave's 8 DMA requests SPREAD through the block of 64 MFMAs (two reads and one
-// request per eight MFMAs, pinned with sched_barriers) instead of bunched behind the barrier, where the four waves'
-// bursts fill the LDS queue and hold their own MFMAs back.  64-byte LDS rows, chunk ^ ((row >> 2) & 3).
-template <int DT>
-__global__ __launch_bounds__(256, 1) void gemm4i_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::elem elem;
-    typedef typename T16<DT>::v8 v8;
-    constexpr int QK = 32, QUARTER = 512 * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    raster(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int nq = g.K / QK;
-    const unsigned key = (unsigned)((lane >> 4) & 3);
-    const unsigned off_a = (unsigned)(lane >> 2) * (unsigned)g.lda * 2u + (((unsigned)(lane & 3) ^ key) << 4);
-    const unsigned off_w = (unsigned)(lane >> 2) * (unsigned)g.ldw * 2u + (((unsigned)(lane & 3) ^ key) << 4);
-    // piece i (0 .. 7) of this wave for quarter q: 16 rows x 64 bytes; i < 4 activation rows, else weight rows
-    auto issue1 = [&](int q, int i) {
-        const int p = wave + 4 * i;
-        const unsigned char *base = i < 4 ? (const unsigned char *)g.A + ((long)(m0 + 16 * p) * g.lda + (long)q * QK) * 2
-                                          : (const unsigned char *)g.W + ((long)(n0 + 16 * (p - 16)) * g.ldw + (long)q * QK) * 2;
-        glds16(base + (i < 4 ? off_a : off_w), smem + (q & 3) * QUARTER + p * 1024);
-    };
-    int offB[8], offA[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int rb = wm * 128 + i * 16 + (lane & 15), ra = 256 + wn * 128 + i * 16 + (lane & 15);
-        offB[i] = rb * 64 + (((lane >> 4) ^ ((rb >> 2) & 3)) << 4);
-        offA[i] = ra * 64 + (((lane >> 4) ^ ((ra >> 2) & 3)) << 4);
-    }
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v8 fb0[8], fa0[8], fb1[8], fa1[8];
-    auto mfma1 = [&](f32x4 &c, const v8 &a, const v8 &b) {
-        if (DT == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    };
-    // one block: the MFMAs of the quarter held in (FB, FA); group i also fetches fragment pair i of quarter QN into
-    // (FBN, FAN) when LOAD, and requests piece i of quarter QI when ISSUE
-#define EC_G4I_BLOCK(FB, FA, FBN, FAN, LOAD, QN, ISSUE, QI)                                       \
-    _Pragma("unroll") for (int i = 0; i < 8; i++) {                                               \
-        if (LOAD) FBN[i] = *reinterpret_cast<const v8 *>(smem + ((QN) & 3) * QUARTER + offB[i]);  \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (LOAD) FAN[i] = *reinterpret_cast<const v8 *>(smem + ((QN) & 3) * QUARTER + offA[i]);  \
-        if (ISSUE) issue1(QI, i);                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        _Pragma("unroll") for (int j = 4; j < 8; j++) mfma1(acc[i][j], FA[j], FB[i]);            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    }
-#define EC_G4I_SYNC(N)                                                    \
-    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");      \
-    __builtin_amdgcn_s_barrier();                                         \
-    __builtin_amdgcn_sched_barrier(0);
-    // quarters 0 .. 3 requested, quarter 0 waited for and fetched
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < 8; i++) issue1(q, i);
-    EC_G4I_SYNC(24)
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        fb0[i] = *reinterpret_cast<const v8 *>(smem + offB[i]);
-        fa0[i] = *reinterpret_cast<const v8 *>(smem + offA[i]);
-    }
-    int q = 0;
-    for (; q + 4 < nq; q += 2) {
-        // quarter q + 1 landed (q + 2, q + 3 may still fly), everyone holds quarter q's fragments: its buffer takes q + 4
-        EC_G4I_SYNC(16)
-        EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, true, q + 4)
-        EC_G4I_SYNC(16)
-        EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, true, q + 5)
-    }
-    EC_G4I_SYNC(16)
-    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 1, false, 0)
-    EC_G4I_SYNC(8)
-    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, true, q + 2, false, 0)
-    EC_G4I_SYNC(0)
-    EC_G4I_BLOCK(fb0, fa0, fb1, fa1, true, q + 3, false, 0)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    EC_G4I_BLOCK(fb1, fa1, fb0, fa0, false, 0, false, 0)
-#undef EC_G4I_BLOCK
-#undef EC_G4I_SYNC
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    const int qq = lane >> 4, lr = lane & 15;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n = n0 + wn * 128 + 16 * j + 4 * qq;
-        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (g.bias) b = *reinterpret_cast<const f32x4 *>(g.bias + n);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int m = m0 + wm * 128 + 16 * i + lr;
-            typedef elem elem4 __attribute__((ext_vector_type(4)));
-            elem4 o;
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = to16(acc[i][j][r] + b[r], elem());
-            *reinterpret_cast<elem4 *>((elem *)g.C + (long)m * g.ldc + n) = o;
-        }
-    }
-}
-
-template <int DT> int launch4i(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    EC_REQUIRE(g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 256 && g.splits <= 1, "ec_gemm variant 21: M, N multiples of 256, K of 64");
-    g.tiles_m = g.M / 256, g.tiles_n = g.N / 256;
-    constexpr int lds = 4 * 512 * 64;
-    auto kern = gemm4i_kernel<DT>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    ec::ProfScope prof(ec::PROF_GEMM_STORE16, stream, 2.0 * g.M * g.N * g.K, 2.0 * g.M * g.K + 2.0 * g.N * g.K + 2.0 * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// Probe (diagnostic build): what one wave per SIMD can issue.  256 threads per CU; a block = 64 independent
-// v_mfma_f32_16x16x32_f16 on AGPR accumulators (the four-wave layout's quarter tile), optionally with what the GEMM
-// loop puts between blocks: bit 0 = 16 ds_read_b128 of fresh fragments, bit 1 = a workgroup barrier, bit 2 = 8 LDS-DMA
-// requests (waited for two blocks later).  tools/mfma_probe.py turns the launch time into cycles per block.
-// ---------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const unsigned char *src, float *out, int iters)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 32768; i += 256) reinterpret_cast<unsigned *>(smem)[i] = 0x3c003c00u;   // f16 1.0
-    __syncthreads();
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 fa[8], fb[8];
-    int off[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) off[i] = (wave * 128 + i * 16 + (lane & 15)) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        fa[i] = *reinterpret_cast<const f16x8 *>(smem + off[i]);
-        fb[i] = *reinterpret_cast<const f16x8 *>(smem + 65536 + off[i]);
-    }
-    const unsigned char *gsrc = src + ((size_t)blockIdx.x * 4 + wave) * 8192 + lane * 16;
-    for (int it = 0; it < iters; it++) {
-        if (MODE & 4) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-            for (int p = 0; p < 8; p++) glds16(gsrc + p * 1024, smem + 98304 + (it & 1) * 16384 + wave * 8192 + p * 1024 - (wave * 8192 / 2));
-        }
-        if (MODE & 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        f16x8 na[8], nb[8];
-        if ((MODE & 1) && !(MODE & 8)) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                na[i] = *reinterpret_cast<const f16x8 *>(smem + ((it & 1) << 15) + off[i]);
-                nb[i] = *reinterpret_cast<const f16x8 *>(smem + 65536 + ((it & 1) << 14) + off[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if ((MODE & 1) && (MODE & 8)) {        // bit 3: the reads spread through the block, one pair per eight MFMAs
-                const unsigned a0 = (unsigned)(((it & 1) << 15) + off[i]), a1 = (unsigned)(65536 + ((it & 1) << 14) + off[i]);
-                asm volatile("ds_read_b128 %0, %1" : "=v"(na[i]) : "v"(a0));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(nb[i]) : "v"(a1));
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[j]), "v"(fb[i]));
-        }
-        if (MODE & 1) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 8; i++) fa[i] = na[i], fb[i] = nb[i];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) s += acc[i][j][0] + acc[i][j][3];
-    if (s == 12345.f) out[threadIdx.x] = s;            // (keeps the accumulators alive)
-}
-
-template <int DT> int launch4w(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    EC_REQUIRE(g.M % 256 == 0 && g.N % 256 == 0 && g.K % BK == 0 && g.splits <= 1, "ec_gemm variant 20: M, N multiples of 256");
-    g.tiles_m = g.M / 256, g.tiles_n = g.N / 256;
-    constexpr int lds = 2 * 512 * 128;
-    auto kern = gemm4w_kernel<DT>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    ec::ProfScope prof(ec::PROF_GEMM_STORE16, stream, 2.0 * g.M * g.N * g.K, 2.0 * g.M * g.K + 2.0 * g.N * g.K + 2.0 * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// Two workgroups per CU: 128 x 256 x 32 tiles, 4 waves (one per SIMD), each wave 128 x 64.
-// A 3-stage LDS-DMA ring of 24-KiB K tiles (72 KiB per workgroup, so two workgroups share a
-// CU's LDS and registers).  The SIMD partner of every wave belongs to the OTHER workgroup:
-// the two run unsynchronised, so one workgroup's prologue / epilogue (exposed for a third of a
-// tile's time at K = 1024 with one workgroup per CU) hides behind the other's MFMAs, and a
-// barrier only stalls four waves.
-// LDS rows are 64 B (4 chunks of 16 B); chunk ^= ((row >> 3) & 1) << 1 for the activation
-// rows (natural fragment order) and ((row >> 5) & 1) << 1 for the weight rows (permuted
-// order), which keeps every ds_read_b128 lane group on 16 distinct 16-B bank slots.
-// ---------------------------------------------------------------------------------------
-template <int DT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_b2_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::v8 v8;
-    constexpr int BM = 128, BN = 256, BK2 = 32, NSTAGE = 3;
-    constexpr int ROWB = BK2 * 2;                  // 64-byte rows
-    constexpr int STAGE = (BM + BN) * ROWB;        // 24 KiB
-    constexpr int PPW = STAGE / 1024 / 4;          // 6 DMA pieces (16 rows each) per wave
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * BM;
-    const int n0 = (tile % g.tiles_n) * BN;
-
-    auto key_a = [](int row) { return ((row >> 3) & 1) << 1; };   // activation rows
-    auto key_w = [](int row) { return ((row >> 5) & 1) << 1; };   // weight rows
-
-    // piece p = i * 4 + wave covers stage rows 16 p .. 16 p + 15; lane -> row 16 p + (lane >> 2),
-    // physical chunk lane & 3
-    const unsigned char *src[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; i++) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        if (row < BM) {
-            const int chunk = (lane & 3) ^ key_a(row);
-            int m = m0 + row;
-            m = m < g.M ? m : g.M - 1;
-            src[i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
-        } else {
-            const int chunk = (lane & 3) ^ key_w(row - BM);
-            int n = n0 + (row - BM);
-            n = n < g.N ? n : g.N - 1;
-            src[i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
-        }
-    }
-    auto issue = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < PPW; i++) {
-            glds16(src[i], smem + slot * STAGE + (i * 4 + wave) * 1024);
-            src[i] += BK2 * 2;
-        }
-    };
-
-    // fragment offsets inside a stage: activation rows natural, weight rows permuted so that
-    // lane group g = lane >> 4 owns output columns 16 g .. 16 g + 15 of the wave's 64
-    int offB[8], offA[4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = i * 16 + (lane & 15);
-        offB[i] = row * ROWB + (((lane >> 4) ^ key_a(row)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int i = lane & 15;
-        const int row = wave * 64 + (i >> 2) * 16 + j * 4 + (i & 3);
-        offA[j] = BM * ROWB + row * ROWB + (((lane >> 4) ^ key_w(row)) << 4);
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK2;
-    issue(0);
-    if (nk > 1) issue(1);
-    int slot = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        // stage kt has landed (this wave's share) once at most one later stage is in flight
-        if (kt + 1 < nk) {
-            EC_VMCNT(6);
-        } else {
-            EC_VMCNT(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();   // everyone's share landed; stage kt-1 is drained
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(slot == 0 ? 2 : slot - 1);   // refill the slot of stage kt-1
-        const unsigned char *sb = smem + slot * STAGE;
-        v8 fa[4], fb[8];
-#pragma unroll
-        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const v8 *>(sb + offA[j]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) fb[i] = *reinterpret_cast<const v8 *>(sb + offB[i]);
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma16(fa[j], fb[i], acc[i][j]);
-        // the reads of this stage must have returned before the next barrier lets its slot be
-        // refilled one iteration later
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        slot = slot == NSTAGE - 1 ? 0 : slot + 1;
-    }
-    epilogue<DT, EPI, 8>(g, acc, m0, n0 + wave * 64, lane);
-}
-
-template <int DT, int EPI> int launch_b2(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    g.tiles_m = ec::ceil_div(g.M, 128);
-    g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 3 * (128 + 256) * 64;
-    auto kern = gemm_b2_kernel<DT, EPI>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-template <int DT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_b2p_kernel(const GemmArgs g)
-{
-    typedef typename T16<DT>::v8 v8;
-    constexpr int BM = 128, BN = 256, BK2 = 32, NSTAGE = 3;
-    constexpr int ROWB = BK2 * 2;                  // 64-byte rows
-    constexpr int STAGE = (BM + BN) * ROWB;        // 24 KiB
-    constexpr int PPW = STAGE / 1024 / 4;          // 6 DMA pieces (16 rows each) per wave
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int m0 = (tile / g.tiles_n) * BM;
-    const int n0 = (tile % g.tiles_n) * BN;
-
-    auto key_a = [](int row) { return ((row >> 3) & 1) << 1; };   // activation rows
-    auto key_w = [](int row) { return ((row >> 5) & 1) << 1; };   // weight rows
-
-    // piece p = i * 4 + wave covers stage rows 16 p .. 16 p + 15; lane -> row 16 p + (lane >> 2),
-    // physical chunk lane & 3
-    const unsigned char *src[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; i++) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        if (row < BM) {
-            const int chunk = (lane & 3) ^ key_a(row);
-            int m = m0 + row;
-            m = m < g.M ? m : g.M - 1;
-            src[i] = (const unsigned char *)g.A + ((long)m * g.lda + chunk * 8) * 2;
-        } else {
-            const int chunk = (lane & 3) ^ key_w(row - BM);
-            int n = n0 + (row - BM);
-            n = n < g.N ? n : g.N - 1;
-            src[i] = (const unsigned char *)g.W + ((long)n * g.K + chunk * 8) * 2;
-        }
-    }
-    auto issue = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < PPW; i++) {
-            glds16(src[i], smem + slot * STAGE + (i * 4 + wave) * 1024);
-            src[i] += BK2 * 2;
-        }
-    };
-
-    // fragment offsets inside a stage: activation rows natural, weight rows permuted so that
-    // lane group g = lane >> 4 owns output columns 16 g .. 16 g + 15 of the wave's 64
-    int offB[8], offA[4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = i * 16 + (lane & 15);
-        offB[i] = row * ROWB + (((lane >> 4) ^ key_a(row)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int i = lane & 15;
-        const int row = wave * 64 + (i >> 2) * 16 + j * 4 + (i & 3);
-        offA[j] = BM * ROWB + row * ROWB + (((lane >> 4) ^ key_w(row)) << 4);
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Register double-buffering: while the MFMAs of stage kt run on one fragment set, the
-    // ds_reads of stage kt+1 fill the other; the DMA ring runs two further stages ahead
-    // (stage kt+3 goes into the slot stage kt occupied, drained one iteration earlier).
-    v8 fa0[4], fb0[8], fa1[4], fb1[8];
-    auto read_frags = [&](int sl, v8(&fa)[4], v8(&fb)[8]) {
-        const unsigned char *sb = smem + sl * STAGE;
-#pragma unroll
-        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const v8 *>(sb + offA[j]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) fb[i] = *reinterpret_cast<const v8 *>(sb + offB[i]);
-    };
-    auto mma = [&](v8(&fa)[4], v8(&fb)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma16(fa[j], fb[i], acc[i][j]);
-    };
-    auto sync = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the previous stage are back
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    const int nk = g.K / BK2;
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if (nk > 2) {
-        EC_VMCNT(12);
-    } else if (nk > 1) {
-        EC_VMCNT(6);
-    } else {
-        EC_VMCNT(0);
-    }
-    sync();
-    read_frags(0, fa0, fb0);
-    // one step: stage kt is in (fa, fb); prefetch stage kt+1 into (na, nb)
-    auto step = [&](int kt, v8(&fa)[4], v8(&fb)[8], v8(&na)[4], v8(&nb)[8]) {
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) {
-                EC_VMCNT(6);      // stage kt+1 landed, kt+2 may still be in flight
-            } else {
-                EC_VMCNT(0);
-            }
-            sync();               // everyone's share of kt+1 landed; stage kt's slot is drained
-            if (kt + 3 < nk) issue(kt % NSTAGE);
-            read_frags((kt + 1) % NSTAGE, na, nb);
-        }
-        mma(fa, fb);
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, fa0, fb0, fa1, fb1);
-        if (kt + 1 < nk) step(kt + 1, fa1, fb1, fa0, fb0);
-    }
-    epilogue<DT, EPI, 8>(g, acc, m0, n0 + wave * 64, lane);
-}
-
-template <int DT, int EPI> int launch_b2p(const GemmArgs &g0, hipStream_t stream)
-{
-    GemmArgs g = g0;
-    g.tiles_m = ec::ceil_div(g.M, 128);
-    g.tiles_n = ec::ceil_div(g.N, 256);
-    constexpr int lds = 3 * (128 + 256) * 64;
-    auto kern = gemm_b2p_kernel<DT, EPI>;
-    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    constexpr int cls = EPI == EC_EPI_STORE16 ? ec::PROF_GEMM_STORE16
-                        : EPI == EC_EPI_GELU16 ? ec::PROF_GEMM_GELU16
-                        : EPI == EC_EPI_RESID32 ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) ? 2.0
-                             : (EPI == EC_EPI_RESID32 ? 8.0 : 4.0);
-    ec::ProfScope prof(cls, stream, 2.0 * g.M * g.N * g.K,
-                       2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N);
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
-    EC_CHECK_HIP(hipGetLastError());
-    return EC_OK;
-}
-
-#endif  // EC_GEMM_DIAG
 
 // Variants that ship: the default and three independent tilings (kept as cross-checks of each
 // other in the GPU tests).  Everything else -- timing experiments that compute wrong results on
@@ -2112,12 +1309,26 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
         return launch2pp<DT, EC_EPI_GELU_BWD16>(g, s);
     // LayerNorm folded into the GEMMs (default kernel only)
     case EC_EPI_RESID_HL:
+#ifdef EC_GEMM_DIAG
+        if (variant == 18 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, true>(g, s);   // timeline records -> args.diag
+        // A / B forms of the hi-lo epilogue (epilogue_hl_buf MODE 0 .. 3)
+        if (variant == 30 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 0>(g, s);
+        if (variant == 31 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 1>(g, s);
+        if (variant == 32 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 2>(g, s);
+        if (variant == 33 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 3>(g, s);
+#endif
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
         return launch2pp<DT, EC_EPI_RESID_HL>(g, s);
     case EC_EPI_STORE16_LN:
+#ifdef EC_GEMM_DIAG
+        if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, true>(g, s);
+#endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs variant 0, row_stats and col_sums");
         return launch2pp<DT, EC_EPI_STORE16_LN>(g, s);
     case EC_EPI_GELU16_LN:
+#ifdef EC_GEMM_DIAG
+        if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, true>(g, s);
+#endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs variant 0, row_stats and col_sums");
         return launch2pp<DT, EC_EPI_GELU16_LN>(g, s);
     default: return ec::fail(EC_ERR_INVALID, "ec_gemm: unknown epilogue %d", epi);
@@ -2206,6 +1417,8 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     EC_REQUIRE(a->A && a->W && a->C, "ec_gemm: null buffer");
     const long lda = a->lda ? a->lda : a->K, ldc = a->ldc ? a->ldc : a->N;
     EC_REQUIRE(lda % 8 == 0 && ldc % 8 == 0, "ec_gemm: lda/ldc must be multiples of 8 elements");
+    // a tile's rows are addressed with 32-bit byte offsets from the tile's origin (256 rows x stride x 4 bytes)
+    EC_REQUIRE(lda < (1L << 21) && ldc < (1L << 21) && a->ldw < (1L << 21), "ec_gemm: row strides must be below 2^21 elements");
     EC_REQUIRE((((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->C) & 15) == 0,
                "ec_gemm: buffers must be 16-byte aligned");
     GemmArgs g;
@@ -2218,6 +1431,10 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     g.stat_out = nullptr, g.stat_groups = 0;
+    // what the epilogues read these with: row_stats by 16-byte LDS-DMA (two pairs at a time at stride 1; the header
+    // states that the array must be readable up to an even row count), col_sums as float4, row_sums written as float2
+    EC_REQUIRE((((uintptr_t)a->row_stats | (uintptr_t)a->col_sums) & 15) == 0, "ec_gemm: row_stats / col_sums must be 16-byte aligned");
+    EC_REQUIRE(((uintptr_t)a->row_sums & 7) == 0, "ec_gemm: row_sums must be 8-byte aligned");
     if (a->epilogue == EC_EPI_RESID_HL && a->row_sums) {
         EC_REQUIRE(a->N % 64 == 0, "ec_gemm: row_sums needs N %% 64 == 0 (N = %d)", a->N);
         g.stat_out = a->row_sums, g.stat_groups = a->N / 64;

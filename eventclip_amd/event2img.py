@@ -196,6 +196,10 @@ def build_event2img_pipeline(params, resolution, max_n, clip_model=None):
     return Event2ImagePipeline(resolution, max_n, params.quantize_args, n_px=n_px, **kw)
 
 
+class _FeederClosed(Exception):
+    """raised inside the producer thread when the feeder is closed while it waits for a slot"""
+
+
 class HostFeeder:
     """Batches that start in HOST memory, overlapped with the GPU's work on the batch before.
 
@@ -233,8 +237,65 @@ class HostFeeder:
         self._free = queue.Queue()
         self._batches = iter(batches)
         self._err = None
+        self._stop = threading.Event()
+        self._closed = False
         self._th = threading.Thread(target=self._produce, daemon=True)
         self._th.start()
+
+    # ---- life time -----------------------------------------------------------------------------------
+    def close(self):
+        """Stop the producer and release the pinned / device rings and the copy pool.  Called when the iteration
+        ends; call it (or use the feeder as a context manager) when the consumer leaves the loop early."""
+        if self._closed:
+            return
+        self._closed = True
+        self._stop.set()
+        # the producer may be blocked handing a batch over or waiting for a free slot: make room for both
+        import queue
+        while self._th.is_alive():
+            try:
+                while True:
+                    self._ready.get_nowait()
+            except queue.Empty:
+                pass
+            self._free.put(-1)
+            self._th.join(timeout=0.05)
+        self._pool.shutdown(wait=False)
+        if self._slots is not None:
+            for sl in self._slots:
+                if sl['consumed'] is not None:
+                    sl['consumed'].synchronize()
+        self._slots = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _put(self, q, item):
+        """queue.put that gives up when the feeder is closed (-> False)"""
+        import queue
+        while not self._stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _take_free(self):
+        i = self._free.get()
+        if i < 0 or self._stop.is_set():
+            raise _FeederClosed()
+        return i
 
     # ---- producer side -------------------------------------------------------------------------------
     def _alloc(self, nbytes):
@@ -263,13 +324,13 @@ class HostFeeder:
         if total > self.capacity:
             # a batch larger than any before it (pass capacity_bytes= to avoid this): wait until no slot is in
             # use any more, then allocate the ring again
-            held = [self._free.get() for _ in range(self.depth)]
+            held = [self._take_free() for _ in range(self.depth)]
             for j in held:
                 if self._slots[j]['consumed'] is not None:
                     self._slots[j]['consumed'].synchronize()
             self._slots = None
             self._alloc(total + total // 4)
-        i = self._free.get()
+        i = self._take_free()
         slot = self._slots[i]
         if slot['consumed'] is not None:
             slot['consumed'].synchronize()        # the kernels that read this slot's device buffer are done
@@ -289,29 +350,47 @@ class HostFeeder:
         try:
             torch.cuda.set_device(self.dev)
             for samples in self._batches:
+                if self._stop.is_set():
+                    break
                 extra = None
                 if isinstance(samples, dict):               # harness-style data_dict: events + anything else
+                    if 'events' not in samples:
+                        # a batch that is model-ready already (the reference's img / valid_mask): handed on as it is
+                        if not self._put(self._ready, dict(passthrough=samples)):
+                            break
+                        continue
                     extra = {k: v for k, v in samples.items() if k != 'events'}
                     samples = samples['events']
+                if torch.is_tensor(samples) or isinstance(samples, np.ndarray):
+                    raise TypeError('HostFeeder: a batch is a LIST of per-sample event arrays (or a dict with such a '
+                                    "list under 'events'); got a single array / tensor")
                 item = self._stage(samples)
                 item['extra'] = extra
-                self._ready.put(item)
+                if not self._put(self._ready, item):
+                    break
+        except _FeederClosed:
+            pass
         except BaseException as e:   # noqa: BLE001 -- handed to the consumer
             self._err = e
         finally:
-            self._ready.put(None)
+            self._put(self._ready, None)
 
     # ---- consumer side -------------------------------------------------------------------------------
     def __iter__(self):
         return self
 
     def __next__(self):
+        if self._closed:
+            raise StopIteration
         item = self._ready.get()
         if item is None:
-            self._pool.shutdown(wait=False)
-            if self._err is not None:
-                raise self._err
+            err = self._err
+            self.close()
+            if err is not None:
+                raise err
             raise StopIteration
+        if 'passthrough' in item:
+            return item['passthrough']
         slot = self._slots[item['slot']]
         cur = torch.cuda.current_stream(self.dev)
         cur.wait_event(item['done'])

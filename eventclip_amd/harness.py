@@ -80,16 +80,22 @@ def evaluate(model, batches, is_nin=False, pipeline=None, prefetch=1):
     ``pipeline`` (Event2ImagePipeline) is given; ``prefetch`` batches are then uploaded ahead of the one the
     GPU is working on (0: the synchronous path)."""
     meters = {}
+    feeder = None
     if pipeline is not None and prefetch:
         # host-resident event batches: staged through pinned memory and uploaded on a copy stream while the GPU
-        # works on the batch before (event2img.HostFeeder) -- the reference's DataLoader prefetch, test.py:36-38
-        batches = pipeline.stream(batches, depth=1 + int(prefetch))
-    for data_dict in batches:
-        if pipeline is not None and 'events' in data_dict:
-            data_dict = {**pipeline(data_dict['events']), 'label': data_dict['label']}
-        data_dict = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
-        out_dict = model(data_dict)
-        labels = data_dict['label']
-        for k, v in batch_accuracies(out_dict, labels, top5=is_nin).items():
-            meters.setdefault(k, AverageMeter()).update(v, labels.shape[0])
+        # works on the batch before (event2img.HostFeeder) -- the reference's DataLoader prefetch, test.py:36-38.
+        # Batches that carry the reference's img / valid_mask instead of events pass through it unchanged
+        batches = feeder = pipeline.stream(batches, depth=1 + int(prefetch))
+    try:
+        for data_dict in batches:
+            if pipeline is not None and 'events' in data_dict:
+                data_dict = {**pipeline(data_dict['events']), 'label': data_dict['label']}
+            data_dict = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
+            out_dict = model(data_dict)
+            labels = data_dict['label']
+            for k, v in batch_accuracies(out_dict, labels, top5=is_nin).items():
+                meters.setdefault(k, AverageMeter()).update(v, labels.shape[0])
+    finally:
+        if feeder is not None:
+            feeder.close()       # an exception mid-iteration must not leave the producer thread holding the rings
     return {k: m.avg for k, m in meters.items()}

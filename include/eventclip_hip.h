@@ -448,9 +448,14 @@ typedef struct {
                                    planes, the residual GEMMs update it in that form (EC_EPI_RESID_HL), ec_row_stats
                                    reads the hi plane (2 bytes per element instead of LayerNorm's 4 + 2) and the QKV /
                                    c_fc GEMMs take the raw hi rows and finish LayerNorm in their epilogues
-                                   (EC_EPI_STORE16_LN / EC_EPI_GELU16_LN).  Same rounding points as the plain chain
-                                   (the A operand is rounded once either way).  Ignored by precise / low_latency
-                                   towers and by the training entry points. */
+                                   (EC_EPI_STORE16_LN / EC_EPI_GELU16_LN).  The SAME NUMBER of 16-bit roundings as the
+                                   plain chain, at different places: the plain chain rounds LN(x), this one rounds x
+                                   itself (the hi plane) and normalises afterwards with statistics of those rounded
+                                   values, the variance taken as E[x^2] - mean^2 in fp32 -- a form that loses digits
+                                   on rows whose mean^2 is much larger than their variance (measured: 2.4e-4 against
+                                   2.1e-4 feature error on ViT-L/14; tests/test_outliers_gpu.py holds the
+                                   outlier-channel statistics of released checkpoints).  Ignored by precise /
+                                   low_latency towers and by the training entry points. */
 } ec_vit_weights;
 
 typedef struct {

@@ -240,3 +240,48 @@ def test_host_feeder_is_bit_identical_to_the_synchronous_path(hip):
     import pytest
     with pytest.raises(IndexError):
         list(pipe.stream(iter([[make_events(0, g['resolution'])]])))
+
+
+def test_host_feeder_passes_ready_batches_through_and_closes(hip):
+    """harness.evaluate wraps every batch stream in a HostFeeder when a pipeline is given.  Batches that carry the
+    reference's img / valid_mask (no 'events' entry, test.py:60) pass through unchanged, in order, between batches
+    that are staged; a consumer that leaves the loop early (or an exception mid-iteration) must not leave the
+    producer thread blocked on its queue holding the pinned and device rings; a single tensor where a list of
+    samples is expected is refused instead of being iterated row by row."""
+    import threading
+    import time
+    import torch
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.synthetic import GEOMETRY, make_events
+    g = GEOMETRY['n_cars']
+    qa = dict(max_imgs=2, N=g['N'], split_method='event_count', convert_method='event_histogram', grayscale=True,
+              count_non_zero=True, background_mask=False)
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=32, kpad=6144)
+    ev = [make_events(12500, g['resolution'], seed=i) for i in range(3)]
+    ready = dict(img=torch.zeros(2, 2, 3, 8, 8), valid_mask=torch.ones(2, 2, dtype=torch.bool), label=torch.tensor([0, 1]))
+    stream = [dict(events=ev, label=torch.tensor([0, 1, 0])), ready, dict(events=ev[:1], label=torch.tensor([1]))]
+    out = list(pipe.stream(iter(stream)))
+    assert len(out) == 3 and out[1] is ready and 'patches' in out[0] and 'patches' in out[2]
+    assert out[0]['label'].tolist() == [0, 1, 0] and out[2]['label'].tolist() == [1]
+    # leaving early: close() ends the producer although it is ahead of the consumer
+    before = threading.active_count()
+    feeder = pipe.stream(iter([ev] * 50), depth=2)
+    first = next(feeder)
+    assert 'patches' in first
+    feeder.close()
+    feeder.close()                                   # idempotent
+    deadline = time.time() + 10
+    while feeder._th.is_alive() and time.time() < deadline:
+        time.sleep(0.05)
+    assert not feeder._th.is_alive() and threading.active_count() <= before + 1
+    with pytest.raises(StopIteration):
+        next(feeder)
+    # context manager + an exception in the loop body
+    with pytest.raises(KeyError):
+        with pipe.stream(iter([ev] * 50)) as f2:
+            for _ in f2:
+                raise KeyError('consumer failed')
+    assert not f2._th.is_alive() or (f2._th.join(5) or not f2._th.is_alive())
+    # a single tensor is not a batch
+    with pytest.raises(TypeError):
+        list(pipe.stream(iter([torch.from_numpy(ev[0])])))

@@ -100,6 +100,33 @@ def test_other_baseline_configs_two_ranks_over_gloo(hip, config, batch, expect):
     assert (cfg['adapter'] is None) == (config == 3)
 
 
+@pytest.mark.parametrize('config,batch,expect', [
+    (3, 20, dict(scaling='strong', samples=[3, 3, 3, 3, 2, 2, 2, 2], views=2)),    # uneven shards over 8 ranks
+    (1, 1, dict(scaling='weak', samples=[1] * 8, views=10)),
+])
+def test_eight_ranks_over_gloo(hip, config, batch, expect):
+    """The rank count the scaling run uses (/root/reference/scripts/sbatch_run.sh:46-51 launches
+    `--nproc_per_node=$GPUS`), exercised before the driver does: eight gloo ranks sharing the one GPU.  Uneven
+    shards (the all-gather's padding path), eight entries in rank_devices / ms_per_step_per_rank, the whole-job
+    value.  A functional check of the N = 8 code path, not a measurement."""
+    env = dict(os.environ, EVENTCLIP_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '8', '--config', str(config), '--batch', str(batch), '--steps', '2',
+           '--warmup', '1', '--arch', 'ViT-B/32', '--classes', '11', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d) and d['n_gpus'] == 8 and d['scaling'] == expect['scaling']
+    cfg = d['config']
+    assert cfg['collective_ranks'] == 8 and len(cfg['rank_devices']) == 8
+    assert cfg['samples_per_rank'] == expect['samples']
+    frames = sum(expect['samples']) * expect['views']
+    assert cfg['frames_per_step_total'] == frames
+    assert abs(d['value'] - frames * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert len(d['ms_per_step_per_rank']) == 8 and all(0 < t <= d['ms_per_step'] * 1.001 for t in d['ms_per_step_per_rank'])
+    assert d['all_gather_ms_per_step'] is not None and d['all_gather_ms_per_step'] >= 0
+
+
 def test_config1_line_keeps_its_keys(hip):
     """--config 1 is the default line: same metric string and config keys as before the other configs existed."""
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--config', '1', '--no-cpu-baseline', '--no-dvfs'] + SMALL,

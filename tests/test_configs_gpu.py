@@ -60,7 +60,12 @@ def oracle_forward(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=None, emulate=
 
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3 relative of the reference's (fp32 oracle)
-SIGNAL_TOL = 1e-2   # input-dependent weights: a sanity bound only -- the assertion that matters there is the yardstick (module docstring)
+# Input-dependent weights: the max-normalised error of full_logits against the fp32 oracle, per config, pinned at
+# 1.5 x what the HIP path measures (profiles/r4_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 3.1e-3 / 2.2e-3) -- a regression of
+# 2 x fails.  north_star's 1e-3 is NOT met there with 16-bit GEMM operands (only ec_vit_weights.precise gets under it:
+# test_precise_tower_meets_1e3_on_signal_weights); DESIGN.md 3.3 and the header say so.
+SIGNAL_TOL = {'n_caltech/ViT-B/32': 2.0e-3, 'n_caltech/ViT-L/14': 2.9e-3, 'n_cars/ViT-L/14': 2.0e-3,
+              'n_imagenet/ViT-L/14@336px': 4.7e-3, 'n_imagenet/ViT-L/14': 3.3e-3}
 # (qk_gain, branch_gain, share of the feature norm that must vary with the input) per geometry: N-ImageNet frames
 # (70 000 events on 480 x 640 pixels under a background mask) are 93 % white paper whatever the events, and the
 # gains that would force 30 % out of them put the tower -- the fp32 one included -- into the chaotic regime where
@@ -89,10 +94,20 @@ def compare(out, evs, geo, qa, cfg, sd, tokens, T, weights, name, adapter=None, 
     want, feats = oracle_forward(evs, geo, qa, cfg, sd, tokens, T, 'mean', adapter=adapter)
     if weights == 'signal':
         emu, _ = oracle_forward(evs, geo, qa, cfg, sd, tokens, T, 'mean', adapter=adapter, emulate='fp16_reference')
-        check(out, want, feats=feats, emu=emu, logit_tol=SIGNAL_TOL, name=name, min_share=SIGNAL_GAINS[key][2])
+        check(out, want, feats=feats, emu=emu, logit_tol=SIGNAL_TOL[key], name=name, min_share=SIGNAL_GAINS[key][2])
     else:
         check(out, want)
     return want
+
+
+def record_parity(line):
+    """EC_PARITY_TABLE=<file>: the measured parity lines are appended there (profiles/r4_parity.txt is such a file,
+    regenerated whenever a tower kernel changes: tools/profile_round.sh)."""
+    import os
+    path = os.environ.get('EC_PARITY_TABLE')
+    if path:
+        with open(path, 'a') as f:
+            f.write(line + '\n')
 
 
 def logit_errors(out, want):
@@ -143,10 +158,13 @@ def check(out, want, feats=None, emu=None, logit_tol=LOGIT_TOL, name='', min_sha
         return
     share = signal_share(feats)
     ee = logit_errors(emu, want)
-    print(f'\n[{name}] input-dependent share of the image features {share:.2f}; full_logits error vs the fp32 '
-          f'oracle, max-normalised / centred: HIP {e["full_logits"][0]:.2e} / {e["full_logits"][1]:.2e}, '
-          f'fp16-reference emulation {ee["full_logits"][0]:.2e} / {ee["full_logits"][1]:.2e}; aggregated logits: '
-          f'HIP {e["logits"][0]:.2e} / {e["logits"][1]:.2e}, emulation {ee["logits"][0]:.2e} / {ee["logits"][1]:.2e}')
+    line = (f'[{name}] input-dependent share of the image features {share:.2f}; full_logits error vs the fp32 '
+            f'oracle, max-normalised / centred: HIP {e["full_logits"][0]:.2e} / {e["full_logits"][1]:.2e}, '
+            f'fp16-reference emulation {ee["full_logits"][0]:.2e} / {ee["full_logits"][1]:.2e}; aggregated logits: '
+            f'HIP {e["logits"][0]:.2e} / {e["logits"][1]:.2e}, emulation {ee["logits"][0]:.2e} / {ee["logits"][1]:.2e}'
+            f'; bound {logit_tol:.1e}')
+    print('\n' + line)
+    record_parity(line)
     assert share >= min_share, share
     # the yardstick: strictly on full_logits (every valid view); the aggregated logits of a handful of samples are
     # the same errors averaged over 1 .. T views and their maximum a single draw: 25 % slack there
@@ -230,6 +248,43 @@ def test_config1_ncaltech_rgb_vitl14_full_depth(hip, weights):
     out = model(pipe(evs))
     want = compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 10, weights, 'configs[1]', key='n_caltech/ViT-L/14')
     assert want['valid_masks'].sum(1).tolist() == [10, 2, 6]
+    assert torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
+
+
+@pytest.mark.parametrize('mode', ['plain_chain', 'precise'])
+def test_config1_signal_weights_other_tower_modes(hip, mode):
+    """configs[1] on the input-dependent weights through the two other forms of the image tower, so that what the
+    round-3 defaults (LayerNorm folded into the GEMMs, pre-scaled q) contribute to the error stays visible:
+      plain_chain  CLIP(ln_folded=False, q_scaled=False): fp32 residual stream, LayerNorm launches, in-kernel q scale;
+                   same bound as the default path;
+      precise      ec_vit_weights.precise (hi + lo operands in every GEMM, 3 x the MFMA work): north_star's 1e-3
+                   holds on these weights too -- the measured price of that tolerance is bench.py --precise."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    key = 'n_caltech/ViT-L/14'
+    g, qa = quantize_args('n_caltech', 10, grayscale=False)
+    cfg = eclip.arch_config('ViT-L/14', text_layers=2)
+    sd = make_weights(key, cfg, 35, 'signal')
+    kw = dict(ln_folded=False, q_scaled=False) if mode == 'plain_chain' else dict(image_precise=True)
+    m = eclip.CLIP(cfg, sd, **kw).cuda().eval()
+    tokens = eclip.synthetic_tokens(101, seed=5)
+    evs = make_events_batch(3, [200000, 47000, 111000], g['resolution'], 5, 'signal')
+    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
+                                            class_names=[str(i) for i in range(101)],
+                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
+    out = model(pipe(evs))
+    want, feats = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 10, 'mean')
+    e = logit_errors({k: v.cpu() for k, v in out.items()}, want)
+    line = (f'[configs[1] {mode}] full_logits error vs the fp32 oracle, max-normalised / centred: '
+            f'{e["full_logits"][0]:.2e} / {e["full_logits"][1]:.2e}; aggregated logits {e["logits"][0]:.2e} / {e["logits"][1]:.2e}')
+    print('\n' + line)
+    record_parity(line)
+    tol = LOGIT_TOL if mode == 'precise' else SIGNAL_TOL[key]
+    assert signal_share(feats) >= SIGNAL_GAINS[key][2]
+    assert e['full_logits'][0] < tol and e['logits'][0] < tol, e
     assert torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
 
 

@@ -28,6 +28,39 @@ def run_hip(ev, shape, kw, max_frame_events=0, float_stage='float64'):
     return frames.cpu().numpy(), raw.cpu().numpy(), kept.cpu().numpy(), stats
 
 
+def run_hip_frames_only(ev, shape, kw, max_frame_events, float_stage):
+    """The PRODUCT form of the launch: uint8 frames only, no debug outputs -- with them set the persistent kernels
+    take their debug branches (events.hip: the row-band kernel is disabled outright and the whole-frame kernel keeps
+    the old survivor pass), so the reference's fixtures would never reach the code bench.py times."""
+    import torch
+    from eventclip_amd import vis
+    idx0, idx1 = vis.chunk_bounds(ev.shape[0], kw['N'])
+    ev_d = torch.from_numpy(np.ascontiguousarray(ev, dtype=np.float32)).cuda()
+    rng = torch.tensor(np.stack([idx0, idx1], 1), dtype=torch.int64).cuda()
+    frames = vis.events_to_frames_device(ev_d, rng, shape, grayscale=kw['grayscale'],
+                                         count_non_zero=kw['count_non_zero'], background_mask=kw['background_mask'],
+                                         max_frame_events=max_frame_events, float_stage=float_stage)
+    torch.cuda.synchronize()
+    assert isinstance(frames, torch.Tensor) and frames.dtype == torch.uint8
+    return frames.cpu().numpy()
+
+
+@pytest.mark.parametrize('path', event_fixture_paths(), ids=os.path.basename)
+def test_frames_only_product_kernels_match_reference_fixture(path, hip):
+    """Reference vis.py:6-41 through the frames-only launch (events_pack10_kernel's lean pass for the small sensors,
+    events_band10_kernel for the 480 x 640 N-ImageNet fixtures): the uint8 frames the reference's own
+    make_event_histogram produced, both float stages, by hash."""
+    from eventclip_amd import vis
+    ev, shape, kw, exp = load_event_fixture(path)
+    idx0, idx1 = vis.chunk_bounds(ev.shape[0], kw['N'])
+    nmax = max(b - a for a, b in zip(idx0, idx1))
+    for stage, key in (('float64', 'frames_sha256'), ('float32', 'frames_f32_sha256')):
+        for cache in (nmax, 0):      # with and without the on-chip event cache
+            frames = run_hip_frames_only(ev, shape, kw, cache, stage)
+            assert frames.shape[0] == exp['n_frames']
+            assert sha(frames) == exp[key], (os.path.basename(path), stage, cache)
+
+
 @pytest.mark.parametrize('path', event_fixture_paths(), ids=os.path.basename)
 def test_hip_matches_reference_fixture(path, hip):
     from oracle import events as oe

@@ -123,6 +123,21 @@ def test_sharded_forward_and_all_gather_gloo_world2():
     assert res == [(0, True), (1, True)]
 
 
+def test_sharded_forward_and_all_gather_gloo_world8():
+    """Eight ranks (one node of the scaling run): B = 7 samples over 8 ranks leaves rank 7 with an EMPTY shard and
+    the others with one sample each -- the all-gather's padding path with a zero-row rank."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(8)]
+
+
 def test_product_fails_loudly_without_gpu():
     from eventclip_amd import _lib
     if torch.cuda.is_available():

@@ -109,16 +109,15 @@ class _Block16(torch.nn.Module):
         return x + self.c_proj(h * torch.sigmoid(1.702 * h))
 
 
-def test_fp16_reference_emulation_matches_torch_half_modules():
-    """The emulation (fp32 arithmetic + an explicit round to fp16 after every op) against torch's OWN fp16 kernels
-    (CPU half): nn.MultiheadAttention / nn.Linear / elementwise ops on half tensors, LayerNorm computed in fp32,
-    convert_weights' split of what is fp16 and what stays fp32.  Two blocks.  The two are independent fp16
-    realisations of the same arithmetic (sums associate differently, so roundings fall differently): what the
-    yardstick needs is that both sit at the SAME distance from fp32 (within 2x) and no further from each other
-    than two such realisations are (< 2x that distance)."""
+def fp16_emulation_distances(device='cpu', W=128, heads=2, S=10, N=4, L=2, seed=3):
+    """(emulation vs torch's half kernels, torch's half kernels vs fp32, emulation vs fp32), max-normalised, for L
+    blocks of openai/CLIP's ResidualAttentionBlock built from torch's OWN modules and run in half precision ON
+    ``device`` (CPU half kernels here; the MI355X's hipBLASLt / elementwise half kernels in
+    tests/test_towers_gpu.py::test_fp16_reference_emulation_against_torch_half_on_the_gpu): nn.MultiheadAttention /
+    nn.Linear / elementwise ops on half tensors, LayerNorm computed in fp32, convert_weights' split of what is
+    fp16 and what stays fp32."""
     from oracle import clip_ref
-    torch.manual_seed(3)
-    W, heads, S, N, L = 128, 2, 10, 4, 2
+    torch.manual_seed(seed)
     blocks = [_Block16(W, heads) for _ in range(L)]
     sd = {}
     for i, b in enumerate(blocks):
@@ -134,18 +133,26 @@ def test_fp16_reference_emulation_matches_torch_half_modules():
         sd[pre + 'attn.out_proj.weight'], sd[pre + 'attn.out_proj.bias'] = b.attn.out_proj.weight.data.float(), b.attn.out_proj.bias.data.float()
         sd[pre + 'mlp.c_fc.weight'], sd[pre + 'mlp.c_fc.bias'] = b.c_fc.weight.data.float(), b.c_fc.bias.data.float()
         sd[pre + 'mlp.c_proj.weight'], sd[pre + 'mlp.c_proj.bias'] = b.c_proj.weight.data.float(), b.c_proj.bias.data.float()
+    sd = {k: v.clone() for k, v in sd.items()}          # CPU fp32 copies for the oracle, whatever the device
     x = torch.randn(N, S, W)
     with torch.no_grad():
-        y = x.half().transpose(0, 1)
+        y = x.half().transpose(0, 1).to(device)
         for b in blocks:
-            y = b(y)
-        y = y.transpose(0, 1).float()
+            y = b.to(device)(y)
+        y = y.transpose(0, 1).float().cpu()
         emu = clip_ref._blocks_h(clip_ref._h(x), clip_ref.fp16_reference_weights(sd), 'visual.transformer', L, heads)
         exact = clip_ref._blocks(x, sd, 'visual.transformer', L, heads)
     scale = float(exact.abs().max())
-    d_emu_torch = float((emu - y).abs().max()) / scale
-    d_torch_exact = float((y - exact).abs().max()) / scale
-    d_emu_exact = float((emu - exact).abs().max()) / scale
+    return (float((emu - y).abs().max()) / scale, float((y - exact).abs().max()) / scale,
+            float((emu - exact).abs().max()) / scale)
+
+
+def test_fp16_reference_emulation_matches_torch_half_modules():
+    """The emulation (fp32 arithmetic + an explicit round to fp16 after every op) against torch's OWN fp16 kernels
+    (CPU half).  Two blocks.  The two are independent fp16 realisations of the same arithmetic (sums associate
+    differently, so roundings fall differently): what the yardstick needs is that both sit at the SAME distance from
+    fp32 (within 2x) and no further from each other than two such realisations are (< 2x that distance)."""
+    d_emu_torch, d_torch_exact, d_emu_exact = fp16_emulation_distances('cpu')
     assert d_emu_torch < 2.0 * d_torch_exact, (d_emu_torch, d_torch_exact)
     assert 0.5 < d_emu_exact / d_torch_exact < 2.0, (d_emu_exact, d_torch_exact)
 

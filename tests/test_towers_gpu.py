@@ -67,6 +67,39 @@ def test_attention(S, heads, causal, dt, hip):
     torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
 
 
+def test_fp16_reference_emulation_against_torch_half_on_the_gpu(hip):
+    """The yardstick of the logit-parity tests (oracle/clip_ref.py emulate='fp16_reference': the arithmetic the
+    reference runs on its GPU, /root/reference/test.py:25-26) against torch's half kernels ON THE GPU -- the vendor
+    GEMM library, fused attention and elementwise kernels a `clip.load(arch, 'cuda')` model would run here -- at
+    ViT-L/14's width, head count and sequence length, four blocks: both fp16 realisations sit at the same distance
+    from fp32 (within 2x) and no further from each other than two such realisations are."""
+    from test_oracle_clip import fp16_emulation_distances
+    d_emu_torch, d_torch_exact, d_emu_exact = fp16_emulation_distances('cuda', W=1024, heads=16, S=257, N=2, L=4, seed=5)
+    print(f'\nfp16 emulation vs torch half on the GPU {d_emu_torch:.2e}; torch half vs fp32 {d_torch_exact:.2e}; '
+          f'emulation vs fp32 {d_emu_exact:.2e}')
+    assert d_emu_torch < 2.0 * d_torch_exact, (d_emu_torch, d_torch_exact)
+    assert 0.5 < d_emu_exact / d_torch_exact < 2.0, (d_emu_exact, d_torch_exact)
+
+
+@pytest.mark.parametrize('S', [609, 640])
+def test_attention_at_the_lds_limit(S, hip):
+    """S = 609 .. 640 is twenty 32-key blocks: exactly 160 KiB of K and V.  The merge area of a split query tile is
+    only reserved where the kernel can split one, so these lengths fit; one more key does not and says why."""
+    import torch
+    from eventclip_amd import _lib
+    n_seq, heads = 2, 2
+    W = heads * 64
+    qkv = (torch.randn(n_seq * S, 3 * W, device='cuda') * 1.5).half()
+    out = torch.empty(n_seq * S, W, dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0, _lib.EC_F16, _lib.stream_ptr()))
+    torch.testing.assert_close(out.float(), ref_attention(qkv, n_seq, S, W, heads, 0), rtol=4e-3, atol=4e-3)
+    if S == 640:
+        big = torch.zeros(641, 3 * W, device='cuda', dtype=torch.float16)
+        with pytest.raises(RuntimeError, match='S <= 640'):
+            _lib.check(_lib.lib().ec_attention(_lib.ptr(big), _lib.ptr(out), 1, 641, W, heads, 0, _lib.EC_F16,
+                                               _lib.stream_ptr()), 'ec_attention')
+
+
 def test_attention_exact_selector(hip):
     """One-hot softmax (huge matching score) must copy the right V row for every query:
     catches any mismatch between the P^T and V^T operand permutations."""

@@ -16,6 +16,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_
 F=$(find gpurun_out/pmc_fetch_$TAG -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/pmc_write_$TAG -name "*counter_collection.csv" | head -1)
 S=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
-python tools/traffic_summary.py $F $W gpurun_out/pmc_fetch_$TAG.json $COMMIT > gpurun_out/traffic_$TAG.json
+# the same two passes over BASELINE configs[3] (N-ImageNet @336: the row-band events kernel, the 480 x 640 -> 336
+# preprocess, attention at S = 577), one quarter of its global batch on this one GPU
+C3="--config 3 --batch 512 --steps 1 --warmup 1 --no-cpu-baseline --no-dvfs"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_c3_$TAG -- python3 bench.py $C3 > gpurun_out/pmc_fetch_c3_$TAG.json 2> gpurun_out/pmc_fetch_c3_$TAG.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_c3_$TAG -- python3 bench.py $C3 > gpurun_out/pmc_write_c3_$TAG.log 2>&1
+F3=$(find gpurun_out/pmc_fetch_c3_$TAG -name "*counter_collection.csv" | head -1)
+W3=$(find gpurun_out/pmc_write_c3_$TAG -name "*counter_collection.csv" | head -1)
+python tools/traffic_summary.py $F $W gpurun_out/pmc_fetch_$TAG.json $COMMIT --config 3 $F3 $W3 gpurun_out/pmc_fetch_c3_$TAG.json > gpurun_out/traffic_$TAG.json
 cp $S gpurun_out/${TAG}_kernel_stats.csv
 ls -la gpurun_out/*$TAG*

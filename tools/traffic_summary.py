@@ -45,7 +45,35 @@ def collect(path, counter):
     return tot, cnt
 
 
+def summarise(fetch_csv, write_csv, bench_json):
+    """{kernel class: counters, HBM bytes per launch, algorithmic bytes, ratio} for one profiled bench command"""
+    bench = json.loads([ln for ln in open(bench_json) if ln.startswith('{')][-1])
+    alg = dict(bench['kernel_algorithmic_bytes_per_launch'])
+    ft, fc = collect(fetch_csv, 'FETCH_SIZE')
+    wt, wc = collect(write_csv, 'WRITE_SIZE')
+    kernels = {}
+    for k in alg:
+        if k not in ft or k not in wt or not alg[k]:
+            continue
+        f, w = ft[k] / fc[k], wt[k] / wc[k]
+        hbm = (2 * f + w) * 1024
+        kernels[k] = {'FETCH_SIZE_KiB_avg': f, 'FETCH_SIZE_dispatches': fc[k], 'WRITE_SIZE_KiB_avg': w,
+                      'WRITE_SIZE_dispatches': wc[k], 'hbm_bytes_per_launch': hbm,
+                      'algorithmic_bytes_per_launch': alg[k], 'ratio': hbm / alg[k]}
+    return bench, kernels
+
+
 def main():
+    # [--config N fetch.csv write.csv bench.json] ... after the four positional arguments: the same two passes over
+    # `bench.py --config N`, folded in under configs[N] (the kernels the other BASELINE configs run: the row-band
+    # events kernel and the 480 x 640 -> 336 preprocess of N-ImageNet, attention at S = 577)
+    argv = sys.argv[1:]
+    extra = []
+    while '--config' in argv:
+        i = argv.index('--config')
+        extra.append(argv[i + 1:i + 5])
+        argv = argv[:i] + argv[i + 5:]
+    sys.argv = sys.argv[:1] + argv
     fetch_csv, write_csv, bench_json = sys.argv[1:4]
     bench = json.loads([ln for ln in open(bench_json) if ln.startswith('{')][-1])
     alg = dict(bench['kernel_algorithmic_bytes_per_launch'])   # the events kernel's figure includes its 16 B / event
@@ -70,6 +98,11 @@ def main():
                    'Infinity-Cache hits are included.'}
     out.update(kernels.get(dom, {}))
     out['all_kernels'] = kernels
+    if extra:
+        out['configs'] = {}
+        for cfg, f_csv, w_csv, b_json in extra:
+            b, ks = summarise(f_csv, w_csv, b_json)
+            out['configs'][cfg] = {'workload': b['config']['workload'], 'kernels': ks}
     json.dump(out, sys.stdout, indent=1)
 
 
