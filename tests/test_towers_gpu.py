@@ -264,7 +264,10 @@ def test_image_tower_matches_oracle_fixture(name, arch, ov, n, dt, tol, hip):
 
 
 @pytest.mark.parametrize('S,heads,causal,q_rows', [(257, 16, 0, 1), (257, 16, 0, 20), (50, 12, 0, 1),
-                                                   (577, 16, 0, 1), (77, 8, 1, 5)])
+                                                   (577, 16, 0, 1), (77, 8, 1, 5),
+                                                   # rows inside the tiles whose keys are split over the waves (S = 577:
+                                                   # tiles 32 .. 36), part of them / all of them requested
+                                                   (577, 16, 0, 530), (577, 16, 0, 576), (593, 4, 0, 550)])
 def test_attention_rows_is_a_prefix_of_full_attention(S, heads, causal, q_rows, hip):
     """ec_attention_rows(q_rows) == the first q_rows rows of every sequence of ec_attention, bit for bit."""
     import torch
