@@ -263,7 +263,9 @@ typedef struct {
     int epilogue;      /* EC_EPI_* */
     int variant;       /* 0 = the kernel; anything else is EC_ERR_INVALID.  (The tilings it grew out of and the
                           stamp / timeline variants exist in the -DEC_GEMM_DIAG build for tools/ only.) */
-    const void *A;     /* [M, K] 16-bit, row stride lda elements (0 = K) */
+    const void *A;     /* [M, K] 16-bit, row stride lda elements (0 = K).  Row strides (lda, ldw, ldc) are multiples of
+                          8 elements below 2^21: a tile's rows are addressed with 32-bit byte offsets from the tile's
+                          origin (buffer descriptors), EC_ERR_INVALID otherwise */
     long lda;
     const void *W;     /* [N, K] 16-bit, dense (nn.Linear weight layout) */
     const float *bias; /* [N] fp32 or NULL */
