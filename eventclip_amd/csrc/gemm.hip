@@ -104,239 +104,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
     return start + (bid >> 3);
 }
 
-// Epilogue shared by the GEMM kernels.  acc[i][j][r]: row m_base + 16 i + (lane & 15),
-// column n_base + 16 (lane >> 4) + 4 j + r  (see the weight-row permutation above).
-template <int DT, int EPI, int TM>
-__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
-                                         int n_base, int lane)
-{
-    const int nb = n_base + (lane >> 4) * 16;
-    if (nb >= g.N) return;
-    float bias[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) bias[c] = 0.f;
-    if (g.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float4 b = *reinterpret_cast<const float4 *>(g.bias + nb + 4 * c);
-            bias[4 * c] = b.x, bias[4 * c + 1] = b.y, bias[4 * c + 2] = b.z, bias[4 * c + 3] = b.w;
-        }
-    }
-    if constexpr (EPI == EC_EPI_RESID32) {
-        // fp32 residual read-modify-write.  The loads of tile row i + DEPTH are issued before
-        // row i is stored: the compiler cannot hoist them itself (same base pointer as the
-        // stores), and one row group in flight per wave leaves the epilogue latency-bound.
-        constexpr int DEPTH = TM < 4 ? TM : 4;
-        float4 x[DEPTH][4];
-        auto fetch = [&](int i) {
-            const int m = m_base + i * 16 + (lane & 15);
-            const float *src = (const float *)g.C + (long)(m < g.M ? m : g.M - 1) * g.ldc + nb;
-#pragma unroll
-            for (int c = 0; c < 4; c++) x[i % DEPTH][c] = *reinterpret_cast<const float4 *>(src + 4 * c);
-        };
-#pragma unroll
-        for (int i = 0; i < DEPTH; i++) fetch(i);
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int m = m_base + i * 16 + (lane & 15);
-            float *dst = (float *)g.C + (long)m * g.ldc + nb;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float4 r = x[i % DEPTH][c];
-                float4 o;
-                o.x = acc[i][c][0] + bias[4 * c] + r.x;
-                o.y = acc[i][c][1] + bias[4 * c + 1] + r.y;
-                o.z = acc[i][c][2] + bias[4 * c + 2] + r.z;
-                o.w = acc[i][c][3] + bias[4 * c + 3] + r.w;
-                if (m < g.M) *reinterpret_cast<float4 *>(dst + 4 * c) = o;
-            }
-            if (i + DEPTH < TM) fetch(i + DEPTH);
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int m = m_base + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
-        if constexpr (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) {
-            typedef typename T16<DT>::elem elem;
-            elem o[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                float x = v[c];
-                if constexpr (EPI == EC_EPI_GELU16) x = quick_gelu(x);
-                o[c] = to16(x, elem());
-            }
-            elem *dst = (elem *)g.C + (long)m * g.ldc + nb;
-            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&o[0]);
-            *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&o[8]);
-        } else {
-            float *dst = (float *)g.C + (long)m * g.ldc + nb;
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                *reinterpret_cast<float4 *>(dst + 4 * c) =
-                    make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-        }
-    }
-}
-
-// fp32 residual epilogue with a transpose through LDS.  In the accumulator layout a quad of
-// consecutive lanes owns four different rows, so every 16-byte access of a lane sits in its own
-// cache line and the texture path serves one quarter of its width (measured: 35 k cycles of
-// epilogue per 256 x 256 tile, as long as the 16 K-tile main loop).  Each wave passes one 16 x 64
-// row group at a time through a private LDS scratch (row pitch 68 dwords: conflict-free for both
-// the 16-B writes by (row, column group) and the 16-B reads by row) and comes back with 16
-// consecutive lanes covering 256 contiguous bytes of one row, for the residual loads and the stores.
-// scratch: NBUF x 16 x 68 floats per wave (one buffer is enough: a wave's LDS accesses execute in
-// program order).
-// NAT: acc[i][j][r] is column n_base + 16 j + 4 (lane >> 4) + r (the transposed-operand kernel's fragments are
-// read in natural column order; no bias there).
-template <int EPI, int TM, int NBUF = 2, bool NAT = false>
-__device__ __forceinline__ void epilogue32_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base,
-                                               int n_base, int lane, float *scratch)
-{
-    static_assert(EPI == EC_EPI_RESID32 || EPI == EC_EPI_STORE32, "fp32 outputs only");
-    constexpr int PITCH = 68;
-    const int q = lane >> 4, lr = lane & 15;
-    f32x4 bias[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nb = n_base + q * 16;
-    if (g.bias && nb < g.N) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
-    }
-    const int col = n_base + lr * 4;          // this lane's 4 output columns after the transpose
-    const bool col_ok = col < g.N;
-    constexpr int DEPTH = EPI == EC_EPI_RESID32 ? (TM < 3 ? TM : 3) : 1;
-    f32x4 x[DEPTH][4];
-    auto fetch = [&](int i) {
-        if constexpr (EPI == EC_EPI_RESID32) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                int m = m_base + i * 16 + q + 4 * p;
-                m = m < g.M ? m : g.M - 1;
-                const float *src = (g.resid ? g.resid : (const float *)g.C) + (long)m * g.ldc + (col_ok ? col : 0);
-                x[i % DEPTH][p] = *reinterpret_cast<const f32x4 *>(src);
-            }
-        }
-    };
-    if constexpr (EPI == EC_EPI_RESID32) {
-#pragma unroll
-        for (int i = 0; i < DEPTH; i++) fetch(i);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        float *buf = scratch + (i % NBUF) * 16 * PITCH;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + (NAT ? j * 16 + q * 4 : q * 16 + j * 4)) = acc[i][j] + bias[j];
-        f32x4 v[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-            v[p] = *reinterpret_cast<const f32x4 *>(buf + (q + 4 * p) * PITCH + lr * 4);
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int m = m_base + i * 16 + q + 4 * p;
-            f32x4 o = v[p];
-            if constexpr (EPI == EC_EPI_RESID32) o += x[i % DEPTH][p];
-            if (m < g.M && col_ok)
-                *reinterpret_cast<f32x4 *>((float *)g.C + (long)m * g.ldc + col) = o;
-        }
-        if constexpr (EPI == EC_EPI_RESID32) {
-            if (i + DEPTH < TM) fetch(i + DEPTH);
-        }
-    }
-}
-
-// Residual epilogue on a residual stream kept as two 16-bit planes, x = hi + lo (EC_EPI_RESID_HL): hi = x rounded to
-// the operand type IS the A operand of the GEMM that follows (its LayerNorm is folded into that GEMM's epilogue),
-// lo = fp16(x - hi) keeps the stream at ~2^-22 relative -- the same 4 bytes per element as the fp32 stream, and no
-// LayerNorm pass in between.  Same transpose through LDS as epilogue32_lds; afterwards a lane holds 8 consecutive
-// columns of two rows, so each plane is read and written with 16-byte accesses (8 lanes = one 128-byte line).
-template <int DT, int TM, bool STATS>
-__device__ __forceinline__ void epilogue_hl_lds(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
-                                                int lane, float *scratch)
-{
-    typedef typename T16<DT>::elem elem;
-    typedef typename T16<DT>::v8 v8;
-    constexpr int PITCH = 68;
-    const int q = lane >> 4, lr = lane & 15;
-    f32x4 bias[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nb = n_base + q * 16;
-    if (g.bias && nb < g.N) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) bias[j] = *reinterpret_cast<const f32x4 *>(g.bias + nb + 4 * j);
-    }
-    const int c8 = lane & 7, r8 = lane >> 3;
-    const int col = n_base + c8 * 8;          // this lane's 8 output columns after the transpose
-    const bool col_ok = col < g.N;
-    constexpr int DEPTH = TM < 3 ? TM : 3;
-    v8 xh[DEPTH][2];
-    f16x8 xl[DEPTH][2];
-    auto fetch = [&](int i) {
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            int m = m_base + i * 16 + r8 + 8 * p;
-            m = m < g.M ? m : g.M - 1;
-            const long off = (long)m * g.ldc + (col_ok ? col : 0);
-            xh[i % DEPTH][p] = *reinterpret_cast<const v8 *>((const elem *)g.C + off);
-            xl[i % DEPTH][p] = *reinterpret_cast<const f16x8 *>((const _Float16 *)g.aux + off);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < DEPTH; i++) fetch(i);
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        float *buf = scratch;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<f32x4 *>(buf + lr * PITCH + q * 16 + j * 4) = acc[i][j] + bias[j];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int row = r8 + 8 * p;
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + row * PITCH + c8 * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(buf + row * PITCH + c8 * 8 + 4);
-            const int m = m_base + i * 16 + row;
-            v8 oh;
-            f16x8 ol;
-            float ps = 0.f, pq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float x = (float)xh[i % DEPTH][p][e] + (float)xl[i % DEPTH][p][e] + (e < 4 ? a[e] : b[e - 4]);
-                oh[e] = to16(x, elem());
-                const float h = (float)oh[e];
-                ol[e] = (_Float16)(x - h);
-                if (STATS) ps += h, pq = __builtin_fmaf(h, h, pq);
-            }
-            if (m < g.M && col_ok) {
-                const long off = (long)m * g.ldc + col;
-                *reinterpret_cast<v8 *>((elem *)g.C + off) = oh;
-                *reinterpret_cast<f16x8 *>((_Float16 *)g.aux + off) = ol;
-            }
-            if (STATS) {
-                // (sum, sum of squares) of the NEW hi values over this wave's 64 columns of the row: eight lanes
-                // hold one row; the LayerNorm statistics the next GEMM needs come out of the same pass
-                // (ec_row_stats_merge adds the N / 64 groups up), instead of a pass over the hi plane
-                // (DPP adds: lanes 1 and 2 apart inside a quad, then the other quad of the eight through
-                // row_half_mirror -- three vector instructions per value, no LDS round trip)
-                ps += dpp_f32<0xB1>(ps), pq += dpp_f32<0xB1>(pq);      // quad_perm [1, 0, 3, 2]
-                ps += dpp_f32<0x4E>(ps), pq += dpp_f32<0x4E>(pq);      // quad_perm [2, 3, 0, 1]
-                ps += dpp_f32<0x141>(ps), pq += dpp_f32<0x141>(pq);    // row_half_mirror
-                if (c8 == 0 && m < g.M && col_ok)
-                    *reinterpret_cast<float2 *>(g.stat_out + ((long)m * g.stat_groups + (n_base >> 6)) * 2) = make_float2(ps, pq);
-            }
-        }
-        if (i + DEPTH < TM) fetch(i + DEPTH);
-    }
-}
+// (The direct epilogue, the general fp32 LDS-transposed epilogue and the general hi-lo epilogue are only used by the
+// diagnostic kernels now: csrc/gemm_diag.inc.  The persistent kernel runs the buffer-addressed forms below; the
+// general 16-bit form stays here for the training epilogues with a second output / input.)
 
 // 16-bit counterpart: a 16 x 64 row group is 16 rows of 128 B (pitch 144 B); after the transpose
 // 8 consecutive lanes cover one full 128-B row and a store instruction writes 8 whole lines.
