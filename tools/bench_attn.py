@@ -34,6 +34,9 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--scale', type=float, default=1.0, help='std of the synthetic q / k / v')
     ap.add_argument('--variants', type=int, nargs='+', default=[0, 1])
+    ap.add_argument('--scaled-q', action='store_true',
+                    help='the tower\'s entry point (ec_attention_scaled_q: q pre-multiplied by log2(e) / 8); variants 3 / 4 '
+                         '(s_setprio around the MFMA groups / around the exponentials) only exist for it')
     a = ap.parse_args()
     h = ctypes.CDLL(os.environ['EVENTCLIP_HIP_LIB'])
     heads = 16
@@ -47,9 +50,19 @@ def main():
         n_ref = 8
         want = ref_attention(qkv[:n_ref * S], n_ref, S, W, heads)
 
+        if a.scaled_q:      # the reference stays the plain softmax(q k^T / 8) v of the unscaled q
+            qkv_in = qkv.clone()
+            qkv_in[:, :W] = (qkv[:, :W].float() * (0.125 * 1.4426950408889634)).half()
+        else:
+            qkv_in = qkv
+
         def launch():
-            _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), a.n_seq, S, W, heads, 0, _lib.EC_F16,
-                                               _lib.stream_ptr()))
+            if a.scaled_q:
+                _lib.check(_lib.lib().ec_attention_scaled_q(_lib.ptr(qkv_in), _lib.ptr(out), a.n_seq, S, W, heads, 0, S,
+                                                            _lib.EC_F16, _lib.stream_ptr()))
+            else:
+                _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), a.n_seq, S, W, heads, 0, _lib.EC_F16,
+                                                   _lib.stream_ptr()))
         times = {v: [] for v in a.variants}
         err = {}
         for v in a.variants:
