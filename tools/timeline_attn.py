@@ -23,8 +23,13 @@ if len(sys.argv) > 3:   # block variant of the diagnostic build (1 = round-1/2 b
     ctypes.CDLL(os.environ['EVENTCLIP_HIP_LIB']).ec_attn_set_variant(int(sys.argv[3]))
 qkv = torch.randn(n_seq * S, 3 * W, device='cuda').half()
 out = torch.empty(n_seq * S, W, dtype=torch.float16, device='cuda')
+scaled = os.environ.get('ATTN_SCALED', '0') != '0'     # the tower's entry point (variant 5 = 32-query tiles needs it)
 for _ in range(3):
-    _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0, _lib.EC_F16, _lib.stream_ptr()))
+    if scaled:
+        _lib.check(_lib.lib().ec_attention_scaled_q(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0, S, _lib.EC_F16,
+                                                    _lib.stream_ptr()))
+    else:
+        _lib.check(_lib.lib().ec_attention(_lib.ptr(qkv), _lib.ptr(out), n_seq, S, W, heads, 0, _lib.EC_F16, _lib.stream_ptr()))
 torch.cuda.synchronize()
 n = min(n_seq * heads, 65536)
 host = np.zeros(n * 4, dtype=np.uint64)
