@@ -58,7 +58,6 @@ struct GemmArgs {
     const float *colsum;        // consumers: [N] sum over k of the (gamma-scaled, rounded) weight row
     float *stat_out;            // RESID_HL: optional [M][stat_groups][2] (sum, sum of squares) of the new hi plane per 64 columns
     int stat_groups;            // N / 64
-    int pf_lead;                // RESID_HL: the tile's residual lines are pulled towards L2 this many K tiles before the epilogue (0 = off)
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -83,6 +82,24 @@ __device__ __forceinline__ float quick_gelu(float x)
     // by hand: without -ffast-math hipcc keeps __expf(-1.702f * x) as two): the epilogue is bound by the vector
     // ALU's issue rate, 8.6 % of the c_fc GEMM went here
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.4426950408889634f)));
+}
+// four at a time: the multiply in front of the exponential and the add behind it as packed fp32 operations (two
+// elements per 4-cycle issue; each still one correctly rounded fp32 operation, so the values are those of quick_gelu)
+__device__ __forceinline__ f32x4 quick_gelu4(f32x4 x)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 y;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const f32x2 v = {x[2 * h], x[2 * h + 1]};
+        const f32x2 t = v * (-1.702f * 1.4426950408889634f);
+        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        const f32x2 d = e + 1.f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 o = v * r;
+        y[2 * h] = o[0], y[2 * h + 1] = o[1];
+    }
+    return y;
 }
 // d QuickGELU / dx = s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x)
 __device__ __forceinline__ float quick_gelu_grad(float x)
@@ -319,7 +336,6 @@ __device__ __forceinline__ void load_bias(const GemmArgs &g, int nb, f32x4 (&bia
 // MODE (A / B switch, diagnostic build variants 30 .. 33): bit 0 = two scratch buffers, row group i + 1 written while
 // the transposed reads of group i are in flight; bit 1 = the residual prefetch grows from DEPTH to the whole tile.
 constexpr int HL_MODE_DEFAULT = 1;
-constexpr int HL_PF_LEAD = 0;          // K tiles before the epilogue at which the residual lines are touched (0 = off)
 template <int DT, int TM, int MODE, typename F>
 __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
                                                 int lane, float *scratch, F &&between)
@@ -496,12 +512,9 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
                 v = acc[i][j] * rs0[i] + (cs[j] * rs1[i] + bias[j]);
             else
                 v = acc[i][j] + bias[j];
+            if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_LN) v = quick_gelu4(v);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float y = v[r];
-                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_LN) y = quick_gelu(y);
-                o[4 * j + r] = to16(y, elem());
-            }
+            for (int r = 0; r < 4; r++) o[4 * j + r] = to16(v[r], elem());
         }
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
@@ -851,32 +864,6 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         }
     };
 
-    // EC_EPI_RESID_HL: the epilogue reads the tile's two residual planes (256 KiB) from HBM with three row groups per
-    // wave in flight, which bounds it by the latency of those reads.  pf_lead K tiles before the main loop ends every
-    // lane touches one 128-byte line of its wave tile's planes (four one-dword LDS-DMA requests per wave into a junk
-    // area: no register is written), so that the epilogue's reads find the lines in L2.  The requests sit in the
-    // vmcnt queue between the staging requests: the two counted waits that follow allow four more (12), and the
-    // third one (1.5 K tiles = ~3.5 k cycles later) is the first that waits for them.
-    constexpr bool PF = EPI == EC_EPI_RESID_HL && !TN;
-    const int tP = PF && g.pf_lead >= 3 && nk > g.pf_lead ? nk - g.pf_lead : -2;
-    auto touch_resid = [&]() {
-        if constexpr (PF) {
-            int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(ln));
-            const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-            const long org = ((long)mb * g.ldc + nb) * 2;
-            const long span = tile_span(g.M, mb, 128, g.ldc * 2);
-            const __amdgpu_buffer_rsrc_t rh = tile_rsrc(reinterpret_cast<const char *>(g.C) + org, span);
-            const __amdgpu_buffer_rsrc_t rl = tile_rsrc(reinterpret_cast<const char *>(g.aux) + org, span);
-            const int voff = nb < g.N ? ln * (int)g.ldc * 2 : BUF_OOB;
-            auto *junk = (__attribute__((address_space(3))) void *)(smem + 2 * KT + 4608 + wave * 256);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, junk, 4, voff + j * 64 * (int)g.ldc * 2, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, junk, 4, voff + j * 64 * (int)g.ldc * 2, 0, 0, 0);
-            }
-        }
-    };
     bool carried = false;     // this tile's K tile 0 was waited for at the hand-over from the tile before
     int id = blockIdx.x;
     tl_open(id);
@@ -916,11 +903,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 // behind a tile hand-over every piece of K tile 0 has landed already (waited for before the hand-over
                 // barrier), and what is in flight besides K tile 1 are the last epilogue stores: no wait here, the
                 // counted wait of phase B (which K tile 1 needs anyway) is the first one they are older than
-                if (t > 0 || !carried) {
-                    if (PF && t == tP + 1) EC_VMCNT(12);     // the four touch requests of K tile tP are younger than region 1
-                    else EC_VMCNT(8);
-                }
-                if (PF && t == tP) touch_resid();
+                if (t > 0 || !carried) EC_VMCNT(8);
             } else {
                 EC_VMCNT(0);
                 // (satisfied already; tells hipcc's wait-count pass that no staging DMA is pending behind the main
@@ -936,8 +919,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 issue(0, buf);
                 issue(2, buf);
                 issue(3, buf);
-                if (PF && t == tP) EC_VMCNT(12);
-                else EC_VMCNT(8);
+                EC_VMCNT(8);
             } else if (has1) {
                 EC_VMCNT(2);
             }
@@ -1030,7 +1012,7 @@ template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_D
     g.tiles_n = ec::ceil_div(g.N, 256);
     // two staging buffers + the row-statistics side area (LN epilogues) / the tail of the hi-lo epilogue's double
     // scratch (8 waves x 2 x 16 rows x 68 floats = 68 KiB from the second staging buffer on)
-    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 + 2048 : 0);
+    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 : 0);
     auto kern = gemm2pp_kernel<DT, EPI, TL, TN, HLM>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
@@ -1119,12 +1101,6 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
         if (variant == 31 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 1>(g, s);
         if (variant == 32 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 2>(g, s);
         if (variant == 33 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 3>(g, s);
-        if (variant >= 34 && variant <= 39 && g.aux) {      // residual touch pf_lead K tiles ahead: off, 3, 4, 6, 8, 12
-            GemmArgs gp = g;
-            const int leads[6] = {0, 3, 4, 6, 8, 12};
-            gp.pf_lead = leads[variant - 34];
-            return launch2pp<DT, EC_EPI_RESID_HL>(gp, s);
-        }
 #endif
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
         return launch2pp<DT, EC_EPI_RESID_HL>(g, s);
@@ -1240,7 +1216,6 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     g.stat_out = nullptr, g.stat_groups = 0;
-    g.pf_lead = HL_PF_LEAD;
     // what the epilogues read these with: row_stats by 16-byte LDS-DMA (two pairs at a time at stride 1; the header
     // states that the array must be readable up to an even row count), col_sums as float4, row_sums written as float2
     EC_REQUIRE((((uintptr_t)a->row_stats | (uintptr_t)a->col_sums) & 15) == 0, "ec_gemm: row_stats / col_sums must be 16-byte aligned");

@@ -15,10 +15,7 @@ os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', '
 from eventclip_amd import ops  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
-# second argument 'touch': variants 34 .. 39 instead (the residual lines touched 0 / 3 / 4 / 6 / 8 / 12 K tiles ahead)
-TOUCH = len(sys.argv) > 2 and sys.argv[2] == 'touch'
-VARIANTS = (0, 34, 35, 36, 37, 38, 39) if TOUCH else (0, 30, 31, 32, 33)
-LEADS = {34: 0, 35: 3, 36: 4, 37: 6, 38: 8, 39: 12}
+VARIANTS = (0, 30, 31, 32, 33)
 M = frames * 257
 for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
     g = torch.Generator(device='cuda').manual_seed(N + K)
@@ -52,7 +49,7 @@ for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
             times[v].append(e0.elapsed_time(e1) / 6)
     for v, t in times.items():
         t = sorted(t)
-        tag = 'default (product)' if v == 0 else f'residual lines touched {LEADS[v]} K tiles ahead' if TOUCH else f'MODE {v - 30}: ' + ('pipelined transposes' if (v - 30) & 1 else 'one scratch buffer') + \
+        tag = 'default (product)' if v == 0 else f'MODE {v - 30}: ' + ('pipelined transposes' if (v - 30) & 1 else 'one scratch buffer') + \
             (', growing prefetch' if (v - 30) & 2 else ', prefetch 3 ahead')
         print(f'{name:9s} N={N} K={K}  {tag:55s}: median {t[2]:.3f} ms = {2.0 * M * N * K / t[2] / 1e9:6.0f} TFLOP/s', flush=True)
     del A, W, hi0, lo0, hi, lo
