@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--precise', action='store_true',
                     help='image tower with hi + lo operands in every GEMM (ec_vit_weights.precise, 3 x the MFMA work): '
                          'the mode that meets 1e-3 on input-dependent weights; a line of its own, never the headline')
+    ap.add_argument('--precise-blocks', type=int, default=0,
+                    help='split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks; '
+                         'n = 4 meets 1e-3 on input-dependent weights): a line of its own, never the headline')
     a = ap.parse_args()
     c = CONFIGS[a.config]
     a.batch = a.batch or c['batch']
@@ -316,7 +319,8 @@ def main():
     # ---- model: seeded random CLIP, text features cached once ----
     cfg = eclip.arch_config(a.arch)
     sd = eclip.random_state_dict(cfg, seed=2)
-    clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk, image_precise=a.precise).cuda().eval()
+    clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk, image_precise=a.precise,
+                            image_precise_blocks=0 if a.precise else a.precise_blocks).cuda().eval()
     tokens = eclip.synthetic_tokens(a.classes, seed=2)
     clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
                      class_names=[f'class {i}' for i in range(a.classes)], agg_func='mean', class_tokens=tokens)
@@ -484,6 +488,8 @@ def main():
             f'event-frames/sec (whole node), BASELINE configs[{a.config}]'
         if a.precise:
             metric += ' -- split-precision image tower (validation mode, not the headline)'
+        elif a.precise_blocks:
+            metric += f' -- first {a.precise_blocks} blocks of the image tower in split precision (not the headline)'
         if c['scaling'] == 'weak':
             batch_txt = f'batch={a.batch} samples x {views} view{"s" if views > 1 else ""} per GPU'
         else:
@@ -506,6 +512,9 @@ def main():
                                       '16-bit MFMA operands, fp32 accumulate / softmax; residual stream as hi + lo '
                                       '16-bit planes (~2^-22), LayerNorm folded into the QKV / c_fc GEMMs (statistics '
                                       'of the 16-bit hi plane); patch embedding and ln_post @ proj with hi + lo operands')
+                                     + (f'; the first {a.precise_blocks} blocks in split precision (fp32 residual '
+                                        'stream, hi + lo operands, fp32 attention: ec_vit_weights.precise_blocks)'
+                                        if a.precise_blocks and not a.precise else '')
                                      + '; text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else
                                       'keys/values for every token; query projection, attention, out_proj, '

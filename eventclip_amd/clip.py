@@ -172,7 +172,8 @@ class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
-                 image_precise=False, full_last_block=None, low_latency=False, ln_folded=None, q_scaled=True):
+                 image_precise=False, full_last_block=None, low_latency=False, ln_folded=None, q_scaled=True,
+                 image_precise_blocks=0):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -187,6 +188,10 @@ class CLIP(nn.Module):
         # split-precision (~fp32) arithmetic: on for the text tower (run once, cached by the
         # classifiers), off for the image tower (3x the GEMM work; validation only)
         self.text_precise, self.image_precise = bool(text_precise), bool(image_precise)
+        # split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks): an early
+        # block's rounding error is carried through every later block, so a few such blocks buy most of what
+        # image_precise buys (1e-3 on input-dependent weights with n = 4) at a fraction of its price
+        self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
         # encode_image returns ln_post(x[:, 0]) @ proj: of the last block only the class-token rows are
         # read, so by default only those go through its attention query / out_proj / MLP (identical
         # features); True (or EVENTCLIP_FULL_LAST_BLOCK=1) computes every token like the reference
@@ -204,7 +209,8 @@ class CLIP(nn.Module):
         # softmax scale folded into the q rows of in_proj before their rounding (ec_vit_weights.q_scaled); False packs
         # the weights exactly as the training path holds them (plain q, plain LayerNorm with ln_folded=False too)
         self.q_scaled = bool(q_scaled)
-        self.workspace_budget = 24 << 30   # bytes of tower scratch at most
+        # bytes of tower scratch at most (precise_blocks carves the buffers of both chains)
+        self.workspace_budget = (48 if self.image_precise_blocks else 24) << 30
         self._packed = None
         self._ws = None
 
@@ -255,11 +261,14 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def blocks(prefix, layers, precise, q_scaled=False, ln_folded=False):
+        def blocks(prefix, layers, precise_all, q_scaled_all=False, ln_folded=False, precise_first=0):
             arr = (_lib.EcBlockWeights * layers)()
             for i in range(layers):
                 ks = _block_keys(prefix, i)
                 b = arr[i]
+                # precise_first: the first blocks are split-precision blocks (plain q, lo parts), the rest as asked
+                precise = precise_all or i < precise_first
+                q_scaled = q_scaled_all and not precise
                 b.ln1_g, b.ln1_b = dev32(sd[ks[0]]), dev32(sd[ks[1]])
                 wqkv, bqkv = sd[ks[2]], sd[ks[3]]
                 if q_scaled:
@@ -273,7 +282,7 @@ class CLIP(nn.Module):
                     wqkv[:width] *= ATTN_Q_SCALE
                     bqkv[:width] *= ATTN_Q_SCALE
                 b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
-                if ln_folded:
+                if ln_folded and not precise:
                     # ec_vit_weights.ln_folded: W' = W diag(gamma) rounded once, its row sums AS ROUNDED, b + W beta
                     def fold(wt, bias, gamma, beta):
                         wt, bias = wt.float().to(dev), bias.float().to(dev)
@@ -321,9 +330,14 @@ class CLIP(nn.Module):
         v.low_latency = int(self.low_latency)
         v.q_scaled = int(self.q_scaled and not self.image_precise)
         v.ln_folded = int(self.ln_folded and not self.image_precise)
+        if self.image_precise_blocks:
+            if not (0 < self.image_precise_blocks < c['layers']) or not v.ln_folded or self.low_latency:
+                raise ValueError(f'image_precise_blocks={self.image_precise_blocks} needs 0 < n < layers={c["layers"]}, '
+                                 'ln_folded and no low_latency')
+        v.precise_blocks = self.image_precise_blocks
         v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
-        vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled=bool(v.q_scaled),
-                    ln_folded=bool(v.ln_folded))
+        vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
+                    ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']

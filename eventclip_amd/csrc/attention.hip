@@ -937,6 +937,7 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     return EC_OK;
 }
 
+#ifdef EC_ATTN_DIAG     // the round-1 form, kept for the A / B only (ec_attn_set_variant(6)); the product runs attention_f32m_kernel
 // ---------------------------------------------------------------------------------------
 // fp32 attention for the split-precision towers (text features are computed once and cached;
 // the image tower uses this only for validation).  One workgroup per (sequence, head,
@@ -1002,7 +1003,9 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, vo
     }
     if (qrow < S) {
         const float inv = 1.f / sum;
-        const float o4[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+        float o4[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(o4[i]));     // see attention_f32m_kernel's epilogue
         v4 hi, lo;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -1012,6 +1015,167 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, vo
         const long off = ((long)seq * S + qrow) * W + head * 64 + sub * 4;
         *reinterpret_cast<v4 *>((elem *)out_hi + off) = hi;
         *reinterpret_cast<v4 *>((elem *)out_lo + off) = lo;
+    }
+}
+
+
+#endif
+
+// ---------------------------------------------------------------------------------------
+// fp32 attention for the split-precision towers on the fp32 matrix instruction (round 4): v_mfma_f32_16x16x4_f32 takes fp32 operands and is bit for bit an
+// fmaf chain (cdna_hip_programming.md, FP32-input MFMA), at the vector ALU's peak rate but with the operands read
+// once per 16 x 16 tile instead of once per product.  One workgroup = 64 queries of one (sequence, head), one
+// 16-query tile per wave, keys in chunks of 32 through two LDS buffers (the next chunk's rows are in flight in
+// registers during the chunk's MFMAs; one barrier per chunk), online softmax in fp32 with expf.
+//  * S^T = K . Q^T: A = the chunk's key rows (lane: key l & 15, head dims 16 c + 4 (l >> 4) + e), B = the wave's
+//    queries in the same dim order (held in registers, pre-scaled by 1/8: exact), so a lane's accumulators are four
+//    keys (4 (l >> 4) + r of each 16-key tile) of ONE query (l & 15);
+//  * O^T += V^T . P^T: step (t, r) takes the keys 16 t + 4 g + r (g = 0 .. 3), whose P values are exactly register r of
+//    tile t in lane group g: no lane movement; A = V read down its columns (one float per lane and step).
+// LDS rows are 64 floats with the 16-byte chunk index XORed with row & 15: the 16 key rows of a b128 read and the
+// column reads of V are spread over the banks.  2560 sequences x 16 heads x S = 257: 96 ms -> see profiles/r4_attention.md.
+// ---------------------------------------------------------------------------------------
+constexpr int F32_KCH = 32;
+template <int DT>
+__global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, void *out_hi, void *out_lo, int S, int W,
+                                                             int heads, int causal)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v4 v4;
+    __shared__ __attribute__((aligned(16))) float lk[2][F32_KCH * 64];
+    __shared__ __attribute__((aligned(16))) float lv[2][F32_KCH * 64];
+    const int n_qb = (S + 63) / 64;
+    const int qb = blockIdx.x % n_qb, head = (blockIdx.x / n_qb) % heads, seq = blockIdx.x / (n_qb * heads);
+    const long ld = 3L * W;
+    const float *base = qkv + (long)seq * S * ld + head * 64;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, j = lane & 15, g = lane >> 4;
+    const int q0 = qb * 64 + wave * 16;
+    const bool active = q0 < S;                    // wave-uniform: the tile has a query that exists
+    const int query = q0 + j, qsrc = query < S ? query : S - 1;
+    f32x4 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long)qsrc * ld + 16 * c + 4 * g);
+        qf[c] = v * 0.125f;
+    }
+    // keys this workgroup needs: all of them, or (causal) those up to its last query
+    const int s_eff = causal ? (qb * 64 + 64 < S ? qb * 64 + 64 : S) : S;
+    const int nch = (s_eff + F32_KCH - 1) / F32_KCH;
+    // staging: thread -> (key row, 16-byte chunk) pairs idx = t, t + 256 of the chunk's 32 x 16
+    f32x4 rk[2], rv[2];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int idx = t + 256 * n, key = ch * F32_KCH + (idx >> 4);
+            const int ks = key < S ? key : S - 1;
+            const float *src = base + (long)ks * ld + (idx & 15) * 4;
+            rk[n] = *reinterpret_cast<const f32x4 *>(src + W);
+            rv[n] = *reinterpret_cast<const f32x4 *>(src + 2 * W);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int idx = t + 256 * n, row = idx >> 4, chunk = (idx & 15) ^ (row & 15);
+            *reinterpret_cast<f32x4 *>(&lk[buf][row * 64 + chunk * 4]) = rk[n];
+            *reinterpret_cast<f32x4 *>(&lv[buf][row * 64 + chunk * 4]) = rv[n];
+        }
+    };
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        const int buf = ch & 1;
+        if (ch + 1 < nch) fetch(ch + 1);
+        if (active) {
+            const float *K = lk[buf], *V = lv[buf];
+            f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                f32x4 kf[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    const int row = tt * 16 + j;
+                    kf[tt] = *reinterpret_cast<const f32x4 *>(K + row * 64 + (((4 * c + g) ^ (row & 15)) << 2));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+                        sc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tt][e], qf[c][e], sc[tt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = ch * F32_KCH + tt * 16 + 4 * g + r;
+                    const bool ok = key < S && (!causal || key <= query);
+                    sc[tt][r] = ok ? sc[tt][r] : -INFINITY;
+                    mx = fmaxf(mx, sc[tt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            // nothing of this query's row seen so far (mn = -inf: only rows that do not exist or a causal row whose
+            // keys all lie ahead, which cannot happen from chunk 0 on): keep everything at zero
+            const float alpha = mn == -INFINITY ? 0.f : expf(m - mn);
+            const float sub = mn == -INFINITY ? 0.f : mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    sc[tt][r] = expf(sc[tt][r] - sub);
+                    ps += sc[tt][r];
+                }
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = tt * 16 + 4 * g + r;
+#pragma unroll
+                    for (int dt = 0; dt < 4; dt++) {
+                        const float a = V[row * 64 + (((4 * dt + (j >> 2)) ^ (row & 15)) << 2) + (j & 3)];
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sc[tt][r], o[dt], 0, 0, 0);
+                    }
+                }
+        }
+        if (ch + 1 < nch) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (active) {
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (query < S) {
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                v4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    // the product as ONE rounded fp32 value for both parts: with -ffp-contract=fast hipcc otherwise
+                    // rounds hi from fl(o inv) but takes lo against a hi of its own rounded straight from the exact
+                    // product (v_fma_mixlo_f16), and where the two differ (a near-tie) lo comes out with the wrong
+                    // sign: one element in ~2000 off by a 16-bit ulp
+                    float x = o[dt][r] * inv;
+                    asm volatile("" : "+v"(x));
+                    hi[r] = to16(x, elem());
+                    lo[r] = to16(x - (float)hi[r], elem());
+                }
+                const long off = ((long)seq * S + query) * W + head * 64 + 16 * dt + 4 * g;
+                *reinterpret_cast<v4 *>((elem *)out_hi + off) = hi;
+                *reinterpret_cast<v4 *>((elem *)out_lo + off) = lo;
+            }
+        }
     }
 }
 
@@ -1098,17 +1262,31 @@ extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out
     EC_REQUIRE(width == heads * 64, "ec_attention_f32: head dim must be 64");
     if (n_seq == 0) return EC_OK;
     EC_REQUIRE(qkv && out_hi && out_lo, "ec_attention_f32: null buffer");
-    const int lds = (16 * 64 + 16 * S) * 4;
-    EC_REQUIRE(lds <= 64 * 1024, "ec_attention_f32: sequence length %d too long", S);
-    const unsigned grid = (unsigned)n_seq * heads * ((S + 15) / 16);
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * S * S * 64.0 * heads * n_seq, 0);
+#ifdef EC_ATTN_DIAG
+    if (g_attn_variant == 6) {      // the round-1 kernel (vector ALU, K / V rows straight from L2), for the A / B
+        const int lds = (16 * 64 + 16 * S) * 4;
+        EC_REQUIRE(lds <= 64 * 1024, "ec_attention_f32: sequence length %d too long", S);
+        const unsigned grid = (unsigned)n_seq * heads * ((S + 15) / 16);
+        if (dtype == EC_F16)
+            hipLaunchKernelGGL(attention_f32_kernel<EC_F16>, dim3(grid), dim3(256), lds, s, qkv, out_hi, out_lo, S, width,
+                               heads, causal);
+        else
+            hipLaunchKernelGGL(attention_f32_kernel<EC_BF16>, dim3(grid), dim3(256), lds, s, qkv, out_hi, out_lo, S, width,
+                               heads, causal);
+        EC_CHECK_HIP(hipGetLastError());
+        return EC_OK;
+    }
+#endif
+    const long blocks = (long)n_seq * heads * ((S + 63) / 64);
+    EC_REQUIRE(blocks < (1L << 31), "ec_attention_f32: %ld workgroups", blocks);
     if (dtype == EC_F16)
-        hipLaunchKernelGGL(attention_f32_kernel<EC_F16>, dim3(grid), dim3(256), lds, s, qkv, out_hi,
-                           out_lo, S, width, heads, causal);
+        hipLaunchKernelGGL(attention_f32m_kernel<EC_F16>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, out_hi, out_lo, S,
+                           width, heads, causal);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL(attention_f32_kernel<EC_BF16>, dim3(grid), dim3(256), lds, s, qkv, out_hi,
-                           out_lo, S, width, heads, causal);
+        hipLaunchKernelGGL(attention_f32m_kernel<EC_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, out_hi, out_lo, S,
+                           width, heads, causal);
     else
         return ec::fail(EC_ERR_INVALID, "ec_attention_f32: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());

@@ -227,7 +227,12 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
         return carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
     }
     BlockBufs b;
-    return carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx) + (w->low_latency ? LATENCY_WS_BYTES : 0);
+    carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
+    if (w->precise_blocks > 0) {     // the first blocks in split precision: both sets of buffers
+        PreciseBufs pb;
+        carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
+    }
+    return sc.off + (w->low_latency ? LATENCY_WS_BYTES : 0);
 }
 
 EC_API size_t ec_text_workspace_bytes(const ec_text_weights *w, int chunk)
@@ -290,6 +295,17 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     void *cls16, *cls16_lo;
     int *idx;
     size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
+    // precise_blocks: the first blocks run the split-precision chain on an fp32 residual stream of their own
+    const int pblocks = w->precise_blocks;
+    PreciseBufs pb{};
+    if (pblocks != 0) {
+        EC_REQUIRE(pblocks > 0 && pblocks < w->layers && w->ln_folded && !w->low_latency,
+                   "ec_vit_encode: precise_blocks=%d needs 0 < precise_blocks < layers=%d, ln_folded and no low_latency",
+                   pblocks, w->layers);
+        void *p_hi, *p_lo;
+        int *pidx;
+        need = carve_precise(sc, chunk, S, W, pb, &p_hi, &p_lo, &pidx);
+    }
     // low-latency mode: under-filled GEMM launches (a few frames) run K-batched through this scratch
     struct ScratchGuard {
         ~ScratchGuard() { latency_scratch() = {nullptr, 0}; }
@@ -303,7 +319,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
                         need);
     const bool folded = w->ln_folded && !w->low_latency;
     if (folded)
-        for (int l = 0; l < w->layers; l++)
+        for (int l = pblocks; l < w->layers; l++)
             EC_REQUIRE(w->blocks[l].qkv_w_ln && w->blocks[l].qkv_cs && w->blocks[l].qkv_bf && w->blocks[l].fc1_w_ln &&
                            w->blocks[l].fc1_cs && w->blocks[l].fc1_bf,
                        "ec_vit_encode: ln_folded but block %d lacks its folded weights", l);
@@ -315,10 +331,17 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         if (folded) {
             // residual stream as hi + lo planes in the fp32 stream's 4 bytes per element
             void *x_hi = b.x, *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)n * S * W * 2;
-            EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,
-                                stream));
-            EC_TRY(run_blocks_folded(w->blocks, w->layers, n, S, W, w->heads, dt, b, stream, w->full_last_block == 0,
-                                     w->q_scaled != 0));
+            if (pblocks > 0) {
+                // the first blocks in split precision on the fp32 stream, which is then split into the planes
+                EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, pb.x, stream));
+                EC_TRY(run_blocks_precise(w->blocks, pblocks, n, S, W, w->heads, 0, dt, pb, stream));
+                EC_TRY(ec_split16(pb.x, (long)n * S * W, 0, x_hi, x_lo, dt, stream));
+            } else {
+                EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,
+                                    stream));
+            }
+            EC_TRY(run_blocks_folded(w->blocks + pblocks, w->layers - pblocks, n, S, W, w->heads, dt, b, stream,
+                                     w->full_last_block == 0, w->q_scaled != 0));
             // the class rows back to fp32 (x = hi + lo) for ln_post; patch_out (the mlp buffer) is free by now
             EC_TRY(join_hl_rows(x_hi, x_lo, (long)S * W, n, W, patch_out, dt, stream));
             EC_TRY(ec_layernorm_split(patch_out, W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16, cls16_lo, W,

@@ -458,6 +458,14 @@ typedef struct {
                                    2.1e-4 feature error on ViT-L/14; tests/test_outliers_gpu.py holds the
                                    outlier-channel statistics of released checkpoints).  Ignored by precise /
                                    low_latency towers and by the training entry points. */
+    int precise_blocks;         /* 0 < precise_blocks < layers with precise == 0 and ln_folded != 0: the FIRST
+                                   precise_blocks blocks run the split-precision chain (fp32 residual stream, hi + lo
+                                   operands, fp32 attention: their qkv_w / qkv_b hold a PLAIN q and their *_lo fields are
+                                   set), the residual stream is then split into its hi + lo planes and the remaining
+                                   blocks run the folded chain.  A rounding error made in an early block is carried
+                                   through every later one; measured on input-dependent weights, four such blocks bring
+                                   the logits inside 1e-3 of the fp32 oracle at 1.6 x the time of the 16-bit path
+                                   (DESIGN.md 3.3).  0 (default): off. */
 } ec_vit_weights;
 
 typedef struct {

@@ -49,6 +49,33 @@ def ref_attention(qkv, n_seq, S, W, heads, causal):
     return out.permute(0, 2, 1, 3).reshape(n_seq * S, W)
 
 
+@pytest.mark.parametrize('S,heads,causal,n_seq', [(257, 16, 0, 3), (577, 4, 0, 2), (77, 8, 1, 5), (77, 12, 1, 3),
+                                                   (50, 12, 0, 4), (197, 3, 0, 2), (1, 2, 0, 2), (1, 1, 1, 1),
+                                                   (33, 2, 1, 3), (64, 1, 0, 2), (65, 1, 1, 2), (129, 2, 1, 2)])
+def test_attention_f32_matches_float64(S, heads, causal, n_seq, hip):
+    """ec_attention_f32 (the split-precision towers' attention: fp32 qkv in, hi + lo 16-bit planes out) on the fp32
+    matrix instruction against a float64 softmax attention: 4e-6 of the largest output (the hi + lo pair itself carries
+    2^-22), every sequence length the towers run plus the chunk / tile edges (32-key chunks, 64-query workgroups)."""
+    import torch
+    from eventclip_amd import _lib
+    W = heads * 64
+    g = torch.Generator(device='cuda').manual_seed(S * 131 + heads)
+    qkv = torch.randn(n_seq * S, 3 * W, device='cuda', generator=g) * 1.7
+    hi = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
+    lo = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_attention_f32(_lib.ptr(qkv), _lib.ptr(hi), _lib.ptr(lo), n_seq, S, W, heads, causal,
+                                           _lib.EC_F16, _lib.stream_ptr()), 'ec_attention_f32')
+    q, k, v = qkv.double().view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        att = att + torch.full((S, S), float('-inf'), device='cuda', dtype=torch.float64).triu_(1)
+    want = (att.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * S, W)
+    got = hi.double() + lo.double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 4e-6, err
+
+
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('S,heads,causal', [(50, 12, 0), (77, 8, 1), (77, 12, 1), (197, 12, 0),
                                             (257, 16, 0), (577, 16, 0), (17, 1, 0), (1, 2, 1)])
