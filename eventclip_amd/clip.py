@@ -173,7 +173,7 @@ class CLIP(nn.Module):
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
                  image_precise=False, full_last_block=None, low_latency=False, ln_folded=None, q_scaled=True,
-                 image_precise_blocks=0):
+                 image_precise_blocks=None):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -188,10 +188,6 @@ class CLIP(nn.Module):
         # split-precision (~fp32) arithmetic: on for the text tower (run once, cached by the
         # classifiers), off for the image tower (3x the GEMM work; validation only)
         self.text_precise, self.image_precise = bool(text_precise), bool(image_precise)
-        # split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks): an early
-        # block's rounding error is carried through every later block, so a few such blocks buy most of what
-        # image_precise buys (1e-3 on input-dependent weights with n = 4) at a fraction of its price
-        self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
         # encode_image returns ln_post(x[:, 0]) @ proj: of the last block only the class-token rows are
         # read, so by default only those go through its attention query / out_proj / MLP (identical
         # features); True (or EVENTCLIP_FULL_LAST_BLOCK=1) computes every token like the reference
@@ -209,6 +205,15 @@ class CLIP(nn.Module):
         # softmax scale folded into the q rows of in_proj before their rounding (ec_vit_weights.q_scaled); False packs
         # the weights exactly as the training path holds them (plain q, plain LayerNorm with ln_folded=False too)
         self.q_scaled = bool(q_scaled)
+        # split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks): an early
+        # block's rounding error is carried through every later block, so a few such blocks buy most of what
+        # image_precise buys (every config inside 1e-3 on input-dependent weights with n = 8) at a fraction of its price
+        # (EVENTCLIP_PRECISE_BLOCKS=n sets it for models built without the argument, where the mode applies)
+        if image_precise_blocks is None:
+            image_precise_blocks = int(os.environ.get('EVENTCLIP_PRECISE_BLOCKS', '0') or 0)
+            if not self.ln_folded or self.low_latency or image_precise_blocks >= cfg['layers']:
+                image_precise_blocks = 0
+        self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
         # bytes of tower scratch at most (precise_blocks carves the buffers of both chains)
         self.workspace_budget = (48 if self.image_precise_blocks else 24) << 30
         self._packed = None

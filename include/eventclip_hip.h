@@ -463,9 +463,10 @@ typedef struct {
                                    operands, fp32 attention: their qkv_w / qkv_b hold a PLAIN q and their *_lo fields are
                                    set), the residual stream is then split into its hi + lo planes and the remaining
                                    blocks run the folded chain.  A rounding error made in an early block is carried
-                                   through every later one; measured on input-dependent weights, four such blocks bring
-                                   the logits inside 1e-3 of the fp32 oracle at 1.6 x the time of the 16-bit path
-                                   (DESIGN.md 3.3).  0 (default): off. */
+                                   through every later one; measured on input-dependent weights, eight such blocks bring
+                                   the logits of every BASELINE config inside 1e-3 of the fp32 oracle at 2.0 x the time
+                                   of the 16-bit path, four those of configs[0], [1] and [3] at 1.5 x.
+                                   0 (default): off. */
 } ec_vit_weights;
 
 typedef struct {
