@@ -73,6 +73,17 @@ def run(name, N, K, epi):
         extra = f'   ({v.mean() / nk:.0f} per K tile; MFMA time 2048)' if k == 'main loop' else ''
         print(f'  {k:40s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f}  '
               f'{100 * v.mean() / period:5.1f} %{extra}')
+    # do the workgroups stay in step?  epilogue + hand-over by round (tile id // workgroups), and the spread of the
+    # epilogues' start times inside a round, in tile periods
+    rounds = tiles // nwg
+    rr = r[:rounds * nwg].reshape(rounds, nwg, 8)
+    t0 = rr[:, :, 1].min()
+    print('  round: epilogue issue + drain / start-time spread (std, in periods) / epilogue start, first wg (cycles since launch)')
+    for k in sorted(set([1, 2, 3, 5, 8, 12, 20, 30, rounds - 2])):
+        if 1 <= k < rounds - 1:
+            epi = (rr[k, :, 5] - rr[k, :, 3]).mean()
+            start = rr[k, :, 3]
+            print(f'    {k:3d}: {epi:8.0f}   {start.std() / period:5.2f}   {start.min() - t0:10d}')
     del A, W, out, dbg
 
 
