@@ -93,6 +93,10 @@ def main():
     ap.add_argument('--mixes', default='', help='extra comma-separated mixes to evaluate, groups '
                     'joined by +, an optional @a:b restricts the rounding to blocks a..b-1; '
                     'each mix lists the groups that STAY rounded')
+    ap.add_argument('--f16-weights', action='store_true',
+                    help='every weight tensor rounded to the 16-bit type FIRST, reference included: weights that are '
+                         'representable in 16 bit, as the parameters clip.load() returns on a GPU are')
+    ap.add_argument('--mixes-only', action='store_true')
     a = ap.parse_args()
     from eventclip_amd import clip as eclip
     from eventclip_amd.synthetic import GEOMETRY, make_events
@@ -101,6 +105,8 @@ def main():
     torch.manual_seed(0)
     cfg = eclip.arch_config(a.arch, layers=a.layers)
     sd = {k: v.float() for k, v in eclip.random_state_dict(cfg, seed=a.seed, qk_gain=a.qk, branch_gain=a.branch).items()}
+    if a.f16_weights:
+        sd = {k: (v.to(getattr(torch, a.dtype)).float() if v.dim() >= 2 else v) for k, v in sd.items()}
     g = GEOMETRY['n_caltech']
     frames = []
     i = 0
@@ -134,9 +140,9 @@ def main():
             return el
 
         report('all rounded (the fast path)', GROUPS)
-        for grp in GROUPS:
+        for grp in ([] if a.mixes_only else GROUPS):
             report(f'only {grp}', [grp])
-        for grp in GROUPS:
+        for grp in ([] if a.mixes_only else GROUPS):
             report(f'all but {grp}', [x for x in GROUPS if x != grp])
         for mix in [m for m in a.mixes.split(',') if m]:
             spec, _, rng = mix.partition('@')
