@@ -1101,6 +1101,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
         if (variant == 31 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 1>(g, s);
         if (variant == 32 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 2>(g, s);
         if (variant == 33 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 3>(g, s);
+        if (variant == 13 && g.aux) return launch_b2p<DT, EC_EPI_RESID_HL>(g, s);   // two 4-wave workgroups per CU
 #endif
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
         return launch2pp<DT, EC_EPI_RESID_HL>(g, s);

@@ -15,7 +15,7 @@ os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', '
 from eventclip_amd import ops  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
-VARIANTS = (0, 30, 31, 32, 33)
+VARIANTS = (0, 30, 31, 32, 33, 13)
 M = frames * 257
 for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
     g = torch.Generator(device='cuda').manual_seed(N + K)
@@ -49,7 +49,7 @@ for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
             times[v].append(e0.elapsed_time(e1) / 6)
     for v, t in times.items():
         t = sorted(t)
-        tag = 'default (product)' if v == 0 else f'MODE {v - 30}: ' + ('pipelined transposes' if (v - 30) & 1 else 'one scratch buffer') + \
+        tag = 'default (product)' if v == 0 else 'two 4-wave workgroups per CU, 128 x 256 x 32 tiles' if v == 13 else f'MODE {v - 30}: ' + ('pipelined transposes' if (v - 30) & 1 else 'one scratch buffer') + \
             (', growing prefetch' if (v - 30) & 2 else ', prefetch 3 ahead')
         print(f'{name:9s} N={N} K={K}  {tag:55s}: median {t[2]:.3f} ms = {2.0 * M * N * K / t[2] / 1e9:6.0f} TFLOP/s', flush=True)
     del A, W, hi0, lo0, hi, lo
