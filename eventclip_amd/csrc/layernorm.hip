@@ -165,8 +165,9 @@ __global__ __launch_bounds__(256) void row_stats_merge_kernel(const float *sums,
     }
 }
 
-// fp32 [n] -> (optionally QuickGELU) -> 16-bit hi and lo parts
-template <int DT>
+// fp32 [n] -> (optionally QuickGELU) -> 16-bit hi and lo parts.  LO_F16: the lo part as fp16 whatever DT (the planes of
+// the folded chain's residual stream: EC_EPI_RESID_HL reads its lo plane as fp16)
+template <int DT, bool LO_F16 = false>
 __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, int gelu, void *hi,
                                                       void *lo)
 {
@@ -181,10 +182,16 @@ __global__ __launch_bounds__(256) void split16_kernel(const float *x, long n, in
             v.w = v.w / (1.f + expf(-1.702f * v.w));
         }
         v4 p = {to16(v.x, elem()), to16(v.y, elem()), to16(v.z, elem()), to16(v.w, elem())};
-        v4 q = {to16(v.x - (float)p[0], elem()), to16(v.y - (float)p[1], elem()),
-                to16(v.z - (float)p[2], elem()), to16(v.w - (float)p[3], elem())};
         *reinterpret_cast<v4 *>((elem *)hi + i) = p;
-        *reinterpret_cast<v4 *>((elem *)lo + i) = q;
+        if constexpr (LO_F16) {
+            const f16x4 q = {(_Float16)(v.x - (float)p[0]), (_Float16)(v.y - (float)p[1]), (_Float16)(v.z - (float)p[2]),
+                             (_Float16)(v.w - (float)p[3])};
+            *reinterpret_cast<f16x4 *>((_Float16 *)lo + i) = q;
+        } else {
+            const v4 q = {to16(v.x - (float)p[0], elem()), to16(v.y - (float)p[1], elem()),
+                          to16(v.z - (float)p[2], elem()), to16(v.w - (float)p[3], elem())};
+            *reinterpret_cast<v4 *>((elem *)lo + i) = q;
+        }
     }
 }
 
@@ -294,6 +301,25 @@ int vit_embed_hl(const float *patch, const float *cls, const float *pos, const f
                            eps, (float *)x_hi, (float *)nullptr, (_Float16 *)x_lo);
     else
         return ec::fail(EC_ERR_INVALID, "vit_embed_hl: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// fp32 residual stream -> the folded chain's planes: hi in `dtype`, lo ALWAYS fp16 (ec_vit_weights.precise_blocks: the
+// hand-over from the split-precision blocks)
+int split_hl(const float *x, long n, void *x_hi, void *x_lo, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(n >= 0 && n % 4 == 0 && x && x_hi && x_lo, "split_hl: bad arguments");
+    if (n == 0) return EC_OK;
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 65536 ? (n / 4 + 255) / 256 : 65536);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)n * 8.0);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL((split16_kernel<EC_F16, true>), dim3(grid), dim3(256), 0, s, x, n, 0, x_hi, x_lo);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL((split16_kernel<EC_BF16, true>), dim3(grid), dim3(256), 0, s, x, n, 0, x_hi, x_lo);
+    else
+        return ec::fail(EC_ERR_INVALID, "split_hl: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -67,6 +67,7 @@ inline int gemm_ln(int M, int N, int K, int dtype, int epi, const void *A, const
 // layernorm.hip: ln_pre'd embedding straight into the hi / lo planes; class rows of the planes back to fp32
 int vit_embed_hl(const float *patch, const float *cls, const float *pos, const float *gamma, const float *beta,
                  int n_img, int seq, int width, float eps, void *x_hi, void *x_lo, int dtype, ec_stream_t stream);
+int split_hl(const float *x, long n, void *x_hi, void *x_lo, int dtype, ec_stream_t stream);
 int join_hl_rows(const void *x_hi, const void *x_lo, long ld, int rows, int width, float *out, int dtype,
                  ec_stream_t stream);
 

@@ -335,7 +335,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
                 // the first blocks in split precision on the fp32 stream, which is then split into the planes
                 EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, pb.x, stream));
                 EC_TRY(run_blocks_precise(w->blocks, pblocks, n, S, W, w->heads, 0, dt, pb, stream));
-                EC_TRY(ec_split16(pb.x, (long)n * S * W, 0, x_hi, x_lo, dt, stream));
+                EC_TRY(split_hl(pb.x, (long)n * S * W, x_hi, x_lo, dt, stream));
             } else {
                 EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,
                                     stream));

@@ -404,6 +404,36 @@ def test_chunked_encode_is_batch_invariant(hip):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+def test_precise_blocks_tower(dt, hip):
+    """ec_vit_weights.precise_blocks on a 4-block ViT-B/32: the error against the fp32 oracle falls with the number of
+    leading split-precision blocks (0 -> 1 -> 3), all of them but one is already close to the split-precision tower;
+    chunked and whole-batch calls agree bit for bit; the class-token-only last block stays bit-identical; and the
+    packing refuses what the mode cannot do (every block, the plain chain, low latency)."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-B/32', layers=4, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=3, qk_gain=2.0, branch_gain=3.0)
+    img = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    want = clip_ref.encode_image(sd, cfg, img)
+    errs = {}
+    for n in (0, 1, 3):
+        m = eclip.CLIP(cfg, sd, dtype=dt, image_precise_blocks=n).cuda().eval()
+        errs[n] = rel_err(m.encode_image(img.cuda()).cpu(), want)
+    print('\n[precise_blocks on 4 blocks, %s] error vs fp32: %s' % (dt, {k: f'{v:.2e}' for k, v in errs.items()}))
+    assert errs[3] < errs[1] < errs[0], errs
+    assert errs[3] < 0.5 * errs[0], errs
+    a = eclip.CLIP(cfg, sd, dtype=dt, image_precise_blocks=2, chunk=256).cuda().encode_image(img.cuda())
+    b = eclip.CLIP(cfg, sd, dtype=dt, image_precise_blocks=2, chunk=2).cuda().encode_image(img.cuda())
+    c = eclip.CLIP(cfg, sd, dtype=dt, image_precise_blocks=2, full_last_block=True).cuda().encode_image(img.cuda())
+    assert torch.equal(a, b) and torch.equal(a, c)
+    for kw in (dict(image_precise_blocks=4), dict(image_precise_blocks=2, ln_folded=False),
+               dict(image_precise_blocks=2, low_latency=True)):
+        with pytest.raises(ValueError):
+            eclip.CLIP(cfg, sd, dtype=dt, **kw).cuda().encode_image(img.cuda())
+
+
 def test_cpu_model_fails_loudly(hip):
     import torch
     from eventclip_amd import _lib
