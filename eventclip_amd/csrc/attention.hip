@@ -626,271 +626,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Round 4: the image tower's attention on 32-query tiles and v_mfma_f32_32x32x16 (f16 operands, not causal, q
-// pre-scaled: ec_attention_scaled_q).  Same K / V images in LDS, same softmax rules as attn_block2 (m moves only past
-// 2^10, P rounded to 16 bit, l = sum of the rounded P) -- what changes is the instruction the vector work hides
-// behind: a 16x16x32 MFMA holds the SIMD's vector issue port for 8 of its 16 cycles, a 32x32x16 one for 8 of 32, and
-// the kernel's compute phase is bound by that port (MFMA time 52 % of it with the 16-row tiles, the exponentials,
-// maxima and converts the rest, next to each other instead of under each other: profiles/r3_attention.md).
-//  * S^T = K . Q^T: A = 32 keys x 16 dims (lane l: key l & 31, dims 16 ks + 8 (l >> 5) ..: one ds_read_b128), B = Q^T
-//    from registers; a lane's 16 accumulators are 16 keys of ONE query (l & 31), the partner lane l ^ 32 holds the
-//    tile's other 16.  Register r <-> key 8 (r >> 2) + 4 (l >> 5) + (r & 3).
-//  * O^T = V^T . P^T: B = the lane's own eight P values per 16-key step (registers 8 t .. 8 t + 7, no lane movement),
-//    A = V^T by two ds_read_b64_tr_b16 per step with the matching key order; the dims are dealt so that a lane ends
-//    up with 16 CONSECUTIVE head dims of its query (32 dt2 + 16 (l >> 5) + r): the stores are 16 bytes per lane.
-//  * -m is the first MFMA's C operand (16 registers of the same value), the row sum comes from v_dot2c on the packed P.
-// A sequence of 32 n + 1 tokens whose tile count is one more than a multiple of the wave count (S = 257 on 8 waves)
-// hands its last row to the 16-row path (keys split over the waves, merged through LDS), as attention_kernel does.
-// ---------------------------------------------------------------------------------------
-// The query's other 16 keys live in lane l ^ 32: combine a value with the partner lane's.  v_permlane32_swap exchanges
-// the upper half of its first operand with the lower half of its second, so with the same value in both the two
-// registers hold {own, partner's} in every lane afterwards.  Inline asm as in mfma.h's xor_max / xor_sum: through the
-// builtin hipcc 7.2 folds max / add over the swap's two results to ONE of them (measured here: l came back as twice
-// the lower half's sum).  s_nop 1 covers the vector-write -> v_permlane-read hazard.
-__device__ __forceinline__ float pair_max(float v)
-{
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_f32 %0, %0, %1"
-                 : "+v"(a), "+v"(b));
-    return a;
-}
-__device__ __forceinline__ float pair_sum(float v)
-{
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\t"
-                 "v_add_f32 %0, %0, %1"
-                 : "+v"(a), "+v"(b));
-    return a;
-}
-
-template <int AT_WAVES>
-__global__ __launch_bounds__(AT_WAVES * 64, 4) void attention32_kernel(const AttnArgs a)
-{
-    typedef _Float16 elem;
-    typedef f16x8 v8;
-    typedef f16x4 v4;
-    constexpr int DT = EC_F16;
-    constexpr int AT_THREADS = AT_WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = a.S, W = a.W;
-    const int n32 = (S + 31) / 32;
-    const int SP = 32 * n32;
-    unsigned char *ldsK = smem;
-    unsigned char *ldsV = smem + SP * 128;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
-    const long ld = 3L * W;
-    const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
-    attn_stamp(0);
-    {   // staging: as attention_kernel (every load of the head requested before the first LDS write)
-        const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
-        u32x4 kv[5], vv[5];
-#pragma unroll
-        for (int p = 0; p < 5; p++) {
-            const int row = r_in + p * (AT_THREADS / 8);
-            if (row < SP) {
-                const int srow = row < S ? row : S - 1;
-                const elem *src = base + (long)srow * ld + ch * 8;
-                kv[p] = *reinterpret_cast<const u32x4 *>(src + W);
-                vv[p] = *reinterpret_cast<const u32x4 *>(src + 2 * W);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 5; p++) {
-            const int row = r_in + p * (AT_THREADS / 8);
-            if (row < SP) {     // image 1 (kkey<1> / vkey<1>): conflict-free for the 32-row fragment reads below
-                *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ kkey<1>(row)) << 4)) = kv[p];
-                *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ (vkey<1>(row) >> 1)) << 4)) = vv[p];
-            }
-        }
-    }
-    const int n_qt_all = (S + 31) / 32;
-    const bool lone = (S & 31) == 1 && n_qt_all > AT_WAVES && n_qt_all % AT_WAVES == 1;
-    const int n_qt_req = (a.q_rows + 31) / 32;
-    const int n_qt = lone ? min(n_qt_req, n_qt_all - 1) : n_qt_req;
-    const bool do_lone = lone && n_qt_req == n_qt_all;
-    auto load_q = [&](int qt, v8(&dst)[4]) {
-        int qsrc = qt * 32 + (lane & 31);
-        qsrc = qsrc < S ? qsrc : S - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-            dst[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 16 + (lane >> 5) * 8);
-    };
-    // (no prefetch of a later tile's Q: its 16 registers are what the K / V^T fragments in flight need; at S = 257 a wave
-    // has one tile, whose Q is requested before the staging barrier)
-    v8 qf[4];
-    if (wave < n_qt) load_q(wave, qf);
-    __syncthreads();
-    attn_stamp(1);
-
-    for (int qt = wave; qt < n_qt; qt += AT_WAVES) {
-        if (qt != wave) load_q(qt, qf);
-        int r32 = lane & 31, h = lane >> 5;
-        asm volatile("" : "+v"(r32), "+v"(h));            // per-tile, opaque: nothing of the addressing is hoisted and spilled
-        f32x16 o0, o1;
-#pragma unroll
-        for (int r = 0; r < 16; r++) o0[r] = 0.f, o1[r] = 0.f;
-        float mneg = 0.f;                                  // -m of this lane's query (the same in both of its lanes)
-        float lsum = 0.f;
-        bool down = true;
-        const int i16 = r32 & 15, gl = r32 >> 4;
-        // V^T: lane 4 q + p of a 16-lane group supplies key row q, dims D(gl, p) .. + 3 (8-byte slot u, at u ^ ((key >> 1) & 3))
-        const int vq = i16 >> 2, vp = i16 & 3;
-        const int vslot = 4 * (vp & 1) + 2 * gl + (vp >> 1);              // + 8 dt2
-        // the tile's four K fragments are requested a whole tile ahead (behind the QK MFMAs of the tile before)
-        v8 kf[4];
-        auto load_k = [&](int key0) {
-            const int krow = key0 + r32;
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-                kf[ks] = *reinterpret_cast<const v8 *>(ldsK + krow * 128 + (((2 * ks + h) ^ kkey<1>(krow)) << 4));
-        };
-        const int full = S >> 5, ntile = full + ((S & 31) ? 1 : 0);
-        load_k(0);
-        auto tile = [&](int kt, bool masked) {
-            const int key0 = 32 * kt;
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], qf[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], qf[3], acc, 0, 0, 0);
-            // next tile's K and this tile's first V^T fragments: requested now, used after the exponentials
-            if (kt + 1 < ntile) load_k(key0 + 32);
-            v8 vf[2][2];
-            auto load_v = [&](int t) {
-#pragma unroll
-                for (int dt2 = 0; dt2 < 2; dt2++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++) {
-                        const int key = key0 + 16 * t + 8 * b + 4 * h + vq;
-                        const int u = (8 * dt2 + vslot) ^ vkey<1>(key);
-                        const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4 *)(ldsV + key * 128 + u * 8));
-                        const v4 tv = __builtin_bit_cast(v4, tr);
-                        vf[t][dt2][4 * b] = tv[0], vf[t][dt2][4 * b + 1] = tv[1], vf[t][dt2][4 * b + 2] = tv[2], vf[t][dt2][4 * b + 3] = tv[3];
-                    }
-            };
-            load_v(0);
-            __builtin_amdgcn_sched_barrier(0);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (masked) {
-                    const int key = key0 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    acc[r] = key < S ? acc[r] : -INFINITY;
-                }
-                mx = fmaxf(mx, acc[r]);
-            }
-            // acc holds RAW scores (log2 units); the thresholds are relative to m = -mneg
-            const float rel = mx + mneg;
-            if (__builtin_amdgcn_ballot_w64(rel > ATTN_THR || (down && rel < -ATTN_LO)) != 0) {
-                const float mq = pair_max(rel);                          // with the query's other 16 keys
-                const float d = (mq > ATTN_THR || (down && mq < -ATTN_LO)) ? mq : 0.f;
-                float alpha = __builtin_amdgcn_exp2f(-d);
-                alpha = down ? 0.f : alpha;
-#pragma unroll
-                for (int r = 0; r < 16; r++) o0[r] *= alpha, o1[r] *= alpha;
-                lsum *= alpha;
-                mneg -= d;
-            }
-            v8 pf[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) pf[t][j] = (elem)__builtin_amdgcn_exp2f(acc[8 * t + j] + mneg);
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const f16x2 pp = {pf[t][j], pf[t][j + 1]}, one2 = {(elem)1.f, (elem)1.f};
-                    lsum = __builtin_amdgcn_fdot2(pp, one2, lsum, false);
-                }
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[0], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pf[0], o1, 0, 0, 0);
-            load_v(1);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[1], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pf[1], o1, 0, 0, 0);
-            down = false;
-        };
-        for (int kt = 0; kt < full; kt++) tile(kt, false);
-        if (S & 31) tile(full, true);
-        // ---- normalise and store: lane owns query r32, head dims 32 dt2 + 16 h .. + 15 ----
-        const float ltot = pair_sum(lsum);
-        const float inv = 1.f / ltot;
-        const int qrow = qt * 32 + r32;
-        if (qrow < a.q_rows) {
-            elem *dst = (elem *)a.out + ((long)seq * a.q_rows + qrow) * W + head * 64 + 16 * h;
-            elem ov[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) ov[r] = (elem)(o0[r] * inv);
-            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&ov[0]);
-            *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
-#pragma unroll
-            for (int r = 0; r < 16; r++) ov[r] = (elem)(o1[r] * inv);
-            *reinterpret_cast<u32x4 *>(dst + 32) = *reinterpret_cast<const u32x4 *>(&ov[0]);
-            *reinterpret_cast<u32x4 *>(dst + 40) = *reinterpret_cast<const u32x4 *>(&ov[8]);
-        }
-    }
-    if (do_lone) {
-        // ---- the sequence's last row (S = 32 n + 1): the 16-row path, its keys split over the waves (attention_kernel) ----
-        const int g_lane = lane >> 4, c_lane = lane & 15;
-        v8 ones;
-#pragma unroll
-        for (int j = 0; j < 8; j++) ones[j] = (elem)1.f;
-        asm volatile("" : "+v"(ones));
-        v8 qf[2];
-        {
-            const long qsrc = S - 1;                             // rows S - 1 + c_lane clamp to S - 1
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                qf[ks] = *reinterpret_cast<const v8 *>(base + qsrc * ld + ks * 32 + g_lane * 8);
-        }
-        float *part = reinterpret_cast<float *>(smem + 2 * SP * 128);
-        const int steps = S >> 5;
-        const int s0 = wave * steps / AT_WAVES, s1 = (wave + 1) * steps / AT_WAVES;
-        const bool tail = wave == AT_WAVES - 1;
-        int g = g_lane, c16 = c_lane;
-        asm volatile("" : "+v"(g), "+v"(c16));
-        f32x4 o[5];
-#pragma unroll
-        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
-        attn_keys<DT, QM_INPUT, 1>(ldsK, ldsV, S, s0, s1, tail, qf, ones, a.scale_log2e, mneg, o, g, c16);
-        if (c16 == 0) {
-            float *dst = part + wave * ATTN_PART;
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<f32x4 *>(dst + 16 * g + 4 * dt) = o[dt];
-            if (g == 0) {
-                dst[64] = (s1 > s0 || tail) ? -mneg[0] : -1e30f;
-                dst[65] = o[4][0];
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            float m = -1e30f;
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; w++) m = fmaxf(m, part[w * ATTN_PART + 64]);
-            float num = 0.f, den = 0.f;
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; w++) {
-                const float f = __builtin_amdgcn_exp2f(part[w * ATTN_PART + 64] - m);
-                num = __builtin_fmaf(f, part[w * ATTN_PART + lane], num);
-                den = __builtin_fmaf(f, part[w * ATTN_PART + 65], den);
-            }
-            ((elem *)a.out)[((long)seq * a.q_rows + (S - 1)) * W + head * 64 + lane] = (elem)(num / den);
-        }
-    }
-    attn_stamp(2);
-}
+#ifdef EC_ATTN_DIAG
+#include "attention_diag.inc"     // attention32_kernel, the round-1 fp32 kernel: A / B forms of the diagnostic build
+#endif
 
 #ifdef EC_ATTN_DIAG
 int g_attn_variant = 0;
@@ -937,89 +675,6 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     return EC_OK;
 }
 
-#ifdef EC_ATTN_DIAG     // the round-1 form, kept for the A / B only (ec_attn_set_variant(6)); the product runs attention_f32m_kernel
-// ---------------------------------------------------------------------------------------
-// fp32 attention for the split-precision towers (text features are computed once and cached;
-// the image tower uses this only for validation).  One workgroup per (sequence, head,
-// 16-query tile); Q tile and the 16 x S score rows in LDS, K / V rows straight from L2.
-// Output is written as 16-bit hi + lo parts (x ~ hi + lo) for the split GEMMs that follow.
-// ---------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float *qkv, void *out_hi,
-                                                            void *out_lo, int S, int W, int heads,
-                                                            int causal)
-{
-    typedef typename T16<DT>::elem elem;
-    typedef typename T16<DT>::v4 v4;
-    extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float *qs = fsm;            // [16][64], pre-scaled by 1/sqrt(64)
-    float *sc = fsm + 16 * 64;  // [16][S]
-    const int n_qt = (S + 15) / 16;
-    const int qt = blockIdx.x % n_qt, head = (blockIdx.x / n_qt) % heads;
-    const int seq = blockIdx.x / (n_qt * heads);
-    const long ld = 3L * W;
-    const float *base = qkv + (long)seq * S * ld + head * 64;
-    const int t = threadIdx.x, q = t >> 4, sub = t & 15;
-    const int qrow = qt * 16 + q, qsrc = qrow < S ? qrow : S - 1;
-    {
-        const float4 v = *reinterpret_cast<const float4 *>(base + (long)qsrc * ld + sub * 4);
-        *reinterpret_cast<float4 *>(qs + q * 64 + sub * 4) =
-            make_float4(v.x * 0.125f, v.y * 0.125f, v.z * 0.125f, v.w * 0.125f);
-    }
-    __syncthreads();
-    const int klimit = causal ? (qrow < S ? qrow + 1 : S) : S;
-    float mx = -INFINITY;
-    for (int key = sub; key < S; key += 16) {
-        const float *kr = base + (long)key * ld + W;
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            const float4 kv = *reinterpret_cast<const float4 *>(kr + d);
-            const float4 qv = *reinterpret_cast<const float4 *>(qs + q * 64 + d);
-            s = fmaf(qv.x, kv.x, s), s = fmaf(qv.y, kv.y, s), s = fmaf(qv.z, kv.z, s),
-            s = fmaf(qv.w, kv.w, s);
-        }
-        s = key < klimit ? s : -INFINITY;
-        sc[q * S + key] = s;
-        mx = fmaxf(mx, s);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-    float sum = 0.f;
-    for (int key = sub; key < S; key += 16) {
-        const float p = expf(sc[q * S + key] - mx);
-        sc[q * S + key] = p;
-        sum += p;
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-    __syncthreads();
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int key = 0; key < S; key++) {
-        const float p = sc[q * S + key];
-        const float4 vv = *reinterpret_cast<const float4 *>(base + (long)key * ld + 2 * W + sub * 4);
-        acc.x = fmaf(p, vv.x, acc.x), acc.y = fmaf(p, vv.y, acc.y), acc.z = fmaf(p, vv.z, acc.z),
-        acc.w = fmaf(p, vv.w, acc.w);
-    }
-    if (qrow < S) {
-        const float inv = 1.f / sum;
-        float o4[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
-#pragma unroll
-        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(o4[i]));     // see attention_f32m_kernel's epilogue
-        v4 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            hi[i] = to16(o4[i], elem());
-            lo[i] = to16(o4[i] - (float)hi[i], elem());
-        }
-        const long off = ((long)seq * S + qrow) * W + head * 64 + sub * 4;
-        *reinterpret_cast<v4 *>((elem *)out_hi + off) = hi;
-        *reinterpret_cast<v4 *>((elem *)out_lo + off) = lo;
-    }
-}
-
-
-#endif
 
 // ---------------------------------------------------------------------------------------
 // fp32 attention for the split-precision towers on the fp32 matrix instruction (round 4): v_mfma_f32_16x16x4_f32 takes fp32 operands and is bit for bit an
