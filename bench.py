@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--precise', action='store_true',
                     help='image tower with hi + lo operands in every GEMM (ec_vit_weights.precise, 3 x the MFMA work): '
                          'the mode that meets 1e-3 on input-dependent weights; a line of its own, never the headline')
+    ap.add_argument('--f16-weights', action='store_true',
+                    help='round the seeded random weights to 16 bit first: a checkpoint stored in 16 bit, as released CLIP '
+                         'weights are (split-precision blocks then skip the product with the weights\' lo parts)')
     ap.add_argument('--precise-blocks', type=int, default=0,
                     help='split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks; '
                          'n = 4 meets 1e-3 on input-dependent weights): a line of its own, never the headline')
@@ -319,6 +322,9 @@ def main():
     # ---- model: seeded random CLIP, text features cached once ----
     cfg = eclip.arch_config(a.arch)
     sd = eclip.random_state_dict(cfg, seed=2)
+    if a.f16_weights:
+        cdt = torch.float16 if a.dtype == 'float16' else torch.bfloat16
+        sd = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
     clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk, image_precise=a.precise,
                             image_precise_blocks=0 if a.precise else a.precise_blocks).cuda().eval()
     tokens = eclip.synthetic_tokens(a.classes, seed=2)
@@ -505,7 +511,8 @@ def main():
                        'events_per_frame': min(N, c['n_ev']), 'resolution': list(geo['resolution']),
                        'event_format': 'packed 8 B' if a.packed_events else 'float32 [n, 4]',
                        'unique_samples': uniq_n,
-                       'tower_chunk_frames': a.chunk, 'weights': 'seeded random',
+                       'tower_chunk_frames': a.chunk,
+                       'weights': 'seeded random' + (', rounded to 16 bit first (a checkpoint stored in 16 bit)' if a.f16_weights else ''),
                        'precision': (('split precision: hi + lo 16-bit operands in every GEMM of the image tower '
                                       '(ec_vit_weights.precise, 3 x the MFMA work), fp32 residual stream and LayerNorm'
                                       if a.precise else

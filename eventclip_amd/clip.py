@@ -266,6 +266,16 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        exact = []          # per split-precision block matrix of the image tower: is it its 16-bit value?
+
+        def dev16_lo_or_null(t):
+            # ec_vit_weights.weights_exact16: a matrix that IS its 16-bit value (a checkpoint stored in 16 bit) has no
+            # lo part: NULL, and its x_hi . w_lo product is skipped
+            t32 = t.to(dev, torch.float32)
+            is_exact = bool((t32 == t32.to(cd).float()).all()) and not getattr(self, 'keep_zero_lo', False)   # (tests)
+            exact.append(is_exact)
+            return None if is_exact else dev16_lo(t)
+
         def blocks(prefix, layers, precise_all, q_scaled_all=False, ln_folded=False, precise_first=0):
             arr = (_lib.EcBlockWeights * layers)()
             for i in range(layers):
@@ -304,8 +314,9 @@ class CLIP(nn.Module):
                 b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
                 b.fc2_w, b.fc2_b = dev16(sd[ks[10]]), dev32(sd[ks[11]])
                 if precise:
-                    b.qkv_w_lo, b.out_w_lo = dev16_lo(sd[ks[2]]), dev16_lo(sd[ks[4]])
-                    b.fc1_w_lo, b.fc2_w_lo = dev16_lo(sd[ks[8]]), dev16_lo(sd[ks[10]])
+                    lo = dev16_lo_or_null if prefix.startswith('visual') else dev16_lo
+                    b.qkv_w_lo, b.out_w_lo = lo(sd[ks[2]]), lo(sd[ks[4]])
+                    b.fc1_w_lo, b.fc2_w_lo = lo(sd[ks[8]]), lo(sd[ks[10]])
             return arr
 
         c = self.cfg
@@ -344,6 +355,7 @@ class CLIP(nn.Module):
         vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
                     ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
+        v.weights_exact16 = int(any(exact))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']
         t.layers, t.heads, t.out_dim = c['text_layers'], c['text_heads'], c['embed_dim']

@@ -82,7 +82,9 @@ inline int gemm3(int M, int N, int K, int dtype, bool accumulate, const void *a_
                  const void *w_hi, const void *w_lo, const float *bias, float *C, ec_stream_t s)
 {
     EC_TRY(gemm(M, N, K, dtype, accumulate ? EC_EPI_RESID32 : EC_EPI_STORE32, a_hi, w_hi, bias, C, s));
-    EC_TRY(gemm(M, N, K, dtype, EC_EPI_RESID32, a_hi, w_lo, nullptr, C, s));
+    // w_lo == NULL: the weight IS its 16-bit value (ec_vit_weights.weights_exact16), the product with its lo part is
+    // a sum of zeros -- skipped, the same bits out
+    if (w_lo) EC_TRY(gemm(M, N, K, dtype, EC_EPI_RESID32, a_hi, w_lo, nullptr, C, s));
     return gemm(M, N, K, dtype, EC_EPI_RESID32, a_lo, w_hi, nullptr, C, s);
 }
 

@@ -141,12 +141,13 @@ struct PreciseBufs {
 };
 
 int run_blocks_precise(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads,
-                       int causal, int dtype, const PreciseBufs &b, ec_stream_t s)
+                       int causal, int dtype, const PreciseBufs &b, ec_stream_t s, bool exact16 = false)
 {
     const int rows = n_seq * S;
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
-        EC_REQUIRE(w.qkv_w_lo && w.out_w_lo && w.fc1_w_lo && w.fc2_w_lo,
+        // exact16 (ec_vit_weights.weights_exact16): a NULL lo part says that the matrix is its 16-bit value
+        EC_REQUIRE(exact16 || (w.qkv_w_lo && w.out_w_lo && w.fc1_w_lo && w.fc2_w_lo),
                    "precise tower: block %d has no lo weight parts", l);
         EC_TRY(ec_layernorm_split(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h_hi, b.h_lo,
                                   W, dtype, s));
@@ -283,7 +284,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
             EC_TRY(patch_embed(w, p, n * G, pb.wide, stream));
             EC_TRY(ec_vit_embed(pb.wide, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS,
                                 pb.x, stream));
-            EC_TRY(run_blocks_precise(w->blocks, w->layers, n, S, W, w->heads, 0, dt, pb, stream));
+            EC_TRY(run_blocks_precise(w->blocks, w->layers, n, S, W, w->heads, 0, dt, pb, stream, w->weights_exact16 != 0));
             EC_TRY(ec_layernorm_split(pb.x, (long)S * W, nullptr, w->ln_post_g, w->ln_post_b, n, W,
                                       LN_EPS, c_hi, c_lo, W, dt, stream));
             EC_TRY(gemm3(n, w->out_dim, W, dt, false, c_hi, c_lo, w->proj_w, w->proj_w_lo, nullptr,
@@ -334,7 +335,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
             if (pblocks > 0) {
                 // the first blocks in split precision on the fp32 stream, which is then split into the planes
                 EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, pb.x, stream));
-                EC_TRY(run_blocks_precise(w->blocks, pblocks, n, S, W, w->heads, 0, dt, pb, stream));
+                EC_TRY(run_blocks_precise(w->blocks, pblocks, n, S, W, w->heads, 0, dt, pb, stream, w->weights_exact16 != 0));
                 EC_TRY(split_hl(pb.x, (long)n * S * W, x_hi, x_lo, dt, stream));
             } else {
                 EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,

@@ -467,6 +467,11 @@ typedef struct {
                                    the logits of every BASELINE config inside 1e-3 of the fp32 oracle at 2.0 x the time
                                    of the 16-bit path, four those of configs[0], [1] and [3] at 1.5 x.
                                    0 (default): off. */
+    int weights_exact16;        /* != 0: the blocks' 16-bit matrices ARE the weights (a checkpoint stored in 16 bit, as
+                                   clip.load() returns one on a GPU): the qkv_w_lo / out_w_lo / fc1_w_lo / fc2_w_lo of a
+                                   split-precision block may be NULL, and the x_hi . w_lo product of such a matrix -- a sum
+                                   of zeros -- is skipped (two MFMA products per GEMM instead of three, the same bits).
+                                   0 (default): a split-precision block without its lo parts is an error. */
 } ec_vit_weights;
 
 typedef struct {

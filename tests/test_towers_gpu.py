@@ -434,6 +434,25 @@ def test_precise_blocks_tower(dt, hip):
             eclip.CLIP(cfg, sd, dtype=dt, **kw).cuda().encode_image(img.cuda())
 
 
+def test_weights_stored_in_16_bit_skip_the_lo_product(hip):
+    """ec_vit_weights.weights_exact16: on a checkpoint whose matrices are 16-bit values already (what clip.load() returns
+    on a GPU) the split-precision blocks pass NULL lo parts and run two MFMA products per GEMM instead of three; the
+    skipped product is a sum of zeros, so the features are bit-identical to the three-product form."""
+    import torch
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=3, text_layers=1, vocab_size=1024)
+    sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in eclip.random_state_dict(cfg, seed=3).items()}
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
+    for kw in (dict(image_precise=True), dict(image_precise_blocks=2)):
+        two = eclip.CLIP(cfg, sd, **kw).cuda().eval()
+        three = eclip.CLIP(cfg, sd, **kw).cuda().eval()
+        three.keep_zero_lo = True
+        a, b = two.encode_image(img), three.encode_image(img)
+        assert two._pack()['vit'].weights_exact16 == 1 and three._pack()['vit'].weights_exact16 == 0
+        assert two._pack()['vb'][0].qkv_w_lo is None and three._pack()['vb'][0].qkv_w_lo is not None
+        assert torch.equal(a, b)
+
+
 def test_cpu_model_fails_loudly(hip):
     import torch
     from eventclip_amd import _lib
