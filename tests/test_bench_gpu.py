@@ -136,3 +136,17 @@ def test_config1_line_keeps_its_keys(hip):
     assert d['metric'] == 'event-frames/sec (whole node) ViT-L/14 zero-shot @224' and d['scaling'] == 'weak'
     assert 'samples_per_rank' not in d['config'] and 'ms_per_step_per_rank' not in d
     assert d['config']['workload'].endswith('batch=4 samples x 10 views per GPU (configs[1])')
+
+
+@pytest.mark.parametrize('flags,tag', [(['--precise-blocks', '2'], 'first 2 blocks'), (['--precise-blocks', '2', '--f16-weights'], 'first 2 blocks'),
+                                       (['--precise'], 'split-precision image tower')])
+def test_split_precision_lines_are_labelled(hip, flags, tag):
+    """--precise-blocks N / --precise / --f16-weights: lines of their own -- the metric string says which mode, the
+    config says how the weights were made -- never to be mistaken for the headline."""
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--no-cpu-baseline', '--no-dvfs'] + flags + SMALL,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['metric'].startswith('event-frames/sec (whole node) ViT-L/14 zero-shot @224 -- ') and tag in d['metric']
+    assert ('rounded to 16 bit first' in d['config']['weights']) == ('--f16-weights' in flags)
+    assert d['value'] > 0
