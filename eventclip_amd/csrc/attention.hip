@@ -681,7 +681,7 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
 // fmaf chain (cdna_hip_programming.md, FP32-input MFMA), at the vector ALU's peak rate but with the operands read
 // once per 16 x 16 tile instead of once per product.  One workgroup = 64 queries of one (sequence, head), one
 // 16-query tile per wave, keys in chunks of 32 through two LDS buffers (the next chunk's rows are in flight in
-// registers during the chunk's MFMAs; one barrier per chunk), online softmax in fp32 with expf.
+// registers during the chunk's MFMAs; one barrier per chunk), online softmax in fp32 (e^t through v_exp_f32, see exp_e).
 //  * S^T = K . Q^T: A = the chunk's key rows (lane: key l & 15, head dims 16 c + 4 (l >> 4) + e), B = the wave's
 //    queries in the same dim order (held in registers, pre-scaled by 1/8: exact), so a lane's accumulators are four
 //    keys (4 (l >> 4) + r of each 16-key tile) of ONE query (l & 15);
@@ -740,6 +740,11 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, v
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // e^t as 2^(t log2 e) on v_exp_f32 (1 ulp), the product with log2 e = hi + lo carried to ~2^-48 relative (one fma):
+    // three vector instructions and one transcendental instead of expf's twenty, the same accuracy class
+    auto exp_e = [](float t) {
+        return __builtin_amdgcn_exp2f(__builtin_fmaf(t, 1.4426950216293335f, t * 1.92596298909109e-8f));
+    };
     fetch(0);
     stash(0);
     __syncthreads();
@@ -778,14 +783,14 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, v
             const float mn = fmaxf(m, mx);
             // nothing of this query's row seen so far (mn = -inf: only rows that do not exist or a causal row whose
             // keys all lie ahead, which cannot happen from chunk 0 on): keep everything at zero
-            const float alpha = mn == -INFINITY ? 0.f : expf(m - mn);
+            const float alpha = mn == -INFINITY ? 0.f : exp_e(m - mn);
             const float sub = mn == -INFINITY ? 0.f : mn;
             float ps = 0.f;
 #pragma unroll
             for (int tt = 0; tt < 2; tt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    sc[tt][r] = expf(sc[tt][r] - sub);
+                    sc[tt][r] = exp_e(sc[tt][r] - sub);
                     ps += sc[tt][r];
                 }
             l = l * alpha + ps;
