@@ -21,6 +21,11 @@ A = torch.randn(M, a.k, device='cuda').half()
 W = (torch.randn(a.n, a.k, device='cuda') / a.k ** 0.5).half()
 bias = torch.randn(a.n, device='cuda')
 out = torch.zeros(M, a.n, device='cuda', dtype=torch.float32 if a.epi in ('resid32', 'store32') else torch.float16)
+kw = {}
+if a.epi == 'resid_hl':      # the tower's residual GEMMs: hi / lo planes + row sums
+    kw = dict(aux=torch.zeros(M, a.n, device='cuda', dtype=torch.float16), row_sums=torch.zeros(M, a.n // 64, 2, device='cuda'))
+elif a.epi.endswith('_ln'):  # ... its LayerNorm-finishing GEMMs
+    kw = dict(row_stats=ops.row_stats(A), col_sums=W.float().sum(1).contiguous())
 for _ in range(a.iters):
-    ops.gemm(A, W, bias, a.epi, out=out, variant=a.variant)
+    ops.gemm(A, W, bias, a.epi, out=out, variant=a.variant, **kw)
 torch.cuda.synchronize()
