@@ -458,7 +458,7 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
 // 16-bit outputs (STORE16 / GELU16 and their folded-LayerNorm forms).  lds_rowstat: the wave row's 128 statistics
 // pairs in LDS (has_lds; always a pointer INTO the shared array, so that the reads compile to ds_read and not to
 // flat loads, whose s_waitcnt vmcnt(0) lgkmcnt(0) also waited for the next tile's first K tile), else g.rowstat
-template <int DT, int EPI, int TM, bool HAS_LDS, typename F>
+template <int DT, int EPI, int TM, bool HAS_LDS, bool EARLY = false, typename F>
 __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
                                                int lane, unsigned char *scratch, const float *lds_rowstat, F &&between)
 {
@@ -494,7 +494,7 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
             }
         }
     }
-    between();       // bias, column sums and (global) row statistics are requested: now the next tile's DMA
+    if constexpr (EARLY) between();     // (A / B: the requests in front of the first use of bias, rounds 1 - 3 and early round 4)
     const __amdgpu_buffer_rsrc_t rc = tile_rsrc(reinterpret_cast<char *>(g.C) + ((long)m_base * g.ldc + n_base) * 2,
                                                 tile_span(g.M, m_base, TM * 16, g.ldc * 2));
     const bool col_ok = n_base + (lane & 7) * 8 < g.N;
@@ -520,6 +520,15 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
     };
     produce(0);
+    // The next tile's DMA is requested HERE, behind the first use of bias / column sums / row statistics: hipcc's
+    // wait-count pass does not count the LDS-DMA requests when it waits for those loads (it asks for vmcnt(1) and
+    // vmcnt(0) where 9 and 8 would do), so with the requests in front of that use every tile's epilogue opened with a
+    // wait for the whole first K tile of the next one
+    if constexpr (!EARLY) {
+        __builtin_amdgcn_sched_barrier(0);     // (all of produce(0), hence every such wait, stays in front of the requests)
+        between();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const unsigned char *buf = scratch + (i & 1) * 16 * PITCH;
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     // buffers by DMA, two slots used alternately (the epilogue of tile T reads slot T & 1 while the pairs of tile
     // T + 1 land in the other).  Waves 0 and 1 issue one piece each, BEFORE the tile's first staging piece: an
     // older request can only retire earlier, so every counted wait below keeps its meaning.  Rows past M read a
-    // clamped pair (never used); the caller keeps the array readable up to an even row count.
+    // pair of zeros (the descriptor's range check; never used).
     constexpr bool LNS = epi_is_ln(EPI);
     const bool lds_stats = LNS && g.rowstat_stride == 1;
     float *side = reinterpret_cast<float *>(smem + 2 * KT);
@@ -856,10 +865,16 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     auto issue_stats = [&](int sl) {
         if constexpr (LNS) {
             if (lds_stats && wave < 2) {
-                long row = (long)m0 + wave * 128 + 2 * lane;
-                const long last = ((long)g.M - 1) & ~1L;
-                row = row < last ? row : last;
-                glds16(g.rowstat + 2 * row, reinterpret_cast<unsigned char *>(side) + sl * 2048 + wave * 1024);
+                // buffer-addressed like the staging DMA (a FLAT-encoded global_load_lds in front of them made hipcc's
+                // wait-count pass answer every wait behind it with vmcnt(0): one in front of each tile's first
+                // accumulator write, one in front of the epilogue's first use of bias / column sums -- both also waits
+                // for the staging DMA in flight).  The range is the pairs that exist: a pair past row M reads zeros
+                // (never used), so the caller's array needs no readable slack.
+                const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g.rowstat, (long)g.M * 8);
+                int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rs, (__attribute__((address_space(3))) void *)(reinterpret_cast<unsigned char *>(side) + sl * 2048 + wave * 1024),
+                    16, (m0 + wave * 128 + 2 * ln) * 8, 0, 0, 0);
             }
         }
     };
@@ -971,10 +986,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             epilogue32_buf<EPI, 8, TN>(ge, acc, wm0, wn0, elane, reinterpret_cast<float *>(smem + KT) + wave * (16 * 68), next_tile);
         else if constexpr (BUF_EPI) {
             if (lds_stats)
-                epilogue16_buf<DT, EPI, 8, true>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
+                epilogue16_buf<DT, EPI, 8, true, (HLM & 4) != 0>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
                                                  side + slot * 512 + wm * 256, next_tile);
             else
-                epilogue16_buf<DT, EPI, 8, false>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
+                epilogue16_buf<DT, EPI, 8, false, (HLM & 4) != 0>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
         }
         else {    // the training epilogues (second output / second input): the general form
             next_tile();
@@ -1065,6 +1080,7 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
     case 16: return launch2p<DT, EPI, 9>(g, s);   // per-workgroup timeline -> args.diag
     case 18: return launch2pp<DT, EPI, true>(g, s);  // persistent, with timeline records -> args.diag
+    case 43: return launch2pp<DT, EPI, false, false, 5>(g, s);   // 16-bit epilogues: next tile's DMA requested in FRONT of the first use of bias (A / B)
     case 20:                                         // probe: four waves x 128 x 128, 16-bit store only
         if constexpr (EPI == EC_EPI_STORE16) return launch4w<DT>(g, s);
         return ec::fail(EC_ERR_INVALID, "ec_gemm variant 20: store16 only");
@@ -1108,12 +1124,14 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_STORE16_LN:
 #ifdef EC_GEMM_DIAG
         if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, true>(g, s);
+        if (variant == 43 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, false, false, 5>(g, s);
 #endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs variant 0, row_stats and col_sums");
         return launch2pp<DT, EC_EPI_STORE16_LN>(g, s);
     case EC_EPI_GELU16_LN:
 #ifdef EC_GEMM_DIAG
         if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, true>(g, s);
+        if (variant == 43 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, false, false, 5>(g, s);
 #endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs variant 0, row_stats and col_sums");
         return launch2pp<DT, EC_EPI_GELU16_LN>(g, s);
@@ -1217,9 +1235,10 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     g.stat_out = nullptr, g.stat_groups = 0;
-    // what the epilogues read these with: row_stats by 16-byte LDS-DMA (two pairs at a time at stride 1; the header
-    // states that the array must be readable up to an even row count), col_sums as float4, row_sums written as float2
+    // what the epilogues read these with: row_stats by 16-byte LDS-DMA (two pairs at a time at stride 1, through a
+    // descriptor whose range ends at pair M - 1: nothing past the array is read), col_sums as float4, row_sums written as float2
     EC_REQUIRE((((uintptr_t)a->row_stats | (uintptr_t)a->col_sums) & 15) == 0, "ec_gemm: row_stats / col_sums must be 16-byte aligned");
+    EC_REQUIRE(!a->row_stats || a->M < (1 << 27), "ec_gemm: row_stats addresses its pairs with 32-bit byte offsets (M = %d)", a->M);
     EC_REQUIRE(((uintptr_t)a->row_sums & 7) == 0, "ec_gemm: row_sums must be 8-byte aligned");
     if (a->epilogue == EC_EPI_RESID_HL && a->row_sums) {
         EC_REQUIRE(a->N % 64 == 0, "ec_gemm: row_sums needs N %% 64 == 0 (N = %d)", a->N);

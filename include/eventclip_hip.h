@@ -295,8 +295,8 @@ typedef struct {
     int k_rows;        /* transposed: the rows that exist (<= splits * K); rows past it read as zero */
     /* EC_EPI_STORE16_LN / EC_EPI_GELU16_LN: */
     const float *row_stats;   /* fp32 pairs (rstd, -rstd * mean) of the A rows; row m at row_stats + 2 * m * row_stats_stride.
-                                 At stride 1 the array must be readable up to an EVEN number of rows (M + 1 pairs for an odd
-                                 M: the kernel fetches the pairs two at a time; the extra one is never used) */
+                                 16-byte aligned, M pairs: at stride 1 the kernel fetches them two at a time through a
+                                 descriptor whose range ends at pair M - 1 (nothing past the array is read); M < 2^27 */
     long row_stats_stride;    /* in rows (0 = 1): the class-token rows of a [n, S] statistics array are S apart */
     const float *col_sums;    /* fp32 [N]: sum over k of W[n][k] as rounded to 16 bit */
     /* EC_EPI_RESID_HL, optional (N % 64 == 0): */
