@@ -468,19 +468,24 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
     const int q = lane >> 4, lr = lane & 15;
     const int nb = n_base + q * 16;
     f32x4 bias[4];
-    load_bias(g, nb, bias);
     f32x4 cs[4];
     float rs0[TM], rs1[TM];
+    if constexpr (epi_is_ln(EPI) && HAS_LDS) {
+        // the statistics first: hipcc guards an LDS read behind LDS-DMA requests with a vmcnt wait (the pairs came by
+        // DMA a tile ago), which is free here and would be a wait for the bias / column-sum loads behind them
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const float2 r = *reinterpret_cast<const float2 *>(lds_rowstat + 2 * (i * 16 + lr));
+            rs0[i] = r.x, rs1[i] = r.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_bias(g, nb, bias);
     if constexpr (epi_is_ln(EPI)) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             cs[j] = nb < g.N ? *reinterpret_cast<const f32x4 *>(g.colsum + nb + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (HAS_LDS) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const float2 r = *reinterpret_cast<const float2 *>(lds_rowstat + 2 * (i * 16 + lr));
-                rs0[i] = r.x, rs1[i] = r.y;
-            }
         } else {
             // pairs [M][2] at a stride of rowstat_stride pairs (the class-token rows of the last block: a handful of
             // rows per launch), rows past M read the last pair.  (Plain global loads: hipcc 7.2 lowers
