@@ -88,8 +88,10 @@ def parse():
                     help='round the seeded random weights to 16 bit first: a checkpoint stored in 16 bit, as released CLIP '
                          'weights are (split-precision blocks then skip the product with the weights\' lo parts)')
     ap.add_argument('--precise-blocks', type=int, default=0,
-                    help='split precision in the FIRST n blocks of the image tower only (ec_vit_weights.precise_blocks; '
-                         'n = 4 meets 1e-3 on input-dependent weights): a line of its own, never the headline')
+                    help='the FIRST n blocks of the image tower as split-operand blocks (ec_vit_weights.precise_blocks; '
+                         'n = 8 meets 1e-3 on the input-dependent weights of every config): a line of its own, never the headline')
+    ap.add_argument('--no-tolerance-mode', action='store_true',
+                    help='skip the extra steps (after the timed region) that price the 1e-3 mode: tolerance_mode')
     a = ap.parse_args()
     c = CONFIGS[a.config]
     a.batch = a.batch or c['batch']
@@ -109,6 +111,58 @@ def _cpu_event2img(args):
     frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
     op.preprocess(frames, n_px)
     return frames.shape[0]
+
+
+TOLERANCE_BLOCKS = 8
+
+
+def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, frames_per_step, default_ms):
+    """The price of north_star's 1e-3 on input-dependent weights, measured AFTER the timed region on the same box and
+    batch (never part of `value`): the image tower with its first TOLERANCE_BLOCKS blocks as split-operand blocks
+    (ec_vit_weights.precise_blocks -- the mode tests/test_configs_gpu.py::test_first_eight_blocks_in_split_precision_meet_
+    1e3_on_signal_weights holds to 1e-3 on all five BASELINE configs), a few steps each on the run's own weights and on
+    the same weights rounded to 16 bit first (what a released checkpoint is: the lo products of the exact matrices are
+    skipped), interleaved with steps of the default model."""
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import ZSCLIPClassifier
+    cdt = torch.float16 if a.dtype == 'float16' else torch.bfloat16
+    if cdt != torch.float16:
+        return None
+    sd16 = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    out = {'precise_blocks': TOLERANCE_BLOCKS, 'steps': 3,
+           'configs_within_1e3': 'all five BASELINE configs on input-dependent weights '
+                                 '(tests/test_configs_gpu.py::test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights; '
+                                 'measured errors in profiles/r5_parity.txt)',
+           'what': 'first 8 image-tower blocks: QKV / c_fc multiply both planes of the residual stream, every GEMM adds the '
+                   'product with its weight\'s lo part (one launch per GEMM), attention in fp32 on hi + lo q, k, v'}
+
+    def timed(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    lines = []
+    for name, weights in (('as_run', sd), ('rounded_to_16_bit', sd16)):
+        if name == 'as_run' and a.f16_weights:
+            continue
+        m = eclip.CLIP(cfg, weights, dtype=a.dtype, chunk=a.chunk, image_precise_blocks=TOLERANCE_BLOCKS).cuda().eval()
+        cls = ZSCLIPClassifier(clip_dict=dict(clip_dict, clip_model=m)).cuda().eval()
+        cls.get_text_feats()
+
+        def tol_step():
+            return cls(pipe(events, n_events))
+        tol_step()                                   # packs the weights, warms the workspace
+        ms_tol = timed(tol_step, out['steps'])
+        ms_def = timed(step, out['steps'])           # the default model right behind it: same clock state
+        lines.append({'weights': name, 'ms_per_step': ms_tol, 'value': frames_per_step / ms_tol * 1e3,
+                      'default_ms_per_step_interleaved': ms_def, 'ratio_to_default': ms_tol / ms_def})
+        del cls, m
+        torch.cuda.empty_cache()
+    out['lines'] = lines
+    return out
 
 
 def cpu_model():
@@ -495,7 +549,7 @@ def main():
         if a.precise:
             metric += ' -- split-precision image tower (validation mode, not the headline)'
         elif a.precise_blocks:
-            metric += f' -- first {a.precise_blocks} blocks of the image tower in split precision (not the headline)'
+            metric += f' -- first {a.precise_blocks} blocks of the image tower as split-operand blocks (not the headline)'
         if c['scaling'] == 'weak':
             batch_txt = f'batch={a.batch} samples x {views} view{"s" if views > 1 else ""} per GPU'
         else:
@@ -519,8 +573,9 @@ def main():
                                       '16-bit MFMA operands, fp32 accumulate / softmax; residual stream as hi + lo '
                                       '16-bit planes (~2^-22), LayerNorm folded into the QKV / c_fc GEMMs (statistics '
                                       'of the 16-bit hi plane); patch embedding and ln_post @ proj with hi + lo operands')
-                                     + (f'; the first {a.precise_blocks} blocks in split precision (fp32 residual '
-                                        'stream, hi + lo operands, fp32 attention: ec_vit_weights.precise_blocks)'
+                                     + (f'; the first {a.precise_blocks} blocks as split-operand blocks (QKV / c_fc multiply both '
+                                        'planes of the stream, every GEMM adds its weight\'s lo product in the same launch, '
+                                        'fp32 attention on hi + lo q, k, v: ec_vit_weights.precise_blocks)'
                                         if a.precise_blocks and not a.precise else '')
                                      + '; text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else
@@ -549,6 +604,9 @@ def main():
                 res['dvfs'] = dv
                 if roof['bound'] == 'mfma':
                     roof['frac_of_peak_at_sclk'] = roof['achieved'] / dv['peak_at_sclk']
+        if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks):
+            res['tolerance_mode'] = tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
+                                                   frames_per_step, res['ms_per_step'])
         if world == 1 and not a.no_cpu_baseline:
             if a.config == 1:
                 res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,

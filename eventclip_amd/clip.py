@@ -211,11 +211,17 @@ class CLIP(nn.Module):
         # (EVENTCLIP_PRECISE_BLOCKS=n sets it for models built without the argument, where the mode applies)
         if image_precise_blocks is None:
             image_precise_blocks = int(os.environ.get('EVENTCLIP_PRECISE_BLOCKS', '0') or 0)
-            if not self.ln_folded or self.low_latency or image_precise_blocks >= cfg['layers']:
+            if image_precise_blocks and (not self.ln_folded or self.low_latency or image_precise_blocks >= cfg['layers']
+                                         or self.compute_dtype != torch.float16 or self.image_precise):
+                # (the explicit argument raises in _pack for the same conditions; the environment variable addresses
+                # every model of the process, some of which the mode does not apply to -- say so)
+                import warnings
+                warnings.warn(f'EVENTCLIP_PRECISE_BLOCKS={image_precise_blocks} ignored for this model (needs ln_folded, '
+                              f'float16, no low_latency / image_precise, and fewer than layers={cfg["layers"]} blocks)')
                 image_precise_blocks = 0
         self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
-        # bytes of tower scratch at most (precise_blocks carves the buffers of both chains)
-        self.workspace_budget = (48 if self.image_precise_blocks else 24) << 30
+        # bytes of tower scratch at most
+        self.workspace_budget = 24 << 30
         self._packed = None
         self._ws = None
 
@@ -260,21 +266,23 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def dev16_lo(t):    # w - round16(w), rounded to 16 bit
-            t = t.to(dev, torch.float32)
-            t = (t - t.to(cd).float()).to(cd).contiguous()
-            keep.append(t)
-            return t.data_ptr()
-
         exact = []          # per split-precision block matrix of the image tower: is it its 16-bit value?
 
-        def dev16_lo_or_null(t):
-            # ec_vit_weights.weights_exact16: a matrix that IS its 16-bit value (a checkpoint stored in 16 bit) has no
-            # lo part: NULL, and its x_hi . w_lo product is skipped
+        def dev16_pair(t, null_if_exact=False):
+            # (hi, lo) = (round16(w), round16(w - hi)), the operands of a split-precision GEMM (ec_gemm_args.W_lo).  null_if_exact
+            # (ec_vit_weights.weights_exact16): a matrix that IS its 16-bit value -- a checkpoint stored in 16 bit --
+            # has no lo part: NULL, and the product with it is skipped
             t32 = t.to(dev, torch.float32)
-            is_exact = bool((t32 == t32.to(cd).float()).all()) and not getattr(self, 'keep_zero_lo', False)   # (tests)
-            exact.append(is_exact)
-            return None if is_exact else dev16_lo(t)
+            pair = torch.empty((2,) + tuple(t32.shape), dtype=cd, device=dev)
+            pair[0] = t32.to(cd)
+            pair[1] = (t32 - pair[0].float()).to(cd)
+            keep.append(pair)
+            if null_if_exact:
+                is_exact = bool((pair[1] == 0).all()) and not getattr(self, 'keep_zero_lo', False)   # (tests)
+                exact.append(is_exact)
+                if is_exact:
+                    return pair[0].data_ptr(), None
+            return pair[0].data_ptr(), pair[1].data_ptr()
 
         def blocks(prefix, layers, precise_all, q_scaled_all=False, ln_folded=False, precise_first=0):
             arr = (_lib.EcBlockWeights * layers)()
@@ -282,7 +290,10 @@ class CLIP(nn.Module):
                 ks = _block_keys(prefix, i)
                 b = arr[i]
                 # precise_first: the first blocks are split-precision blocks (plain q, lo parts), the rest as asked
-                precise = precise_all or i < precise_first
+                # precise_first (ec_vit_weights.precise_blocks): the first blocks are split-operand blocks of the folded
+                # chain -- the same packing plus the lo parts of all four matrices (of the FOLDED ones for in_proj / c_fc)
+                precise = precise_all
+                split_ops = i < precise_first and not precise_all
                 q_scaled = q_scaled_all and not precise
                 b.ln1_g, b.ln1_b = dev32(sd[ks[0]]), dev32(sd[ks[1]])
                 wqkv, bqkv = sd[ks[2]], sd[ks[3]]
@@ -297,26 +308,43 @@ class CLIP(nn.Module):
                     wqkv[:width] *= ATTN_Q_SCALE
                     bqkv[:width] *= ATTN_Q_SCALE
                 b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
+                vis = prefix.startswith('visual')
+                if precise:     # plain matrices with their lo parts
+                    b.qkv_w, b.qkv_w_lo = dev16_pair(wqkv, vis)
+                    b.qkv_b = dev32(bqkv)
+                else:
+                    b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
                 if ln_folded and not precise:
                     # ec_vit_weights.ln_folded: W' = W diag(gamma) rounded once, its row sums AS ROUNDED, b + W beta
+                    # (split-operand blocks: W' as hi + lo, the row sums those of hi + lo)
                     def fold(wt, bias, gamma, beta):
                         wt, bias = wt.float().to(dev), bias.float().to(dev)
-                        wp = (wt * gamma.float().to(dev)[None, :]).to(cd).contiguous()
-                        keep.append(wp)
-                        cs = wp.float().sum(1).contiguous()
+                        wf = wt * gamma.float().to(dev)[None, :]
                         bf = (bias + wt @ beta.float().to(dev)).contiguous()
+                        if split_ops:
+                            hi, lo = dev16_pair(wf, True)
+                            pair = keep[-1]
+                            cs = (pair[0].float() + (pair[1].float() if lo is not None else 0)).sum(1).contiguous()
+                        else:
+                            wp = wf.to(cd).contiguous()
+                            keep.append(wp)
+                            hi, lo, cs = wp.data_ptr(), None, wp.float().sum(1).contiguous()
                         keep.extend([cs, bf])
-                        return wp.data_ptr(), cs.data_ptr(), bf.data_ptr()
-                    b.qkv_w_ln, b.qkv_cs, b.qkv_bf = fold(wqkv, bqkv, sd[ks[0]], sd[ks[1]])
-                    b.fc1_w_ln, b.fc1_cs, b.fc1_bf = fold(sd[ks[8]], sd[ks[9]], sd[ks[6]], sd[ks[7]])
-                b.out_w, b.out_b = dev16(sd[ks[4]]), dev32(sd[ks[5]])
+                        return hi, lo, cs.data_ptr(), bf.data_ptr()
+                    b.qkv_w_ln, b.qkv_w_ln_lo, b.qkv_cs, b.qkv_bf = fold(wqkv, bqkv, sd[ks[0]], sd[ks[1]])
+                    b.fc1_w_ln, b.fc1_w_ln_lo, b.fc1_cs, b.fc1_bf = fold(sd[ks[8]], sd[ks[9]], sd[ks[6]], sd[ks[7]])
+                b.out_b = dev32(sd[ks[5]])
                 b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
-                b.fc1_w, b.fc1_b = dev16(sd[ks[8]]), dev32(sd[ks[9]])
-                b.fc2_w, b.fc2_b = dev16(sd[ks[10]]), dev32(sd[ks[11]])
-                if precise:
-                    lo = dev16_lo_or_null if prefix.startswith('visual') else dev16_lo
-                    b.qkv_w_lo, b.out_w_lo = lo(sd[ks[2]]), lo(sd[ks[4]])
-                    b.fc1_w_lo, b.fc2_w_lo = lo(sd[ks[8]]), lo(sd[ks[10]])
+                b.fc1_b, b.fc2_b = dev32(sd[ks[9]]), dev32(sd[ks[11]])
+                if precise or split_ops:
+                    b.out_w, b.out_w_lo = dev16_pair(sd[ks[4]], vis)
+                    b.fc2_w, b.fc2_w_lo = dev16_pair(sd[ks[10]], vis)
+                    if precise:
+                        b.fc1_w, b.fc1_w_lo = dev16_pair(sd[ks[8]], vis)
+                    else:
+                        b.fc1_w = dev16(sd[ks[8]])
+                else:
+                    b.out_w, b.fc1_w, b.fc2_w = dev16(sd[ks[4]]), dev16(sd[ks[8]]), dev16(sd[ks[10]])
             return arr
 
         c = self.cfg
@@ -340,18 +368,18 @@ class CLIP(nn.Module):
         v.ln_pre_g, v.ln_pre_b = dev32(sd['visual.ln_pre.weight']), dev32(sd['visual.ln_pre.bias'])
         v.ln_post_g, v.ln_post_b = (dev32(sd['visual.ln_post.weight']),
                                     dev32(sd['visual.ln_post.bias']))
-        v.proj_w = dev16(sd['visual.proj'].t())
+        v.proj_w, v.proj_w_lo = dev16_pair(sd['visual.proj'].t())
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
         v.low_latency = int(self.low_latency)
         v.q_scaled = int(self.q_scaled and not self.image_precise)
         v.ln_folded = int(self.ln_folded and not self.image_precise)
         if self.image_precise_blocks:
-            if not (0 < self.image_precise_blocks < c['layers']) or not v.ln_folded or self.low_latency:
+            if not (0 < self.image_precise_blocks < c['layers']) or not v.ln_folded or self.low_latency or cd != torch.float16:
                 raise ValueError(f'image_precise_blocks={self.image_precise_blocks} needs 0 < n < layers={c["layers"]}, '
-                                 'ln_folded and no low_latency')
+                                 'ln_folded, float16 and no low_latency')
         v.precise_blocks = self.image_precise_blocks
-        v.conv_w_lo, v.proj_w_lo = dev16_lo(conv_lo), dev16_lo(sd['visual.proj'].t())
+        v.conv_w_lo = dev16_pair(conv_lo)[1]
         vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
                     ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
@@ -362,10 +390,10 @@ class CLIP(nn.Module):
         t.token_embedding = dev32(sd['token_embedding.weight'])
         t.pos = dev32(sd['positional_embedding'])
         t.ln_final_g, t.ln_final_b = dev32(sd['ln_final.weight']), dev32(sd['ln_final.bias'])
-        t.proj_w = dev16(sd['text_projection'].t())
+        t.proj_w, proj_lo = dev16_pair(sd['text_projection'].t())
         t.precise = int(self.text_precise)
         if self.text_precise:
-            t.proj_w_lo = dev16_lo(sd['text_projection'].t())
+            t.proj_w_lo = proj_lo
         tb = blocks('transformer', c['text_layers'], self.text_precise)
         t.blocks = ctypes.cast(tb, ctypes.POINTER(_lib.EcBlockWeights))
         self._packed = dict(vit=v, text=t, keep=keep, vb=vb, tb=tb, kpad=kpad, code=code, dev=dev)

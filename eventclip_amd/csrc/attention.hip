@@ -20,6 +20,8 @@
 //    row order is permuted so each lane ends with 16 contiguous head-dim outputs
 //    (two 16-B stores).
 //  * fp32 scores / softmax / accumulation; the 1/sqrt(64) scale is a power of two.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -690,19 +692,34 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
 // LDS rows are 64 floats with the 16-byte chunk index XORed with row & 15: the 16 key rows of a b128 read and the
 // column reads of V are spread over the banks.  2560 sequences x 16 heads x S = 257: 96 ms -> see profiles/r4_attention.md.
 // ---------------------------------------------------------------------------------------
+// SIN (round 5, the split-operand blocks of ec_vit_weights.precise_blocks): q | k | v arrive as hi + lo 16-bit parts
+// (two [rows, 3W] tensors, what EC_EPI_STORE16_LN leaves with args.aux) and are joined to fp32 on the way in; the q
+// columns already hold q log2(e) / sqrt(64) (ec_vit_weights.q_scaled), so the scores are the exponent's arguments in
+// log2 units and e^t is one v_exp_f32.
 constexpr int F32_KCH = 32;
-template <int DT>
-__global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, void *out_hi, void *out_lo, int S, int W,
-                                                             int heads, int causal)
+template <int DT, bool SIN = false>
+__global__ __launch_bounds__(256) void attention_f32m_kernel(const void *qkv_v, const void *qkv_lo_v, void *out_hi, void *out_lo,
+                                                             int S, int W, int heads, int causal)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v4 v4;
+    typedef typename std::conditional<SIN, elem, float>::type in_t;
+    const in_t *qkv = static_cast<const in_t *>(qkv_v), *qkv_lo = static_cast<const in_t *>(qkv_lo_v);
+    // four consecutive values of q | k | v at element offset `off` as fp32 (SIN: hi + lo)
+    auto ld4 = [&](long off) -> f32x4 {
+        if constexpr (SIN) {
+            const v4 h = *reinterpret_cast<const v4 *>(qkv + off), l = *reinterpret_cast<const v4 *>(qkv_lo + off);
+            return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+        } else {
+            return *reinterpret_cast<const f32x4 *>(qkv + off);
+        }
+    };
     __shared__ __attribute__((aligned(16))) float lk[2][F32_KCH * 64];
     __shared__ __attribute__((aligned(16))) float lv[2][F32_KCH * 64];
     const int n_qb = (S + 63) / 64;
     const int qb = blockIdx.x % n_qb, head = (blockIdx.x / n_qb) % heads, seq = blockIdx.x / (n_qb * heads);
     const long ld = 3L * W;
-    const float *base = qkv + (long)seq * S * ld + head * 64;
+    const long base = (long)seq * S * ld + head * 64;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, j = lane & 15, g = lane >> 4;
     const int q0 = qb * 64 + wave * 16;
     const bool active = q0 < S;                    // wave-uniform: the tile has a query that exists
@@ -710,8 +727,8 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, v
     f32x4 qf[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long)qsrc * ld + 16 * c + 4 * g);
-        qf[c] = v * 0.125f;
+        const f32x4 v = ld4(base + (long)qsrc * ld + 16 * c + 4 * g);
+        qf[c] = SIN ? v : v * 0.125f;
     }
     // keys this workgroup needs: all of them, or (causal) those up to its last query
     const int s_eff = causal ? (qb * 64 + 64 < S ? qb * 64 + 64 : S) : S;
@@ -723,9 +740,9 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, v
         for (int n = 0; n < 2; n++) {
             const int idx = t + 256 * n, key = ch * F32_KCH + (idx >> 4);
             const int ks = key < S ? key : S - 1;
-            const float *src = base + (long)ks * ld + (idx & 15) * 4;
-            rk[n] = *reinterpret_cast<const f32x4 *>(src + W);
-            rv[n] = *reinterpret_cast<const f32x4 *>(src + 2 * W);
+            const long src = base + (long)ks * ld + (idx & 15) * 4;
+            rk[n] = ld4(src + W);
+            rv[n] = ld4(src + 2 * W);
         }
     };
     auto stash = [&](int buf) {
@@ -743,6 +760,7 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const float *qkv, v
     // e^t as 2^(t log2 e) on v_exp_f32 (1 ulp), the product with log2 e = hi + lo carried to ~2^-48 relative (one fma):
     // three vector instructions and one transcendental instead of expf's twenty, the same accuracy class
     auto exp_e = [](float t) {
+        if constexpr (SIN) return __builtin_amdgcn_exp2f(t);
         return __builtin_amdgcn_exp2f(__builtin_fmaf(t, 1.4426950216293335f, t * 1.92596298909109e-8f));
     };
     fetch(0);
@@ -942,13 +960,38 @@ extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out
     const long blocks = (long)n_seq * heads * ((S + 63) / 64);
     EC_REQUIRE(blocks < (1L << 31), "ec_attention_f32: %ld workgroups", blocks);
     if (dtype == EC_F16)
-        hipLaunchKernelGGL(attention_f32m_kernel<EC_F16>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, out_hi, out_lo, S,
-                           width, heads, causal);
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_F16, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
+                           out_lo, S, width, heads, causal);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL(attention_f32m_kernel<EC_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, out_hi, out_lo, S,
-                           width, heads, causal);
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_BF16, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
+                           out_lo, S, width, heads, causal);
     else
         return ec::fail(EC_ERR_INVALID, "ec_attention_f32: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
+                                         int width, int heads, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention_split: bad shape");
+    EC_REQUIRE(width == heads * 64, "ec_attention_split: head dim must be 64");
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo, "ec_attention_split: null buffer");
+    EC_REQUIRE((((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+               "ec_attention_split: buffers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * S * S * 64.0 * heads * n_seq, (double)n_seq * S * width * 2.0 * 8.0);
+    const long blocks = (long)n_seq * heads * ((S + 63) / 64);
+    EC_REQUIRE(blocks < (1L << 31), "ec_attention_split: %ld workgroups", blocks);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_F16, true>), dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi,
+                           out_lo, S, width, heads, 0);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_BF16, true>), dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi,
+                           out_lo, S, width, heads, 0);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_attention_split: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -58,6 +58,14 @@ struct GemmArgs {
     const float *colsum;        // consumers: [N] sum over k of the (gamma-scaled, rounded) weight row
     float *stat_out;            // RESID_HL: optional [M][stat_groups][2] (sum, sum of squares) of the new hi plane per 64 columns
     int stat_groups;            // N / 64
+    // Split-precision products in ONE launch (ec_gemm_args.A_lo / W_lo): the reduction runs over nseg segments of K
+    // columns each, segment s multiplying the hi or the lo part of A by the hi or the lo part of W (the same row
+    // strides), all into the same accumulators -- [a_lo | a_hi | a_hi] . [w_hi | w_lo | w_hi] without the operands being
+    // laid out that way.
+    int nseg;
+    long seg_da, seg_dw;        // bytes from A / W (the hi parts) to the lo parts
+    unsigned seg_mask;          // bit s: segment s reads A's lo part; bit 4 + s: W's lo part
+    int stat_x;                 // RESID_HL row sums: of x = hi + lo (the fp32 value before the split) instead of the new hi plane
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -341,6 +349,9 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                                                 int lane, float *scratch, F &&between)
 {
     constexpr bool PIPE = (MODE & 1) != 0, GROW = (MODE & 2) != 0;
+    // bit 3: the row sums are those of x = hi + lo, the fp32 value BEFORE the split (what a consumer that multiplies
+    // both planes -- ec_gemm_args.A_lo -- normalises), instead of those of the new hi plane
+    constexpr bool XS = (MODE & 8) != 0;
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     constexpr int PITCH = 68;
@@ -410,8 +421,13 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                     const unsigned o2 = __builtin_bit_cast(unsigned, o);
                     const f16x2 d = {(_Float16)mix_sub16<0>(x0, o2), (_Float16)mix_sub16<1>(x1, o2)};
                     oh[p][k] = o2, ol[p][k] = __builtin_bit_cast(unsigned, d);
-                    ps[p] = mix_acc16<0>(o2, ps[p]), pq[p] = mix_sq16<0>(o2, pq[p]);
-                    ps[p] = mix_acc16<1>(o2, ps[p]), pq[p] = mix_sq16<1>(o2, pq[p]);
+                    if constexpr (XS) {
+                        ps[p] += x0, pq[p] = __builtin_fmaf(x0, x0, pq[p]);
+                        ps[p] += x1, pq[p] = __builtin_fmaf(x1, x1, pq[p]);
+                    } else {
+                        ps[p] = mix_acc16<0>(o2, ps[p]), pq[p] = mix_sq16<0>(o2, pq[p]);
+                        ps[p] = mix_acc16<1>(o2, ps[p]), pq[p] = mix_sq16<1>(o2, pq[p]);
+                    }
                 }
             } else {
                 const v8 vh = __builtin_bit_cast(v8, xh[i][p]);
@@ -424,7 +440,8 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                     wh[e] = to16(x, elem());
                     const float h = (float)wh[e];
                     wl[e] = (_Float16)(x - h);
-                    ps[p] += h, pq[p] = __builtin_fmaf(h, h, pq[p]);
+                    const float sv = XS ? x : h;
+                    ps[p] += sv, pq[p] = __builtin_fmaf(sv, sv, pq[p]);
                 }
                 oh[p] = __builtin_bit_cast(u32x4, wh), ol[p] = __builtin_bit_cast(u32x4, wl);
             }
@@ -458,7 +475,7 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
 // 16-bit outputs (STORE16 / GELU16 and their folded-LayerNorm forms).  lds_rowstat: the wave row's 128 statistics
 // pairs in LDS (has_lds; always a pointer INTO the shared array, so that the reads compile to ds_read and not to
 // flat loads, whose s_waitcnt vmcnt(0) lgkmcnt(0) also waited for the next tile's first K tile), else g.rowstat
-template <int DT, int EPI, int TM, bool HAS_LDS, bool EARLY = false, typename F>
+template <int DT, int EPI, int TM, bool HAS_LDS, bool EARLY = false, bool LOUT = false, typename F>
 __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
                                                int lane, unsigned char *scratch, const float *lds_rowstat, F &&between)
 {
@@ -524,6 +541,56 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
         *reinterpret_cast<u32x4 *>(buf + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
     };
+    if constexpr (LOUT) {
+        // Split output (ec_gemm_args.aux with an *_LN epilogue): C = hi = round16(v), aux = lo = round16(v - hi), the
+        // operand pair of a split-precision consumer (ec_gemm_args.A_lo; the attention of the split-operand blocks).
+        // One scratch buffer per part, no pipelining of the row groups (this form runs in a few blocks of the tolerance
+        // mode only); twice the stores.
+        const __amdgpu_buffer_rsrc_t rl = tile_rsrc(reinterpret_cast<char *>(g.aux) + ((long)m_base * g.ldc + n_base) * 2,
+                                                    tile_span(g.M, m_base, TM * 16, g.ldc * 2));
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            elem o[16], l[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f32x4 v;
+                if constexpr (epi_is_ln(EPI))
+                    v = acc[i][j] * rs0[i] + (cs[j] * rs1[i] + bias[j]);
+                else
+                    v = acc[i][j] + bias[j];
+                if constexpr (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_LN) v = quick_gelu4(v);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float x = v[r];
+                    asm volatile("" : "+v"(x));      // ONE rounded fp32 value for both parts (see attention_f32m_kernel)
+                    o[4 * j + r] = to16(x, elem());
+                    l[4 * j + r] = to16(x - (float)o[4 * j + r], elem());
+                }
+            }
+            unsigned char *b0 = scratch, *b1 = scratch + 16 * PITCH;
+            *reinterpret_cast<u32x4 *>(b0 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
+            *reinterpret_cast<u32x4 *>(b0 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
+            *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&l[0]);
+            *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&l[8]);
+            if (i == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                between();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            u32x4 t[2], u[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                t[p] = *reinterpret_cast<const u32x4 *>(b0 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
+                u[p] = *reinterpret_cast<const u32x4 *>(b1 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                bstore16(t[p], rc, voff + (2 * i + p) * step8);
+                bstore16(u[p], rl, voff + (2 * i + p) * step8);
+            }
+        }
+        return;
+    }
     produce(0);
     // The next tile's DMA is requested HERE, behind the first use of bias / column sums / row statistics: hipcc's
     // wait-count pass does not count the LDS-DMA requests when it waits for those loads (it asks for vmcnt(1) and
@@ -628,7 +695,12 @@ __device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm
 // prologue's HBM latency (~2.9 k cycles of a 48 k-cycle tile at K = 1024) is exposed.
 // TL: per-tile timeline records as in gemm2p_kernel<DBG = 9>.
 // ---------------------------------------------------------------------------------------
-template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT>
+// SEG: the reduction runs over g.nseg segments (split-precision operands, see GemmArgs): K tile t belongs to segment
+// t / (K / 64).  A segment's parts are reached by rebuilding the tile's descriptors on the other part at the segment
+// change (2 - 3 times per tile, scalar work; the instruction's scalar offset is no way there: it IS part of the range
+// check on gfx950 -- offset + soffset >= num_records reads zeros -- so a range that covers it no longer ends at the
+// tile's last row).  Region 1 is requested one K tile apart from regions 0, 2, 3 and has a descriptor of its own.
+template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
 __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 {
     typedef typename T16<DT>::v8 v8;
@@ -645,7 +717,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles_mn = g.tiles_m * g.tiles_n;
     const int ntiles = ntiles_mn * g.splits;   // K-batches are further tiles of the same launch
-    const int nk = g.K / BK;
+    static_assert(!SEG || !TN, "segments: row-major operands only");
+    const int nk = SEG ? g.nseg * (g.K / BK) : g.K / BK;
 
     auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
 
@@ -676,6 +749,16 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     }
     // transposed operands: reduction rows of this batch still to be issued per region (rows past k_valid read
     // tn_zero16), and the bytes one K tile advances an operand's pointer by
+    // SEG: regions 0, 2, 3 are always requested together (stream X, advanced behind region 3), region 1 a K tile apart
+    // (stream Y): bytes into the segment and the segment's index, per stream
+    int kx = 0, ky = 0, sx = 0, sy = 0;
+    const int kseg = g.K * 2;
+    __amdgpu_buffer_rsrc_t rsAy = rsA;
+    auto seg_rsrc = [&](int sg, bool w) {
+        const long d = ((g.seg_mask >> (w ? 4 + sg : sg)) & 1u) ? (w ? g.seg_dw : g.seg_da) : 0;
+        return w ? tile_rsrc(static_cast<const unsigned char *>(g.W) + (long)n0 * g.ldw * 2 + d, tile_span(g.N, n0, BN, g.ldw * 2))
+                 : tile_rsrc(static_cast<const unsigned char *>(g.A) + (long)m0 * g.lda * 2 + d, tile_span(g.M, m0, BM, g.lda * 2));
+    };
     int rem[4] = {0, 0, 0, 0};
     const long adv_a = TN ? (long)g.lda * BK * 2 : BK * 2, adv_w = TN ? (long)g.ldw * BK * 2 : BK * 2;
     auto setup = [&](int id) {
@@ -721,6 +804,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         rsW = tile_rsrc(static_cast<const unsigned char *>(g.W) + ((long)n0 * g.ldw + koff) * 2, tile_span(g.N, n0, BN, g.ldw * 2));
 #pragma unroll
         for (int r = 0; r < 4; r++) kk[r] = 0;
+        kx = ky = sx = sy = 0;
+        if constexpr (SEG) rsA = rsAy = seg_rsrc(0, false), rsW = seg_rsrc(0, true);
     };
     auto issue = [&](int r, int buf) {
         if (TN && rem[r] < BK) {       // the batch's last K tile runs past the rows that exist
@@ -733,6 +818,23 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         } else if constexpr (TN) {
 #pragma unroll
             for (int i = 0; i < 2; i++) glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
+        } else if constexpr (SEG) {
+            int &kb = r == 1 ? ky : kx, &sg = r == 1 ? sy : sx;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r == 1 ? rsAy : r == 0 ? rsA : rsW,
+                                                         (__attribute__((address_space(3))) void *)(smem + buf * KT + r * REGION + (i * 8 + wave) * 1024),
+                                                         16, (r < 2 ? vbA : vbW) + (srow[r][i] + kb), 0, 0, 0);
+            if (r == 1 || r == 3) {
+                kb += BK * 2;
+                if (kb == kseg) {
+                    kb = 0, sg++;
+                    if (sg < g.nseg) {
+                        if (r == 1) rsAy = seg_rsrc(sg, false);
+                        else rsA = seg_rsrc(sg, false), rsW = seg_rsrc(sg, true);
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -982,7 +1084,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         // wait-count pass what has completed.
         constexpr bool BUF_EPI = EPI == EC_EPI_RESID_HL || EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI) ||
                                  EPI == EC_EPI_STORE32 || EPI == EC_EPI_RESID32;
-        constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? 48 : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : 16;
+        constexpr bool LOUT = epi_is_ln(EPI) && (HLM & 16) != 0;      // 16-bit output as hi + lo parts (args.aux)
+        constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? 48 : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : LOUT ? 32 : 16;
         constexpr int enc_tail = (TAIL & 15) | (7 << 4) | (15 << 8) | ((TAIL >> 4) << 14);
         if constexpr (EPI == EC_EPI_RESID_HL)
             epilogue_hl_buf<DT, 8, HLM>(ge, acc, wm0, wn0, elane,
@@ -991,10 +1094,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             epilogue32_buf<EPI, 8, TN>(ge, acc, wm0, wn0, elane, reinterpret_cast<float *>(smem + KT) + wave * (16 * 68), next_tile);
         else if constexpr (BUF_EPI) {
             if (lds_stats)
-                epilogue16_buf<DT, EPI, 8, true, (HLM & 4) != 0>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
+                epilogue16_buf<DT, EPI, 8, true, (HLM & 4) != 0, LOUT>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
                                                  side + slot * 512 + wm * 256, next_tile);
             else
-                epilogue16_buf<DT, EPI, 8, false, (HLM & 4) != 0>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
+                epilogue16_buf<DT, EPI, 8, false, (HLM & 4) != 0, LOUT>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
         }
         else {    // the training epilogues (second output / second input): the general form
             next_tile();
@@ -1025,7 +1128,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     }
 }
 
-template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT> int launch2pp(const GemmArgs &g0, hipStream_t stream)
+template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
+int launch2pp(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
     g.tiles_m = ec::ceil_div(g.M, 256);
@@ -1033,18 +1137,22 @@ template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_D
     // two staging buffers + the row-statistics side area (LN epilogues) / the tail of the hi-lo epilogue's double
     // scratch (8 waves x 2 x 16 rows x 68 floats = 68 KiB from the second staging buffer on)
     constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 : 0);
-    auto kern = gemm2pp_kernel<DT, EPI, TL, TN, HLM>;
+    auto kern = gemm2pp_kernel<DT, EPI, TL, TN, HLM, SEG>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
     EC_REQUIRE(cus > 0, "ec_gemm: cannot read the device's compute-unit count");
     constexpr int cls = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU_BWD16 || EPI == EC_EPI_STORE16_LN) ? ec::PROF_GEMM_STORE16
                         : (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU16_LN) ? ec::PROF_GEMM_GELU16
                         : (EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI)) ? 2.0
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI)) ? (epi_is_ln(EPI) && (HLM & 16) ? 4.0 : 2.0)
                              : (EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU_BWD16) ? 4.0
                              : ((EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? 8.0 : 4.0);
-    ec::ProfScope prof(g.splits > 1 ? (int)ec::PROF_GEMM_DW : cls, stream, 2.0 * g.M * g.N * g.K * g.splits,
-                       (2.0 * g.M * g.K + 2.0 * g.N * g.K + out_b * g.M * g.N) * g.splits);
+    // segments: every product's flops; the bytes of the parts that exist (a part shared by two segments counts once)
+    const int nseg = SEG ? g.nseg : 1;
+    const unsigned full = (1u << nseg) - 1, ma = g.seg_mask & full, mw = (g.seg_mask >> 4) & full;
+    const int parts_a = SEG && ma != 0 && ma != full ? 2 : 1, parts_w = SEG && mw != 0 && mw != full ? 2 : 1;
+    ec::ProfScope prof(g.splits > 1 ? (int)ec::PROF_GEMM_DW : cls, stream, 2.0 * g.M * g.N * g.K * g.splits * nseg,
+                       (2.0 * g.M * g.K * parts_a + 2.0 * g.N * g.K * parts_w + out_b * g.M * g.N) * g.splits);
     const int tiles = g.tiles_m * g.tiles_n * g.splits;
     hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), lds, stream, g);
     EC_CHECK_HIP(hipGetLastError());
@@ -1101,6 +1209,34 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
 
 template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipStream_t s)
 {
+    constexpr int HLX = HL_MODE_DEFAULT | 8;     // hi-lo epilogue with the row sums of x = hi + lo
+    if (g.nseg > 1) {
+        // split-precision operands: the segmented main loop (default variant only)
+        EC_REQUIRE(variant == 0, "ec_gemm: A_lo / W_lo need variant 0");
+        switch (epi) {
+        case EC_EPI_STORE16: return launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_RESID32: return launch2pp<DT, EC_EPI_RESID32, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_RESID_HL:
+            EC_REQUIRE(g.aux, "ec_gemm: EC_EPI_RESID_HL needs args.aux (the lo plane)");
+            return g.stat_x ? launch2pp<DT, EC_EPI_RESID_HL, false, false, HLX, true>(g, s)
+                            : launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_STORE16_LN:
+            EC_REQUIRE(g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs row_stats and col_sums");
+            return g.aux ? launch2pp<DT, EC_EPI_STORE16_LN, false, false, HL_MODE_DEFAULT | 16, true>(g, s)      // (hi, lo) out
+                         : launch2pp<DT, EC_EPI_STORE16_LN, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_GELU16_LN:
+            EC_REQUIRE(g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs row_stats and col_sums");
+            return g.aux ? launch2pp<DT, EC_EPI_GELU16_LN, false, false, HL_MODE_DEFAULT | 16, true>(g, s)
+                         : launch2pp<DT, EC_EPI_GELU16_LN, false, false, HL_MODE_DEFAULT, true>(g, s);
+        default: return ec::fail(EC_ERR_INVALID, "ec_gemm: A_lo / W_lo go with the STORE16, STORE32, RESID32, RESID_HL and *_LN epilogues (got %d)", epi);
+        }
+    }
+    EC_REQUIRE(!(epi_is_ln(epi) && g.aux), "ec_gemm: an *_LN epilogue writes its lo part (args.aux) in the launches that take A_lo / W_lo only");
+    if (epi == EC_EPI_RESID_HL && g.stat_x) {
+        EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
+        return launch2pp<DT, EC_EPI_RESID_HL, false, false, HLX>(g, s);
+    }
     switch (epi) {
     case EC_EPI_STORE16: return dispatch_variant<DT, EC_EPI_STORE16>(g, variant, s);
     case EC_EPI_GELU16: return dispatch_variant<DT, EC_EPI_GELU16>(g, variant, s);
@@ -1240,6 +1376,22 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     g.stat_out = nullptr, g.stat_groups = 0;
+    g.nseg = 1, g.stat_x = a->row_sums_x != 0;
+    g.seg_da = g.seg_dw = g.seg_mask = 0;
+    if (a->A_lo || a->W_lo) {
+        // split-precision operands: up to three products into the same accumulators, the small ones first
+        // (a_lo . w + a . w_lo + a . w; a_lo . w_lo, ~2^-22 of the result, is left out)
+        EC_REQUIRE(!a->transposed && a->splits <= 1 && !a->ws && !a->resid && a->variant == 0,
+                   "ec_gemm: A_lo / W_lo take no transposed operands, splits, ws or resid, and variant 0");
+        EC_REQUIRE((((uintptr_t)a->A_lo | (uintptr_t)a->W_lo) & 15) == 0, "ec_gemm: A_lo / W_lo must be 16-byte aligned");
+        g.seg_da = a->A_lo ? (long)((intptr_t)a->A_lo - (intptr_t)a->A) : 0;
+        g.seg_dw = a->W_lo ? (long)((intptr_t)a->W_lo - (intptr_t)a->W) : 0;
+        int n = 0;
+        if (a->A_lo) g.seg_mask |= 1u << n, n++;             // a_lo . w
+        if (a->W_lo) g.seg_mask |= 1u << (4 + n), n++;       // a . w_lo
+        n++;                                                 // a . w
+        g.nseg = n;
+    }
     // what the epilogues read these with: row_stats by 16-byte LDS-DMA (two pairs at a time at stride 1, through a
     // descriptor whose range ends at pair M - 1: nothing past the array is read), col_sums as float4, row_sums written as float2
     EC_REQUIRE((((uintptr_t)a->row_stats | (uintptr_t)a->col_sums) & 15) == 0, "ec_gemm: row_stats / col_sums must be 16-byte aligned");

@@ -44,23 +44,28 @@ inline int gemm(int M, int N, int K, int dtype, int epi, const void *A, const vo
 }
 
 // the folded-LayerNorm forms (EC_EPI_RESID_HL: aux = lo plane; EC_EPI_*_LN: row statistics + column sums)
+// W_lo (split-precision blocks): the weight's lo part, one more MFMA product in the same launch; sums_x: the row
+// sums of x = hi + lo instead of the hi plane's (the GEMM that consumes them multiplies both planes)
 inline int gemm_hl(int M, int N, int K, int dtype, const void *A, const void *W, const float *bias, void *x_hi,
-                   void *x_lo, ec_stream_t s, long ldc = 0, float *row_sums = nullptr)
+                   void *x_lo, ec_stream_t s, long ldc = 0, float *row_sums = nullptr, const void *W_lo = nullptr,
+                   bool sums_x = false, const void *A_lo = nullptr)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = EC_EPI_RESID_HL, g.variant = 0;
     g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = x_hi, g.ldc = ldc ? ldc : N, g.aux = x_lo;
-    g.row_sums = row_sums;
+    g.row_sums = row_sums, g.W_lo = W_lo, g.row_sums_x = sums_x ? 1 : 0, g.A_lo = A_lo;
     return ec_gemm(&g, s);
 }
+// A_lo / W_lo (split-precision blocks): the lo plane of the residual stream / the lo part of the folded weight
 inline int gemm_ln(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
                    const float *row_stats, long row_stats_stride, const float *col_sums, void *C, ec_stream_t s,
-                   long ldc = 0, long lda = 0)
+                   long ldc = 0, long lda = 0, const void *A_lo = nullptr, const void *W_lo = nullptr, void *C_lo = nullptr)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
     g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
     g.row_stats = row_stats, g.row_stats_stride = row_stats_stride, g.col_sums = col_sums;
+    g.A_lo = A_lo, g.W_lo = W_lo, g.aux = C_lo;      // C_lo: the output's lo part (split-operand blocks)
     return ec_gemm(&g, s);
 }
 
@@ -77,15 +82,18 @@ int join_hl_rows(const void *x_hi, const void *x_lo, long ld, int rows, int widt
         if (_rc != EC_OK) return _rc; \
     } while (0)
 
-// Split-precision product: x.w = xh.wh + xh.wl + xl.wh accumulated in fp32 (three launches).
+// Split-precision product: x.w = xl.wh + xh.wl + xh.wh accumulated in fp32 -- ONE launch since round 5 (ec_gemm_args.A_lo /
+// W_lo: the three products run into the same accumulators; rounds 1 - 4 launched three GEMMs that read and wrote the
+// fp32 C twice more).  w_lo == NULL: the weight IS its 16-bit value (ec_vit_weights.weights_exact16), the product with
+// its lo part -- a sum of zeros -- is skipped, the same bits out.
 inline int gemm3(int M, int N, int K, int dtype, bool accumulate, const void *a_hi, const void *a_lo,
                  const void *w_hi, const void *w_lo, const float *bias, float *C, ec_stream_t s)
 {
-    EC_TRY(gemm(M, N, K, dtype, accumulate ? EC_EPI_RESID32 : EC_EPI_STORE32, a_hi, w_hi, bias, C, s));
-    // w_lo == NULL: the weight IS its 16-bit value (ec_vit_weights.weights_exact16), the product with its lo part is
-    // a sum of zeros -- skipped, the same bits out
-    if (w_lo) EC_TRY(gemm(M, N, K, dtype, EC_EPI_RESID32, a_hi, w_lo, nullptr, C, s));
-    return gemm(M, N, K, dtype, EC_EPI_RESID32, a_lo, w_hi, nullptr, C, s);
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = accumulate ? EC_EPI_RESID32 : EC_EPI_STORE32, g.variant = 0;
+    g.A = a_hi, g.lda = K, g.W = w_hi, g.bias = bias, g.C = C, g.ldc = N;
+    g.A_lo = a_lo, g.W_lo = w_lo;
+    return ec_gemm(&g, s);
 }
 
 // conv1 (kernel = stride = patch, no bias) as a GEMM over im2col rows, to fp32 accuracy: a patch

@@ -75,7 +75,7 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
 // (tools/bench_fold.py; 15.87 with a statistics pass over the hi plane instead of the epilogue's sums), same
 // rounding points.
 int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads, int dtype,
-                      const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled)
+                      const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled, int nsplit = 0, bool exact16 = false)
 {
     const int rows = n_seq * S;
     void *x_hi = b.x;
@@ -87,9 +87,23 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
     const bool fused = W % 64 == 0;
     float *sums = fused ? b.sums : nullptr;
     const int groups = W / 64;
-    EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+    // Split-operand blocks (ec_vit_weights.precise_blocks, round 5): the first nsplit blocks run the SAME chain with
+    // the two GEMMs that consume the residual stream multiplying BOTH planes (A = hi, A_lo = lo: the LayerNorm'd row
+    // enters at ~2^-22 instead of rounded to 16 bit) and every GEMM taking its weight's lo part where one exists --
+    // two or three MFMA products into the same accumulators of ONE launch (ec_gemm_args.A_lo / W_lo).  The row
+    // statistics such a GEMM normalises with are those of x = hi + lo (row_sums_x / ec_row_stats_hl).
+    EC_REQUIRE(nsplit >= 0 && nsplit < layers + (first_only ? 0 : 1), "folded chain: %d split-operand blocks of %d", nsplit, layers);
+    for (int l = 0; l < nsplit; l++)
+        EC_REQUIRE(exact16 || (blocks[l].qkv_w_ln_lo && blocks[l].out_w_lo && blocks[l].fc1_w_ln_lo && blocks[l].fc2_w_lo),
+                   "folded chain: split-operand block %d has no lo weight parts (and weights_exact16 is not set)", l);
+    EC_TRY(ec_row_stats_hl(x_hi, nsplit > 0 ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
+    // (measured with 16-bit attention in these blocks: configs[2] / [3] / [4] stay at 1.4e-3 .. 1.6e-3 -- where attention
+    // is sharp the rounding of q and k is the largest single contribution, profiles/r5_parity.txt)
+    EC_REQUIRE(nsplit == 0 || q_scaled, "folded chain: split-operand blocks take pre-scaled q rows (ec_vit_weights.q_scaled)");
+    const bool split_attn = true;
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
+        const bool sp = l < nsplit, sp_next = l + 1 < nsplit;
         if (first_only && l == layers - 1) {
             // the class-token-only last block (see run_blocks): keys and values of every token, the rest for row 0
             // of every sequence, the planes addressed at row stride S * W and the statistics at stride S
@@ -111,21 +125,35 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             EC_TRY(gemm_hl(n_seq, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, ldx));
             break;
         }
-        EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s));
-        EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
-                        : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
-        EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums));
+        if (sp && split_attn) {
+            // q | k | v as hi + lo parts (the lo parts in the MLP buffer, dead until c_fc), attention in fp32 on them,
+            // its output as hi + lo parts into out_proj
+            void *qkv_lo = b.mlp;
+            void *att_lo = static_cast<unsigned char *>(b.mlp) + (size_t)rows * 3 * W * esz;
+            EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s,
+                           0, 0, x_lo, w.qkv_w_ln_lo, qkv_lo));
+            EC_TRY(ec_attention_split(b.qkv, qkv_lo, b.h, att_lo, n_seq, S, W, heads, dtype, s));
+            EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums, w.out_w_lo, true, att_lo));
+        } else {
+            EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s,
+                           0, 0, sp ? x_lo : nullptr, sp ? w.qkv_w_ln_lo : nullptr));
+            EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
+                            : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
+            EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums, sp ? w.out_w_lo : nullptr, sp));
+        }
         if (fused)
             EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
         else
-            EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
-        EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s));
-        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, l + 1 < layers ? sums : nullptr));
+            EC_TRY(ec_row_stats_hl(x_hi, sp ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
+        EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s,
+                       0, 0, sp ? x_lo : nullptr, sp ? w.fc1_w_ln_lo : nullptr));
+        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, l + 1 < layers ? sums : nullptr,
+                       sp ? w.fc2_w_lo : nullptr, sp_next));
         if (l + 1 < layers) {
             if (fused)
                 EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
             else
-                EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+                EC_TRY(ec_row_stats_hl(x_hi, sp_next ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
         }
     }
     return EC_OK;
@@ -229,10 +257,6 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
     }
     BlockBufs b;
     carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
-    if (w->precise_blocks > 0) {     // the first blocks in split precision: both sets of buffers
-        PreciseBufs pb;
-        carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
-    }
     return sc.off + (w->low_latency ? LATENCY_WS_BYTES : 0);
 }
 
@@ -296,16 +320,15 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     void *cls16, *cls16_lo;
     int *idx;
     size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
-    // precise_blocks: the first blocks run the split-precision chain on an fp32 residual stream of their own
+    // precise_blocks: the first blocks of the folded chain multiply both planes of the residual stream and the
+    // weights' lo parts (run_blocks_folded)
     const int pblocks = w->precise_blocks;
-    PreciseBufs pb{};
     if (pblocks != 0) {
         EC_REQUIRE(pblocks > 0 && pblocks < w->layers && w->ln_folded && !w->low_latency,
                    "ec_vit_encode: precise_blocks=%d needs 0 < precise_blocks < layers=%d, ln_folded and no low_latency",
                    pblocks, w->layers);
-        void *p_hi, *p_lo;
-        int *pidx;
-        need = carve_precise(sc, chunk, S, W, pb, &p_hi, &p_lo, &pidx);
+        // the lo plane of the stream is fp16 whatever the operand type: only an f16 tower can multiply it
+        EC_REQUIRE(dt == EC_F16, "ec_vit_encode: precise_blocks needs dtype EC_F16 (the lo plane of the residual stream is fp16)");
     }
     // low-latency mode: under-filled GEMM launches (a few frames) run K-batched through this scratch
     struct ScratchGuard {
@@ -320,7 +343,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
                         need);
     const bool folded = w->ln_folded && !w->low_latency;
     if (folded)
-        for (int l = pblocks; l < w->layers; l++)
+        for (int l = 0; l < w->layers; l++)
             EC_REQUIRE(w->blocks[l].qkv_w_ln && w->blocks[l].qkv_cs && w->blocks[l].qkv_bf && w->blocks[l].fc1_w_ln &&
                            w->blocks[l].fc1_cs && w->blocks[l].fc1_bf,
                        "ec_vit_encode: ln_folded but block %d lacks its folded weights", l);
@@ -332,17 +355,9 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
         if (folded) {
             // residual stream as hi + lo planes in the fp32 stream's 4 bytes per element
             void *x_hi = b.x, *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)n * S * W * 2;
-            if (pblocks > 0) {
-                // the first blocks in split precision on the fp32 stream, which is then split into the planes
-                EC_TRY(ec_vit_embed(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, pb.x, stream));
-                EC_TRY(run_blocks_precise(w->blocks, pblocks, n, S, W, w->heads, 0, dt, pb, stream, w->weights_exact16 != 0));
-                EC_TRY(split_hl(pb.x, (long)n * S * W, x_hi, x_lo, dt, stream));
-            } else {
-                EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt,
-                                    stream));
-            }
-            EC_TRY(run_blocks_folded(w->blocks + pblocks, w->layers - pblocks, n, S, W, w->heads, dt, b, stream,
-                                     w->full_last_block == 0, w->q_scaled != 0));
+            EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt, stream));
+            EC_TRY(run_blocks_folded(w->blocks, w->layers, n, S, W, w->heads, dt, b, stream, w->full_last_block == 0,
+                                     w->q_scaled != 0, pblocks, w->weights_exact16 != 0));
             // the class rows back to fp32 (x = hi + lo) for ln_post; patch_out (the mlp buffer) is free by now
             EC_TRY(join_hl_rows(x_hi, x_lo, (long)S * W, n, W, patch_out, dt, stream));
             EC_TRY(ec_layernorm_split(patch_out, W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16, cls16_lo, W,

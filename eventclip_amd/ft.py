@@ -115,7 +115,8 @@ class VisualTower:
         W, D = self.W, self.D
         z16 = lambda *shape: torch.zeros(shape, dtype=self.cd, device=dev)      # noqa: E731
         self.packed = dict(conv=z16(W, self.kpad), conv_lo=z16(W, self.klo), conv_hi_tmp=z16(W, k),
-                           conv_lo_tmp=z16(W, k), proj_t=z16(D, W), proj_lo_tmp=z16(W, D), proj_lo_t=z16(D, W))
+                           conv_lo_tmp=z16(W, k), proj_lo_tmp=z16(W, D), proj_pair=z16(2, D, W))
+        self.packed['proj_t'], self.packed['proj_lo_t'] = self.packed['proj_pair'][0], self.packed['proj_pair'][1]
         shapes = dict(qkv_w=(3 * W, W), out_w=(W, W), fc1_w=(4 * W, W), fc2_w=(W, 4 * W))
         for i in range(self.L):
             for f in _MATRICES:

@@ -18,14 +18,17 @@ def dtype_code(t):
 
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
-         splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None):
+         splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None,
+         A_lo=None, W_lo=None, row_sums_x=False):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
     splits > 1: A [M, splits * K], W [N, splits * K] -> out [splits, M, N] partial products (fp32).
     LayerNorm folded into the GEMM: resid_hl (``out`` = the hi plane in A's dtype, ``aux`` = the fp16 lo plane, both
     updated in place: (hi, lo) <- split(hi + lo + acc + bias)); store16_ln / gelu16_ln (``row_stats`` fp32 [M, 2] =
-    (rstd, -rstd mean) of A's rows from ``row_stats``, ``col_sums`` fp32 [N] = row sums of W as rounded)."""
+    (rstd, -rstd mean) of A's rows from ``row_stats``, ``col_sums`` fp32 [N] = row sums of W as rounded).
+    Split-precision operands in one launch: ``A_lo`` / ``W_lo`` (the lo parts, same shapes and strides): out = epi(A_lo W^T + A W_lo^T + A W^T + bias);
+    ``row_sums_x``: resid_hl's row sums are those of hi + lo instead of the hi plane's."""
     import torch
     _lib.require_gpu()
     epi = {'store16': _lib.EC_EPI_STORE16, 'gelu16': _lib.EC_EPI_GELU16,
@@ -69,6 +72,13 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     if row_sums is not None:      # resid_hl: (sum, sum of squares) of the new hi plane per 64-column group
         assert row_sums.dtype == torch.float32 and row_sums.is_contiguous() and row_sums.numel() == M * (N // 64) * 2
         a.row_sums = row_sums.data_ptr()
+    if A_lo is not None:
+        assert A_lo.dtype == A.dtype and A_lo.shape == A.shape and A_lo.stride() == A.stride()
+        a.A_lo = A_lo.data_ptr()
+    if W_lo is not None:
+        assert W_lo.dtype == W.dtype and W_lo.shape == W.shape and W_lo.stride() == W.stride()
+        a.W_lo = W_lo.data_ptr()
+    a.row_sums_x = int(bool(row_sums_x))
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
@@ -102,6 +112,18 @@ def gemm_rows(A, W, splits=1, out=None):
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
+    return out
+
+
+def row_stats_hl(x_hi, x_lo, eps=1e-5):
+    """(rstd, -rstd * mean) of the rows of hi + lo (x_lo: the fp16 lo plane, same shape / stride) -> fp32 [rows, 2]."""
+    import torch
+    _lib.require_gpu()
+    rows, width = x_hi.shape
+    assert x_lo.dtype == torch.float16 and x_lo.shape == x_hi.shape and x_lo.stride() == x_hi.stride()
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x_hi.device)
+    _lib.check(_lib.lib().ec_row_stats_hl(x_hi.data_ptr(), x_lo.data_ptr(), x_hi.stride(0), rows, width, float(eps),
+                                          out.data_ptr(), dtype_code(x_hi.dtype), _lib.stream_ptr()), 'ec_row_stats_hl')
     return out
 
 

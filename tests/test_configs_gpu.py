@@ -153,9 +153,9 @@ def check(out, want, feats=None, emu=None, logit_tol=LOGIT_TOL, name='', min_sha
     assert torch.equal(out['valid_masks'].cpu(), want['valid_masks'])
     o = {k: v.cpu() for k, v in out.items()}
     e = logit_errors(o, want)
-    for k in ('full_logits', 'logits'):
-        assert e[k][0] < logit_tol, (k, e[k])
     if emu is None:
+        for k in ('full_logits', 'logits'):
+            assert e[k][0] < logit_tol, (k, e[k])
         return
     share = signal_share(feats)
     ee = logit_errors(emu, want)
@@ -166,6 +166,8 @@ def check(out, want, feats=None, emu=None, logit_tol=LOGIT_TOL, name='', min_sha
             f'; bound {logit_tol:.1e}')
     print('\n' + line)
     record_parity(line)
+    for k in ('full_logits', 'logits'):
+        assert e[k][0] < logit_tol, (k, e[k])
     assert share >= min_share, share
     # the yardstick: strictly on full_logits (every valid view); the aggregated logits of a handful of samples are
     # the same errors averaged over 1 .. T views and their maximum a single draw: 25 % slack there
@@ -260,9 +262,9 @@ def test_config1_signal_weights_other_tower_modes(hip, mode):
                    same bound as the default path;
       precise      ec_vit_weights.precise (hi + lo operands in every GEMM, 3 x the MFMA work): north_star's 1e-3
                    holds on these weights too -- the measured price of that tolerance is bench.py --precise;
-      first2 / first4   ec_vit_weights.precise_blocks: only the first 2 / 4 blocks in split precision (an early block's
-                   rounding error is carried through every later block); four blocks meet 1e-3 as well, at a fraction
-                   of the price (bench.py --precise-blocks 4);
+      first2 / first4   ec_vit_weights.precise_blocks: only the first 2 / 4 blocks as split-operand blocks (an early block's
+                   rounding error is carried through every later block); four blocks meet 1e-3 on this config, at a
+                   fraction of the price (bench.py --precise-blocks 4);
       f16_weights  the default tower on the same weights ROUNDED TO 16 BIT FIRST (oracle included): what a released
                    checkpoint is -- clip.load() on a GPU returns fp16 parameters (reference test.py:25-26) -- so the
                    rounding of the fp32 random weights, which the other cases count as the HIP path's error, is not

@@ -76,6 +76,34 @@ def test_attention_f32_matches_float64(S, heads, causal, n_seq, hip):
     assert err < 4e-6, err
 
 
+@pytest.mark.parametrize('S,heads,n_seq', [(257, 16, 3), (577, 4, 2), (50, 12, 4), (197, 3, 2), (1, 2, 2), (64, 1, 2), (65, 1, 2)])
+def test_attention_split_matches_float64(S, heads, n_seq, hip):
+    """ec_attention_split (the attention of the split-operand blocks): q | k | v as hi + lo fp16 parts, the q columns
+    pre-multiplied by log2(e) / sqrt(64), against a float64 softmax attention of the joined values."""
+    import torch
+    from eventclip_amd import _lib
+    W = heads * 64
+    g = torch.Generator(device='cuda').manual_seed(S * 17 + heads)
+    qkv = torch.randn(n_seq * S, 3 * W, device='cuda', generator=g) * 1.7
+    scaled = qkv.clone()
+    scaled[:, :W] *= 0.125 * 1.4426950408889634
+    pair = torch.empty((2, n_seq * S, 3 * W), dtype=torch.float16, device='cuda')
+    pair[0] = scaled.half()
+    pair[1] = (scaled - pair[0].float()).half()
+    joined = pair[0].double() + pair[1].double()
+    joined[:, :W] /= 1.4426950408889634       # back to q / 8 (natural-log softmax below)
+    hi = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
+    lo = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
+    _lib.check(_lib.lib().ec_attention_split(_lib.ptr(pair[0]), _lib.ptr(pair[1]), _lib.ptr(hi), _lib.ptr(lo), n_seq, S, W,
+                                             heads, _lib.EC_F16, _lib.stream_ptr()), 'ec_attention_split')
+    q, k, v = joined.view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = ((q @ k.transpose(-1, -2)).softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * S, W)
+    got = hi.double() + lo.double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 4e-6, err
+
+
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('S,heads,causal', [(50, 12, 0), (77, 8, 1), (77, 12, 1), (197, 12, 0),
                                             (257, 16, 0), (577, 16, 0), (17, 1, 0), (1, 2, 1)])
@@ -407,15 +435,20 @@ def test_chunked_encode_is_batch_invariant(hip):
 @pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
 def test_precise_blocks_tower(dt, hip):
     """ec_vit_weights.precise_blocks on a 4-block ViT-B/32: the error against the fp32 oracle falls with the number of
-    leading split-precision blocks (0 -> 1 -> 3), all of them but one is already close to the split-precision tower;
+    leading split-operand blocks (0 -> 1 -> 3), all of them but one is already close to the split-precision tower;
     chunked and whole-batch calls agree bit for bit; the class-token-only last block stays bit-identical; and the
-    packing refuses what the mode cannot do (every block, the plain chain, low latency)."""
+    packing refuses what the mode cannot do (every block, the plain chain, low latency, a bf16 tower: the lo plane of
+    the residual stream is fp16 and only an f16 MFMA can multiply it)."""
     import torch
     from eventclip_amd import clip as eclip
     from oracle import clip_ref
     cfg = eclip.arch_config('ViT-B/32', layers=4, text_layers=1, vocab_size=1024)
     sd = eclip.random_state_dict(cfg, seed=3, qk_gain=2.0, branch_gain=3.0)
     img = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    if dt == 'bfloat16':
+        with pytest.raises(ValueError):
+            eclip.CLIP(cfg, sd, dtype=dt, image_precise_blocks=2).cuda().encode_image(img.cuda())
+        return
     want = clip_ref.encode_image(sd, cfg, img)
     errs = {}
     for n in (0, 1, 3):
@@ -436,8 +469,10 @@ def test_precise_blocks_tower(dt, hip):
 
 def test_weights_stored_in_16_bit_skip_the_lo_product(hip):
     """ec_vit_weights.weights_exact16: on a checkpoint whose matrices are 16-bit values already (what clip.load() returns
-    on a GPU) the split-precision blocks pass NULL lo parts and run two MFMA products per GEMM instead of three; the
-    skipped product is a sum of zeros, so the features are bit-identical to the three-product form."""
+    on a GPU) the split-precision blocks pass NULL lo parts and run one MFMA product per GEMM less; the skipped product
+    is a sum of zeros, so the features are bit-identical to the form that multiplies the zeros.  (In a split-operand
+    block -- precise_blocks -- that holds for out_proj / c_proj; in_proj and c_fc are multiplied by the LayerNorm gain
+    before the split, which leaves them a lo part.)"""
     import torch
     from eventclip_amd import clip as eclip
     cfg = eclip.arch_config('ViT-B/32', layers=3, text_layers=1, vocab_size=1024)
@@ -449,7 +484,8 @@ def test_weights_stored_in_16_bit_skip_the_lo_product(hip):
         three.keep_zero_lo = True
         a, b = two.encode_image(img), three.encode_image(img)
         assert two._pack()['vit'].weights_exact16 == 1 and three._pack()['vit'].weights_exact16 == 0
-        assert two._pack()['vb'][0].qkv_w_lo is None and three._pack()['vb'][0].qkv_w_lo is not None
+        field = 'qkv_w_lo' if 'image_precise' in kw else 'out_w_lo'
+        assert getattr(two._pack()['vb'][0], field) is None and getattr(three._pack()['vb'][0], field) is not None
         assert torch.equal(a, b)
 
 

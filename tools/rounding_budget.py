@@ -8,7 +8,7 @@ group causes alone, all of them together, and all but one.  The groups:
   patch   pixel values and conv1.weight rounded (the patch-embedding GEMM operands)
   h       ln_1 / ln_2 outputs rounded (A operands of QKV and c_fc)
   wqkv wout wfc1 wfc2   the four block weights rounded
-  qkv     QKV GEMM output rounded (attention operands)
+  qkv     QKV GEMM output rounded (attention operands); in plans also 'qk' (q and k only) and 'v'
   p       softmax probabilities rounded (P operand of P.V)
   att     attention output rounded (A operand of out_proj)
   gelu    QuickGELU output rounded (A operand of c_proj)
@@ -44,6 +44,8 @@ def tower(sd, cfg, image, on, rnd, first_layer=0, last_layer=None):
     heads = W // 64
 
     def q(name, x, l=None):
+        if callable(on):      # a plan: on(group, block) -> bool (block None for patch / post)
+            return rnd(x) if on(name, l) else x
         if name not in on:
             return x
         if l is not None and not (first_layer <= l < last_layer):
@@ -62,6 +64,7 @@ def tower(sd, cfg, image, on, rnd, first_layer=0, last_layer=None):
         qkv = q('qkv', F.linear(h, q('wqkv', sd[p + 'attn.in_proj_weight'], l),
                                 sd[p + 'attn.in_proj_bias']), l)
         qq, kk, vv = qkv.split(W, dim=-1)
+        qq, kk, vv = q('qk', qq, l), q('qk', kk, l), q('v', vv, l)      # (finer than 'qkv': plans only)
         qq = qq.view(N, S, heads, 64).transpose(1, 2)
         kk = kk.view(N, S, heads, 64).transpose(1, 2)
         vv = vv.view(N, S, heads, 64).transpose(1, 2)
@@ -145,6 +148,21 @@ def main():
         for grp in ([] if a.mixes_only else GROUPS):
             report(f'all but {grp}', [x for x in GROUPS if x != grp])
         for mix in [m for m in a.mixes.split(',') if m]:
+            if ';' in mix:
+                # a plan: 'groups@a:b;groups@c:d;...' -- the union of (group, block range) pairs that stay rounded
+                parts = []
+                for part in mix.split(';'):
+                    spec, _, rng = part.partition('@')
+                    lo, hi = (rng.split(':') if rng else (0, a.layers))
+                    parts.append((set(x for x in spec.split('+') if x), int(lo), int(hi)))
+
+                def plan(name, l, parts=parts):
+                    return any(name in g and (l is None or lo <= l < hi) for g, lo, hi in parts)
+                f = tower(sd, cfg, imgs, plan, rnd)
+                ef = float((f - ref).abs().max() / ref.abs().max())
+                el = float((logits(f) - lref).abs().max() / lref.abs().max())
+                print(f'plan {mix:60s} feats {ef:.2e}  logits {el:.2e}', flush=True)
+                continue
             spec, _, rng = mix.partition('@')
             kw = {}
             if rng:
