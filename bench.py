@@ -323,10 +323,56 @@ def self_launch(a):
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env = dict(os.environ)       # (the ranks themselves decide about HSA_ENABLE_IPC_MODE_LEGACY: dist_env below)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def dist_diag(rank, local, what):
+    """One readable block on stderr when the collective library does not come up: which rank, which device, and the
+    environment RCCL / the HSA runtime read."""
+    keys = sorted(k for k in os.environ if k.startswith(('HSA_', 'NCCL_', 'RCCL_', 'MASTER_', 'HIP_VISIBLE', 'ROCR_VISIBLE',
+                                                         'CUDA_VISIBLE', 'GPU_DEVICE')) or
+                  k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'EVENTCLIP_DIST_BACKEND'))
+    env = ' '.join(f'{k}={os.environ[k]}' for k in keys)
+    sys.stderr.write(f'[bench] rank {rank} on {socket.gethostname()}:cuda{local} ({torch.cuda.device_count()} visible GPU(s)): '
+                     f'{what}\n[bench]   env: {env}\n')
+    sys.stderr.flush()
+
+
+def dist_init(a, world, rank, local, backend):
+    """init_process_group with a SHORT timeout and, right behind it, one 4-byte all-gather under a watchdog -- before
+    any weight packing or data generation, so that a fabric / IPC set-up that does not work costs seconds and leaves a
+    readable diagnostic instead of the driver's time limit.  On expiry the watchdog prints and leaves with a fresh
+    exit (never a re-exec: the GPU is initialised)."""
+    import datetime
+    import threading
+    limit = float(os.environ.get('EVENTCLIP_DIST_TIMEOUT', '120'))
+
+    def expired():
+        dist_diag(rank, local, f'no answer from the {backend} first all-gather within {limit:.0f} s -- giving up '
+                               '(P2P / IPC set-up between the ranks? see DESIGN.md 5)')
+        os._exit(3)
+    dog = threading.Timer(limit, expired)
+    dog.daemon = True
+    dog.start()
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local),
+                                    timeout=datetime.timedelta(seconds=limit))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=limit))
+        mine = torch.full((1,), rank, dtype=torch.int32, device='cuda')
+        seen = torch.empty(world, dtype=torch.int32, device='cuda')
+        dist.all_gather_into_tensor(seen, mine)
+        torch.cuda.synchronize()
+        assert seen.tolist() == list(range(world)), f'first all-gather returned {seen.tolist()}'
+    except BaseException as e:      # noqa: BLE001 -- whatever the library raises: say where, then fail
+        dog.cancel()
+        dist_diag(rank, local, f'{backend} did not come up: {type(e).__name__}: {str(e)[:500]}')
+        raise SystemExit(3)
+    dog.cancel()
 
 
 def main():
@@ -336,19 +382,28 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     # one process per GPU over RCCL; EVENTCLIP_DIST_BACKEND=gloo lets two ranks share one GPU so the
     # N > 1 code path can be exercised on a single-GPU box (a functional check, not a measurement)
     backend = os.environ.get('EVENTCLIP_DIST_BACKEND', 'nccl')
-    local = local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # HSA_ENABLE_IPC_MODE_LEGACY: this pool's host driver supports dmabuf IPC only (the platform note of this build:
+        # without the variable at 0, RCCL's P2P set-up fails in hipIpcGetMemHandle).  The launch environment's value is
+        # never overridden; when there is none, 0 is set and said so.
+        if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ:
+            os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+            if rank == 0:
+                sys.stderr.write('[bench] HSA_ENABLE_IPC_MODE_LEGACY was unset: using 0 (dmabuf IPC)\n')
+    n_dev = torch.cuda.device_count()
+    # EVENTCLIP_DIST_SHARE_DEVICE=1 (tests): ranks wrap around the devices that exist even under nccl
+    share = backend != 'nccl' or os.environ.get('EVENTCLIP_DIST_SHARE_DEVICE', '0') not in ('', '0')
+    if world > 1 and not share and local >= n_dev:
+        dist_diag(rank, local, f'LOCAL_RANK {local} has no GPU of its own ({n_dev} visible): RCCL needs one device per rank')
+        sys.exit(3)
+    local = local % max(n_dev, 1) if share else local
     torch.cuda.set_device(local)
     if world > 1:
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend)
+        dist_init(a, world, rank, local, backend)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     # proof that the collective library saw every rank: world size after init and each rank's device
     ranks_seen, devices = 1, [local]

@@ -104,7 +104,8 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
-                ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int), ('precise_blocks', c_int), ('weights_exact16', c_int)]
+                ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int), ('precise_blocks', c_int), ('precise_attn_blocks', c_int),
+                ('weights_exact16', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):
@@ -228,8 +229,9 @@ SIGNATURES = {
     'ec_randaugment_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     'ec_randaugment': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                c_void_p, ctypes.c_size_t, c_void_p]),
-    'ec_classify': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ec_classify_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
+    'ec_classify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     'ec_attention_train': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),

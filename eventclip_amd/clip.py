@@ -168,12 +168,15 @@ def _assign(root, key, tensor):
     m.register_parameter(parts[-1], nn.Parameter(tensor.clone().float(), requires_grad=False))
 
 
+DEFAULT_PRECISE_ATTN_BLOCKS = 4     # of the split-operand blocks (image_precise_blocks), how many run fp32 attention
+
+
 class CLIP(nn.Module):
     """Frozen CLIP (ViT image tower + text tower) running on hand-written HIP kernels."""
 
     def __init__(self, cfg, state_dict, dtype='float16', chunk=2560, text_precise=True,
                  image_precise=False, full_last_block=None, low_latency=False, ln_folded=None, q_scaled=True,
-                 image_precise_blocks=None):
+                 image_precise_blocks=None, image_precise_attn_blocks=None):
         super().__init__()
         self.cfg = dict(cfg)
         for k in ('input_resolution', 'context_length', 'vocab_size'):
@@ -220,6 +223,10 @@ class CLIP(nn.Module):
                               f'float16, no low_latency / image_precise, and fewer than layers={cfg["layers"]} blocks)')
                 image_precise_blocks = 0
         self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
+        # ... of which the first few also run attention in fp32 on hi + lo q, k, v (ec_vit_weights.precise_attn_blocks)
+        if image_precise_attn_blocks is None:
+            image_precise_attn_blocks = int(os.environ.get('EVENTCLIP_PRECISE_ATTN_BLOCKS', str(DEFAULT_PRECISE_ATTN_BLOCKS)))
+        self.image_precise_attn_blocks = max(0, min(int(image_precise_attn_blocks), self.image_precise_blocks))
         # bytes of tower scratch at most
         self.workspace_budget = 24 << 30
         self._packed = None
@@ -379,6 +386,7 @@ class CLIP(nn.Module):
                 raise ValueError(f'image_precise_blocks={self.image_precise_blocks} needs 0 < n < layers={c["layers"]}, '
                                  'ln_folded, float16 and no low_latency')
         v.precise_blocks = self.image_precise_blocks
+        v.precise_attn_blocks = self.image_precise_attn_blocks
         v.conv_w_lo = dev16_pair(conv_lo)[1]
         vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
                     ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)

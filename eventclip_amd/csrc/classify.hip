@@ -1,4 +1,4 @@
-// Logits, view aggregation and probabilities (gfx950, fp32).
+// Logits, view aggregation and probabilities (gfx950).
 //
 // Replaces the tail of the reference classifiers' forward:
 //   ZSCLIPClassifier.forward  models/clip_cls.py:148-154
@@ -9,28 +9,21 @@
 //   FSCLIPClassifier.forward  models/clip_cls.py:326-343
 //     F.normalize(feats), zero invalid views, the same logits / aggregation.
 //
-// One 256-thread workgroup per sample.  The sample's <= 16 view features sit in LDS
-// (gathered through row_idx, so the ragged `imgs[valid_masks]` batch never needs a
-// boolean gather/scatter); thread k walks column k of the transposed text matrix
-// (coalesced) and accumulates all views at once.  The work is tiny (<= 31 GFLOP
-// per batch at 1000 classes) and stays in fp32 so the logits carry no extra
-// rounding.
+// Round 5: the product [n_rows, C] x [C, K] runs on the matrix pipe (rounds 1 - 4: a scalar fp32 kernel, 5.8 ms for
+// the 31 GFLOP of configs[4]) WITHOUT giving up fp32 accuracy -- both operands as hi + lo fp16 parts, three MFMA
+// products in one ec_gemm launch (ec_gemm_args.A_lo / W_lo, EC_EPI_STORE32):
+//   classify_prep_rows   feats row -> (F.normalize,) x 2^e (e per row: the row's largest element lands in [2^10, 2^11),
+//                        so the lo parts are normal fp16 numbers) -> hi | lo, and the row's 2^-e
+//   classify_prep_text   text_t [C, K] -> [K16, C64] hi | lo, x 2^12 (unit rows)
+//   ec_gemm              raw [n_rows, K16] fp32
+//   classify_aggregate   per sample: logit = logit_scale 2^-e 2^-12 raw (powers of two: exact), softmax per view,
+//                        aggregation over the valid views.
 #include "common.h"
 
 namespace {
 
 constexpr int CL_THREADS = 256;
 constexpr int CL_MAXT = 16;
-
-struct ClsArgs {
-    const float *feats;
-    const int *row_idx;
-    const float *text_t;
-    int B, T, C, K;
-    float scale;
-    int agg, normalize;
-    float *full_logits, *logits, *probs;
-};
 
 __device__ __forceinline__ float wave_red_sum(float v)
 {
@@ -67,63 +60,87 @@ __device__ void block_reduce(float (&v)[CL_MAXT], int T, float *red)
         }
 }
 
-__global__ __launch_bounds__(CL_THREADS) void classify_kernel(const ClsArgs a)
+// One wave per row: (L2-normalise,) scale by a power of two, split into fp16 hi + lo, columns C .. Cp - 1 zero.
+__global__ __launch_bounds__(256) void classify_prep_rows(const float *feats, int n_rows, int C, int Cp, int normalize,
+                                                          _Float16 *hi, _Float16 *lo, float *inv_scale)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *f = sm;                        // [T][C]
-    float *red = sm + a.T * a.C;          // [4][CL_MAXT]
-    __shared__ int s_row[CL_MAXT];
-    const int b = blockIdx.x, T = a.T, C = a.C, K = a.K;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float *f = feats + row * C;
+    float ss = 0.f, mx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = f[c];
+        ss = fmaf(v, v, ss), mx = fmaxf(mx, fabsf(v));
+    }
+    ss = wave_red_sum(ss), mx = wave_red_max(mx);
+    // F.normalize(p=2, dim=-1, eps=1e-12): v / max(||v||, eps), the division as the reference does it
+    const float d = normalize ? fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+    if (normalize) mx = mx / d;
+    // 2^e with mx 2^e in [2^10, 2^11); a zero / non-finite row keeps scale 1
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) e = 10 - (int)floorf(log2f(mx));
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    const float sc = ldexpf(1.f, e);
+    for (int c = lane; c < Cp; c += 64) {
+        float v = 0.f;
+        if (c < C) v = (normalize ? f[c] / d : f[c]) * sc;
+        const _Float16 h = (_Float16)v;
+        hi[row * Cp + c] = h;
+        lo[row * Cp + c] = (_Float16)(v - (float)h);
+    }
+    if (lane == 0) inv_scale[row] = ldexpf(1.f, -e);
+}
 
-    if (threadIdx.x < T) s_row[threadIdx.x] = a.row_idx[b * T + threadIdx.x];
+// text_t fp32 [C, K] -> rows k of [Kp, Cp] fp16 hi | lo, x 2^12; rows K .. Kp - 1 and columns C .. Cp - 1 zero
+constexpr int CL_TEXT_SHIFT = 12;
+__global__ __launch_bounds__(256) void classify_prep_text(const float *text_t, int C, int K, int Cp, int Kp, _Float16 *hi,
+                                                          _Float16 *lo)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Kp * Cp) return;
+    const int k = (int)(i / Cp), c = (int)(i - (long)k * Cp);
+    float v = 0.f;
+    if (k < K && c < C) v = ldexpf(text_t[(long)c * K + k], CL_TEXT_SHIFT);
+    const _Float16 h = (_Float16)v;
+    hi[i] = h;
+    lo[i] = (_Float16)(v - (float)h);
+}
+
+struct AggArgs {
+    const float *raw;         // [n_rows, Kp] fp32: (feats 2^e) . (text 2^12)
+    const float *inv_scale;   // [n_rows] 2^-e
+    const int *row_idx;
+    int B, T, K, Kp;
+    float scale;              // logit_scale 2^-12
+    int agg;
+    float *full_logits, *logits, *probs;
+};
+
+__global__ __launch_bounds__(CL_THREADS) void classify_aggregate_kernel(const AggArgs a)
+{
+    __shared__ float red[4 * CL_MAXT];
+    __shared__ int s_row[CL_MAXT];
+    __shared__ float s_mul[CL_MAXT];
+    const int b = blockIdx.x, T = a.T, K = a.K;
+    if (threadIdx.x < T) {
+        const int r = a.row_idx[b * T + threadIdx.x];
+        s_row[threadIdx.x] = r;
+        s_mul[threadIdx.x] = r >= 0 ? a.scale * a.inv_scale[r] : 0.f;
+    }
     __syncthreads();
     int n_valid = 0;
     for (int t = 0; t < T; t++) n_valid += s_row[t] >= 0;
-
-    // ---- gather the view features (zeros for invalid views) ----
-    for (int i = threadIdx.x; i < T * C; i += CL_THREADS) {
-        const int t = i / C, c = i - t * C;
-        f[i] = s_row[t] >= 0 ? a.feats[(long)s_row[t] * C + c] : 0.f;
-    }
-    __syncthreads();
-    if (a.normalize) {                    // F.normalize(p=2, dim=-1, eps=1e-12)
-        float ss[CL_MAXT];
-#pragma unroll
-        for (int t = 0; t < CL_MAXT; t++) {
-            float s = 0.f;
-            if (t < T)
-                for (int c = threadIdx.x; c < C; c += CL_THREADS) s += f[t * C + c] * f[t * C + c];
-            ss[t] = s;
-        }
-        block_reduce<false>(ss, T, red);
-#pragma unroll
-        for (int t = 0; t < CL_MAXT; t++)
-            if (t < T) {
-                const float d = fmaxf(sqrtf(ss[t]), 1e-12f);
-                for (int c = threadIdx.x; c < C; c += CL_THREADS) f[t * C + c] = f[t * C + c] / d;
-            }
-        __syncthreads();
-    }
-
-    // ---- logits: thread k owns class k (+256, ...) for every view ----
+    // ---- logits of every view (invalid views: zeros, clip_cls.py:151-152), per-view maximum ----
     float *fl = a.full_logits + (long)b * T * K;
     float vmax[CL_MAXT], vsum[CL_MAXT];
 #pragma unroll
     for (int t = 0; t < CL_MAXT; t++) vmax[t] = -INFINITY;
     for (int k = threadIdx.x; k < K; k += CL_THREADS) {
-        float acc[CL_MAXT];
-#pragma unroll
-        for (int t = 0; t < CL_MAXT; t++) acc[t] = 0.f;
-        for (int c = 0; c < C; c++) {
-            const float w = a.text_t[(long)c * K + k];
-#pragma unroll
-            for (int t = 0; t < CL_MAXT; t++)
-                if (t < T) acc[t] = fmaf(f[t * C + c], w, acc[t]);
-        }
 #pragma unroll
         for (int t = 0; t < CL_MAXT; t++)
             if (t < T) {
-                const float l = s_row[t] >= 0 ? a.scale * acc[t] : 0.f;
+                const float l = s_row[t] >= 0 ? s_mul[t] * a.raw[(long)s_row[t] * a.Kp + k] : 0.f;
                 fl[(long)t * K + k] = l;
                 vmax[t] = fmaxf(vmax[t], l);
             }
@@ -138,7 +155,6 @@ __global__ __launch_bounds__(CL_THREADS) void classify_kernel(const ClsArgs a)
             if (t < T) vsum[t] += expf(fl[(long)t * K + k] - vmax[t]);
     }
     block_reduce<false>(vsum, T, red);
-
     // ---- aggregate over views ----
     const float nv = (float)n_valid;
     for (int k = threadIdx.x; k < K; k += CL_THREADS) {
@@ -160,29 +176,70 @@ __global__ __launch_bounds__(CL_THREADS) void classify_kernel(const ClsArgs a)
     }
 }
 
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct ClsCarve {
+    size_t a_hi, a_lo, w_hi, w_lo, inv, raw, total;
+    int Cp, Kp;
+};
+ClsCarve cls_carve(int n_rows, int C, int K)
+{
+    ClsCarve c;
+    c.Cp = (C + 63) / 64 * 64, c.Kp = (K + 15) / 16 * 16;
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t at = off; off += up256(b); return at; };
+    c.a_hi = take((size_t)n_rows * c.Cp * 2), c.a_lo = take((size_t)n_rows * c.Cp * 2);
+    c.w_hi = take((size_t)c.Kp * c.Cp * 2), c.w_lo = take((size_t)c.Kp * c.Cp * 2);
+    c.inv = take((size_t)n_rows * 4), c.raw = take((size_t)n_rows * c.Kp * 4);
+    c.total = off;
+    return c;
+}
+
 }  // namespace
 
-extern "C" EC_API int ec_classify(const float *feats, const int32_t *row_idx, const float *text_t,
+extern "C" EC_API size_t ec_classify_workspace_bytes(int n_rows, int C, int K)
+{
+    if (n_rows <= 0 || C <= 0 || K <= 0) return 0;
+    return cls_carve(n_rows, C, K).total;
+}
+
+extern "C" EC_API int ec_classify(const float *feats, int n_rows, const int32_t *row_idx, const float *text_t,
                                   int B, int T, int C, int K, float logit_scale, int agg,
                                   int normalize, float *full_logits, float *logits, float *probs,
-                                  ec_stream_t stream)
+                                  void *workspace, size_t workspace_bytes, ec_stream_t stream)
 {
-    EC_REQUIRE(B >= 0 && T > 0 && T <= CL_MAXT && C > 0 && K > 0,
-               "ec_classify: bad shape B=%d T=%d C=%d K=%d (T <= %d)", B, T, C, K, CL_MAXT);
+    EC_REQUIRE(B >= 0 && T > 0 && T <= CL_MAXT && C > 0 && K > 0 && n_rows >= 0,
+               "ec_classify: bad shape n_rows=%d B=%d T=%d C=%d K=%d (T <= %d)", n_rows, B, T, C, K, CL_MAXT);
     EC_REQUIRE(agg == EC_AGG_SUM || agg == EC_AGG_MEAN || agg == EC_AGG_MAX,
                "ec_classify: unknown agg %d", agg);   // clip_cls.py:53
     if (B == 0) return EC_OK;
-    EC_REQUIRE(feats && row_idx && text_t && full_logits && logits && probs,
-               "ec_classify: null buffer");
-    ClsArgs a;
-    a.feats = feats, a.row_idx = row_idx, a.text_t = text_t;
-    a.B = B, a.T = T, a.C = C, a.K = K, a.scale = logit_scale, a.agg = agg, a.normalize = normalize;
+    EC_REQUIRE(row_idx && text_t && full_logits && logits && probs && (feats || n_rows == 0), "ec_classify: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ec::ProfScope prof(ec::PROF_CLASSIFY, s, 2.0 * n_rows * C * K, 0);
+    const ClsCarve c = cls_carve(n_rows > 0 ? n_rows : 1, C, K);
+    EC_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "ec_classify: workspace must be 256-byte aligned");
+    if (workspace_bytes < c.total)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_classify: workspace %zu < %zu bytes (ec_classify_workspace_bytes)", workspace_bytes, c.total);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    _Float16 *a_hi = reinterpret_cast<_Float16 *>(ws + c.a_hi), *a_lo = reinterpret_cast<_Float16 *>(ws + c.a_lo);
+    _Float16 *w_hi = reinterpret_cast<_Float16 *>(ws + c.w_hi), *w_lo = reinterpret_cast<_Float16 *>(ws + c.w_lo);
+    float *inv = reinterpret_cast<float *>(ws + c.inv), *raw = reinterpret_cast<float *>(ws + c.raw);
+    if (n_rows > 0) {
+        hipLaunchKernelGGL(classify_prep_rows, dim3(ec::ceil_div(n_rows, 4)), dim3(256), 0, s, feats, n_rows, C, c.Cp, normalize,
+                           a_hi, a_lo, inv);
+        const long nt = (long)c.Kp * c.Cp;
+        hipLaunchKernelGGL(classify_prep_text, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, text_t, C, K, c.Cp, c.Kp, w_hi,
+                           w_lo);
+        EC_CHECK_HIP(hipGetLastError());
+        ec_gemm_args g = {};
+        g.M = n_rows, g.N = c.Kp, g.K = c.Cp, g.dtype = EC_F16, g.epilogue = EC_EPI_STORE32, g.variant = 0;
+        g.A = a_hi, g.lda = c.Cp, g.W = w_hi, g.ldw = c.Cp, g.C = raw, g.ldc = c.Kp, g.A_lo = a_lo, g.W_lo = w_lo;
+        if (int rc = ec_gemm(&g, stream)) return rc;
+    }
+    AggArgs a;
+    a.raw = raw, a.inv_scale = inv, a.row_idx = row_idx, a.B = B, a.T = T, a.K = K, a.Kp = c.Kp;
+    a.scale = ldexpf(logit_scale, -CL_TEXT_SHIFT), a.agg = agg;
     a.full_logits = full_logits, a.logits = logits, a.probs = probs;
-    const int lds = (T * C + 4 * CL_MAXT) * 4;
-    EC_REQUIRE(lds <= 64 * 1024, "ec_classify: T*C=%d too large for LDS", T * C);
-    ec::ProfScope prof(ec::PROF_CLASSIFY, static_cast<hipStream_t>(stream), 2.0 * B * T * C * K, 0);
-    hipLaunchKernelGGL(classify_kernel, dim3(B), dim3(CL_THREADS), lds,
-                       static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(classify_aggregate_kernel, dim3(B), dim3(CL_THREADS), 0, s, a);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -258,8 +258,9 @@ __device__ __forceinline__ void epilogue16_lds(const GemmArgs &g, f32x4 (&acc)[T
 //    The hardware's range check drops the stores and zeroes the loads of rows >= M and columns >= N, so edge
 //    tiles and interior tiles run the SAME predicate-free code (a row's result cannot depend on which of the two
 //    its tile is in this launch: batch invariance), and every store instruction is always issued, which is what
-//    the counted hand-over wait of the tile loop needs.  (The offset that is range-checked is the vector one;
-//    a scalar offset would bypass the check.)
+//    the counted hand-over wait of the tile loop needs.  (What is range-checked on gfx950 is the SUM of the vector
+//    and the scalar offset -- measured in round 5, when a segment's part addressed through the scalar offset read
+//    zeros: the row / column offsets here are vector offsets and the scalar one stays 0.)
 //  * The general forms above spend 64 - 80 quarter-rate v_mul_lo_u32 / v_mad_u64_u32 and ~100 64-bit vector adds
 //    per wave tile on `(long)m * ldc + col` -- more vector-ALU time than the arithmetic of the epilogue itself
 //    (tile timelines: profiles/r4_gemm.md).  They stay for the diagnostic kernels and the training epilogues.
@@ -283,7 +284,10 @@ __device__ __forceinline__ void bstore16(u32x4 v, __amdgpu_buffer_rsrc_t r, int 
 {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 }
-constexpr int BUF_OOB = 0x7ffffff0;     // a vector offset no tile's range reaches: loads give 0, stores are dropped
+// a vector offset no tile's range reaches (a tile spans <= 256 rows x stride < 2^21 elements x 4 bytes = 2^31 is excluded by
+// ec_gemm's checks: spans stay <= 2^30): loads give 0, stores are dropped.  0x40000000 and not INT_MAX: the row-group
+// steps added to it (<= 31 x 16 x stride bytes < 2^30) must not overflow a signed int.
+constexpr int BUF_OOB = 0x40000000;
 // rows of a TMx16-row wave tile at m_base that exist, as a byte range of `pitch`-byte rows
 __device__ __forceinline__ long tile_span(int M, int m_base, int rows, long pitch)
 {

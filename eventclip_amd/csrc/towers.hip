@@ -75,7 +75,8 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
 // (tools/bench_fold.py; 15.87 with a statistics pass over the hi plane instead of the epilogue's sums), same
 // rounding points.
 int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads, int dtype,
-                      const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled, int nsplit = 0, bool exact16 = false)
+                      const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled, int nsplit = 0, bool exact16 = false,
+                      int nattn = 0)
 {
     const int rows = n_seq * S;
     void *x_hi = b.x;
@@ -100,7 +101,7 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
     // (measured with 16-bit attention in these blocks: configs[2] / [3] / [4] stay at 1.4e-3 .. 1.6e-3 -- where attention
     // is sharp the rounding of q and k is the largest single contribution, profiles/r5_parity.txt)
     EC_REQUIRE(nsplit == 0 || q_scaled, "folded chain: split-operand blocks take pre-scaled q rows (ec_vit_weights.q_scaled)");
-    const bool split_attn = true;
+    EC_REQUIRE(nattn >= 0 && nattn <= nsplit, "folded chain: %d fp32-attention blocks of %d split-operand blocks", nattn, nsplit);
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
         const bool sp = l < nsplit, sp_next = l + 1 < nsplit;
@@ -125,7 +126,7 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             EC_TRY(gemm_hl(n_seq, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, ldx));
             break;
         }
-        if (sp && split_attn) {
+        if (l < nattn) {
             // q | k | v as hi + lo parts (the lo parts in the MLP buffer, dead until c_fc), attention in fp32 on them,
             // its output as hi + lo parts into out_proj
             void *qkv_lo = b.mlp;
@@ -357,7 +358,8 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
             void *x_hi = b.x, *x_lo = reinterpret_cast<unsigned char *>(b.x) + (size_t)n * S * W * 2;
             EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt, stream));
             EC_TRY(run_blocks_folded(w->blocks, w->layers, n, S, W, w->heads, dt, b, stream, w->full_last_block == 0,
-                                     w->q_scaled != 0, pblocks, w->weights_exact16 != 0));
+                                     w->q_scaled != 0, pblocks, w->weights_exact16 != 0,
+                                     w->precise_attn_blocks < pblocks ? w->precise_attn_blocks : pblocks));
             // the class rows back to fp32 (x = hi + lo) for ln_post; patch_out (the mlp buffer) is free by now
             EC_TRY(join_hl_rows(x_hi, x_lo, (long)S * W, n, W, patch_out, dt, stream));
             EC_TRY(ec_layernorm_split(patch_out, W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16, cls16_lo, W,

@@ -222,6 +222,8 @@ class HostFeeder:
     bit-identical to ``pipe(list_of_arrays)``.
     """
 
+    CLOSE_WAIT_S = 5.0      # how long close() waits for the producer thread
+
     def __init__(self, pipe, batches, depth=2, copy_threads=8, capacity_bytes=None, **call_kw):
         import queue
         import threading
@@ -250,9 +252,14 @@ class HostFeeder:
             return
         self._closed = True
         self._stop.set()
-        # the producer may be blocked handing a batch over or waiting for a free slot: make room for both
+        # the producer may be blocked handing a batch over or waiting for a free slot: make room for both.  Bounded:
+        # a producer stuck inside the USER's iterator (a loader that never yields again) cannot be woken from here --
+        # after CLOSE_WAIT_S the daemon thread is left behind rather than hanging the caller (harness.evaluate calls
+        # this from a `finally`, where a hang would hide the exception that got it there)
         import queue
-        while self._th.is_alive():
+        import time
+        deadline = time.monotonic() + self.CLOSE_WAIT_S
+        while self._th.is_alive() and time.monotonic() < deadline:
             try:
                 while True:
                     self._ready.get_nowait()
@@ -261,11 +268,17 @@ class HostFeeder:
             self._free.put(-1)
             self._th.join(timeout=0.05)
         self._pool.shutdown(wait=False)
+        # Batches the producer staged but the consumer never took still have their host-to-device copy in flight on the
+        # copy stream, into device buffers that were allocated on another stream: the ring may only be released (the
+        # caching allocator may hand the blocks to anyone) once the copy engine is done with them, and the kernels
+        # that read the consumed ones too
+        self._copy_stream.synchronize()
         if self._slots is not None:
             for sl in self._slots:
                 if sl['consumed'] is not None:
                     sl['consumed'].synchronize()
-        self._slots = None
+        if not self._th.is_alive():
+            self._slots = None      # (a producer that is still alive keeps its ring: it may yet write into it)
 
     def __enter__(self):
         return self

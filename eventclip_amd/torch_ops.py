@@ -211,9 +211,11 @@ def classify(feats: torch.Tensor, row_idx: torch.Tensor, text_t: torch.Tensor, l
     full = torch.empty((B, T, K), dtype=torch.float32, device=feats.device)
     logits = torch.empty((B, K), dtype=torch.float32, device=feats.device)
     probs = torch.empty((B, K), dtype=torch.float32, device=feats.device)
-    rc = _lib.lib().ec_classify(_lib.ptr(feats), _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C, K,
+    n_rows = int(feats.shape[0])
+    ws = torch.empty(max(int(_lib.lib().ec_classify_workspace_bytes(n_rows, C, K)), 256), dtype=torch.uint8, device=feats.device)
+    rc = _lib.lib().ec_classify(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C, K,
                                 logit_scale, agg, int(normalize), _lib.ptr(full), _lib.ptr(logits),
-                                _lib.ptr(probs), _lib.stream_ptr())
+                                _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, 'ec_classify')
     return full, logits, probs
 

@@ -497,6 +497,11 @@ typedef struct {
                                    (Rounds 1 - 4 ran these blocks as the fp32-stream chain of `precise`, three launches
                                    per GEMM and fp32 attention: 2.0 x the step; this form costs 1.2 - 1.5 x.)
                                    0 (default): off. */
+    int precise_attn_blocks;    /* <= precise_blocks: in the first precise_attn_blocks of the split-operand blocks the QKV
+                                   GEMM also writes the lo parts of q | k | v (ec_gemm_args.aux) and attention runs in fp32
+                                   on hi + lo (ec_attention_split), its output entering out_proj as hi + lo: where attention
+                                   is sharp the 16-bit rounding of q and k in the FIRST blocks is the largest single error
+                                   (tools/rounding_budget.py; profiles/r5_parity.txt); behind them the 16-bit kernel. */
     int weights_exact16;        /* != 0: the blocks' 16-bit matrices ARE the weights (a checkpoint stored in 16 bit, as
                                    clip.load() returns one on a GPU): the qkv_w_lo / out_w_lo / fc1_w_lo / fc2_w_lo of a
                                    split-precision block may be NULL, and the x_hi . w_lo product of such a matrix -- a sum
@@ -544,10 +549,14 @@ enum { EC_AGG_SUM = 0, EC_AGG_MEAN = 1, EC_AGG_MAX = 2 };
  * row_idx: int32 [B, T]: row of feats for view (b, t), or -1 for an invalid view.
  * text_t:  fp32 [C, K] text features, transposed.
  * normalize != 0: L2-normalise each view's features first (F.normalize, eps 1e-12).
- * Outputs fp32: full_logits [B, T, K] (invalid views 0), logits [B, K], probs [B, K]. */
-EC_API int ec_classify(const float *feats, const int32_t *row_idx, const float *text_t, int B, int T,
+ * Outputs fp32: full_logits [B, T, K] (invalid views 0), logits [B, K], probs [B, K].
+ * The product runs on the matrix pipe at fp32 accuracy: both operands as hi + lo fp16 parts (scaled by powers of two so
+ * that the lo parts are normal numbers), three MFMA products in one ec_gemm launch (ec_gemm_args.A_lo / W_lo), the
+ * scales taken out again exactly.  workspace: ec_classify_workspace_bytes(n_rows, C, K) bytes, 256-byte aligned. */
+EC_API size_t ec_classify_workspace_bytes(int n_rows, int C, int K);
+EC_API int ec_classify(const float *feats, int n_rows, const int32_t *row_idx, const float *text_t, int B, int T,
                        int C, int K, float logit_scale, int agg, int normalize, float *full_logits,
-                       float *logits, float *probs, ec_stream_t stream);
+                       float *logits, float *probs, void *workspace, size_t workspace_bytes, ec_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Few-shot feature adapter.  Replaces TransformerAdapter.forward

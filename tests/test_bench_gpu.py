@@ -73,6 +73,30 @@ def test_gpus_2_launches_itself(hip):
     assert bad.returncode != 0
 
 
+@pytest.mark.parametrize('share', [False, True])
+def test_rccl_that_cannot_come_up_fails_fast_and_readably(hip, share):
+    """`--gpus 2` over nccl (= RCCL) on the ONE GPU of this box cannot work: without a device of its own a rank stops
+    before it touches the library; with both ranks forced onto device 0 (EVENTCLIP_DIST_SHARE_DEVICE=1) RCCL itself
+    refuses or never answers, and the short init timeout / the first 4-byte all-gather's watchdog end the run.  Either
+    way: non-zero exit in well under the driver's limit, and a diagnostic block that names rank, device and the HSA_* /
+    NCCL_* environment -- the failure mode of a fabric that does not come up on a real 8-GPU node."""
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip('needs a single-GPU box')
+    env = dict(os.environ, EVENTCLIP_DIST_TIMEOUT='40')
+    env.pop('WORLD_SIZE', None)
+    env.pop('EVENTCLIP_DIST_BACKEND', None)
+    if share:
+        env['EVENTCLIP_DIST_SHARE_DEVICE'] = '1'
+    t0 = time.time()
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--no-cpu-baseline'] + SMALL, cwd=ROOT, capture_output=True,
+                       text=True, timeout=400, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 300
+    assert '[bench] rank' in r.stderr and 'env:' in r.stderr and 'HSA_ENABLE_IPC_MODE_LEGACY' in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]      # no line is printed for a run that did not happen
+
+
 @pytest.mark.parametrize('config,batch,expect', [
     (2, 3, dict(scaling='weak', samples=[3, 3], views=1)),            # per-GPU batch, one short view per sample
     (3, 5, dict(scaling='strong', samples=[3, 2], views=2)),          # GLOBAL batch over the ranks, uneven shards

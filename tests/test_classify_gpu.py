@@ -14,9 +14,11 @@ def run_classify(feats, row_idx, text, scale, agg, normalize):
     probs = torch.empty(B, K, device='cuda')
     text_t = text.t().contiguous()
     code = {'sum': _lib.EC_AGG_SUM, 'mean': _lib.EC_AGG_MEAN, 'max': _lib.EC_AGG_MAX}[agg]
-    _lib.check(_lib.lib().ec_classify(_lib.ptr(feats), _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C,
+    n_rows = feats.shape[0]
+    ws = torch.empty(_lib.lib().ec_classify_workspace_bytes(n_rows, C, K), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().ec_classify(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C,
                                       K, scale, code, int(normalize), _lib.ptr(full),
-                                      _lib.ptr(logits), _lib.ptr(probs), _lib.stream_ptr()))
+                                      _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return full, logits, probs
 
 
