@@ -263,7 +263,8 @@ def sample_dvfs(step, fence, n_steps=6, device=0):
     directly, with a clean environment: under rocprofv3 a child inherits the profiler's preload, and
     an `env`-shebang hop after the GPU is initialised is exactly what the GPU pool forbids).
     The MFMA peak in `roofline` is quoted at the 2.4 GHz boost clock; under its 1400 W cap the chip
-    sustains less on this workload, and `peak_at_sclk` restates the peak at the observed clock."""
+    sustains less on this workload.  These samples are informational: the sysfs clock is an average over whole steps
+    and is not the clock inside the GEMMs (profiles/r5_gemm.md has the in-kernel one)."""
     import re
     import threading
     sysfs = _amdgpu_sysfs(device)
@@ -310,9 +311,11 @@ def sample_dvfs(step, fence, n_steps=6, device=0):
     if not busy:
         return None
     sclk = sum(s[0] for s in busy) / len(busy)
+    # (informational: the sysfs clock is NOT the clock inside the GEMMs -- profiles/r5_gemm.md has that one, stamped in
+    # the kernels of the diagnostic build: 1.74 - 1.92 GHz on random operands, 2.39 on zeros -- and no fraction is built on it)
     return {'sclk_mhz': sclk, 'socket_power_w': sum(s[1] for s in busy) / len(busy),
             'samples': len(busy), 'boost_mhz': 2400, 'source': 'sysfs' if sysfs else 'rocm-smi',
-            'peak_at_sclk': PEAK_MFMA_TFLOPS * sclk / 2400.}
+            'in_kernel_clock': 'profiles/r5_gemm.md (s_memtime / s_memrealtime stamps, diagnostic build)'}
 
 
 def self_launch(a):
@@ -657,8 +660,6 @@ def main():
             dv = sample_dvfs(step, fence, device=local)
             if dv:
                 res['dvfs'] = dv
-                if roof['bound'] == 'mfma':
-                    roof['frac_of_peak_at_sclk'] = roof['achieved'] / dv['peak_at_sclk']
         if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks):
             res['tolerance_mode'] = tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
                                                    frames_per_step, res['ms_per_step'])

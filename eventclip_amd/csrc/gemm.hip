@@ -669,6 +669,16 @@ __device__ __forceinline__ void epilogue32_buf(const GemmArgs &g, f32x4 (&acc)[T
 
 #define EC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// (diagnostic build) shader-clock and 100 MHz reference counters of this workgroup -> diag[4 b + at], diag[4 b + at + 1]
+__device__ __forceinline__ void clock_stamp(unsigned long long *diag, int at)
+{
+    unsigned long long c, r;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) diag[4 * blockIdx.x + at] = c, diag[4 * blockIdx.x + at + 1] = r;
+}
+
 // Tile raster inside an XCD's contiguous id range: 8 row panels x 4 column tiles per group of
 // 32 ids (one per CU of the XCD), so the 32 workgroups an XCD runs at a time stream 8 + 4
 // distinct operand panels through its L2 instead of 2-3 + tiles_n.  Rows beyond the last full
@@ -697,14 +707,16 @@ __device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm
 // is on its way into staging buffer 0 while the epilogue drains the accumulators through a
 // scratch area in buffer 1, so neither the workgroup turnaround (~1.5 k cycles) nor the
 // prologue's HBM latency (~2.9 k cycles of a 48 k-cycle tile at K = 1024) is exposed.
-// TL: per-tile timeline records as in gemm2p_kernel<DBG = 9>.
+// TL (diagnostic build): 1 = per-tile timeline records as in gemm2p_kernel<DBG = 9>; 2 = nothing but (s_memtime,
+// s_memrealtime) of wave 0 at the workgroup's start and end -> args.diag[4 b .. 4 b + 3]: the in-kernel clock
+// (shader cycles per 100 MHz tick) with no stamp inside the tile loop.
 // ---------------------------------------------------------------------------------------
 // SEG: the reduction runs over g.nseg segments (split-precision operands, see GemmArgs): K tile t belongs to segment
 // t / (K / 64).  A segment's parts are reached by rebuilding the tile's descriptors on the other part at the segment
 // change (2 - 3 times per tile, scalar work; the instruction's scalar offset is no way there: it IS part of the range
 // check on gfx950 -- offset + soffset >= num_records reads zeros -- so a range that covers it no longer ends at the
 // tile's last row).  Region 1 is requested one K tile apart from regions 0, 2, 3 and has a descriptor of its own.
-template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
+template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
 __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 {
     typedef typename T16<DT>::v8 v8;
@@ -944,7 +956,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 
     unsigned long long *tl = nullptr;
     auto tstamp = [&](int i) {
-        if (TL) {
+        if (TL == 1) {
             unsigned long long now;
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         }
     };
     auto tl_open = [&](int id) {
-        if (TL && threadIdx.x == 0) {
+        if (TL == 1 && threadIdx.x == 0) {
             tl = g.diag + (long)id * 8;
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -990,6 +1002,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         }
     };
 
+    if constexpr (TL == 2) clock_stamp(g.diag, 0);
     bool carried = false;     // this tile's K tile 0 was waited for at the hand-over from the tile before
     int id = blockIdx.x;
     tl_open(id);
@@ -1126,13 +1139,14 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         tl_open(id);
         tstamp(1);
     }
-    if (TL) {
+    if (TL == 1) {
         EC_VMCNT(0);
         tstamp(5);
     }
+    if constexpr (TL == 2) clock_stamp(g.diag, 2);
 }
 
-template <int DT, int EPI, bool TL = false, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
+template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
 int launch2pp(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
@@ -1197,6 +1211,7 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
     case 15: return launch2p<DT, EPI, 8>(g, s);   // ... over half a period
     case 16: return launch2p<DT, EPI, 9>(g, s);   // per-workgroup timeline -> args.diag
     case 18: return launch2pp<DT, EPI, true>(g, s);  // persistent, with timeline records -> args.diag
+    case 19: return launch2pp<DT, EPI, 2>(g, s);     // persistent, clock stamps at the workgroup's start and end -> args.diag
     case 43: return launch2pp<DT, EPI, false, false, 5>(g, s);   // 16-bit epilogues: next tile's DMA requested in FRONT of the first use of bias (A / B)
     case 20:                                         // probe: four waves x 128 x 128, 16-bit store only
         if constexpr (EPI == EC_EPI_STORE16) return launch4w<DT>(g, s);
@@ -1257,6 +1272,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_RESID_HL:
 #ifdef EC_GEMM_DIAG
         if (variant == 18 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, true>(g, s);   // timeline records -> args.diag
+        if (variant == 19 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, 2>(g, s);      // clock stamps
         // A / B forms of the hi-lo epilogue (epilogue_hl_buf MODE 0 .. 3)
         if (variant == 30 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 0>(g, s);
         if (variant == 31 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 1>(g, s);
@@ -1269,6 +1285,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_STORE16_LN:
 #ifdef EC_GEMM_DIAG
         if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, true>(g, s);
+        if (variant == 19 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, 2>(g, s);
         if (variant == 43 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_STORE16_LN, false, false, 5>(g, s);
 #endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs variant 0, row_stats and col_sums");
@@ -1276,6 +1293,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     case EC_EPI_GELU16_LN:
 #ifdef EC_GEMM_DIAG
         if (variant == 18 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, true>(g, s);
+        if (variant == 19 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, 2>(g, s);
         if (variant == 43 && g.rowstat && g.colsum) return launch2pp<DT, EC_EPI_GELU16_LN, false, false, 5>(g, s);
 #endif
         EC_REQUIRE(variant == 0 && g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs variant 0, row_stats and col_sums");
@@ -1432,7 +1450,7 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
 #ifdef EC_GEMM_DIAG
     {
         const int v = a->variant;
-        EC_REQUIRE(!(v == 10 || v == 16 || v == 18) || a->diag, "ec_gemm: variant %d needs args.diag", v);
+        EC_REQUIRE(!(v == 10 || v == 16 || v == 18 || v == 19) || a->diag, "ec_gemm: variant %d needs args.diag", v);
     }
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
