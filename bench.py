@@ -133,8 +133,10 @@ def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, f
            'configs_within_1e3': 'all five BASELINE configs on input-dependent weights '
                                  '(tests/test_configs_gpu.py::test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights; '
                                  'measured errors in profiles/r5_parity.txt)',
-           'what': 'first 8 image-tower blocks: QKV / c_fc multiply both planes of the residual stream, every GEMM adds the '
-                   'product with its weight\'s lo part (one launch per GEMM), attention in fp32 on hi + lo q, k, v'}
+           'what': 'first 8 image-tower blocks as split-operand blocks: LayerNorm of both planes of the residual stream into '
+                   'hi + lo parts, QKV / c_fc multiply both parts, every GEMM adds the product with its weight\'s lo part '
+                   '(one launch per GEMM; none where the matrix is its 16-bit value); the first 5 of them with attention in '
+                   'fp32 on hi + lo q, k, v (ec_vit_weights.precise_blocks / precise_attn_blocks)'}
 
     def timed(fn, n):
         fence()
@@ -631,9 +633,10 @@ def main():
                                       '16-bit MFMA operands, fp32 accumulate / softmax; residual stream as hi + lo '
                                       '16-bit planes (~2^-22), LayerNorm folded into the QKV / c_fc GEMMs (statistics '
                                       'of the 16-bit hi plane); patch embedding and ln_post @ proj with hi + lo operands')
-                                     + (f'; the first {a.precise_blocks} blocks as split-operand blocks (QKV / c_fc multiply both '
-                                        'planes of the stream, every GEMM adds its weight\'s lo product in the same launch, '
-                                        'fp32 attention on hi + lo q, k, v: ec_vit_weights.precise_blocks)'
+                                     + (f'; the first {a.precise_blocks} blocks as split-operand blocks (LayerNorm of both planes '
+                                        'into hi + lo parts, QKV / c_fc multiply both, every GEMM adds its weight\'s lo product '
+                                        f'in the same launch; fp32 attention on hi + lo q, k, v in the first '
+                                        f'{clip_model.image_precise_attn_blocks}: ec_vit_weights.precise_blocks / precise_attn_blocks)'
                                         if a.precise_blocks and not a.precise else '')
                                      + '; text tower split-precision (cached)'),
                        'last_block': ('every token' if clip_model.full_last_block else

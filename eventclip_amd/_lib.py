@@ -66,8 +66,7 @@ class EcGemmArgs(ctypes.Structure):
                 ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
                 ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t),
                 ('transposed', c_int), ('k_rows', c_int), ('row_stats', c_void_p), ('row_stats_stride', c_long),
-                ('col_sums', c_void_p), ('row_sums', c_void_p), ('A_lo', c_void_p), ('W_lo', c_void_p),
-                ('row_sums_x', c_int)]
+                ('col_sums', c_void_p), ('row_sums', c_void_p), ('A_lo', c_void_p), ('W_lo', c_void_p)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
@@ -82,7 +81,7 @@ class EcBlockWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
         'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo', 'qkv_w_ln', 'qkv_cs', 'qkv_bf', 'fc1_w_ln',
-        'fc1_cs', 'fc1_bf', 'qkv_w_ln_lo', 'fc1_w_ln_lo')]
+        'fc1_cs', 'fc1_bf')]
 
 
 class EcAdapterTrainLayer(ctypes.Structure):
@@ -204,7 +203,7 @@ SIGNATURES = {
     'ec_split16': (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'ec_attention_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_void_p]),
-    'ec_attention_split': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ec_attention_split': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_vit_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_float, c_void_p, c_void_p]),
     'ec_text_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
@@ -213,7 +212,8 @@ SIGNATURES = {
                              c_void_p]),
     'ec_row_stats_merge': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, c_void_p, c_void_p]),
     'ec_row_stats': (c_int, [c_void_p, c_long, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
-    'ec_row_stats_hl': (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
+    'ec_layernorm_hl': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                                c_long, c_int, c_void_p]),
     'ec_attention_scaled_q': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     'ec_attention_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

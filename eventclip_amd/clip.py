@@ -168,7 +168,7 @@ def _assign(root, key, tensor):
     m.register_parameter(parts[-1], nn.Parameter(tensor.clone().float(), requires_grad=False))
 
 
-DEFAULT_PRECISE_ATTN_BLOCKS = 4     # of the split-operand blocks (image_precise_blocks), how many run fp32 attention
+DEFAULT_PRECISE_ATTN_BLOCKS = 5     # of the split-operand blocks (image_precise_blocks), how many run fp32 attention (profiles/r5_tolerance_sweep.txt)
 
 
 class CLIP(nn.Module):
@@ -296,11 +296,10 @@ class CLIP(nn.Module):
             for i in range(layers):
                 ks = _block_keys(prefix, i)
                 b = arr[i]
-                # precise_first: the first blocks are split-precision blocks (plain q, lo parts), the rest as asked
-                # precise_first (ec_vit_weights.precise_blocks): the first blocks are split-operand blocks of the folded
-                # chain -- the same packing plus the lo parts of all four matrices (of the FOLDED ones for in_proj / c_fc)
-                precise = precise_all
+                # precise_first (ec_vit_weights.precise_blocks): the first blocks are split-operand blocks -- PLAIN matrices
+                # (no softmax scale, no LayerNorm gain folded in) with their lo parts; the rest as asked
                 split_ops = i < precise_first and not precise_all
+                precise = precise_all or split_ops
                 q_scaled = q_scaled_all and not precise
                 b.ln1_g, b.ln1_b = dev32(sd[ks[0]]), dev32(sd[ks[1]])
                 wqkv, bqkv = sd[ks[2]], sd[ks[3]]
@@ -314,44 +313,31 @@ class CLIP(nn.Module):
                     wqkv, bqkv = wqkv.float().clone(), bqkv.float().clone()
                     wqkv[:width] *= ATTN_Q_SCALE
                     bqkv[:width] *= ATTN_Q_SCALE
-                b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
                 vis = prefix.startswith('visual')
-                if precise:     # plain matrices with their lo parts
-                    b.qkv_w, b.qkv_w_lo = dev16_pair(wqkv, vis)
-                    b.qkv_b = dev32(bqkv)
-                else:
-                    b.qkv_w, b.qkv_b = dev16(wqkv), dev32(bqkv)
-                if ln_folded and not precise:
-                    # ec_vit_weights.ln_folded: W' = W diag(gamma) rounded once, its row sums AS ROUNDED, b + W beta
-                    # (split-operand blocks: W' as hi + lo, the row sums those of hi + lo)
-                    def fold(wt, bias, gamma, beta):
-                        wt, bias = wt.float().to(dev), bias.float().to(dev)
-                        wf = wt * gamma.float().to(dev)[None, :]
-                        bf = (bias + wt @ beta.float().to(dev)).contiguous()
-                        if split_ops:
-                            hi, lo = dev16_pair(wf, True)
-                            pair = keep[-1]
-                            cs = (pair[0].float() + (pair[1].float() if lo is not None else 0)).sum(1).contiguous()
-                        else:
-                            wp = wf.to(cd).contiguous()
-                            keep.append(wp)
-                            hi, lo, cs = wp.data_ptr(), None, wp.float().sum(1).contiguous()
-                        keep.extend([cs, bf])
-                        return hi, lo, cs.data_ptr(), bf.data_ptr()
-                    b.qkv_w_ln, b.qkv_w_ln_lo, b.qkv_cs, b.qkv_bf = fold(wqkv, bqkv, sd[ks[0]], sd[ks[1]])
-                    b.fc1_w_ln, b.fc1_w_ln_lo, b.fc1_cs, b.fc1_bf = fold(sd[ks[8]], sd[ks[9]], sd[ks[6]], sd[ks[7]])
+                b.qkv_b = dev32(bqkv)
                 b.out_b = dev32(sd[ks[5]])
                 b.ln2_g, b.ln2_b = dev32(sd[ks[6]]), dev32(sd[ks[7]])
                 b.fc1_b, b.fc2_b = dev32(sd[ks[9]]), dev32(sd[ks[11]])
-                if precise or split_ops:
+                if precise:     # plain matrices with their lo parts (NULL where the matrix is its 16-bit value)
+                    b.qkv_w, b.qkv_w_lo = dev16_pair(wqkv, vis)
                     b.out_w, b.out_w_lo = dev16_pair(sd[ks[4]], vis)
+                    b.fc1_w, b.fc1_w_lo = dev16_pair(sd[ks[8]], vis)
                     b.fc2_w, b.fc2_w_lo = dev16_pair(sd[ks[10]], vis)
-                    if precise:
-                        b.fc1_w, b.fc1_w_lo = dev16_pair(sd[ks[8]], vis)
-                    else:
-                        b.fc1_w = dev16(sd[ks[8]])
-                else:
-                    b.out_w, b.fc1_w, b.fc2_w = dev16(sd[ks[4]]), dev16(sd[ks[8]]), dev16(sd[ks[10]])
+                    continue
+                b.qkv_w = dev16(wqkv)
+                b.out_w, b.fc1_w, b.fc2_w = dev16(sd[ks[4]]), dev16(sd[ks[8]]), dev16(sd[ks[10]])
+                if ln_folded:
+                    # ec_vit_weights.ln_folded: W' = W diag(gamma) rounded once, its row sums AS ROUNDED, b + W beta
+                    def fold(wt, bias, gamma, beta):
+                        wt, bias = wt.float().to(dev), bias.float().to(dev)
+                        wp = (wt * gamma.float().to(dev)[None, :]).to(cd).contiguous()
+                        keep.append(wp)
+                        cs = wp.float().sum(1).contiguous()
+                        bf = (bias + wt @ beta.float().to(dev)).contiguous()
+                        keep.extend([cs, bf])
+                        return wp.data_ptr(), cs.data_ptr(), bf.data_ptr()
+                    b.qkv_w_ln, b.qkv_cs, b.qkv_bf = fold(wqkv, bqkv, sd[ks[0]], sd[ks[1]])
+                    b.fc1_w_ln, b.fc1_cs, b.fc1_bf = fold(sd[ks[8]], sd[ks[9]], sd[ks[6]], sd[ks[7]])
             return arr
 
         c = self.cfg

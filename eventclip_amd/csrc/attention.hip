@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "mfma.h"
+#include "tower_ops.h"
 
 #ifdef EC_ATTN_DIAG
 // diagnostic build only (python -m eventclip_amd.build --diag, tools/timeline_attn.py): s_memtime at
@@ -58,7 +59,7 @@ struct AttnArgs {
     int q_rows;       // only the first q_rows query rows of every sequence are computed; out is
                       // [n_seq * q_rows, W] (q_rows = S: the whole sequence)
     float scale_log2e;
-    int q_scaled;     // the q columns already hold q * scale_log2e (QM_INPUT)
+    int q_scaled;     // 1: the q columns already hold q * scale_log2e (QM_INPUT); 2: plain q, scores scaled in fp32 (QM_RAW)
     float *lse;       // LSE kernels only: [n_seq, heads, S] fp32, log2 of the softmax denominator in the
                       // scaled-score domain (m * scale_log2e + log2 l), kept for ec_attention_backward
 };
@@ -657,8 +658,11 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     const bool wide = kv + 16 * ATTN_PART * 4 > 80 * 1024;
     void (*kern)(const AttnArgs) = a.lse ? (wide ? attention_kernel<DT, 16, true> : attention_kernel<DT, 8, true>)
                                          : (wide ? attention_kernel<DT, 16> : attention_kernel<DT, 8>);
-    if (a.q_scaled)   // the inference towers (never with a log-sum-exp)
+    if (a.q_scaled == 1)   // the inference towers (never with a log-sum-exp)
         kern = wide ? attention_kernel<DT, 16, false, true, QM_INPUT> : attention_kernel<DT, 8, false, true, QM_INPUT>;
+    if (a.q_scaled == 2)   // a plain q, every score scaled in fp32: q is rounded ONCE (the split-operand blocks behind the
+                           // fp32-attention ones; QM_KERNEL's second rounding of q cost configs[2] 30 % there)
+        kern = wide ? attention_kernel<DT, 16, false, true, QM_RAW> : attention_kernel<DT, 8, false, true, QM_RAW>;
 #ifdef EC_ATTN_DIAG
     if (g_attn_variant == 5 && a.q_scaled && DT == EC_F16 && !a.causal && !a.lse)   // round 4: 32-query tiles (A / B)
         kern = wide ? attention32_kernel<16> : attention32_kernel<8>;
@@ -692,12 +696,12 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
 // LDS rows are 64 floats with the 16-byte chunk index XORed with row & 15: the 16 key rows of a b128 read and the
 // column reads of V are spread over the banks.  2560 sequences x 16 heads x S = 257: 96 ms -> see profiles/r4_attention.md.
 // ---------------------------------------------------------------------------------------
-// SIN (round 5, the split-operand blocks of ec_vit_weights.precise_blocks): q | k | v arrive as hi + lo 16-bit parts
-// (two [rows, 3W] tensors, what EC_EPI_STORE16_LN leaves with args.aux) and are joined to fp32 on the way in; the q
+// SIN (round 5, the split-operand blocks of ec_vit_weights.precise_attn_blocks): q | k | v arrive as hi + lo 16-bit parts
+// (two [rows, 3W] tensors, what EC_EPI_STORE16 leaves with args.aux) and are joined to fp32 on the way in.  PRE: the q
 // columns already hold q log2(e) / sqrt(64) (ec_vit_weights.q_scaled), so the scores are the exponent's arguments in
 // log2 units and e^t is one v_exp_f32.
 constexpr int F32_KCH = 32;
-template <int DT, bool SIN = false>
+template <int DT, bool SIN = false, bool PRE = false>
 __global__ __launch_bounds__(256) void attention_f32m_kernel(const void *qkv_v, const void *qkv_lo_v, void *out_hi, void *out_lo,
                                                              int S, int W, int heads, int causal)
 {
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const void *qkv_v, 
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const f32x4 v = ld4(base + (long)qsrc * ld + 16 * c + 4 * g);
-        qf[c] = SIN ? v : v * 0.125f;
+        qf[c] = PRE ? v : v * 0.125f;
     }
     // keys this workgroup needs: all of them, or (causal) those up to its last query
     const int s_eff = causal ? (qb * 64 + 64 < S ? qb * 64 + 64 : S) : S;
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(256) void attention_f32m_kernel(const void *qkv_v, 
     // e^t as 2^(t log2 e) on v_exp_f32 (1 ulp), the product with log2 e = hi + lo carried to ~2^-48 relative (one fma):
     // three vector instructions and one transcendental instead of expf's twenty, the same accuracy class
     auto exp_e = [](float t) {
-        if constexpr (SIN) return __builtin_amdgcn_exp2f(t);
+        if constexpr (PRE) return __builtin_amdgcn_exp2f(t);
         return __builtin_amdgcn_exp2f(__builtin_fmaf(t, 1.4426950216293335f, t * 1.92596298909109e-8f));
     };
     fetch(0);
@@ -883,6 +887,16 @@ static int attention_rows(const void *qkv, void *out, int n_seq, int S, int widt
     return ec::fail(EC_ERR_INVALID, "ec_attention: unknown dtype %d", dtype);
 }
 
+// tower_ops.h: a plain q whose scores are scaled in fp32 (no second rounding of q), no mask
+int ec_tower::attention_exact_scale(const void *qkv, void *out, int n_seq, int S, int width, int heads, int dtype,
+                                    ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0 && width == heads * 64, "attention_exact_scale: bad shape");
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv && out, "attention_exact_scale: null buffer");
+    return attention_rows(qkv, out, n_seq, S, width, heads, 0, S, 2, dtype, stream);
+}
+
 extern "C" EC_API int ec_attention(const void *qkv, void *out, int n_seq, int S, int width,
                                    int heads, int causal, int dtype, ec_stream_t stream)
 {
@@ -960,10 +974,10 @@ extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out
     const long blocks = (long)n_seq * heads * ((S + 63) / 64);
     EC_REQUIRE(blocks < (1L << 31), "ec_attention_f32: %ld workgroups", blocks);
     if (dtype == EC_F16)
-        hipLaunchKernelGGL((attention_f32m_kernel<EC_F16, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_F16, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
                            out_lo, S, width, heads, causal);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL((attention_f32m_kernel<EC_BF16, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
+        hipLaunchKernelGGL((attention_f32m_kernel<EC_BF16, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, qkv, nullptr, out_hi,
                            out_lo, S, width, heads, causal);
     else
         return ec::fail(EC_ERR_INVALID, "ec_attention_f32: unknown dtype %d", dtype);
@@ -972,7 +986,7 @@ extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out
 }
 
 extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
-                                         int width, int heads, int dtype, ec_stream_t stream)
+                                         int width, int heads, int q_prescaled, int dtype, ec_stream_t stream)
 {
     EC_REQUIRE(n_seq >= 0 && S > 0 && heads > 0, "ec_attention_split: bad shape");
     EC_REQUIRE(width == heads * 64, "ec_attention_split: head dim must be 64");
@@ -984,12 +998,11 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * S * S * 64.0 * heads * n_seq, (double)n_seq * S * width * 2.0 * 8.0);
     const long blocks = (long)n_seq * heads * ((S + 63) / 64);
     EC_REQUIRE(blocks < (1L << 31), "ec_attention_split: %ld workgroups", blocks);
-    if (dtype == EC_F16)
-        hipLaunchKernelGGL((attention_f32m_kernel<EC_F16, true>), dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi,
-                           out_lo, S, width, heads, 0);
-    else if (dtype == EC_BF16)
-        hipLaunchKernelGGL((attention_f32m_kernel<EC_BF16, true>), dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi,
-                           out_lo, S, width, heads, 0);
+    void (*kern)(const void *, const void *, void *, void *, int, int, int, int) = nullptr;
+    if (dtype == EC_F16) kern = q_prescaled ? attention_f32m_kernel<EC_F16, true, true> : attention_f32m_kernel<EC_F16, true, false>;
+    else if (dtype == EC_BF16) kern = q_prescaled ? attention_f32m_kernel<EC_BF16, true, true> : attention_f32m_kernel<EC_BF16, true, false>;
+    if (kern)
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi, out_lo, S, width, heads, 0);
     else
         return ec::fail(EC_ERR_INVALID, "ec_attention_split: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());

@@ -65,7 +65,6 @@ struct GemmArgs {
     int nseg;
     long seg_da, seg_dw;        // bytes from A / W (the hi parts) to the lo parts
     unsigned seg_mask;          // bit s: segment s reads A's lo part; bit 4 + s: W's lo part
-    int stat_x;                 // RESID_HL row sums: of x = hi + lo (the fp32 value before the split) instead of the new hi plane
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -353,9 +352,6 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                                                 int lane, float *scratch, F &&between)
 {
     constexpr bool PIPE = (MODE & 1) != 0, GROW = (MODE & 2) != 0;
-    // bit 3: the row sums are those of x = hi + lo, the fp32 value BEFORE the split (what a consumer that multiplies
-    // both planes -- ec_gemm_args.A_lo -- normalises), instead of those of the new hi plane
-    constexpr bool XS = (MODE & 8) != 0;
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     constexpr int PITCH = 68;
@@ -425,13 +421,8 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                     const unsigned o2 = __builtin_bit_cast(unsigned, o);
                     const f16x2 d = {(_Float16)mix_sub16<0>(x0, o2), (_Float16)mix_sub16<1>(x1, o2)};
                     oh[p][k] = o2, ol[p][k] = __builtin_bit_cast(unsigned, d);
-                    if constexpr (XS) {
-                        ps[p] += x0, pq[p] = __builtin_fmaf(x0, x0, pq[p]);
-                        ps[p] += x1, pq[p] = __builtin_fmaf(x1, x1, pq[p]);
-                    } else {
-                        ps[p] = mix_acc16<0>(o2, ps[p]), pq[p] = mix_sq16<0>(o2, pq[p]);
-                        ps[p] = mix_acc16<1>(o2, ps[p]), pq[p] = mix_sq16<1>(o2, pq[p]);
-                    }
+                    ps[p] = mix_acc16<0>(o2, ps[p]), pq[p] = mix_sq16<0>(o2, pq[p]);
+                    ps[p] = mix_acc16<1>(o2, ps[p]), pq[p] = mix_sq16<1>(o2, pq[p]);
                 }
             } else {
                 const v8 vh = __builtin_bit_cast(v8, xh[i][p]);
@@ -444,8 +435,7 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                     wh[e] = to16(x, elem());
                     const float h = (float)wh[e];
                     wl[e] = (_Float16)(x - h);
-                    const float sv = XS ? x : h;
-                    ps[p] += sv, pq[p] = __builtin_fmaf(sv, sv, pq[p]);
+                    ps[p] += h, pq[p] = __builtin_fmaf(h, h, pq[p]);
                 }
                 oh[p] = __builtin_bit_cast(u32x4, wh), ol[p] = __builtin_bit_cast(u32x4, wl);
             }
@@ -1101,7 +1091,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         // wait-count pass what has completed.
         constexpr bool BUF_EPI = EPI == EC_EPI_RESID_HL || EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI) ||
                                  EPI == EC_EPI_STORE32 || EPI == EC_EPI_RESID32;
-        constexpr bool LOUT = epi_is_ln(EPI) && (HLM & 16) != 0;      // 16-bit output as hi + lo parts (args.aux)
+        constexpr bool LOUT = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) && (HLM & 16) != 0;   // 16-bit output as hi + lo parts (args.aux)
         constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? 48 : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : LOUT ? 32 : 16;
         constexpr int enc_tail = (TAIL & 15) | (7 << 4) | (15 << 8) | ((TAIL >> 4) << 14);
         if constexpr (EPI == EC_EPI_RESID_HL)
@@ -1162,7 +1152,7 @@ int launch2pp(const GemmArgs &g0, hipStream_t stream)
     constexpr int cls = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU_BWD16 || EPI == EC_EPI_STORE16_LN) ? ec::PROF_GEMM_STORE16
                         : (EPI == EC_EPI_GELU16 || EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU16_LN) ? ec::PROF_GEMM_GELU16
                         : (EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? ec::PROF_GEMM_RESID32 : ec::PROF_GEMM_STORE32;
-    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI)) ? (epi_is_ln(EPI) && (HLM & 16) ? 4.0 : 2.0)
+    constexpr double out_b = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI)) ? (!epi_is_ln(EPI) && (HLM & 16) ? 4.0 : 2.0)
                              : (EPI == EC_EPI_GELU16_SAVE || EPI == EC_EPI_GELU_BWD16) ? 4.0
                              : ((EPI == EC_EPI_RESID32 || EPI == EC_EPI_RESID_HL) ? 8.0 : 4.0);
     // segments: every product's flops; the bytes of the parts that exist (a part shared by two segments counts once)
@@ -1228,34 +1218,27 @@ template <int DT, int EPI> int dispatch_variant(const GemmArgs &g, int variant, 
 
 template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipStream_t s)
 {
-    constexpr int HLX = HL_MODE_DEFAULT | 8;     // hi-lo epilogue with the row sums of x = hi + lo
+    constexpr int HLO = HL_MODE_DEFAULT | 16;    // 16-bit epilogues that also write the lo part (args.aux)
     if (g.nseg > 1) {
         // split-precision operands: the segmented main loop (default variant only)
         EC_REQUIRE(variant == 0, "ec_gemm: A_lo / W_lo need variant 0");
         switch (epi) {
-        case EC_EPI_STORE16: return launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_STORE16:
+            return g.aux ? launch2pp<DT, EC_EPI_STORE16, false, false, HLO, true>(g, s)
+                         : launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, true>(g, s);
+        case EC_EPI_GELU16:
+            return g.aux ? launch2pp<DT, EC_EPI_GELU16, false, false, HLO, true>(g, s)
+                         : launch2pp<DT, EC_EPI_GELU16, false, false, HL_MODE_DEFAULT, true>(g, s);
         case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, true>(g, s);
         case EC_EPI_RESID32: return launch2pp<DT, EC_EPI_RESID32, false, false, HL_MODE_DEFAULT, true>(g, s);
         case EC_EPI_RESID_HL:
             EC_REQUIRE(g.aux, "ec_gemm: EC_EPI_RESID_HL needs args.aux (the lo plane)");
-            return g.stat_x ? launch2pp<DT, EC_EPI_RESID_HL, false, false, HLX, true>(g, s)
-                            : launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, true>(g, s);
-        case EC_EPI_STORE16_LN:
-            EC_REQUIRE(g.rowstat && g.colsum, "ec_gemm: EC_EPI_STORE16_LN needs row_stats and col_sums");
-            return g.aux ? launch2pp<DT, EC_EPI_STORE16_LN, false, false, HL_MODE_DEFAULT | 16, true>(g, s)      // (hi, lo) out
-                         : launch2pp<DT, EC_EPI_STORE16_LN, false, false, HL_MODE_DEFAULT, true>(g, s);
-        case EC_EPI_GELU16_LN:
-            EC_REQUIRE(g.rowstat && g.colsum, "ec_gemm: EC_EPI_GELU16_LN needs row_stats and col_sums");
-            return g.aux ? launch2pp<DT, EC_EPI_GELU16_LN, false, false, HL_MODE_DEFAULT | 16, true>(g, s)
-                         : launch2pp<DT, EC_EPI_GELU16_LN, false, false, HL_MODE_DEFAULT, true>(g, s);
-        default: return ec::fail(EC_ERR_INVALID, "ec_gemm: A_lo / W_lo go with the STORE16, STORE32, RESID32, RESID_HL and *_LN epilogues (got %d)", epi);
+            return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, true>(g, s);
+        default: return ec::fail(EC_ERR_INVALID, "ec_gemm: A_lo / W_lo go with the STORE16, GELU16, STORE32, RESID32 and RESID_HL epilogues (got %d)", epi);
         }
     }
-    EC_REQUIRE(!(epi_is_ln(epi) && g.aux), "ec_gemm: an *_LN epilogue writes its lo part (args.aux) in the launches that take A_lo / W_lo only");
-    if (epi == EC_EPI_RESID_HL && g.stat_x) {
-        EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
-        return launch2pp<DT, EC_EPI_RESID_HL, false, false, HLX>(g, s);
-    }
+    EC_REQUIRE(!((epi == EC_EPI_STORE16 || epi == EC_EPI_GELU16) && g.aux),
+               "ec_gemm: STORE16 / GELU16 write their lo part (args.aux) in the launches that take A_lo / W_lo only");
     switch (epi) {
     case EC_EPI_STORE16: return dispatch_variant<DT, EC_EPI_STORE16>(g, variant, s);
     case EC_EPI_GELU16: return dispatch_variant<DT, EC_EPI_GELU16>(g, variant, s);
@@ -1398,7 +1381,7 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.tn = a->transposed ? 1 : 0, g.k_valid = a->k_rows;
     g.rowstat = a->row_stats, g.rowstat_stride = a->row_stats_stride > 0 ? a->row_stats_stride : 1, g.colsum = a->col_sums;
     g.stat_out = nullptr, g.stat_groups = 0;
-    g.nseg = 1, g.stat_x = a->row_sums_x != 0;
+    g.nseg = 1;
     g.seg_da = g.seg_dw = g.seg_mask = 0;
     if (a->A_lo || a->W_lo) {
         // split-precision operands: up to three products into the same accumulators, the small ones first

@@ -64,8 +64,10 @@ __device__ __forceinline__ int units(int width, int lane)
     return (total - lane + 63) / 64;  // number of i with i*64 + lane < total
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx,
+// HLIN: the row arrives as the two planes of the folded chain's residual stream (x = hi plane in DT, x_lo = fp16 lo plane,
+// both at row stride ldx) and is joined to fp32 on the way in: the LayerNorm of the split-operand blocks
+template <int DT, bool HLIN = false>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void *x_v, const _Float16 *x_lo, long ldx,
                                                         const int *row_idx, const float *gamma,
                                                         const float *beta, int rows, int width,
                                                         float eps, void *out, long ldo, void *out_lo)
@@ -77,10 +79,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx
     if (row >= rows) return;
     const int nv = units(width, lane);
     float4 v[LN_MAXV];
-    const float *xr = x + (row_idx ? (long)row_idx[row] : row) * ldx;
+    const long src = (row_idx ? (long)row_idx[row] : row) * ldx;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++)
-        if (i < nv) v[i] = *reinterpret_cast<const float4 *>(xr + (i * 64 + lane) * 4);
+        if (i < nv) {
+            if constexpr (HLIN) {
+                const v4 h = *reinterpret_cast<const v4 *>(static_cast<const elem *>(x_v) + src + (i * 64 + lane) * 4);
+                const f16x4 l = *reinterpret_cast<const f16x4 *>(x_lo + src + (i * 64 + lane) * 4);
+                v[i] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                                   (float)h[3] + (float)l[3]);
+            } else {
+                v[i] = *reinterpret_cast<const float4 *>(static_cast<const float *>(x_v) + src + (i * 64 + lane) * 4);
+            }
+        }
     ln_row(v, nv, width, lane, gamma, beta, eps);
     elem *o = (elem *)out + row * ldo;
 #pragma unroll
@@ -99,10 +110,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, long ldx
 
 // LayerNorm statistics of 16-bit rows (the hi plane of the residual stream): one wave per row, the row in
 // registers as eight-element chunks, mean and centred variance like ln_row -> (rstd, -rstd * mean)
-// HL: the statistics of x = hi + lo (lo plane fp16), what a GEMM that multiplies both planes normalises
-template <int DT, bool HL = false>
-__global__ __launch_bounds__(256) void row_stats_kernel(const void *x, const _Float16 *x_lo, long ldx, int rows, int width,
-                                                        float eps, float *stats)
+template <int DT>
+__global__ __launch_bounds__(256) void row_stats_kernel(const void *x, long ldx, int rows, int width, float eps,
+                                                        float *stats)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
@@ -113,20 +123,15 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *x, const _Fl
     constexpr int MAXC = LN_MAXV / 2;          // 8-element chunks per lane: width <= 2048
     const int total = width / 8, nc = (total - lane + 63) / 64;
     v8 v[MAXC];
-    f16x8 vl[HL ? MAXC : 1];
 #pragma unroll
     for (int i = 0; i < MAXC; i++)
-        if (i < nc) {
-            v[i] = *reinterpret_cast<const v8 *>(xr + (i * 64 + lane) * 8);
-            if constexpr (HL) vl[i] = *reinterpret_cast<const f16x8 *>(x_lo + row * ldx + (i * 64 + lane) * 8);
-        }
-    auto val = [&](int i, int e) { return HL ? (float)v[i][e] + (float)vl[HL ? i : 0][e] : (float)v[i][e]; };
+        if (i < nc) v[i] = *reinterpret_cast<const v8 *>(xr + (i * 64 + lane) * 8);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; i++)
         if (i < nc) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) s += val(i, e);
+            for (int e = 0; e < 8; e++) s += (float)v[i][e];
         }
     const float mean = wave_sum(s) / (float)width;
     float q = 0.f;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *x, const _Fl
         if (i < nc) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float d = val(i, e) - mean;
+                const float d = (float)v[i][e] - mean;
                 q += d * d;
             }
         }
@@ -359,36 +364,23 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
                               dtype, stream);
 }
 
-EC_API int ec_row_stats_hl(const void *x16, const void *x16_lo, long ldx, int rows, int width, float eps, float *stats,
-                           int dtype, ec_stream_t stream)
+EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
+                        ec_stream_t stream)
 {
     EC_REQUIRE(rows >= 0 && width > 0 && width % 8 == 0 && width <= LN_MAXV * 256,
                "ec_row_stats: width=%d must be a multiple of 8 and <= %d", width, LN_MAXV * 256);
     if (rows == 0) return EC_OK;
-    EC_REQUIRE(x16 && stats && ldx % 8 == 0 && (((uintptr_t)x16 | (uintptr_t)x16_lo) & 15) == 0,
-               "ec_row_stats: null or misaligned buffer");
+    EC_REQUIRE(x16 && stats && ldx % 8 == 0 && ((uintptr_t)x16 & 15) == 0, "ec_row_stats: null or misaligned buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * (x16_lo ? 4.0 : 2.0));
-    const _Float16 *lo = static_cast<const _Float16 *>(x16_lo);
-    const dim3 grid(ec::ceil_div(rows, 4));
-    if (dtype == EC_F16 && lo)
-        hipLaunchKernelGGL((row_stats_kernel<EC_F16, true>), grid, dim3(256), 0, s, x16, lo, ldx, rows, width, eps, stats);
-    else if (dtype == EC_F16)
-        hipLaunchKernelGGL((row_stats_kernel<EC_F16, false>), grid, dim3(256), 0, s, x16, lo, ldx, rows, width, eps, stats);
-    else if (dtype == EC_BF16 && lo)
-        hipLaunchKernelGGL((row_stats_kernel<EC_BF16, true>), grid, dim3(256), 0, s, x16, lo, ldx, rows, width, eps, stats);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 2.0);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL(row_stats_kernel<EC_F16>, dim3(ec::ceil_div(rows, 4)), dim3(256), 0, s, x16, ldx, rows, width, eps, stats);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL((row_stats_kernel<EC_BF16, false>), grid, dim3(256), 0, s, x16, lo, ldx, rows, width, eps, stats);
+        hipLaunchKernelGGL(row_stats_kernel<EC_BF16>, dim3(ec::ceil_div(rows, 4)), dim3(256), 0, s, x16, ldx, rows, width, eps, stats);
     else
         return ec::fail(EC_ERR_INVALID, "ec_row_stats: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
-}
-
-EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
-                        ec_stream_t stream)
-{
-    return ec_row_stats_hl(x16, nullptr, ldx, rows, width, eps, stats, dtype, stream);
 }
 
 EC_API int ec_row_stats_merge(const float *sums, int rows, int groups, int width, float eps, float *stats,
@@ -438,13 +430,37 @@ EC_API int ec_layernorm_split(const float *x, long ldx, const int32_t *row_idx, 
     const dim3 grid(ec::ceil_div(rows, 4)), block(256);
     ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 6.0);
     if (dtype == EC_F16)
-        hipLaunchKernelGGL(layernorm_kernel<EC_F16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
-                           width, eps, out16, ldo, out16_lo);
+        hipLaunchKernelGGL((layernorm_kernel<EC_F16, false>), grid, block, 0, s, x, (const _Float16 *)nullptr, ldx, row_idx, gamma,
+                           beta, rows, width, eps, out16, ldo, out16_lo);
     else if (dtype == EC_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<EC_BF16>, grid, block, 0, s, x, ldx, row_idx, gamma, beta, rows,
-                           width, eps, out16, ldo, out16_lo);
+        hipLaunchKernelGGL((layernorm_kernel<EC_BF16, false>), grid, block, 0, s, x, (const _Float16 *)nullptr, ldx, row_idx, gamma,
+                           beta, rows, width, eps, out16, ldo, out16_lo);
     else
         return ec::fail(EC_ERR_INVALID, "ec_layernorm: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_layernorm_hl(const void *x_hi, const void *x_lo, long ldx, const float *gamma, const float *beta, int rows,
+                           int width, float eps, void *out16, void *out16_lo, long ldo, int dtype, ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && width <= LN_MAXV * 256,
+               "ec_layernorm_hl: width=%d must be a multiple of 4 and <= %d", width, LN_MAXV * 256);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(x_hi && x_lo && gamma && beta && out16 && out16_lo, "ec_layernorm_hl: null buffer");
+    EC_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "ec_layernorm_hl: strides must be multiples of 4");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(ec::ceil_div(rows, 4)), block(256);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * 8.0);
+    const _Float16 *lo = static_cast<const _Float16 *>(x_lo);
+    if (dtype == EC_F16)
+        hipLaunchKernelGGL((layernorm_kernel<EC_F16, true>), grid, block, 0, s, x_hi, lo, ldx, (const int *)nullptr, gamma, beta,
+                           rows, width, eps, out16, ldo, out16_lo);
+    else if (dtype == EC_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<EC_BF16, true>), grid, block, 0, s, x_hi, lo, ldx, (const int *)nullptr, gamma, beta,
+                           rows, width, eps, out16, ldo, out16_lo);
+    else
+        return ec::fail(EC_ERR_INVALID, "ec_layernorm_hl: unknown dtype %d", dtype);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

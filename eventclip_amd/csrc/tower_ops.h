@@ -44,28 +44,37 @@ inline int gemm(int M, int N, int K, int dtype, int epi, const void *A, const vo
 }
 
 // the folded-LayerNorm forms (EC_EPI_RESID_HL: aux = lo plane; EC_EPI_*_LN: row statistics + column sums)
-// W_lo (split-precision blocks): the weight's lo part, one more MFMA product in the same launch; sums_x: the row
-// sums of x = hi + lo instead of the hi plane's (the GEMM that consumes them multiplies both planes)
+// W_lo / A_lo (split-operand blocks): the weight's / the activation's lo part, one more MFMA product each in the same launch
 inline int gemm_hl(int M, int N, int K, int dtype, const void *A, const void *W, const float *bias, void *x_hi,
                    void *x_lo, ec_stream_t s, long ldc = 0, float *row_sums = nullptr, const void *W_lo = nullptr,
-                   bool sums_x = false, const void *A_lo = nullptr)
+                   const void *A_lo = nullptr)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = EC_EPI_RESID_HL, g.variant = 0;
     g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = x_hi, g.ldc = ldc ? ldc : N, g.aux = x_lo;
-    g.row_sums = row_sums, g.W_lo = W_lo, g.row_sums_x = sums_x ? 1 : 0, g.A_lo = A_lo;
+    g.row_sums = row_sums, g.W_lo = W_lo, g.A_lo = A_lo;
     return ec_gemm(&g, s);
 }
-// A_lo / W_lo (split-precision blocks): the lo plane of the residual stream / the lo part of the folded weight
 inline int gemm_ln(int M, int N, int K, int dtype, int epi, const void *A, const void *W, const float *bias,
                    const float *row_stats, long row_stats_stride, const float *col_sums, void *C, ec_stream_t s,
-                   long ldc = 0, long lda = 0, const void *A_lo = nullptr, const void *W_lo = nullptr, void *C_lo = nullptr)
+                   long ldc = 0, long lda = 0)
 {
     ec_gemm_args g = {};
     g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
     g.A = A, g.lda = lda ? lda : K, g.W = W, g.bias = bias, g.C = C, g.ldc = ldc ? ldc : N;
     g.row_stats = row_stats, g.row_stats_stride = row_stats_stride, g.col_sums = col_sums;
-    g.A_lo = A_lo, g.W_lo = W_lo, g.aux = C_lo;      // C_lo: the output's lo part (split-operand blocks)
+    return ec_gemm(&g, s);
+}
+
+// 16-bit output from split operands (EC_EPI_STORE16 / EC_EPI_GELU16 with A_lo / W_lo; C_lo: the output's lo part too):
+// the QKV and c_fc GEMMs of the split-operand blocks
+inline int gemm_split16(int M, int N, int K, int dtype, int epi, const void *A, const void *A_lo, const void *W,
+                        const void *W_lo, const float *bias, void *C, void *C_lo, ec_stream_t s)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = dtype, g.epilogue = epi, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = N;
+    g.A_lo = A_lo, g.W_lo = W_lo, g.aux = C_lo;
     return ec_gemm(&g, s);
 }
 
@@ -75,6 +84,10 @@ int vit_embed_hl(const float *patch, const float *cls, const float *pos, const f
 int split_hl(const float *x, long n, void *x_hi, void *x_lo, int dtype, ec_stream_t stream);
 int join_hl_rows(const void *x_hi, const void *x_lo, long ld, int rows, int width, float *out, int dtype,
                  ec_stream_t stream);
+
+// attention.hip: 16-bit attention on a PLAIN q with every score scaled in fp32 (q rounded once; ec_attention's kernel
+// multiplies q by the scale and rounds it again)
+int attention_exact_scale(const void *qkv, void *out, int n_seq, int S, int width, int heads, int dtype, ec_stream_t stream);
 
 #define EC_TRY(expr)                  \
     do {                              \

@@ -88,23 +88,21 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
     const bool fused = W % 64 == 0;
     float *sums = fused ? b.sums : nullptr;
     const int groups = W / 64;
-    // Split-operand blocks (ec_vit_weights.precise_blocks, round 5): the first nsplit blocks run the SAME chain with
-    // the two GEMMs that consume the residual stream multiplying BOTH planes (A = hi, A_lo = lo: the LayerNorm'd row
-    // enters at ~2^-22 instead of rounded to 16 bit) and every GEMM taking its weight's lo part where one exists --
-    // two or three MFMA products into the same accumulators of ONE launch (ec_gemm_args.A_lo / W_lo).  The row
-    // statistics such a GEMM normalises with are those of x = hi + lo (row_sums_x / ec_row_stats_hl).
+    // Split-operand blocks (ec_vit_weights.precise_blocks, round 5): the first nsplit blocks run on the SAME planes with
+    // LayerNorm of both planes into hi + lo parts (ec_layernorm_hl), QKV and c_fc multiplying both parts (A_lo) and every
+    // GEMM adding the product with its weight's lo part where it has one (W_lo): two or three MFMA products into the same
+    // accumulators of ONE launch.  Plain matrices (no LayerNorm gain, no softmax scale folded in: a checkpoint stored in
+    // 16 bit then has no lo parts).  In the first nattn of them attention runs in fp32 on hi + lo q, k, v.
     EC_REQUIRE(nsplit >= 0 && nsplit < layers + (first_only ? 0 : 1), "folded chain: %d split-operand blocks of %d", nsplit, layers);
-    for (int l = 0; l < nsplit; l++)
-        EC_REQUIRE(exact16 || (blocks[l].qkv_w_ln_lo && blocks[l].out_w_lo && blocks[l].fc1_w_ln_lo && blocks[l].fc2_w_lo),
-                   "folded chain: split-operand block %d has no lo weight parts (and weights_exact16 is not set)", l);
-    EC_TRY(ec_row_stats_hl(x_hi, nsplit > 0 ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
-    // (measured with 16-bit attention in these blocks: configs[2] / [3] / [4] stay at 1.4e-3 .. 1.6e-3 -- where attention
-    // is sharp the rounding of q and k is the largest single contribution, profiles/r5_parity.txt)
-    EC_REQUIRE(nsplit == 0 || q_scaled, "folded chain: split-operand blocks take pre-scaled q rows (ec_vit_weights.q_scaled)");
     EC_REQUIRE(nattn >= 0 && nattn <= nsplit, "folded chain: %d fp32-attention blocks of %d split-operand blocks", nattn, nsplit);
+    for (int l = 0; l < nsplit; l++) {
+        EC_REQUIRE(blocks[l].qkv_w && blocks[l].fc1_w && blocks[l].ln1_g && blocks[l].ln2_g, "folded chain: split-operand block %d lacks its plain weights", l);
+        EC_REQUIRE(exact16 || (blocks[l].qkv_w_lo && blocks[l].out_w_lo && blocks[l].fc1_w_lo && blocks[l].fc2_w_lo),
+                   "folded chain: split-operand block %d has no lo weight parts (and weights_exact16 is not set)", l);
+    }
+    if (nsplit == 0) EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
     for (int l = 0; l < layers; l++) {
         const ec_block_weights &w = blocks[l];
-        const bool sp = l < nsplit, sp_next = l + 1 < nsplit;
         if (first_only && l == layers - 1) {
             // the class-token-only last block (see run_blocks): keys and values of every token, the rest for row 0
             // of every sequence, the planes addressed at row stride S * W and the statistics at stride S
@@ -126,35 +124,50 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             EC_TRY(gemm_hl(n_seq, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, ldx));
             break;
         }
-        if (l < nattn) {
-            // q | k | v as hi + lo parts (the lo parts in the MLP buffer, dead until c_fc), attention in fp32 on them,
-            // its output as hi + lo parts into out_proj
-            void *qkv_lo = b.mlp;
-            void *att_lo = static_cast<unsigned char *>(b.mlp) + (size_t)rows * 3 * W * esz;
-            EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s,
-                           0, 0, x_lo, w.qkv_w_ln_lo, qkv_lo));
-            EC_TRY(ec_attention_split(b.qkv, qkv_lo, b.h, att_lo, n_seq, S, W, heads, dtype, s));
-            EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums, w.out_w_lo, true, att_lo));
-        } else {
-            EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s,
-                           0, 0, sp ? x_lo : nullptr, sp ? w.qkv_w_ln_lo : nullptr));
-            EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
-                            : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
-            EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums, sp ? w.out_w_lo : nullptr, sp));
+        if (l < nsplit) {
+            // ---- a split-operand block ----
+            // lo parts live in buffers that are dead at the time: LN(x)'s in the tail of the MLP buffer (ln_1) / in the
+            // qkv buffer (ln_2); q | k | v's in the head of the MLP buffer, the attention output's in its tail
+            unsigned char *mlp8 = static_cast<unsigned char *>(b.mlp);
+            void *h_lo1 = mlp8 + (size_t)rows * 3 * W * esz, *qkv_lo = mlp8, *att_lo = h_lo1, *h_lo2 = b.qkv;
+            const bool pa = l < nattn, next_default = l + 1 >= nsplit && l + 1 < layers;
+            EC_TRY(ec_layernorm_hl(x_hi, x_lo, W, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, h_lo1, W, dtype, s));
+            EC_TRY(gemm_split16(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, h_lo1, w.qkv_w, w.qkv_w_lo, w.qkv_b, b.qkv,
+                                pa ? qkv_lo : nullptr, s));
+            if (pa) {
+                EC_TRY(ec_attention_split(b.qkv, qkv_lo, b.h, att_lo, n_seq, S, W, heads, 0, dtype, s));
+            } else {
+                EC_TRY(attention_exact_scale(b.qkv, b.h, n_seq, S, W, heads, dtype, s));
+            }
+            EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, nullptr, w.out_w_lo, pa ? att_lo : nullptr));
+            EC_TRY(ec_layernorm_hl(x_hi, x_lo, W, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, h_lo2, W, dtype, s));
+            EC_TRY(gemm_split16(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, h_lo2, w.fc1_w, w.fc1_w_lo, w.fc1_b, b.mlp, nullptr, s));
+            // the first default block behind the split-operand blocks takes its statistics from this epilogue's sums
+            EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, next_default ? sums : nullptr,
+                           w.fc2_w_lo));
+            if (next_default) {
+                if (fused)
+                    EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
+                else
+                    EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+            }
+            continue;
         }
+        EC_TRY(gemm_ln(rows, 3 * W, W, dtype, EC_EPI_STORE16_LN, x_hi, w.qkv_w_ln, w.qkv_bf, b.stats, 1, w.qkv_cs, b.qkv, s));
+        EC_TRY(q_scaled ? ec_attention_scaled_q(b.qkv, b.h, n_seq, S, W, heads, 0, S, dtype, s)
+                        : ec_attention(b.qkv, b.h, n_seq, S, W, heads, 0, dtype, s));
+        EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, sums));
         if (fused)
             EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
         else
-            EC_TRY(ec_row_stats_hl(x_hi, sp ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
-        EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s,
-                       0, 0, sp ? x_lo : nullptr, sp ? w.fc1_w_ln_lo : nullptr));
-        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, l + 1 < layers ? sums : nullptr,
-                       sp ? w.fc2_w_lo : nullptr, sp_next));
+            EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
+        EC_TRY(gemm_ln(rows, 4 * W, W, dtype, EC_EPI_GELU16_LN, x_hi, w.fc1_w_ln, w.fc1_bf, b.stats, 1, w.fc1_cs, b.mlp, s));
+        EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, l + 1 < layers ? sums : nullptr));
         if (l + 1 < layers) {
             if (fused)
                 EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
             else
-                EC_TRY(ec_row_stats_hl(x_hi, sp_next ? x_lo : nullptr, W, rows, W, LN_EPS, b.stats, dtype, s));
+                EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
         }
     }
     return EC_OK;
@@ -344,7 +357,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
                         need);
     const bool folded = w->ln_folded && !w->low_latency;
     if (folded)
-        for (int l = 0; l < w->layers; l++)
+        for (int l = pblocks; l < w->layers; l++)
             EC_REQUIRE(w->blocks[l].qkv_w_ln && w->blocks[l].qkv_cs && w->blocks[l].qkv_bf && w->blocks[l].fc1_w_ln &&
                            w->blocks[l].fc1_cs && w->blocks[l].fc1_bf,
                        "ec_vit_encode: ln_folded but block %d lacks its folded weights", l);

@@ -19,7 +19,7 @@ def dtype_code(t):
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
          splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None,
-         A_lo=None, W_lo=None, row_sums_x=False):
+         A_lo=None, W_lo=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
@@ -27,8 +27,8 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     LayerNorm folded into the GEMM: resid_hl (``out`` = the hi plane in A's dtype, ``aux`` = the fp16 lo plane, both
     updated in place: (hi, lo) <- split(hi + lo + acc + bias)); store16_ln / gelu16_ln (``row_stats`` fp32 [M, 2] =
     (rstd, -rstd mean) of A's rows from ``row_stats``, ``col_sums`` fp32 [N] = row sums of W as rounded).
-    Split-precision operands in one launch: ``A_lo`` / ``W_lo`` (the lo parts, same shapes and strides): out = epi(A_lo W^T + A W_lo^T + A W^T + bias);
-    ``row_sums_x``: resid_hl's row sums are those of hi + lo instead of the hi plane's."""
+    Split-precision operands in one launch: ``A_lo`` / ``W_lo`` (the lo parts, same shapes and strides):
+    out = epi(A_lo W^T + A W_lo^T + A W^T + bias); with them store16 / gelu16 take ``aux`` as the output's lo part."""
     import torch
     _lib.require_gpu()
     epi = {'store16': _lib.EC_EPI_STORE16, 'gelu16': _lib.EC_EPI_GELU16,
@@ -78,7 +78,6 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     if W_lo is not None:
         assert W_lo.dtype == W.dtype and W_lo.shape == W.shape and W_lo.stride() == W.stride()
         a.W_lo = W_lo.data_ptr()
-    a.row_sums_x = int(bool(row_sums_x))
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
@@ -115,16 +114,17 @@ def gemm_rows(A, W, splits=1, out=None):
     return out
 
 
-def row_stats_hl(x_hi, x_lo, eps=1e-5):
-    """(rstd, -rstd * mean) of the rows of hi + lo (x_lo: the fp16 lo plane, same shape / stride) -> fp32 [rows, 2]."""
+def layernorm_hl(x_hi, x_lo, gamma, beta, eps=1e-5):
+    """LayerNorm of the rows of hi + lo (x_lo: the fp16 lo plane) -> (hi, lo) parts in x_hi's dtype (ec_layernorm_hl)."""
     import torch
     _lib.require_gpu()
     rows, width = x_hi.shape
     assert x_lo.dtype == torch.float16 and x_lo.shape == x_hi.shape and x_lo.stride() == x_hi.stride()
-    out = torch.empty((rows, 2), dtype=torch.float32, device=x_hi.device)
-    _lib.check(_lib.lib().ec_row_stats_hl(x_hi.data_ptr(), x_lo.data_ptr(), x_hi.stride(0), rows, width, float(eps),
-                                          out.data_ptr(), dtype_code(x_hi.dtype), _lib.stream_ptr()), 'ec_row_stats_hl')
-    return out
+    out = torch.empty((2, rows, width), dtype=x_hi.dtype, device=x_hi.device)
+    _lib.check(_lib.lib().ec_layernorm_hl(x_hi.data_ptr(), x_lo.data_ptr(), x_hi.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                          rows, width, float(eps), out[0].data_ptr(), out[1].data_ptr(), width,
+                                          dtype_code(x_hi.dtype), _lib.stream_ptr()), 'ec_layernorm_hl')
+    return out[0], out[1]
 
 
 def row_stats(x16, eps=1e-5):

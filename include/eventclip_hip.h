@@ -303,7 +303,7 @@ typedef struct {
     float *row_sums;          /* fp32 [M][N / 64][2]: (sum, sum of squares) of the NEW hi plane over each 64-column group
                                  of every row; ec_row_stats_merge turns them into the row statistics of the GEMM that
                                  follows, so no pass over the hi plane is needed */
-    /* Split-precision operands in ONE launch (variant 0; EC_EPI_STORE16 / STORE32 / RESID32 / RESID_HL / *_LN; no
+    /* Split-precision operands in ONE launch (variant 0; EC_EPI_STORE16 / GELU16 / STORE32 / RESID32 / RESID_HL; no
      * splits, ws, resid or transposed operands).  A value is carried as hi = round16(x), lo = round16(x - hi); with
      * A_lo and / or W_lo given, C = epi(A_lo . W^T + A . W_lo^T + A . W^T + bias): up to three MFMA products over K
      * columns each, the small ones first, into the SAME fp32 accumulators and through ONE epilogue (where the three
@@ -311,9 +311,9 @@ typedef struct {
      * 16-bit value: its product is skipped (a product with zeros would add nothing: the same bits). */
     const void *A_lo;         /* [M, K] 16-bit at row stride lda, or NULL */
     const void *W_lo;         /* [N, K] 16-bit at row stride ldw, or NULL */
-    int row_sums_x;           /* EC_EPI_RESID_HL with row_sums: != 0 -> the sums are those of x = hi + lo + acc + bias, the
-                                 fp32 value BEFORE it is split into the planes (what a GEMM that multiplies BOTH planes,
-                                 A = hi and A_lo = lo, has to normalise), instead of those of the new hi plane */
+    /* ... and with them EC_EPI_STORE16 / EC_EPI_GELU16 take `aux` as a SECOND OUTPUT: C16 = hi = round16(v) and
+     * aux16 = lo = round16(v - hi) of the epilogue's fp32 value v, [M, N] at stride ldc -- the operand pair of a
+     * split-precision consumer (ec_attention_split; A_lo of the next GEMM). */
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -330,10 +330,6 @@ EC_API int ec_layernorm(const float *x, long ldx, const int32_t *row_idx, const 
  * EC_EPI_GELU16_LN multiply and add.  Reads 2 bytes per element where ec_layernorm reads 4 and writes 2. */
 EC_API int ec_row_stats(const void *x16, long ldx, int rows, int width, float eps, float *stats, int dtype,
                         ec_stream_t stream);
-/* The same of x = hi + lo, both planes of the residual stream (x16_lo: fp16 [rows, width] at the same row stride;
- * NULL = ec_row_stats): the statistics of a GEMM that multiplies both planes (ec_gemm_args.A_lo). */
-EC_API int ec_row_stats_hl(const void *x16, const void *x16_lo, long ldx, int rows, int width, float eps, float *stats,
-                           int dtype, ec_stream_t stream);
 
 /* (sum, sum of squares) per 64-column group as EC_EPI_RESID_HL leaves them (ec_gemm_args.row_sums, `groups` = width / 64
  * groups of row r at sums + 2 * r * groups * sums_stride ... in rows: row r at sums + 2 * groups * r) -> stats
@@ -349,6 +345,10 @@ EC_API int ec_row_stats_merge(const float *sums, int rows, int groups, int width
 EC_API int ec_layernorm_split(const float *x, long ldx, const int32_t *row_idx, const float *gamma,
                               const float *beta, int rows, int width, float eps, void *out16,
                               void *out16_lo, long ldo, int dtype, ec_stream_t stream);
+/* LayerNorm of rows given as the two planes of the folded chain's residual stream (x_hi in `dtype`, x_lo fp16, both at row
+ * stride ldx) into hi / lo parts at row stride ldo: the LayerNorm of the split-operand blocks (precise_blocks). */
+EC_API int ec_layernorm_hl(const void *x_hi, const void *x_lo, long ldx, const float *gamma, const float *beta, int rows,
+                           int width, float eps, void *out16, void *out16_lo, long ldo, int dtype, ec_stream_t stream);
 /* fp32 [n] -> (QuickGELU if gelu) -> hi / lo 16-bit parts */
 EC_API int ec_split16(const float *x, long n, int gelu, void *hi16, void *lo16, int dtype,
                       ec_stream_t stream);
@@ -357,11 +357,11 @@ EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_
                             int width, int heads, int causal, int dtype, ec_stream_t stream);
 
 /* fp32 attention (no mask) over q | k | v given as hi + lo 16-bit parts, two [n_seq * S, 3 * width] tensors as
- * EC_EPI_STORE16_LN leaves them with ec_gemm_args.aux, whose q columns already hold q * log2(e) / sqrt(64)
- * (ec_vit_weights.q_scaled); output as hi / lo parts [n_seq * S, width].  The attention of the split-operand blocks
- * (ec_vit_weights.precise_blocks): scores, softmax and P.V in fp32 on v_mfma_f32_16x16x4_f32. */
+ * EC_EPI_STORE16 leaves them with ec_gemm_args.aux; output as hi / lo parts [n_seq * S, width].  q_prescaled != 0: the q
+ * columns already hold q * log2(e) / sqrt(64) (ec_vit_weights.q_scaled), else a plain q.  The attention of the first
+ * split-operand blocks (ec_vit_weights.precise_attn_blocks): scores, softmax and P.V in fp32 on v_mfma_f32_16x16x4_f32. */
 EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
-                              int width, int heads, int dtype, ec_stream_t stream);
+                              int width, int heads, int q_prescaled, int dtype, ec_stream_t stream);
 
 /* x[n, 0] = class_embedding, x[n, 1 + p] = patch[n * (seq - 1) + p]; + positional
  * embedding; ln_pre -> fp32 residual stream x [n_img, seq, width]. */
@@ -424,7 +424,9 @@ typedef struct {
     const float *fc1_b;
     const void *fc2_w;          /* mlp.c_proj.weight [W, 4W] 16-bit */
     const float *fc2_b;
-    /* lo parts (w - round16(w)) of the four matrices; only read by precise towers, else NULL */
+    /* lo parts (w - round16(w)) of the four matrices; read by precise towers and by the split-operand blocks of
+     * ec_vit_weights.precise_blocks (whose qkv_w / qkv_b hold a PLAIN q), else NULL.  NULL in such a block = the matrix
+     * is its 16-bit value (ec_vit_weights.weights_exact16). */
     const void *qkv_w_lo, *out_w_lo, *fc1_w_lo, *fc2_w_lo;
     /* LayerNorm folded into the two GEMMs that consume it (ec_vit_weights.ln_folded; EC_EPI_*_LN): the weight
      * with its columns scaled by the LayerNorm gain BEFORE the rounding to 16 bit, W' = W diag(gamma) [N, W]; the
@@ -434,10 +436,6 @@ typedef struct {
     const float *qkv_cs, *qkv_bf;
     const void *fc1_w_ln;
     const float *fc1_cs, *fc1_bf;
-    /* split-operand blocks (ec_vit_weights.precise_blocks): the lo parts W' - round16(W') of the two folded matrices
-     * (their *_cs are then the row sums of hi + lo as rounded), next to out_w_lo / fc2_w_lo above.  NULL = the folded
-     * matrix is its 16-bit value (or the block is not a split-operand block). */
-    const void *qkv_w_ln_lo, *fc1_w_ln_lo;
 } ec_block_weights;
 
 typedef struct {
@@ -484,24 +482,24 @@ typedef struct {
                                    2.1e-4 feature error on ViT-L/14; tests/test_outliers_gpu.py holds the
                                    outlier-channel statistics of released checkpoints).  Ignored by precise /
                                    low_latency towers and by the training entry points. */
-    int precise_blocks;         /* 0 < precise_blocks < layers with precise == 0 and ln_folded != 0: the FIRST
-                                   precise_blocks blocks are split-operand blocks -- the same folded chain, but the two
-                                   GEMMs that consume the residual stream (QKV, c_fc) multiply BOTH of its planes
-                                   (ec_gemm_args.A_lo: the LayerNorm'd row enters at ~2^-22 instead of rounded to 16 bit,
-                                   normalised with the statistics of hi + lo) and all four GEMMs add the product with
-                                   their weight's lo part where it has one (W_lo; out_w_lo, fc2_w_lo, qkv_w_ln_lo,
-                                   fc1_w_ln_lo) -- every product of a GEMM in ONE launch.  Attention and the GEMM outputs
-                                   that feed it / out_proj / c_proj stay 16-bit.  A rounding error made in an early
-                                   block is carried through every later one, and the residual-stream operand and the
-                                   weights are where most of it is made (tools/rounding_budget.py).
-                                   (Rounds 1 - 4 ran these blocks as the fp32-stream chain of `precise`, three launches
-                                   per GEMM and fp32 attention: 2.0 x the step; this form costs 1.2 - 1.5 x.)
-                                   0 (default): off. */
+    int precise_blocks;         /* 0 < precise_blocks < layers with precise == 0, ln_folded != 0, dtype EC_F16: the FIRST
+                                   precise_blocks blocks are split-operand blocks on the SAME hi + lo planes of the
+                                   residual stream: LayerNorm of both planes into hi + lo parts (ec_layernorm_hl), QKV and
+                                   c_fc multiplying both parts (ec_gemm_args.A_lo), all four GEMMs adding the product with
+                                   their weight's lo part where it has one (W_lo) -- every product of a GEMM in ONE launch.
+                                   Their matrices are the PLAIN ones (qkv_w with an unscaled q, fc1_w: neither the LayerNorm
+                                   gain nor the softmax scale folded in, so that a checkpoint stored in 16 bit has no lo
+                                   parts and pays one product less per GEMM).  A rounding error made in an early block is
+                                   carried through every later one, and the residual-stream operand and the weights are
+                                   where most of it is made (tools/rounding_budget.py).  (Rounds 1 - 4 ran
+                                   these blocks as the fp32-stream chain of `precise`, three launches per GEMM and fp32
+                                   attention everywhere: 2.0 x the step; this form costs 1.3 - 1.5 x.)  0 (default): off. */
     int precise_attn_blocks;    /* <= precise_blocks: in the first precise_attn_blocks of the split-operand blocks the QKV
                                    GEMM also writes the lo parts of q | k | v (ec_gemm_args.aux) and attention runs in fp32
                                    on hi + lo (ec_attention_split), its output entering out_proj as hi + lo: where attention
                                    is sharp the 16-bit rounding of q and k in the FIRST blocks is the largest single error
-                                   (tools/rounding_budget.py; profiles/r5_parity.txt); behind them the 16-bit kernel. */
+                                   (tools/rounding_budget.py; profiles/r5_tolerance_sweep.txt); behind them the 16-bit
+                                   kernel on a plain q (ec_attention). */
     int weights_exact16;        /* != 0: the blocks' 16-bit matrices ARE the weights (a checkpoint stored in 16 bit, as
                                    clip.load() returns one on a GPU): the qkv_w_lo / out_w_lo / fc1_w_lo / fc2_w_lo of a
                                    split-precision block may be NULL, and the x_hi . w_lo product of such a matrix -- a sum

@@ -49,6 +49,26 @@ def ref_attention(qkv, n_seq, S, W, heads, causal):
     return out.permute(0, 2, 1, 3).reshape(n_seq * S, W)
 
 
+@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('rows,width', [(301, 1024), (9, 768), (64, 64), (1000, 1280)])
+def test_layernorm_of_the_planes(rows, width, dt, hip):
+    """ec_layernorm_hl: LayerNorm of x = hi + lo (the folded chain's residual planes) into hi + lo parts, against fp64."""
+    import torch
+    from eventclip_amd import ops
+    dtype = getattr(torch, dt)
+    g = torch.Generator(device='cuda').manual_seed(rows + width)
+    x = torch.randn(rows, width, device='cuda', generator=g) * 3 + 0.7
+    hi = x.to(dtype)
+    lo = (x - hi.float()).half()
+    gamma = 1 + 0.2 * torch.randn(width, device='cuda', generator=g)
+    beta = 0.3 * torch.randn(width, device='cuda', generator=g)
+    o_hi, o_lo = ops.layernorm_hl(hi, lo, gamma, beta)
+    want = torch.nn.functional.layer_norm(hi.double() + lo.double(), (width,), gamma.double(), beta.double(), 1e-5)
+    err = float(((o_hi.double() + o_lo.double()) - want).abs().max() / want.abs().max())
+    assert err < (2e-6 if dt == 'float16' else 4e-5), err           # (bf16 parts carry 16 bits together)
+    assert float((o_hi.double() - want).abs().max()) <= (2 ** -10 if dt == 'float16' else 2 ** -7) * float(want.abs().max())
+
+
 @pytest.mark.parametrize('S,heads,causal,n_seq', [(257, 16, 0, 3), (577, 4, 0, 2), (77, 8, 1, 5), (77, 12, 1, 3),
                                                    (50, 12, 0, 4), (197, 3, 0, 2), (1, 2, 0, 2), (1, 1, 1, 1),
                                                    (33, 2, 1, 3), (64, 1, 0, 2), (65, 1, 1, 2), (129, 2, 1, 2)])
@@ -76,26 +96,28 @@ def test_attention_f32_matches_float64(S, heads, causal, n_seq, hip):
     assert err < 4e-6, err
 
 
+@pytest.mark.parametrize('prescaled', [0, 1])
 @pytest.mark.parametrize('S,heads,n_seq', [(257, 16, 3), (577, 4, 2), (50, 12, 4), (197, 3, 2), (1, 2, 2), (64, 1, 2), (65, 1, 2)])
-def test_attention_split_matches_float64(S, heads, n_seq, hip):
-    """ec_attention_split (the attention of the split-operand blocks): q | k | v as hi + lo fp16 parts, the q columns
-    pre-multiplied by log2(e) / sqrt(64), against a float64 softmax attention of the joined values."""
+def test_attention_split_matches_float64(S, heads, n_seq, prescaled, hip):
+    """ec_attention_split (the attention of the first split-operand blocks): q | k | v as hi + lo fp16 parts -- a plain q, or
+    the q columns pre-multiplied by log2(e) / sqrt(64) -- against a float64 softmax attention of the joined values."""
     import torch
     from eventclip_amd import _lib
     W = heads * 64
     g = torch.Generator(device='cuda').manual_seed(S * 17 + heads)
     qkv = torch.randn(n_seq * S, 3 * W, device='cuda', generator=g) * 1.7
     scaled = qkv.clone()
-    scaled[:, :W] *= 0.125 * 1.4426950408889634
+    if prescaled:
+        scaled[:, :W] *= 0.125 * 1.4426950408889634
     pair = torch.empty((2, n_seq * S, 3 * W), dtype=torch.float16, device='cuda')
     pair[0] = scaled.half()
     pair[1] = (scaled - pair[0].float()).half()
     joined = pair[0].double() + pair[1].double()
-    joined[:, :W] /= 1.4426950408889634       # back to q / 8 (natural-log softmax below)
+    joined[:, :W] *= (1 / 1.4426950408889634) if prescaled else 0.125       # to q / 8 (natural-log softmax below)
     hi = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
     lo = torch.full((n_seq * S, W), float('nan'), dtype=torch.float16, device='cuda')
     _lib.check(_lib.lib().ec_attention_split(_lib.ptr(pair[0]), _lib.ptr(pair[1]), _lib.ptr(hi), _lib.ptr(lo), n_seq, S, W,
-                                             heads, _lib.EC_F16, _lib.stream_ptr()), 'ec_attention_split')
+                                             heads, prescaled, _lib.EC_F16, _lib.stream_ptr()), 'ec_attention_split')
     q, k, v = joined.view(n_seq, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = ((q @ k.transpose(-1, -2)).softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * S, W)
     got = hi.double() + lo.double()
