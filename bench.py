@@ -136,7 +136,8 @@ def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, f
            'what': 'first 8 image-tower blocks as split-operand blocks: LayerNorm of both planes of the residual stream into '
                    'hi + lo parts, QKV / c_fc multiply both parts, every GEMM adds the product with its weight\'s lo part '
                    '(one launch per GEMM; none where the matrix is its 16-bit value); the first 5 of them with attention in '
-                   'fp32 on hi + lo q, k, v (ec_vit_weights.precise_blocks / precise_attn_blocks)'}
+                   'fp32 on hi + lo q, k, v and the MLP activation as hi + lo into c_proj '
+                   '(ec_vit_weights.precise_blocks / precise_attn_blocks)'}
 
     def timed(fn, n):
         fence()

@@ -22,6 +22,7 @@ struct BlockBufs {
     void *mlp;    // [rows, 4W] 16-bit
     float *stats; // [rows, 2] fp32: (rstd, -rstd mean) of the hi plane's rows (folded LayerNorm)
     float *sums;  // [rows, W / 64, 2] fp32: per-group (sum, sum of squares) out of the residual GEMMs' epilogues
+    void *mlp_lo; // [rows, 4W] 16-bit: the lo part of the MLP activation (split-operand blocks with fp32 attention), or NULL
 };
 
 // first_only: the caller reads nothing but row 0 of every sequence after the last block (the vision
@@ -141,10 +142,13 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             }
             EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, nullptr, w.out_w_lo, pa ? att_lo : nullptr));
             EC_TRY(ec_layernorm_hl(x_hi, x_lo, W, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, h_lo2, W, dtype, s));
-            EC_TRY(gemm_split16(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, h_lo2, w.fc1_w, w.fc1_w_lo, w.fc1_b, b.mlp, nullptr, s));
+            // (with fp32 attention also the MLP activation as hi + lo parts into c_proj: where attention is sharp the 16-bit
+            // rounding of QuickGELU's output in the first blocks is the next contribution behind q / k)
+            void *m_lo = pa ? b.mlp_lo : nullptr;
+            EC_TRY(gemm_split16(rows, 4 * W, W, dtype, EC_EPI_GELU16, b.h, h_lo2, w.fc1_w, w.fc1_w_lo, w.fc1_b, b.mlp, m_lo, s));
             // the first default block behind the split-operand blocks takes its statistics from this epilogue's sums
             EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, next_default ? sums : nullptr,
-                           w.fc2_w_lo));
+                           w.fc2_w_lo, m_lo));
             if (next_default) {
                 if (fused)
                     EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
@@ -227,7 +231,7 @@ size_t carve_precise(Scratch &sc, int chunk, int S, int W, PreciseBufs &b, void 
 // carve the scratch for `chunk` sequences of length S; patch_rows > 0 adds the fp32
 // patch-GEMM output (aliased onto the mlp buffer: both are dead at the same time)
 size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs &b, void **small16,
-             int **idx, void **small16_lo = nullptr)
+             int **idx, void **small16_lo = nullptr, bool with_mlp_lo = false)
 {
     const size_t rows = (size_t)chunk * S;
     b.x = (float *)sc.take(rows * W * 4);
@@ -236,6 +240,7 @@ size_t carve(Scratch &sc, int chunk, int S, int W, int out_rows_extra, BlockBufs
     b.mlp = sc.take(rows * 4 * W * 2);   // >= rows * W * 4 bytes: also holds the patch GEMM output
     b.stats = (float *)sc.take(rows * 8 + 16);   // (+ one pair: the LN epilogues fetch the pairs two at a time)
     b.sums = (float *)sc.take(rows * (size_t)(W / 64 + 1) * 8);
+    b.mlp_lo = with_mlp_lo ? sc.take(rows * 4 * W * 2) : nullptr;
     *small16 = sc.take((size_t)chunk * W * 2);
     void *lo = sc.take((size_t)chunk * W * 2);
     if (small16_lo) *small16_lo = lo;
@@ -270,7 +275,7 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
         return carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
     }
     BlockBufs b;
-    carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx);
+    carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx, nullptr, w->precise_blocks > 0 && w->precise_attn_blocks > 0);
     return sc.off + (w->low_latency ? LATENCY_WS_BYTES : 0);
 }
 
@@ -333,7 +338,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     BlockBufs b;
     void *cls16, *cls16_lo;
     int *idx;
-    size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo);
+    size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo, w->precise_blocks > 0 && w->precise_attn_blocks > 0);
     // precise_blocks: the first blocks of the folded chain multiply both planes of the residual stream and the
     // weights' lo parts (run_blocks_folded)
     const int pblocks = w->precise_blocks;

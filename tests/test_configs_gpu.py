@@ -61,20 +61,22 @@ def oracle_forward(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=None, emulate=
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3 relative of the reference's (fp32 oracle)
 # Input-dependent weights: the max-normalised error of full_logits against the fp32 oracle, per config, pinned at
-# 1.5 x what the HIP path measures (profiles/r4_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 3.1e-3 / 2.2e-3) -- a regression of
-# 2 x fails.  north_star's 1e-3 is NOT met there with 16-bit GEMM operands (only ec_vit_weights.precise gets under it:
-# test_precise_tower_meets_1e3_on_signal_weights); DESIGN.md 3.3 and the header say so.
+# 1.5 x what the HIP path measures (profiles/r5_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 4.9e-3 / 5.3e-3; the two N-ImageNet
+# cases were 3.1e-3 / 2.2e-3 on round 4's wide blobs, where 8 - 15 % of their features depended on the input: they now
+# carry 25 - 27 %, make_events_batch) -- a regression of 2 x fails.  north_star's 1e-3 is NOT met there with 16-bit GEMM
+# operands: ec_vit_weights.precise_blocks = 8 gets every config under it
+# (test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights); DESIGN.md 3.3 and the header say so.
 SIGNAL_TOL = {'n_caltech/ViT-B/32': 2.0e-3, 'n_caltech/ViT-L/14': 2.9e-3, 'n_cars/ViT-L/14': 2.0e-3,
-              'n_imagenet/ViT-L/14@336px': 4.7e-3, 'n_imagenet/ViT-L/14': 3.3e-3}
+              'n_imagenet/ViT-L/14@336px': 7.4e-3, 'n_imagenet/ViT-L/14': 8.0e-3}
 # (qk_gain, branch_gain, share of the feature norm that must vary with the input) per geometry: N-ImageNet frames
-# (70 000 events on 480 x 640 pixels under a background mask) are 93 % white paper whatever the events, and the
-# gains that would force 30 % out of them put the tower -- the fp32 one included -- into the chaotic regime where
-# one flipped attention maximum changes the answer (the emulation's error jumps from 5e-3 to 5e-2 between
-# qk_gain 4 and 6): those two configs are held to 10 %
-# (configs[0] is ONE sample: its five views show the same scene, 20 %)
+# (70 000 events on 480 x 640 pixels under a background mask) are mostly white paper whatever the events, and the
+# gains that would force 30 % out of uniform-ish frames put the tower -- the fp32 one included -- into the chaotic
+# regime where one flipped attention maximum changes the answer (the emulation's error jumps from 5e-3 to 5e-2
+# between qk_gain 4 and 6); with the compact blobs of make_events_batch those two configs are held to 20 % (round 4:
+# 10 % / 8 % on the wide blobs).  (configs[0] is ONE sample: its five views show the same scene, 15 %)
 SIGNAL_GAINS = {'n_caltech/ViT-L/14': (2.5, 4.0, 0.3), 'n_caltech/ViT-B/32': (3.0, 4.0, 0.15),
-                'n_cars/ViT-L/14': (2.5, 4.0, 0.3), 'n_imagenet/ViT-L/14@336px': (4.0, 4.0, 0.1),
-                'n_imagenet/ViT-L/14': (4.0, 4.0, 0.08)}
+                'n_cars/ViT-L/14': (2.5, 4.0, 0.3), 'n_imagenet/ViT-L/14@336px': (4.0, 4.0, 0.2),
+                'n_imagenet/ViT-L/14': (4.0, 4.0, 0.2)}
 WEIGHTS = pytest.mark.parametrize('weights', ['init', 'signal'])
 LINE_TAG = ''      # appended to the config's name in the printed / recorded parity lines (the precise_blocks runs)
 
@@ -87,7 +89,15 @@ def make_weights(key, cfg, seed, weights):
 
 def make_events_batch(batch, n_ev, resolution, seed, weights):
     from eventclip_amd.synthetic import make_batch
-    return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.7 if weights == 'signal' else 0.1)
+    if weights != 'signal':
+        return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.1)
+    if tuple(resolution) == (480, 640):
+        # N-ImageNet frames (70 000 events on 480 x 640 pixels under a background mask) stay 84 % white paper with the
+        # sigma = H / 8 blob of the other geometries, and the features then vary by 8 - 15 % only: a compact blob
+        # (95 % of the events within sigma = 24 pixels of a per-sample centre) puts 25 - 30 % of the feature norm into
+        # the input-dependent part at the same gains (round 5; CPU probe of the fp32 oracle: 0.27 / 0.27)
+        return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.95, blob_sigma=24)
+    return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.7)
 
 
 def compare(out, evs, geo, qa, cfg, sd, tokens, T, weights, name, adapter=None, key=None):
@@ -530,10 +540,12 @@ def test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights(hip, c
     first eight blocks of the image tower as split-operand blocks, the first five of them with fp32 attention, the rest
     as the folded 16-bit chain; EVENTCLIP_PRECISE_BLOCKS sets it for the models the config tests build): the same five
     tests with the absolute bound at 1e-3 instead of the per-config 16-bit bounds.  Measured (round 5, profiles/
-    r5_parity.txt): 5.0e-4 / 7.5e-4 / 8.5e-4 / 9.5e-4 / 8.9e-4 at 1.33 x the step on a checkpoint stored in 16 bit
-    (rounds 1 - 4, the fp32-stream chain in those blocks: 3.4e-4 / 7.2e-4 / 5.9e-4 / 9.0e-4 / 7.5e-4 at 1.69 x).  The
-    maximum over a handful of frames is a noisy statistic (profiles/r5_tolerance_sweep.txt: +- 20 % between neighbouring
-    settings); the mode is the cheapest measured one with all five inside."""
+    r5_parity.txt): 4.5e-4 / 6.7e-4 / 6.2e-4 / 8.2e-4 / 8.8e-4 at 1.41 x the step on a checkpoint stored in 16 bit, the two
+    N-ImageNet cases on their round-5 inputs (25 - 27 % of the features input-dependent; rounds 1 - 4, the fp32-stream
+    chain in those blocks on the round-4 inputs: 3.4e-4 / 7.2e-4 / 5.9e-4 / 9.0e-4 / 7.5e-4 at 1.69 x).  The maximum over a
+    handful of frames is a noisy statistic (profiles/r5_tolerance_sweep.txt: +- 20 % between neighbouring settings); the
+    mode is the cheapest measured one with all five inside with some margin (7 : 5 and 8 : 5 without the MLP's lo part
+    are inside on four or at 9.5e-4)."""
     import sys
     mod = sys.modules[__name__]
     fn = [test_config0_ncaltech_gray_vitb32_batch1, test_config1_ncaltech_rgb_vitl14_full_depth,

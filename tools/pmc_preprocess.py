@@ -3,7 +3,9 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eventclip_amd import preprocess  # noqa: E402
-shape, n_px, frames = ((180, 240), 224, 2560) if len(sys.argv) < 2 or sys.argv[1] == 'caltech' else ((480, 640), 224, 1024)
+geo = sys.argv[1] if len(sys.argv) > 1 else 'caltech'
+shape, n_px, frames = {'caltech': ((180, 240), 224, 2560), 'imagenet': ((480, 640), 224, 1024),
+                       'imagenet336': ((480, 640), 336, 1024)}[geo]
 fr = torch.randint(0, 256, (frames, *shape, 3), dtype=torch.uint8, device='cuda')
 kpad = ((2 * 3 * 14 * 14 + 63) // 64) * 64
 out = torch.empty((frames, (n_px // 14) ** 2, kpad), dtype=torch.float16, device='cuda')
