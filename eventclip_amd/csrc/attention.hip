@@ -629,6 +629,134 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Key-half workgroup pair (round 5) for sequences whose K and V leave room for one 16-wave workgroup per CU only
+// (S = 577: 148 KiB).  Each (sequence, head) is handled by TWO 8-wave workgroups that stage HALF of the keys and
+// values each (keys [0, split) / [split, S), split a multiple of 32), so two workgroups are resident per CU and one's
+// staging runs under the other's compute (the one-workgroup kernel spends 26 % of its time in un-overlapped staging,
+// profiles/r4_attention.md) and the 37 query tiles make 4.6 rounds of 8 waves instead of 2.3 of 16 (92 % against 77 %
+// occupancy).  Every workgroup walks ALL query tiles against its keys; a tile's partial (m, l, O) goes to a fp32
+// workspace, a ticket per (unit, tile) says who is second, and the second one merges -- always as (half 0, half 1), so
+// the result does not depend on who finished first -- and writes the output.  The pair is mapped onto ONE XCD
+// (workgroup ids b and b + 8 share an XCD): the exchange stays in that XCD's L2.
+// ---------------------------------------------------------------------------------------
+constexpr int PAIR_REC = 68;     // floats per query in a partial record: O[64], m (log2 units), l, 2 pad
+template <int DT, int QM>
+__global__ __launch_bounds__(512, 2) void attention_pair_kernel(const AttnArgs a, float *part, int *ticket, int split, int SPL,
+                                                                int n_units)
+{
+    typedef typename T16<DT>::elem elem;
+    typedef typename T16<DT>::v8 v8;
+    constexpr int WAVES = 8, THREADS = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = a.S, W = a.W;
+    const int w = blockIdx.x, half = (w >> 3) & 1, unit = (w >> 4) * 8 + (w & 7);
+    if (unit >= n_units) return;
+    const int key0 = half ? split : 0, Sl = half ? S - split : split;      // this workgroup's keys
+    unsigned char *ldsK = smem;
+    unsigned char *ldsV = smem + SPL * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g_lane = lane >> 4, c_lane = lane & 15;
+    const int head = unit % a.heads, seq = unit / a.heads;
+    const long ld = 3L * W;
+    const elem *base = (const elem *)a.qkv + (long)seq * S * ld + head * 64;
+    {   // stage this half's K and V: every load in flight before the first LDS write (rows behind the last key: copies of it)
+        const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
+        u32x4 kv[5], vv[5];
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int row = r_in + p * (THREADS / 8);
+            if (row < SPL) {
+                const int srow = key0 + (row < Sl ? row : Sl - 1);
+                const elem *src = base + (long)srow * ld + ch * 8;
+                kv[p] = *reinterpret_cast<const u32x4 *>(src + W);
+                vv[p] = *reinterpret_cast<const u32x4 *>(src + 2 * W);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int row = r_in + p * (THREADS / 8);
+            if (row < SPL) {
+                *reinterpret_cast<u32x4 *>(ldsK + row * 128 + ((ch ^ (row & 7)) << 4)) = kv[p];
+                u32x4 t = vv[p];
+                if ((row >> 1) & 1) t = u32x4{t[2], t[3], t[0], t[1]};
+                *reinterpret_cast<u32x4 *>(ldsV + row * 128 + ((ch ^ ((row >> 2) & 1)) << 4)) = t;
+            }
+        }
+    }
+    const int n_qt_all = (S + 15) / 16, n_qt = (a.q_rows + 15) / 16;
+    v8 qf[2], qn[2];
+    auto load_q = [&](int qt, v8(&dst)[2]) {
+        int qsrc = qt * 16 + c_lane;
+        qsrc = qsrc < S ? qsrc : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+            dst[ks] = *reinterpret_cast<const v8 *>(base + (long)qsrc * ld + ks * 32 + g_lane * 8);
+    };
+    if (wave < n_qt) load_q(wave, qn);
+    __syncthreads();
+    v8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = to16(1.f, elem());
+    asm volatile("" : "+v"(ones));
+    for (int qt = wave; qt < n_qt; qt += WAVES) {
+        qf[0] = qn[0], qf[1] = qn[1];
+        if (qt + WAVES < n_qt) load_q(qt + WAVES, qn);
+        const int qrow = qt * 16 + c_lane;
+        int g = g_lane, c16 = c_lane;
+        asm volatile("" : "+v"(g), "+v"(c16));
+        f32x4 o[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (QM == QM_KERNEL) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) qf[ks][j] = to16((float)qf[ks][j] * a.scale_log2e, elem());
+        }
+        attn_keys<DT, QM>(ldsK, ldsV, Sl, 0, Sl >> 5, true, qf, ones, a.scale_log2e, mneg, o, g, c16);
+        float l_me = o[4][0];
+        float m_me = QM != QM_RAW ? -mneg[0] : -mneg[0] * a.scale_log2e;     // log2 units
+        // ---- this half's partial -> workspace; the ticket says whether the other half is there already ----
+        const long rec = ((long)unit * n_qt_all + qt) * 2;
+        float *mine = part + ((rec + half) * 16 + c16) * PAIR_REC, *theirs = part + ((rec + (half ^ 1)) * 16 + c16) * PAIR_REC;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) *reinterpret_cast<f32x4 *>(mine + 16 * g + 4 * dt) = o[dt];
+        if (g == 0) *reinterpret_cast<float2 *>(mine + 64) = make_float2(m_me, l_me);
+        int old = 0;
+        if (lane == 0)
+            old = __hip_atomic_fetch_add(ticket + (long)unit * n_qt_all + qt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == 0) continue;       // first: the other half's workgroup finishes the tile
+        // second: merge as (half 0, half 1) whoever we are
+        f32x4 ot[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) ot[dt] = *reinterpret_cast<const volatile f32x4 *>(theirs + 16 * g + 4 * dt);
+        const float mlx = *reinterpret_cast<const volatile float *>(theirs + 64), mly = *reinterpret_cast<const volatile float *>(theirs + 65);
+        const float2 ml = make_float2(mlx, mly);
+        const float m0 = half ? ml.x : m_me, m1 = half ? m_me : ml.x, l0 = half ? ml.y : l_me, l1 = half ? l_me : ml.y;
+        const float m = fmaxf(m0, m1);
+        const float f0 = __builtin_amdgcn_exp2f(m0 - m), f1 = __builtin_amdgcn_exp2f(m1 - m);
+        const float inv = 1.f / (l0 * f0 + l1 * f1);
+        if (lane == 0) ticket[(long)unit * n_qt_all + qt] = 0;     // ready for the next launch on this workspace
+        if (qrow < a.q_rows) {
+            elem ov[16];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float x0 = half ? ot[dt][r] : o[dt][r], x1 = half ? o[dt][r] : ot[dt][r];
+                    ov[4 * dt + r] = to16((x0 * f0 + x1 * f1) * inv, elem());
+                }
+            elem *dst = (elem *)a.out + ((long)seq * a.q_rows + qrow) * W + head * 64 + g * 16;
+            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&ov[0]);
+            *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
+        }
+    }
+}
+
 #ifdef EC_ATTN_DIAG
 #include "attention_diag.inc"     // attention32_kernel, the round-1 fp32 kernel: A / B forms of the diagnostic build
 #endif
@@ -1005,6 +1133,51 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, qkv_hi, qkv_lo, out_hi, out_lo, S, width, heads, 0);
     else
         return ec::fail(EC_ERR_INVALID, "ec_attention_split: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// ---- key-half workgroup pair (see attention_pair_kernel) ----
+static inline int pair_split(int S) { return (S / 2) & ~31; }
+static inline int pair_rows(int S)
+{
+    const int split = pair_split(S), sl = S - split;          // the second half is the longer one
+    return (sl & 31) == 1 ? ((sl + 15 + 15) / 16) * 16 : ((sl + 31) / 32) * 32;   // its odd key's 16 copies, else whole steps
+}
+extern "C" EC_API size_t ec_attention_pair_workspace_bytes(int n_seq, int S, int heads)
+{
+    if (n_seq <= 0 || S <= 0 || heads <= 0) return 0;
+    const size_t tiles = (size_t)n_seq * heads * ((S + 15) / 16);
+    return tiles * 2 * 16 * PAIR_REC * 4 + ((tiles * 4 + 255) & ~(size_t)255);
+}
+extern "C" EC_API int ec_attention_pair(const void *qkv, void *out, int n_seq, int S, int width, int heads, int q_rows,
+                                        int q_scaled, int dtype, void *workspace, size_t workspace_bytes, ec_stream_t stream)
+{
+    EC_REQUIRE(n_seq >= 0 && S >= 64 && heads > 0 && width == heads * 64, "ec_attention_pair: bad shape (S >= 64, head dim 64)");
+    EC_REQUIRE(q_rows >= 1 && q_rows <= S, "ec_attention_pair: q_rows=%d outside 1..%d", q_rows, S);
+    if (n_seq == 0) return EC_OK;
+    EC_REQUIRE(qkv && out && workspace && ((uintptr_t)workspace & 255) == 0, "ec_attention_pair: null or misaligned buffer");
+    const size_t need = ec_attention_pair_workspace_bytes(n_seq, S, heads);
+    if (workspace_bytes < need)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_attention_pair: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int SPL = pair_rows(S), lds = SPL * 128 * 2;
+    EC_REQUIRE(SPL <= 5 * 64 && lds <= 80 * 1024, "ec_attention_pair: sequence length %d needs %d bytes of LDS per workgroup (<= 81920)", S, lds);
+    AttnArgs a;
+    a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = 0, a.q_rows = q_rows, a.lse = nullptr;
+    a.scale_log2e = 0.125f * 1.4426950408889634f, a.q_scaled = q_scaled;
+    const size_t tiles = (size_t)n_seq * heads * ((S + 15) / 16);
+    float *part = static_cast<float *>(workspace);
+    int *ticket = reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + tiles * 2 * 16 * PAIR_REC * 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    EC_CHECK_HIP(hipMemsetAsync(ticket, 0, tiles * 4, s));
+    void (*kern)(const AttnArgs, float *, int *, int, int, int) = nullptr;
+    if (dtype == EC_F16) kern = q_scaled ? attention_pair_kernel<EC_F16, QM_INPUT> : attention_pair_kernel<EC_F16, QM_KERNEL>;
+    else if (dtype == EC_BF16) kern = q_scaled ? attention_pair_kernel<EC_BF16, QM_INPUT> : attention_pair_kernel<EC_BF16, QM_RAW>;
+    else return ec::fail(EC_ERR_INVALID, "ec_attention_pair: unknown dtype %d", dtype);
+    if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 80 * 1024)) return rc;
+    const int n_units = n_seq * heads;
+    ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * q_rows * S * 64.0 * heads * n_seq, (double)n_seq * width * 2.0 * (2.0 * S + 2.0 * q_rows));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_units + 7) / 8 * 16)), dim3(512), lds, s, a, part, ticket, pair_split(S), SPL, n_units);
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
