@@ -203,9 +203,6 @@ SIGNATURES = {
     'ec_split16': (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'ec_attention_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_void_p]),
-    'ec_attention_pair_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
-    'ec_attention_pair': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t,
-                                  c_void_p]),
     'ec_attention_split': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_vit_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_float, c_void_p, c_void_p]),

@@ -20,6 +20,7 @@
 //    row order is permuted so each lane ends with 16 contiguous head-dim outputs
 //    (two 16-B stores).
 //  * fp32 scores / softmax / accumulation; the 1/sqrt(64) scale is a power of two.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -629,7 +630,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 }
 
 
+#ifdef EC_ATTN_DIAG
 // ---------------------------------------------------------------------------------------
+// DIAGNOSTIC BUILD ONLY (measured, not kept: profiles/r5_attention.md).
 // Key-half workgroup pair (round 5) for sequences whose K and V leave room for one 16-wave workgroup per CU only
 // (S = 577: 148 KiB).  Each (sequence, head) is handled by TWO 8-wave workgroups that stage HALF of the keys and
 // values each (keys [0, split) / [split, S), split a multiple of 32), so two workgroups are resident per CU and one's
@@ -703,7 +706,6 @@ __global__ __launch_bounds__(512, 2) void attention_pair_kernel(const AttnArgs a
     for (int qt = wave; qt < n_qt; qt += WAVES) {
         qf[0] = qn[0], qf[1] = qn[1];
         if (qt + WAVES < n_qt) load_q(qt + WAVES, qn);
-        const int qrow = qt * 16 + c_lane;
         int g = g_lane, c16 = c_lane;
         asm volatile("" : "+v"(g), "+v"(c16));
         f32x4 o[5];
@@ -717,45 +719,73 @@ __global__ __launch_bounds__(512, 2) void attention_pair_kernel(const AttnArgs a
                 for (int j = 0; j < 8; j++) qf[ks][j] = to16((float)qf[ks][j] * a.scale_log2e, elem());
         }
         attn_keys<DT, QM>(ldsK, ldsV, Sl, 0, Sl >> 5, true, qf, ones, a.scale_log2e, mneg, o, g, c16);
-        float l_me = o[4][0];
-        float m_me = QM != QM_RAW ? -mneg[0] : -mneg[0] * a.scale_log2e;     // log2 units
-        // ---- this half's partial -> workspace; the ticket says whether the other half is there already ----
+        const float l_me = o[4][0];
+        const float m_me = QM != QM_RAW ? -mneg[0] : -mneg[0] * a.scale_log2e;     // log2 units
+        // ---- this half's partial -> workspace (no wait here: the exchange of all of the wave's tiles comes behind the loop) ----
+        // The exchange is made of agent-scope ACCESSES, not fences: stores and loads with the sc1 bit are coherent at the
+        // device's coherence point line by line.  (The first version took an acq_rel ticket per tile: hipcc brackets that
+        // with buffer_wbl2 / buffer_inv -- a write-back and an invalidate of the whole L2 -- 26 x slower than the kernel it
+        // was meant to beat; the second waited per tile for store acknowledgement, ticket and loads in a row: 3.3 x slower.)
+        float *mine = part + ((((long)unit * n_qt_all + qt) * 2 + half) * 16 + c16) * PAIR_REC;
+        if (a.causal == 2) continue;      // (timing experiment: no exchange at all -- nothing is written)
+        if (a.causal != 1) {              // write-back stores: the pair shares an XCD, hence an L2 (the form that is correct and least slow)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<f32x4 *>(mine + 16 * g + 4 * dt) = o[dt];
+            if (g == 0) *reinterpret_cast<float2 *>(mine + 64) = make_float2(m_me, l_me);
+            continue;
+        }
+        // (a.causal == 1: agent-scope write-through stores -- slower still, and the merger's sc1 loads of its OWN partial
+        // came back stale in this form)
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + 16 * g + 4 * dt), "v"(o[dt]) : "memory");
+        if (g == 0) {
+            const float2 mlv = make_float2(m_me, l_me);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(mine + 64), "v"(mlv) : "memory");
+        }
+    }
+    if (a.causal == 2) return;
+    // ---- exchange: every partial of this wave is acknowledged, then one ticket per tile (lane i takes tile wave + 8 i),
+    // then the tiles this workgroup came second on are merged -- as (half 0, half 1) whoever merges -- and written ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int my_tiles = n_qt > wave ? (n_qt - wave + WAVES - 1) / WAVES : 0;
+    int old = 0;
+    if (lane < my_tiles)
+        old = __hip_atomic_fetch_add(ticket + (long)unit * n_qt_all + wave + WAVES * lane, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long second = __builtin_amdgcn_ballot_w64(old != 0);
+    for (int i = 0; i < my_tiles; i++) {
+        if (!((second >> i) & 1)) continue;       // first on this tile: the other half's workgroup finishes it
+        const int qt = wave + WAVES * i, qrow = qt * 16 + c_lane, g = g_lane, c16 = c_lane;
         const long rec = ((long)unit * n_qt_all + qt) * 2;
-        float *mine = part + ((rec + half) * 16 + c16) * PAIR_REC, *theirs = part + ((rec + (half ^ 1)) * 16 + c16) * PAIR_REC;
+        const float *p0 = part + ((rec + 0) * 16 + c16) * PAIR_REC, *p1 = part + ((rec + 1) * 16 + c16) * PAIR_REC;
+        f32x4 o0[4], o1[4];
+        float2 ml0, ml1;
 #pragma unroll
-        for (int dt = 0; dt < 4; dt++) *reinterpret_cast<f32x4 *>(mine + 16 * g + 4 * dt) = o[dt];
-        if (g == 0) *reinterpret_cast<float2 *>(mine + 64) = make_float2(m_me, l_me);
-        int old = 0;
-        if (lane == 0)
-            old = __hip_atomic_fetch_add(ticket + (long)unit * n_qt_all + qt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old == 0) continue;       // first: the other half's workgroup finishes the tile
-        // second: merge as (half 0, half 1) whoever we are
-        f32x4 ot[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; dt++) ot[dt] = *reinterpret_cast<const volatile f32x4 *>(theirs + 16 * g + 4 * dt);
-        const float mlx = *reinterpret_cast<const volatile float *>(theirs + 64), mly = *reinterpret_cast<const volatile float *>(theirs + 65);
-        const float2 ml = make_float2(mlx, mly);
-        const float m0 = half ? ml.x : m_me, m1 = half ? m_me : ml.x, l0 = half ? ml.y : l_me, l1 = half ? l_me : ml.y;
-        const float m = fmaxf(m0, m1);
-        const float f0 = __builtin_amdgcn_exp2f(m0 - m), f1 = __builtin_amdgcn_exp2f(m1 - m);
-        const float inv = 1.f / (l0 * f0 + l1 * f1);
+        for (int dt = 0; dt < 4; dt++) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(o0[dt]) : "v"(p0 + 16 * g + 4 * dt) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(o1[dt]) : "v"(p1 + 16 * g + 4 * dt) : "memory");
+        }
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(ml0) : "v"(p0 + 64) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ml1) : "v"(p1 + 64) : "memory");
+        asm volatile("" : "+v"(o0[0]), "+v"(o0[1]), "+v"(o0[2]), "+v"(o0[3]), "+v"(o1[0]), "+v"(o1[1]), "+v"(o1[2]), "+v"(o1[3]), "+v"(ml0));
+        const float m = fmaxf(ml0.x, ml1.x);
+        const float f0 = __builtin_amdgcn_exp2f(ml0.x - m), f1 = __builtin_amdgcn_exp2f(ml1.x - m);
+        const float inv = 1.f / (ml0.y * f0 + ml1.y * f1);
         if (lane == 0) ticket[(long)unit * n_qt_all + qt] = 0;     // ready for the next launch on this workspace
         if (qrow < a.q_rows) {
             elem ov[16];
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float x0 = half ? ot[dt][r] : o[dt][r], x1 = half ? o[dt][r] : ot[dt][r];
-                    ov[4 * dt + r] = to16((x0 * f0 + x1 * f1) * inv, elem());
-                }
+                for (int r = 0; r < 4; r++) ov[4 * dt + r] = to16((o0[dt][r] * f0 + o1[dt][r] * f1) * inv, elem());
             elem *dst = (elem *)a.out + ((long)seq * a.q_rows + qrow) * W + head * 64 + g * 16;
             *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(&ov[0]);
             *reinterpret_cast<u32x4 *>(dst + 8) = *reinterpret_cast<const u32x4 *>(&ov[8]);
         }
     }
 }
+
+#endif
 
 #ifdef EC_ATTN_DIAG
 #include "attention_diag.inc"     // attention32_kernel, the round-1 fp32 kernel: A / B forms of the diagnostic build
@@ -1137,6 +1167,8 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
     return EC_OK;
 }
 
+#ifdef EC_ATTN_DIAG
+// (diagnostic build only; not part of the public header)
 // ---- key-half workgroup pair (see attention_pair_kernel) ----
 static inline int pair_split(int S) { return (S / 2) & ~31; }
 static inline int pair_rows(int S)
@@ -1144,13 +1176,13 @@ static inline int pair_rows(int S)
     const int split = pair_split(S), sl = S - split;          // the second half is the longer one
     return (sl & 31) == 1 ? ((sl + 15 + 15) / 16) * 16 : ((sl + 31) / 32) * 32;   // its odd key's 16 copies, else whole steps
 }
-extern "C" EC_API size_t ec_attention_pair_workspace_bytes(int n_seq, int S, int heads)
+extern "C" __attribute__((visibility("default"))) size_t ec_attention_pair_workspace_bytes(int n_seq, int S, int heads)
 {
     if (n_seq <= 0 || S <= 0 || heads <= 0) return 0;
     const size_t tiles = (size_t)n_seq * heads * ((S + 15) / 16);
     return tiles * 2 * 16 * PAIR_REC * 4 + ((tiles * 4 + 255) & ~(size_t)255);
 }
-extern "C" EC_API int ec_attention_pair(const void *qkv, void *out, int n_seq, int S, int width, int heads, int q_rows,
+extern "C" __attribute__((visibility("default"))) int ec_attention_pair(const void *qkv, void *out, int n_seq, int S, int width, int heads, int q_rows,
                                         int q_scaled, int dtype, void *workspace, size_t workspace_bytes, ec_stream_t stream)
 {
     EC_REQUIRE(n_seq >= 0 && S >= 64 && heads > 0 && width == heads * 64, "ec_attention_pair: bad shape (S >= 64, head dim 64)");
@@ -1165,6 +1197,7 @@ extern "C" EC_API int ec_attention_pair(const void *qkv, void *out, int n_seq, i
     AttnArgs a;
     a.qkv = qkv, a.out = out, a.S = S, a.W = width, a.heads = heads, a.causal = 0, a.q_rows = q_rows, a.lse = nullptr;
     a.scale_log2e = 0.125f * 1.4426950408889634f, a.q_scaled = q_scaled;
+    if (const char *dbg = getenv("EC_PAIR_DEBUG")) a.causal = atoi(dbg);      // 1: sc1 stores, 2: no exchange (timing experiments)
     const size_t tiles = (size_t)n_seq * heads * ((S + 15) / 16);
     float *part = static_cast<float *>(workspace);
     int *ticket = reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + tiles * 2 * 16 * PAIR_REC * 4);
@@ -1181,3 +1214,4 @@ extern "C" EC_API int ec_attention_pair(const void *qkv, void *out, int n_seq, i
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }
+#endif

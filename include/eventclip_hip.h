@@ -396,15 +396,6 @@ EC_API int ec_attention_rows(const void *qkv, void *out, int n_seq, int S, int w
 EC_API int ec_attention_scaled_q(const void *qkv, void *out, int n_seq, int S, int width, int heads,
                                  int causal, int q_rows, int dtype, ec_stream_t stream);
 
-/* Key-half workgroup pair (round 5): ec_attention_rows (q_scaled == 0) / ec_attention_scaled_q (!= 0) without a mask, each
- * (sequence, head) handled by two 8-wave workgroups that stage half of the keys and values each and merge their partial
- * (m, l, O) through `workspace` (ec_attention_pair_workspace_bytes, 256-byte aligned) in a fixed order -- for sequences whose
- * K and V leave room for one workgroup per CU only (S = 577).  Results differ from the one-workgroup kernel in the
- * summation order; a call with q_rows < S is a bit-exact prefix of the call with q_rows = S. */
-EC_API size_t ec_attention_pair_workspace_bytes(int n_seq, int S, int heads);
-EC_API int ec_attention_pair(const void *qkv, void *out, int n_seq, int S, int width, int heads, int q_rows, int q_scaled,
-                             int dtype, void *workspace, size_t workspace_bytes, ec_stream_t stream);
-
 /* Training forms (fine-tuning the vision tower, models/clip_cls_ft.py:44-80): the same forward that also
  * keeps, per (sequence, head, query), the log2 of its softmax denominator in the scaled-score domain
  * (lse fp32 [n_seq, heads, S]), and the backward pass torch autograd runs for nn.MultiheadAttention:

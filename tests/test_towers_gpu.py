@@ -96,43 +96,6 @@ def test_attention_f32_matches_float64(S, heads, causal, n_seq, hip):
     assert err < 4e-6, err
 
 
-@pytest.mark.parametrize('dt', ['float16', 'bfloat16'])
-@pytest.mark.parametrize('scaled', [0, 1])
-@pytest.mark.parametrize('S,heads,n_seq', [(577, 16, 3), (577, 3, 11), (353, 2, 5), (608, 1, 9), (64, 2, 3), (129, 4, 2)])
-def test_attention_key_half_pair(S, heads, n_seq, scaled, dt, hip):
-    """ec_attention_pair: two workgroups per (sequence, head), half the keys each, partial (m, l, O) merged through the
-    workspace in a fixed order -- against an fp32 reference at the one-workgroup kernel's tolerance, bit-identical from run
-    to run (the merge does not depend on which half finishes first), unit counts that are not a multiple of the 8 XCDs, and a
-    q_rows < S call as a bit-exact prefix of the full one (the class-token-only last block)."""
-    import torch
-    from eventclip_amd import _lib
-    dtype = getattr(torch, dt)
-    code = _lib.EC_F16 if dt == 'float16' else _lib.EC_BF16
-    W = heads * 64
-    g = torch.Generator(device='cuda').manual_seed(S + heads)
-    qkv = (torch.randn(n_seq * S, 3 * W, device='cuda', generator=g) * 1.5).to(dtype)
-    want = ref_attention(qkv, n_seq, S, W, heads, 0)
-    fed = qkv.clone()
-    if scaled:
-        fed[:, :W] = (qkv[:, :W].float() * (0.125 * 1.4426950408889634)).to(dtype)
-    lib = _lib.lib()
-    ws = torch.empty(lib.ec_attention_pair_workspace_bytes(n_seq, S, heads), dtype=torch.uint8, device='cuda')
-
-    def run(q_rows):
-        out = torch.full((n_seq * q_rows, W), float('nan'), dtype=dtype, device='cuda')
-        _lib.check(lib.ec_attention_pair(_lib.ptr(fed), _lib.ptr(out), n_seq, S, W, heads, q_rows, scaled, code, _lib.ptr(ws),
-                                         ws.numel(), _lib.stream_ptr()), 'ec_attention_pair')
-        return out
-    out = run(S)
-    tol = 4e-3 if dt == 'float16' else 2.5e-2
-    torch.testing.assert_close(out.float(), want, rtol=tol, atol=tol)
-    for _ in range(3):
-        assert torch.equal(run(S), out)
-    for q_rows in (1, 17):
-        if q_rows <= S:
-            assert torch.equal(run(q_rows).view(n_seq, q_rows, W), out.view(n_seq, S, W)[:, :q_rows])
-
-
 @pytest.mark.parametrize('prescaled', [0, 1])
 @pytest.mark.parametrize('S,heads,n_seq', [(257, 16, 3), (577, 4, 2), (50, 12, 4), (197, 3, 2), (1, 2, 2), (64, 1, 2), (65, 1, 2)])
 def test_attention_split_matches_float64(S, heads, n_seq, prescaled, hip):

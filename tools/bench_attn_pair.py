@@ -1,7 +1,8 @@
-"""The key-half workgroup pair (ec_attention_pair, round 5) against the one-workgroup kernel (ec_attention_scaled_q) at the
-sequence lengths whose K and V fill a CU's LDS, interleaved in one process (product library).
+"""The key-half workgroup pair (round 5; diagnostic build only: measured, not kept -- profiles/r5_attention.md) against the
+one-workgroup kernel (ec_attention_scaled_q) at the sequence lengths whose K and V fill a CU's LDS, interleaved in one process.
 
-    python tools/bench_attn_pair.py [--S 577] [--n-seq 256]
+    python -m eventclip_amd.build --diag && python tools/bench_attn_pair.py [--S 577] [--n-seq 256]
+    EC_PAIR_DEBUG=2 ...   no exchange at all (compute only: wrong output)      EC_PAIR_DEBUG=1 ...   agent-scope write-through stores
 
 Prints ms per launch (median over the rounds), both kernels' error against an fp32 torch reference on the same data, and
 whether a q_rows = 1 call of the pair is a bit-exact prefix of its full call.
@@ -14,6 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', 'libeventclip_hip_diag.so'))
 from eventclip_amd import _lib  # noqa: E402
 
 
@@ -30,7 +32,13 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--iters', type=int, default=20)
     a = ap.parse_args()
+    import ctypes
     lib = _lib.lib()
+    diag = ctypes.CDLL(os.environ['EVENTCLIP_HIP_LIB'])
+    diag.ec_attention_pair_workspace_bytes.restype = ctypes.c_size_t
+    diag.ec_attention_pair_workspace_bytes.argtypes = [ctypes.c_int] * 3
+    diag.ec_attention_pair.restype = ctypes.c_int
+    diag.ec_attention_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     heads, W = 16, 1024
     for S in a.S:
         torch.manual_seed(S)
@@ -39,13 +47,13 @@ def main():
         scaled[:, :W] = (qkv[:, :W].float() * (0.125 * 1.4426950408889634)).half()
         out_a = torch.empty(a.n_seq * S, W, dtype=torch.float16, device='cuda')
         out_b = torch.empty_like(out_a)
-        ws = torch.empty(lib.ec_attention_pair_workspace_bytes(a.n_seq, S, heads), dtype=torch.uint8, device='cuda')
+        ws = torch.empty(diag.ec_attention_pair_workspace_bytes(a.n_seq, S, heads), dtype=torch.uint8, device='cuda')
 
         def one():
             _lib.check(lib.ec_attention_scaled_q(_lib.ptr(scaled), _lib.ptr(out_a), a.n_seq, S, W, heads, 0, S, _lib.EC_F16, _lib.stream_ptr()))
 
         def pair(q_rows=S, out=out_b):
-            _lib.check(lib.ec_attention_pair(_lib.ptr(scaled), _lib.ptr(out), a.n_seq, S, W, heads, q_rows, 1, _lib.EC_F16, _lib.ptr(ws),
+            _lib.check(diag.ec_attention_pair(_lib.ptr(scaled), _lib.ptr(out), a.n_seq, S, W, heads, q_rows, 1, _lib.EC_F16, _lib.ptr(ws),
                                              ws.numel(), _lib.stream_ptr()))
         for fn in (one, pair):
             for _ in range(3):
