@@ -377,6 +377,8 @@ class CLIP(nn.Module):
         vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
                     ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))
+        # (a mixed checkpoint -- some matrices exact, some not -- sets the flag and relies on the per-matrix NULL lo
+        # pointers: the C side checks every pointer it is about to use, the flag only says that NULL is allowed)
         v.weights_exact16 = int(any(exact))
         t = _lib.EcTextWeights()
         t.dtype, t.ctx, t.vocab, t.width = code, c['context_length'], c['vocab_size'], c['text_width']

@@ -390,6 +390,13 @@ __device__ __forceinline__ void attn_keys(const unsigned char *ldsK, const unsig
 
 // Floats per wave in the merge area of a tile whose keys are split over the waves: O (64), m, l
 constexpr int ATTN_PART = 66;
+// Is the sequence's LAST query tile (a single row, S = 16 n + 1) split over the waves?  ONE predicate for the kernel (which
+// writes the merge area behind the K / V images) and for the host (which reserves it): depends on S, the mask and the wave
+// count alone, never on q_rows.
+__host__ __device__ constexpr bool attn_lone_tile(int S, int causal, int waves)
+{
+    return !causal && (S & 15) == 1 && (S + 15) / 16 > waves && ((S + 15) / 16) % waves == 1;
+}
 
 template <int DT, int AT_WAVES, bool LSE = false, bool V2 = true, int QM = (DT == 0 ? QM_KERNEL : QM_RAW)>
 __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnArgs a)
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
     // through LDS (V2 kernels, not causal).  Whether a tile is split depends on S alone, never on q_rows, so
     // ec_attention_rows stays a bit-exact prefix of ec_attention.
     const int n_qt_all = (S + 15) / 16;
-    const bool lone = V2 && !a.causal && (S & 15) == 1 && n_qt_all > AT_WAVES && n_qt_all % AT_WAVES == 1;
+    const bool lone = V2 && attn_lone_tile(S, a.causal, AT_WAVES);
     const int n_qt_req = (a.q_rows + 15) / 16;                           // tiles the caller asked for
     const int n_qt = lone ? min(n_qt_req, n_qt_all - 1) : n_qt_req;      // ... that are walked tile by tile
     const bool do_lone = lone && n_qt_req == n_qt_all;
@@ -629,6 +636,305 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void attention_kernel(const AttnA
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Attention on hi + lo fp16 operands (round 5): the fp32-class attention of the tolerance mode's first blocks
+// (ec_vit_weights.precise_attn_blocks) on the 16-bit matrix instruction instead of the fp32 one -- 2.5 PFLOP/s against
+// 157 TFLOP/s of peak, three products per tile:
+//   scores   s = q_hi k_hi + q_lo k_hi + q_hi k_lo            (q = c (q_hi + q_lo) re-split in registers, c = log2 e / 8)
+//   P V      o += v_hi p_hi + v_hi p_lo + v_lo p_hi,  l += 1 p_hi + 1 p_lo     (p = exp2(s - m) as p_hi + p_lo)
+// (the lo . lo products, 2^-22 of the result, are left out).  Structure of attention_kernel: one 8-wave workgroup per
+// (sequence, head), K_hi, K_lo, V_hi, V_lo of the head in LDS (4 x S x 128 B: S <= 288 in 160 KiB -- longer sequences take
+// ec_attention_split's fp32 kernel), S^T = K Q^T so that a lane holds one query column, P as the B operand of O^T = V^T P^T,
+// the running maximum that moves only when a score exceeds it by 2^10, the odd key of S = 32 n + 1 as a rank-one update (in
+// fp32 on the vector ALU), the lone 17th tile of S = 257 split over the waves.  Plain builtin MFMAs and plain C++ for the
+// seldom-taken rescale (no inline-asm accumulators: nothing for tools/check_attn_isa.py to check here).
+// ---------------------------------------------------------------------------------------
+struct AttnHlArgs {
+    const _Float16 *qkv_hi, *qkv_lo;   // [n_seq * S, 3W]: q | k | v, a PLAIN q
+    _Float16 *out_hi, *out_lo;         // [n_seq * S, W]
+    int S, W, heads;
+};
+
+__device__ __forceinline__ void hl_move(float d, bool down, f32x4 &mneg, f32x4 (&o)[5])
+{
+    float alpha = __builtin_amdgcn_exp2f(-d);
+    alpha = down ? 0.f : alpha;
+#pragma unroll
+    for (int dt = 0; dt < 5; dt++) o[dt] *= alpha;
+    mneg -= d;
+}
+
+// one 32-key step.  `down`: the tile has added nothing yet (m may move down too)
+template <bool MASK>
+__device__ __forceinline__ void attn_step_hl(const unsigned char *kh, const unsigned char *kl, const unsigned char *vh,
+                                             const unsigned char *vl, int key0, int klimit, const f16x8 (&qh)[2],
+                                             const f16x8 (&ql)[2], const f16x8 &ones, bool down, f32x4 &mneg, f32x4 (&o)[5],
+                                             int g, int c16)
+{
+    f32x4 acc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++) {
+        const int row = key0 + kt * 16 + c16;
+        const int o0 = row * 128 + (((0 + g) ^ (row & 7)) << 4), o1 = row * 128 + (((4 + g) ^ (row & 7)) << 4);
+        const f16x8 k0h = *reinterpret_cast<const f16x8 *>(kh + o0), k1h = *reinterpret_cast<const f16x8 *>(kh + o1);
+        const f16x8 k0l = *reinterpret_cast<const f16x8 *>(kl + o0), k1l = *reinterpret_cast<const f16x8 *>(kl + o1);
+        f32x4 a = mfma16(k0l, qh[0], mneg);       // the small products first
+        a = mfma16(k1l, qh[1], a);
+        a = mfma16(k0h, ql[0], a);
+        a = mfma16(k1h, ql[1], a);
+        a = mfma16(k0h, qh[0], a);
+        acc[kt] = mfma16(k1h, qh[1], a);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (MASK) {
+                const int key = key0 + kt * 16 + 4 * g + r;
+                acc[kt][r] = key < klimit ? acc[kt][r] : -INFINITY;
+            }
+            mx = fmaxf(mx, acc[kt][r]);
+        }
+    if (__builtin_amdgcn_ballot_w64(mx > ATTN_THR || (down && mx < -ATTN_LO)) != 0) {
+        const float mq = xor_max(mx);
+        const float d = (mq > ATTN_THR || (down && mq < -ATTN_LO)) ? mq : 0.f;      // only the queries that need it move
+        acc[0] -= d, acc[1] -= d;
+        hl_move(d, down, mneg, o);
+    }
+    // V^T fragments of both parts: A operand row i <-> head dim (i >> 2) * 16 + 4 dt + (i & 3)
+    f16x8 vfh[4], vfl[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int row = key0 + 16 * hh + 4 * g + (c16 >> 2);
+            const int off = row * 128 + ((((c16 & 3) * 4 + dt) ^ ((row >> 1) & 3)) << 3);
+            const f16x4 th = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vh + off)));
+            const f16x4 tl = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vl + off)));
+#pragma unroll
+            for (int e = 0; e < 4; e++) vfh[dt][4 * hh + e] = th[e], vfl[dt][4 * hh + e] = tl[e];
+        }
+    // P = exp2(s - m) as hi + lo; B operand element j <-> key key0 + 16 (j >> 2) + 4 g + (j & 3)
+    f16x8 ph, pl;
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float pv = __builtin_amdgcn_exp2f(acc[kt][r]);
+            const _Float16 h = (_Float16)pv;
+            ph[4 * kt + r] = h;
+            pl[4 * kt + r] = (_Float16)(pv - (float)h);
+        }
+    o[4] = mfma16(ones, pl, o[4]);
+    o[4] = mfma16(ones, ph, o[4]);
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        f32x4 t = mfma16(vfl[dt], ph, o[dt]);
+        t = mfma16(vfh[dt], pl, t);
+        o[dt] = mfma16(vfh[dt], ph, t);
+    }
+}
+
+// the single key behind the last full step (S = 32 n + 1): the LDS rows behind it are copies of it, so every accumulator
+// register of a lane is the lane's query against THIS key; P V in fp32 on the vector ALU (no rounding of p at all)
+__device__ __forceinline__ void attn_odd_key_hl(const unsigned char *kh, const unsigned char *kl, const unsigned char *vh,
+                                                const unsigned char *vl, int key, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
+                                                bool down, f32x4 &mneg, f32x4 (&o)[5], int g, int c16)
+{
+    const int row = key + c16;
+    const int o0 = row * 128 + (((0 + g) ^ (row & 7)) << 4), o1 = row * 128 + (((4 + g) ^ (row & 7)) << 4);
+    const f16x8 k0h = *reinterpret_cast<const f16x8 *>(kh + o0), k1h = *reinterpret_cast<const f16x8 *>(kh + o1);
+    const f16x8 k0l = *reinterpret_cast<const f16x8 *>(kl + o0), k1l = *reinterpret_cast<const f16x8 *>(kl + o1);
+    f16x4 vvh[4], vvl[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {      // logical 8-byte slot 4 g + dt of V's row, stored at slot ^ ((key >> 1) & 3)
+        const int off = key * 128 + ((4 * g + dt) ^ ((key >> 1) & 3)) * 8;
+        vvh[dt] = *reinterpret_cast<const f16x4 *>(vh + off), vvl[dt] = *reinterpret_cast<const f16x4 *>(vl + off);
+    }
+    f32x4 a = mfma16(k0l, qh[0], mneg);
+    a = mfma16(k1l, qh[1], a);
+    a = mfma16(k0h, ql[0], a);
+    a = mfma16(k1h, ql[1], a);
+    a = mfma16(k0h, qh[0], a);
+    a = mfma16(k1h, qh[1], a);
+    float sc = a[0];
+    if (__builtin_amdgcn_ballot_w64(sc > ATTN_THR || (down && sc < -ATTN_LO)) != 0) {
+        const float d = (sc > ATTN_THR || (down && sc < -ATTN_LO)) ? sc : 0.f;
+        sc -= d;
+        hl_move(d, down, mneg, o);
+    }
+    const float pv = __builtin_amdgcn_exp2f(sc);
+    o[4][0] += pv;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[dt][r] = __builtin_fmaf(pv, (float)vvh[dt][r] + (float)vvl[dt][r], o[dt][r]);
+}
+
+// keys of one tile: the full 32-key steps [step0, step1), then (`tail`) what lies behind the last full step
+__device__ __forceinline__ void attn_keys_hl(const unsigned char *kh, const unsigned char *kl, const unsigned char *vh,
+                                             const unsigned char *vl, int S, int step0, int step1, bool tail,
+                                             const f16x8 (&qh)[2], const f16x8 (&ql)[2], const f16x8 &ones, f32x4 &mneg,
+                                             f32x4 (&o)[5], int g, int c16)
+{
+    bool down = true;
+    for (int s = step0; s < step1; s++) {
+        attn_step_hl<false>(kh, kl, vh, vl, 32 * s, S, qh, ql, ones, down, mneg, o, g, c16);
+        down = false;
+    }
+    if (tail) {
+        const int full = S >> 5, nt = S - 32 * full;
+        if (nt == 1)
+            attn_odd_key_hl(kh, kl, vh, vl, S - 1, qh, ql, down, mneg, o, g, c16);
+        else if (nt > 1)
+            attn_step_hl<true>(kh, kl, vh, vl, 32 * full, S, qh, ql, ones, down, mneg, o, g, c16);
+    }
+}
+
+constexpr int HL_WAVES = 8;
+__global__ __launch_bounds__(HL_WAVES * 64, 1) void attention_hl_kernel(const AttnHlArgs a)
+{
+    constexpr int THREADS = HL_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = a.S, W = a.W;
+    const int SP = 32 * ((S + 31) / 32);
+    unsigned char *kh = smem, *kl = smem + SP * 128, *vh = smem + 2 * SP * 128, *vl = smem + 3 * SP * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g_lane = lane >> 4, c_lane = lane & 15;
+    const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
+    const long ld = 3L * W;
+    const long base = (long)seq * S * ld + head * 64;
+    {   // stage the four planes: every load of a pass pair in flight before its LDS writes
+        const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
+        for (int p0 = 0; p0 < SP; p0 += 2 * (THREADS / 8)) {
+            u32x4 t[2][4];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int row = p0 + r_in + p * (THREADS / 8);
+                if (row < SP) {
+                    const long src = base + (long)(row < S ? row : S - 1) * ld + ch * 8;   // rows behind the last key: copies of it
+                    t[p][0] = *reinterpret_cast<const u32x4 *>(a.qkv_hi + src + W), t[p][1] = *reinterpret_cast<const u32x4 *>(a.qkv_lo + src + W);
+                    t[p][2] = *reinterpret_cast<const u32x4 *>(a.qkv_hi + src + 2 * W), t[p][3] = *reinterpret_cast<const u32x4 *>(a.qkv_lo + src + 2 * W);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int row = p0 + r_in + p * (THREADS / 8);
+                if (row < SP) {
+                    const int ko = row * 128 + ((ch ^ (row & 7)) << 4), vo = row * 128 + ((ch ^ ((row >> 2) & 1)) << 4);
+                    *reinterpret_cast<u32x4 *>(kh + ko) = t[p][0];
+                    *reinterpret_cast<u32x4 *>(kl + ko) = t[p][1];
+                    u32x4 x = t[p][2], y = t[p][3];
+                    if ((row >> 1) & 1) x = u32x4{x[2], x[3], x[0], x[1]}, y = u32x4{y[2], y[3], y[0], y[1]};
+                    *reinterpret_cast<u32x4 *>(vh + vo) = x;
+                    *reinterpret_cast<u32x4 *>(vl + vo) = y;
+                }
+            }
+        }
+    }
+    const int n_qt_all = (S + 15) / 16;
+    const bool lone = attn_lone_tile(S, 0, HL_WAVES);
+    const int n_qt = lone ? n_qt_all - 1 : n_qt_all;
+    constexpr float C = 0.125f * 1.4426950408889634f;
+    // q of one tile: c (q_hi + q_lo) in fp32, split again (the softmax scale and the base change enter before the split)
+    auto load_q = [&](int qt, f16x8(&qh)[2], f16x8(&ql)[2]) {
+        int qsrc = qt * 16 + c_lane;
+        qsrc = qsrc < S ? qsrc : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const f16x8 h = *reinterpret_cast<const f16x8 *>(a.qkv_hi + base + (long)qsrc * ld + ks * 32 + g_lane * 8);
+            const f16x8 l = *reinterpret_cast<const f16x8 *>(a.qkv_lo + base + (long)qsrc * ld + ks * 32 + g_lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float x = ((float)h[j] + (float)l[j]) * C;
+                asm volatile("" : "+v"(x));
+                qh[ks][j] = (_Float16)x;
+                ql[ks][j] = (_Float16)(x - (float)qh[ks][j]);
+            }
+        }
+    };
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = (_Float16)1.f;
+    asm volatile("" : "+v"(ones));
+    __syncthreads();
+    auto store = [&](int qrow, int g, const f32x4(&o)[5], float inv) {
+        _Float16 hi[16], lo[16];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float x = o[dt][r] * inv;
+                asm volatile("" : "+v"(x));      // ONE rounded fp32 value for both parts (see attention_f32m_kernel)
+                hi[4 * dt + r] = (_Float16)x;
+                lo[4 * dt + r] = (_Float16)(x - (float)hi[4 * dt + r]);
+            }
+        const long off = ((long)seq * S + qrow) * W + head * 64 + g * 16;
+        *reinterpret_cast<u32x4 *>(a.out_hi + off) = *reinterpret_cast<const u32x4 *>(&hi[0]);
+        *reinterpret_cast<u32x4 *>(a.out_hi + off + 8) = *reinterpret_cast<const u32x4 *>(&hi[8]);
+        *reinterpret_cast<u32x4 *>(a.out_lo + off) = *reinterpret_cast<const u32x4 *>(&lo[0]);
+        *reinterpret_cast<u32x4 *>(a.out_lo + off + 8) = *reinterpret_cast<const u32x4 *>(&lo[8]);
+    };
+    for (int qt = wave; qt < n_qt; qt += HL_WAVES) {
+        f16x8 qh[2], ql[2];
+        load_q(qt, qh, ql);
+        int g = g_lane, c16 = c_lane;
+        asm volatile("" : "+v"(g), "+v"(c16));
+        f32x4 o[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
+        attn_keys_hl(kh, kl, vh, vl, S, 0, S >> 5, true, qh, ql, ones, mneg, o, g, c16);
+        const int qrow = qt * 16 + c16;
+        if (qrow < S) store(qrow, g, o, 1.f / o[4][0]);
+    }
+    if (lone) {
+        // the tile left over (one query row): this wave's share of its keys, then the merge through LDS
+        float *part = reinterpret_cast<float *>(smem + 4 * SP * 128);
+        const int steps = S >> 5, s0 = wave * steps / HL_WAVES, s1 = (wave + 1) * steps / HL_WAVES;
+        const bool tail = wave == HL_WAVES - 1;
+        f16x8 qh[2], ql[2];
+        load_q(n_qt_all - 1, qh, ql);
+        int g = g_lane, c16 = c_lane;
+        asm volatile("" : "+v"(g), "+v"(c16));
+        f32x4 o[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 mneg = f32x4{0.f, 0.f, 0.f, 0.f};
+        attn_keys_hl(kh, kl, vh, vl, S, s0, s1, tail, qh, ql, ones, mneg, o, g, c16);
+        if (c16 == 0) {   // the tile's one valid query (row S - 1) lives in lanes 0, 16, 32, 48
+            float *dst = part + wave * ATTN_PART;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<f32x4 *>(dst + 16 * g + 4 * dt) = o[dt];
+            if (g == 0) {
+                dst[64] = (s1 > s0 || tail) ? -mneg[0] : -1e30f;   // a wave without keys: weight 0
+                dst[65] = o[4][0];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {   // lane = head dim
+            float m = -1e30f;
+#pragma unroll
+            for (int w = 0; w < HL_WAVES; w++) m = fmaxf(m, part[w * ATTN_PART + 64]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int w = 0; w < HL_WAVES; w++) {
+                const float f = __builtin_amdgcn_exp2f(part[w * ATTN_PART + 64] - m);
+                num = __builtin_fmaf(f, part[w * ATTN_PART + lane], num);
+                den = __builtin_fmaf(f, part[w * ATTN_PART + 65], den);
+            }
+            float x = num / den;
+            asm volatile("" : "+v"(x));
+            const _Float16 h = (_Float16)x;
+            const long off = ((long)seq * S + S - 1) * W + head * 64 + lane;
+            a.out_hi[off] = h;
+            a.out_lo[off] = (_Float16)(x - (float)h);
+        }
+    }
+}
 
 #ifdef EC_ATTN_DIAG
 // ---------------------------------------------------------------------------------------
@@ -802,9 +1108,8 @@ template <int DT> int dispatch(const AttnArgs &a, int n_seq, int heads, hipStrea
     // kernel can take that path for this S (its `lone` condition: not causal, S = 16 n + 1, the tile count one more
     // than a multiple of the wave count), so that S = 609 .. 640 (n32 = 20: exactly 160 KiB of K and V) still fits
     const int kv = 32 * n32 * 128 * 2;
-    const int n_qt_all = (a.S + 15) / 16;
     const int waves_if = kv + 16 * ATTN_PART * 4 > 80 * 1024 ? 16 : 8;      // the wave count the full carve would pick
-    const bool may_split = !a.causal && (a.S & 15) == 1 && n_qt_all > waves_if && n_qt_all % waves_if == 1;
+    const bool may_split = attn_lone_tile(a.S, a.causal, waves_if);
     const int lds = kv + (may_split ? 16 * ATTN_PART * 4 : 0);
     if (lds > 160 * 1024)
         return ec::fail(EC_ERR_UNSUPPORTED, "ec_attention: sequence length %d needs %d bytes of LDS (K and V images%s), "
@@ -1154,6 +1459,20 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
                "ec_attention_split: buffers must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_ATTENTION, s, 4.0 * S * S * 64.0 * heads * n_seq, (double)n_seq * S * width * 2.0 * 8.0);
+    // a plain f16 q and a sequence whose four planes fit the CU's LDS: three products per tile on the 16-bit matrix
+    // instruction (attention_hl_kernel); anything else: fp32 on v_mfma_f32_16x16x4_f32
+    const int sp = 32 * ((S + 31) / 32);
+    const int hl_lds = 4 * sp * 128 + (attn_lone_tile(S, 0, HL_WAVES) ? HL_WAVES * ATTN_PART * 4 : 0);
+    if (dtype == EC_F16 && !q_prescaled && hl_lds <= 160 * 1024 && !getenv("EC_ATTN_SPLIT_F32")) {
+        AttnHlArgs h;
+        h.qkv_hi = static_cast<const _Float16 *>(qkv_hi), h.qkv_lo = static_cast<const _Float16 *>(qkv_lo);
+        h.out_hi = static_cast<_Float16 *>(out_hi), h.out_lo = static_cast<_Float16 *>(out_lo);
+        h.S = S, h.W = width, h.heads = heads;
+        if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(attention_hl_kernel), 160 * 1024)) return rc;
+        hipLaunchKernelGGL(attention_hl_kernel, dim3((unsigned)heads * (unsigned)n_seq), dim3(HL_WAVES * 64), hl_lds, s, h);
+        EC_CHECK_HIP(hipGetLastError());
+        return EC_OK;
+    }
     const long blocks = (long)n_seq * heads * ((S + 63) / 64);
     EC_REQUIRE(blocks < (1L << 31), "ec_attention_split: %ld workgroups", blocks);
     void (*kern)(const void *, const void *, void *, void *, int, int, int, int) = nullptr;

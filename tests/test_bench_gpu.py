@@ -42,6 +42,13 @@ def test_single_rank_line(hip):
     assert re_['algorithmic_bytes_per_launch'] == frames * (16 * 20000 + 3 * 180 * 240)
     assert abs(re_['frac'] - re_['achieved_GBps'] / re_['peak_GBps']) < 1e-9
     assert d['config']['unique_samples'] == 4
+    # the price of the 1e-3 mode, measured behind the timed region on the same batch: never part of `value`
+    tm = d['tolerance_mode']
+    assert tm['precise_blocks'] == 8 and 'configs_within_1e3' in tm and len(tm['lines']) == 2
+    for ln in tm['lines']:
+        assert ln['weights'] in ('as_run', 'rounded_to_16_bit') and ln['ms_per_step'] > 0
+        assert abs(ln['ratio_to_default'] - ln['ms_per_step'] / ln['default_ms_per_step_interleaved']) < 1e-9
+        assert ln['ratio_to_default'] > 1.0          # it is a mode one pays for
 
 
 def test_two_ranks_share_the_gpu_over_gloo(hip):
