@@ -197,9 +197,17 @@ int run_blocks_precise(const ec_block_weights *blocks, int layers, int n_seq, in
                    "precise tower: block %d has no lo weight parts", l);
         EC_TRY(ec_layernorm_split(b.x, W, nullptr, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h_hi, b.h_lo,
                                   W, dtype, s));
-        EC_TRY(gemm3(rows, 3 * W, W, dtype, false, b.h_hi, b.h_lo, w.qkv_w, w.qkv_w_lo, w.qkv_b,
-                     b.wide, s));
-        EC_TRY(ec_attention_f32(b.wide, b.h_hi, b.h_lo, n_seq, S, W, heads, causal, dtype, s));
+        if (!causal) {
+            // the image tower: q | k | v leave the GEMM as hi + lo 16-bit parts (12 of the wide buffer's 16 bytes per row
+            // element) and attention runs on them -- on the 16-bit matrix instruction where the four planes fit the LDS
+            void *qkv_hi = b.wide, *qkv_lo = reinterpret_cast<unsigned char *>(b.wide) + (size_t)rows * 3 * W * 2;
+            EC_TRY(gemm_split16(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h_hi, b.h_lo, w.qkv_w, w.qkv_w_lo, w.qkv_b, qkv_hi, qkv_lo, s));
+            EC_TRY(ec_attention_split(qkv_hi, qkv_lo, b.h_hi, b.h_lo, n_seq, S, W, heads, 0, dtype, s));
+        } else {
+            EC_TRY(gemm3(rows, 3 * W, W, dtype, false, b.h_hi, b.h_lo, w.qkv_w, w.qkv_w_lo, w.qkv_b,
+                         b.wide, s));
+            EC_TRY(ec_attention_f32(b.wide, b.h_hi, b.h_lo, n_seq, S, W, heads, causal, dtype, s));
+        }
         EC_TRY(gemm3(rows, W, W, dtype, true, b.h_hi, b.h_lo, w.out_w, w.out_w_lo, w.out_b, b.x, s));
         EC_TRY(ec_layernorm_split(b.x, W, nullptr, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h_hi, b.h_lo,
                                   W, dtype, s));

@@ -1,0 +1,44 @@
+"""Host-side behaviour of the CLIP wrapper and of the new C entry points that do not need a GPU."""
+import warnings
+
+import pytest
+
+
+def test_precise_blocks_env_is_reported_when_it_cannot_apply(monkeypatch):
+    """EVENTCLIP_PRECISE_BLOCKS addresses every model of the process; where the mode cannot apply (too many blocks, bf16,
+    the plain chain, low latency) the model says so instead of silently running the 16-bit path (advisor, round 4), and
+    the explicit argument keeps its own error path in _pack."""
+    from eventclip_amd import clip as eclip
+    cfg = eclip.arch_config('ViT-B/32', layers=4, text_layers=1, vocab_size=64)
+    sd = eclip.random_state_dict(cfg, seed=0)
+    monkeypatch.setenv('EVENTCLIP_PRECISE_BLOCKS', '8')            # 8 >= 4 layers
+    with pytest.warns(UserWarning, match='EVENTCLIP_PRECISE_BLOCKS=8 ignored'):
+        m = eclip.CLIP(cfg, sd)
+    assert m.image_precise_blocks == 0 and m.image_precise_attn_blocks == 0
+    monkeypatch.setenv('EVENTCLIP_PRECISE_BLOCKS', '2')
+    with pytest.warns(UserWarning, match='ignored'):
+        assert eclip.CLIP(cfg, sd, dtype='bfloat16').image_precise_blocks == 0
+    with pytest.warns(UserWarning, match='ignored'):
+        assert eclip.CLIP(cfg, sd, ln_folded=False).image_precise_blocks == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m = eclip.CLIP(cfg, sd)                                     # applies: no warning
+    assert m.image_precise_blocks == 2 and m.image_precise_attn_blocks == 2          # min(default 5, 2)
+    monkeypatch.setenv('EVENTCLIP_PRECISE_ATTN_BLOCKS', '1')
+    assert eclip.CLIP(cfg, sd).image_precise_attn_blocks == 1
+    monkeypatch.delenv('EVENTCLIP_PRECISE_BLOCKS')
+    assert eclip.CLIP(cfg, sd).image_precise_blocks == 0
+    assert eclip.CLIP(cfg, sd, image_precise_blocks=3, image_precise_attn_blocks=9).image_precise_attn_blocks == 3
+
+
+def test_classify_workspace_size_is_a_host_function():
+    """ec_classify_workspace_bytes: hi + lo fp16 copies of the features and of the text matrix (columns padded to 64, classes
+    to 16), one fp32 scale per row, the fp32 product."""
+    from eventclip_amd import _lib
+    lib = _lib.lib()
+    assert lib.ec_classify_workspace_bytes(0, 768, 101) == 0
+    n, C, K = 2560, 768, 101
+    want = 2 * n * 768 * 2 + 2 * 112 * 768 * 2 + n * 4 + n * 112 * 4
+    got = lib.ec_classify_workspace_bytes(n, C, K)
+    assert want <= got <= want + 6 * 256
+    assert lib.ec_classify_workspace_bytes(n, 100, K) > lib.ec_classify_workspace_bytes(n, 64, K)      # 100 -> 128 columns
