@@ -151,5 +151,38 @@ for (M, N, K) in ((65792, 3072, 1024), (65792, 4096, 1024), (70001, 768, 640), (
             return e if not e <= 2e-3 else None
         repeat((epi, M, N, K), run_ln, check_ln)
 
+# split-precision products in one launch (round 5): segments a_lo . w / a . w_lo / a . w, every epilogue the tower runs on
+# them, the 16-bit ones with and without the lo output
+for (M, N, K) in ((65792, 3072, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
+    g = torch.Generator(device='cuda').manual_seed(M * 3 + N + K * 11)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    pa, pw = torch.empty((2, M, K), dtype=torch.float16, device='cuda'), torch.empty((2, N, K), dtype=torch.float16, device='cuda')
+    pa[0], pw[0] = a.half(), w.half()
+    pa[1], pw[1] = (a - pa[0].float()).half(), (w - pw[0].float()).half()
+    bias = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g) * 3
+    hi0, lo0 = x.half(), (x - x.half().float()).half()
+    full = (pa[0].double() + pa[1].double()) @ (pw[0].double() + pw[1].double()).t() + bias.double()
+    for epi, with_lo in (('store32', False), ('store16', False), ('store16', True), ('gelu16', False), ('gelu16', True), ('resid_hl', False)):
+        def run_seg(epi=epi, with_lo=with_lo):
+            if epi == 'resid_hl':
+                hi, lo = hi0.clone(), lo0.clone()
+                ops.gemm(pa[0], pw[0], bias, epi, out=hi, aux=lo, A_lo=pa[1], W_lo=pw[1])
+                return hi, lo
+            out = torch.full((M, N), float('nan'), dtype=torch.float32 if epi == 'store32' else torch.float16, device='cuda')
+            if with_lo:
+                aux = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda')
+                return ops.gemm(pa[0], pw[0], bias, epi, out=out, aux=aux, A_lo=pa[1], W_lo=pw[1]), aux
+            return ops.gemm(pa[0], pw[0], bias, epi, out=out, A_lo=pa[1], W_lo=pw[1])
+
+        def check_seg(out, *rest, epi=epi, with_lo=with_lo):
+            ref = full + x.double() if epi == 'resid_hl' else (full * torch.sigmoid(1.702 * full) if epi == 'gelu16' else full)
+            got = out.double() + (rest[0].double() if rest else 0)
+            tol = 2e-5 if (rest or epi == 'store32') else 2e-3
+            e = float((got - ref).abs().max() / ref.abs().max())
+            return e if not e <= tol else None
+        repeat(('segments', epi, 'lo out' if with_lo else '', M, N, K), run_seg, check_seg)
+
 print('race screen:', 'CLEAN' if bad == 0 else f'{bad} problems', f'({reps} repeats per case)')
 sys.exit(1 if bad else 0)
