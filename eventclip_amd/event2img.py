@@ -241,7 +241,12 @@ class HostFeeder:
         self._err = None
         self._stop = threading.Event()
         self._closed = False
-        self._th = threading.Thread(target=self._produce, daemon=True)
+        # The producer holds a WEAK reference to the feeder (and the queues / stop flag themselves): a feeder the
+        # consumer simply drops is collected, its __del__ closes it, and the thread ends -- with a bound method as the
+        # target the thread kept the feeder, its pinned and device rings alive for ever (advisor, round 4)
+        import weakref
+        self._th = threading.Thread(target=HostFeeder._produce, daemon=True,
+                                    args=(weakref.ref(self), self._batches, self._ready, self._free, self._stop))
         self._th.start()
 
     # ---- life time -----------------------------------------------------------------------------------
@@ -257,9 +262,11 @@ class HostFeeder:
         # after CLOSE_WAIT_S the daemon thread is left behind rather than hanging the caller (harness.evaluate calls
         # this from a `finally`, where a hang would hide the exception that got it there)
         import queue
+        import threading
         import time
         deadline = time.monotonic() + self.CLOSE_WAIT_S
-        while self._th.is_alive() and time.monotonic() < deadline:
+        # (a feeder whose last reference the producer itself dropped is finalised ON the producer thread: nothing to join)
+        while self._th.is_alive() and time.monotonic() < deadline and threading.current_thread() is not self._th:
             try:
                 while True:
                     self._ready.get_nowait()
@@ -293,17 +300,6 @@ class HostFeeder:
         except Exception:   # noqa: BLE001 -- interpreter shutdown
             pass
 
-    def _put(self, q, item):
-        """queue.put that gives up when the feeder is closed (-> False)"""
-        import queue
-        while not self._stop.is_set():
-            try:
-                q.put(item, timeout=0.1)
-                return True
-            except queue.Full:
-                continue
-        return False
-
     def _take_free(self):
         i = self._free.get()
         if i < 0 or self._stop.is_set():
@@ -322,7 +318,8 @@ class HostFeeder:
             self._free.put(i)
         self.capacity = cap
 
-    def _stage(self, samples):
+    def _parse(self, samples):
+        """host-side part of staging a batch: contiguous per-sample arrays, their sizes, the ring allocated for them"""
         host = [e.cpu() if torch.is_tensor(e) else e for e in samples]
         packed = all(not isinstance(e, dict) and vis.is_packed(e) for e in host)
         if packed:
@@ -343,7 +340,11 @@ class HostFeeder:
                     self._slots[j]['consumed'].synchronize()
             self._slots = None
             self._alloc(total + total // 4)
-        i = self._take_free()
+        return dict(arrs=arrs, n_events=n_events, esz=esz, total=total, packed=packed)
+
+    def _fill(self, prep, i):
+        """copy the parsed batch into slot i's pinned buffer and issue its upload"""
+        arrs, n_events, esz, total, packed = prep['arrs'], prep['n_events'], prep['esz'], prep['total'], prep['packed']
         slot = self._slots[i]
         if slot['consumed'] is not None:
             slot['consumed'].synchronize()        # the kernels that read this slot's device buffer are done
@@ -359,17 +360,53 @@ class HostFeeder:
             done.record(self._copy_stream)
         return dict(slot=i, total=total, packed=packed, n_events=n_events, done=done)
 
-    def _produce(self):
-        try:
-            torch.cuda.set_device(self.dev)
-            for samples in self._batches:
-                if self._stop.is_set():
+    @staticmethod
+    def _produce(ref, batches, ready, free, stop):
+        """Producer thread.  Holds the feeder only while it works on a batch; every wait (for the user's iterator, for a
+        free slot, for room in the ready queue) runs on the queues and the stop flag alone."""
+        import queue
+
+        def alive():
+            return not stop.is_set() and ref() is not None
+
+        def put(item):          # queue.put that gives up when the feeder is closed or gone (-> False)
+            while alive():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def take_free():
+            while alive():
+                try:
+                    i = free.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+                if i < 0:
                     break
+                return i
+            raise _FeederClosed()
+
+        err = None
+        try:
+            dev_set = False
+            for samples in batches:
+                if not alive():
+                    break
+                feeder = ref()
+                if feeder is None:
+                    break
+                if not dev_set:
+                    torch.cuda.set_device(feeder.dev)
+                    dev_set = True
                 extra = None
                 if isinstance(samples, dict):               # harness-style data_dict: events + anything else
                     if 'events' not in samples:
                         # a batch that is model-ready already (the reference's img / valid_mask): handed on as it is
-                        if not self._put(self._ready, dict(passthrough=samples)):
+                        del feeder
+                        if not put(dict(passthrough=samples)):
                             break
                         continue
                     extra = {k: v for k, v in samples.items() if k != 'events'}
@@ -377,16 +414,27 @@ class HostFeeder:
                 if torch.is_tensor(samples) or isinstance(samples, np.ndarray):
                     raise TypeError('HostFeeder: a batch is a LIST of per-sample event arrays (or a dict with such a '
                                     "list under 'events'); got a single array / tensor")
-                item = self._stage(samples)
+                prep = feeder._parse(samples)
+                del feeder
+                i = take_free()
+                feeder = ref()
+                if feeder is None:
+                    break
+                item = feeder._fill(prep, i)
+                del feeder
                 item['extra'] = extra
-                if not self._put(self._ready, item):
+                if not put(item):
                     break
         except _FeederClosed:
             pass
         except BaseException as e:   # noqa: BLE001 -- handed to the consumer
-            self._err = e
+            err = e
         finally:
-            self._put(self._ready, None)
+            feeder = ref()
+            if feeder is not None:
+                feeder._err = err
+                del feeder
+            put(None)
 
     # ---- consumer side -------------------------------------------------------------------------------
     def __iter__(self):

@@ -285,3 +285,16 @@ def test_host_feeder_passes_ready_batches_through_and_closes(hip):
     # a single tensor is not a batch
     with pytest.raises(TypeError):
         list(pipe.stream(iter([torch.from_numpy(ev[0])])))
+    # a feeder that is simply dropped: the producer holds only a weak reference, so the object is collected, closed by
+    # its finaliser, and the thread ends (it kept the feeder and its pinned / device rings alive for ever before)
+    import gc
+    import weakref
+    f3 = pipe.stream(iter([ev] * 50), depth=2)
+    next(f3)
+    th, ref = f3._th, weakref.ref(f3)
+    del f3
+    deadline = time.time() + 10
+    while (ref() is not None or th.is_alive()) and time.time() < deadline:
+        gc.collect()
+        time.sleep(0.05)
+    assert ref() is None and not th.is_alive()
