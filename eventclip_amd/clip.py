@@ -168,7 +168,10 @@ def _assign(root, key, tensor):
     m.register_parameter(parts[-1], nn.Parameter(tensor.clone().float(), requires_grad=False))
 
 
-DEFAULT_PRECISE_ATTN_BLOCKS = 5     # of the split-operand blocks (image_precise_blocks), how many run fp32 attention (profiles/r5_tolerance_sweep.txt)
+# of the split-operand blocks (image_precise_blocks), how many run fp32-class attention (+ the MLP activation as hi + lo):
+# (up to 288 tokens, beyond) -- measured, profiles/r5_tolerance_sweep.txt: at S = 577 (configs[3], sharp attention over 2.2 x
+# the keys) five such blocks leave the logits at 1.0 - 1.4e-3, seven at 7e-4; at S = 257 five are enough
+DEFAULT_PRECISE_ATTN_BLOCKS = (5, 7)
 
 
 class CLIP(nn.Module):
@@ -225,7 +228,9 @@ class CLIP(nn.Module):
         self.image_precise_blocks = 0 if self.image_precise else int(image_precise_blocks)
         # ... of which the first few also run attention in fp32 on hi + lo q, k, v (ec_vit_weights.precise_attn_blocks)
         if image_precise_attn_blocks is None:
-            image_precise_attn_blocks = int(os.environ.get('EVENTCLIP_PRECISE_ATTN_BLOCKS', str(DEFAULT_PRECISE_ATTN_BLOCKS)))
+            tokens = (cfg['image_size'] // cfg['patch']) ** 2 + 1
+            image_precise_attn_blocks = int(os.environ.get('EVENTCLIP_PRECISE_ATTN_BLOCKS',
+                                                           str(DEFAULT_PRECISE_ATTN_BLOCKS[0 if tokens <= 288 else 1])))
         self.image_precise_attn_blocks = max(0, min(int(image_precise_attn_blocks), self.image_precise_blocks))
         # bytes of tower scratch at most
         self.workspace_budget = 24 << 30

@@ -777,9 +777,8 @@ __device__ __forceinline__ void attn_odd_key_hl(const unsigned char *kh, const u
 __device__ __forceinline__ void attn_keys_hl(const unsigned char *kh, const unsigned char *kl, const unsigned char *vh,
                                              const unsigned char *vl, int S, int step0, int step1, bool tail,
                                              const f16x8 (&qh)[2], const f16x8 (&ql)[2], const f16x8 &ones, f32x4 &mneg,
-                                             f32x4 (&o)[5], int g, int c16)
+                                             f32x4 (&o)[5], int g, int c16, bool down = true)
 {
-    bool down = true;
     for (int s = step0; s < step1; s++) {
         attn_step_hl<false>(kh, kl, vh, vl, 32 * s, S, qh, ql, ones, down, mneg, o, g, c16);
         down = false;
@@ -932,6 +931,124 @@ __global__ __launch_bounds__(HL_WAVES * 64, 1) void attention_hl_kernel(const At
             const long off = ((long)seq * S + S - 1) * W + head * 64 + lane;
             a.out_hi[off] = h;
             a.out_lo[off] = (_Float16)(x - (float)h);
+        }
+    }
+}
+
+// The same for sequences whose four planes do not fit the LDS but half of them does (288 < S <= 608: S = 577): the keys in
+// TWO passes of one workgroup -- stage K_hi, K_lo, V_hi, V_lo of keys [0, split), walk every query tile of the wave against
+// them, stage the rest, walk the tiles again -- with each tile's (m, l, O) kept in registers between the passes (at most five
+// tiles per wave x 24 registers: the 8-wave workgroup has 256 per lane).  No exchange, no merge: a tile's running maximum
+// simply goes on where the first pass left it.
+constexpr int HL2_TILES = 5;      // query tiles per wave at most: S <= 8 x 5 x 16 = 640
+__global__ __launch_bounds__(HL_WAVES * 64, 1) void attention_hl2_kernel(const AttnHlArgs a, int split, int SPL)
+{
+    constexpr int THREADS = HL_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = a.S, W = a.W;
+    unsigned char *kh = smem, *kl = smem + SPL * 128, *vh = smem + 2 * SPL * 128, *vl = smem + 3 * SPL * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g_lane = lane >> 4, c_lane = lane & 15;
+    const int head = blockIdx.x % a.heads, seq = blockIdx.x / a.heads;
+    const long ld = 3L * W;
+    const long base = (long)seq * S * ld + head * 64;
+    const int n_qt = (S + 15) / 16;
+    constexpr float C = 0.125f * 1.4426950408889634f;
+    auto load_q = [&](int qt, f16x8(&qh)[2], f16x8(&ql)[2]) {
+        int qsrc = qt * 16 + c_lane;
+        qsrc = qsrc < S ? qsrc : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const f16x8 h = *reinterpret_cast<const f16x8 *>(a.qkv_hi + base + (long)qsrc * ld + ks * 32 + g_lane * 8);
+            const f16x8 l = *reinterpret_cast<const f16x8 *>(a.qkv_lo + base + (long)qsrc * ld + ks * 32 + g_lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float x = ((float)h[j] + (float)l[j]) * C;
+                asm volatile("" : "+v"(x));
+                qh[ks][j] = (_Float16)x;
+                ql[ks][j] = (_Float16)(x - (float)qh[ks][j]);
+            }
+        }
+    };
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = (_Float16)1.f;
+    asm volatile("" : "+v"(ones));
+    f32x4 o[HL2_TILES][5];
+    float mneg[HL2_TILES];          // (-m of a tile: one register between the passes, the MFMA's C operand inside one)
+#pragma unroll
+    for (int t = 0; t < HL2_TILES; t++) {
+        mneg[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 5; dt++) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int half = 0; half < 2; half++) {
+        const int key0 = half ? split : 0, Sl = half ? S - split : split;
+        if (half) __syncthreads();      // every wave is done with the first pass's planes
+        {
+            const int r_in = threadIdx.x >> 3, ch = threadIdx.x & 7;
+            for (int p0 = 0; p0 < SPL; p0 += 2 * (THREADS / 8)) {
+                u32x4 t[2][4];
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int row = p0 + r_in + p * (THREADS / 8);
+                    if (row < SPL) {
+                        const long src = base + (long)(key0 + (row < Sl ? row : Sl - 1)) * ld + ch * 8;
+                        t[p][0] = *reinterpret_cast<const u32x4 *>(a.qkv_hi + src + W), t[p][1] = *reinterpret_cast<const u32x4 *>(a.qkv_lo + src + W);
+                        t[p][2] = *reinterpret_cast<const u32x4 *>(a.qkv_hi + src + 2 * W), t[p][3] = *reinterpret_cast<const u32x4 *>(a.qkv_lo + src + 2 * W);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int row = p0 + r_in + p * (THREADS / 8);
+                    if (row < SPL) {
+                        const int ko = row * 128 + ((ch ^ (row & 7)) << 4), vo = row * 128 + ((ch ^ ((row >> 2) & 1)) << 4);
+                        *reinterpret_cast<u32x4 *>(kh + ko) = t[p][0];
+                        *reinterpret_cast<u32x4 *>(kl + ko) = t[p][1];
+                        u32x4 x = t[p][2], y = t[p][3];
+                        if ((row >> 1) & 1) x = u32x4{x[2], x[3], x[0], x[1]}, y = u32x4{y[2], y[3], y[0], y[1]};
+                        *reinterpret_cast<u32x4 *>(vh + vo) = x;
+                        *reinterpret_cast<u32x4 *>(vl + vo) = y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < HL2_TILES; t++) {
+            const int qt = wave + HL_WAVES * t;
+            if (qt < n_qt) {      // (wave-uniform)
+                f16x8 qh[2], ql[2];
+                load_q(qt, qh, ql);
+                int g = g_lane, c16 = c_lane;
+                asm volatile("" : "+v"(g), "+v"(c16));
+                f32x4 mn = f32x4{mneg[t], mneg[t], mneg[t], mneg[t]};
+                attn_keys_hl(kh, kl, vh, vl, Sl, 0, Sl >> 5, true, qh, ql, ones, mn, o[t], g, c16, half == 0);
+                mneg[t] = mn[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < HL2_TILES; t++) {
+        const int qt = wave + HL_WAVES * t, qrow = qt * 16 + c_lane;
+        if (qt < n_qt && qrow < S) {
+            const float inv = 1.f / o[t][4][0];
+            _Float16 hi[16], lo[16];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float x = o[t][dt][r] * inv;
+                    asm volatile("" : "+v"(x));
+                    hi[4 * dt + r] = (_Float16)x;
+                    lo[4 * dt + r] = (_Float16)(x - (float)hi[4 * dt + r]);
+                }
+            const long off = ((long)seq * S + qrow) * W + head * 64 + g_lane * 16;
+            *reinterpret_cast<u32x4 *>(a.out_hi + off) = *reinterpret_cast<const u32x4 *>(&hi[0]);
+            *reinterpret_cast<u32x4 *>(a.out_hi + off + 8) = *reinterpret_cast<const u32x4 *>(&hi[8]);
+            *reinterpret_cast<u32x4 *>(a.out_lo + off) = *reinterpret_cast<const u32x4 *>(&lo[0]);
+            *reinterpret_cast<u32x4 *>(a.out_lo + off + 8) = *reinterpret_cast<const u32x4 *>(&lo[8]);
         }
     }
 }
@@ -1472,6 +1589,22 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
         hipLaunchKernelGGL(attention_hl_kernel, dim3((unsigned)heads * (unsigned)n_seq), dim3(HL_WAVES * 64), hl_lds, s, h);
         EC_CHECK_HIP(hipGetLastError());
         return EC_OK;
+    }
+    // ... or whose planes fit in two passes over the keys (S <= 608): attention_hl2_kernel
+    {
+        const int split = (S / 2) & ~31, sl = S - split;
+        const int spl = (sl & 31) == 1 ? ((sl + 15 + 15) / 16) * 16 : ((sl + 31) / 32) * 32;     // the odd key's 16 copies, else whole steps
+        if (dtype == EC_F16 && !q_prescaled && split >= 32 && 4 * spl * 128 <= 160 * 1024 && (S + 15) / 16 <= HL_WAVES * HL2_TILES &&
+            !getenv("EC_ATTN_SPLIT_F32")) {
+            AttnHlArgs h;
+            h.qkv_hi = static_cast<const _Float16 *>(qkv_hi), h.qkv_lo = static_cast<const _Float16 *>(qkv_lo);
+            h.out_hi = static_cast<_Float16 *>(out_hi), h.out_lo = static_cast<_Float16 *>(out_lo);
+            h.S = S, h.W = width, h.heads = heads;
+            if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(attention_hl2_kernel), 160 * 1024)) return rc;
+            hipLaunchKernelGGL(attention_hl2_kernel, dim3((unsigned)heads * (unsigned)n_seq), dim3(HL_WAVES * 64), 4 * spl * 128, s, h, split, spl);
+            EC_CHECK_HIP(hipGetLastError());
+            return EC_OK;
+        }
     }
     const long blocks = (long)n_seq * heads * ((S + 63) / 64);
     EC_REQUIRE(blocks < (1L << 31), "ec_attention_split: %ld workgroups", blocks);

@@ -24,6 +24,10 @@ def test_precise_blocks_env_is_reported_when_it_cannot_apply(monkeypatch):
         warnings.simplefilter('error')
         m = eclip.CLIP(cfg, sd)                                     # applies: no warning
     assert m.image_precise_blocks == 2 and m.image_precise_attn_blocks == 2          # min(default 5, 2)
+    big = eclip.arch_config('ViT-L/14@336px', layers=10, text_layers=1, vocab_size=64)
+    monkeypatch.setenv('EVENTCLIP_PRECISE_BLOCKS', '8')
+    assert eclip.CLIP(big, eclip.random_state_dict(big, seed=0)).image_precise_attn_blocks == 7       # 577 tokens: seven
+    monkeypatch.setenv('EVENTCLIP_PRECISE_BLOCKS', '2')
     monkeypatch.setenv('EVENTCLIP_PRECISE_ATTN_BLOCKS', '1')
     assert eclip.CLIP(cfg, sd).image_precise_attn_blocks == 1
     monkeypatch.delenv('EVENTCLIP_PRECISE_BLOCKS')

@@ -97,10 +97,14 @@ def test_attention_f32_matches_float64(S, heads, causal, n_seq, hip):
 
 
 @pytest.mark.parametrize('prescaled', [0, 1])
-@pytest.mark.parametrize('S,heads,n_seq', [(257, 16, 3), (577, 4, 2), (50, 12, 4), (197, 3, 2), (1, 2, 2), (64, 1, 2), (65, 1, 2)])
+@pytest.mark.parametrize('S,heads,n_seq', [(257, 16, 3), (577, 4, 2), (50, 12, 4), (197, 3, 2), (1, 2, 2), (64, 1, 2), (65, 1, 2),
+                                           (288, 2, 2), (289, 2, 3), (353, 2, 3), (608, 1, 2), (609, 1, 2), (320, 3, 2)])
 def test_attention_split_matches_float64(S, heads, n_seq, prescaled, hip):
     """ec_attention_split (the attention of the first split-operand blocks): q | k | v as hi + lo fp16 parts -- a plain q, or
-    the q columns pre-multiplied by log2(e) / sqrt(64) -- against a float64 softmax attention of the joined values."""
+    the q columns pre-multiplied by log2(e) / sqrt(64) -- against a float64 softmax attention of the joined values.  A plain q
+    runs on the 16-bit matrix instruction with hi + lo operands: one pass over the keys up to S = 288 (attention_hl_kernel),
+    two passes with the tiles' state in registers up to S = 608 (attention_hl2_kernel), the fp32-MFMA kernel beyond and for a
+    pre-scaled q: the sequence lengths sit on both sides of each boundary."""
     import torch
     from eventclip_amd import _lib
     W = heads * 64
