@@ -359,9 +359,10 @@ EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_
 /* fp32 attention (no mask) over q | k | v given as hi + lo 16-bit parts, two [n_seq * S, 3 * width] tensors as
  * EC_EPI_STORE16 leaves them with ec_gemm_args.aux; output as hi / lo parts [n_seq * S, width].  q_prescaled != 0: the q
  * columns already hold q * log2(e) / sqrt(64) (ec_vit_weights.q_scaled), else a plain q.  The attention of the first
- * split-operand blocks (ec_vit_weights.precise_attn_blocks).  A plain f16 q and a sequence whose K_hi, K_lo, V_hi, V_lo fit a CU's LDS (S <= 288):
- * three 16-bit MFMA products per score and per P.V tile (the lo . lo terms left out), ~1e-6 from float64; otherwise scores,
- * softmax and P.V in fp32 on v_mfma_f32_16x16x4_f32. */
+ * split-operand blocks (ec_vit_weights.precise_attn_blocks).  A plain f16 q and a sequence whose K_hi, K_lo, V_hi, V_lo fit a CU's LDS in one pass
+ * (S <= 288) or in two passes over the keys (S <= 608, the tiles' state in registers between them): three 16-bit MFMA products
+ * per score and per P.V tile (the lo . lo terms left out), ~1e-6 from float64; otherwise scores, softmax and P.V in fp32 on
+ * v_mfma_f32_16x16x4_f32. */
 EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
                               int width, int heads, int q_prescaled, int dtype, ec_stream_t stream);
 
