@@ -68,3 +68,33 @@ def test_few_shot_tail_matches_oracle(agg, hip):
     full, logits, probs = run_classify(feats.view(B * T, C).cuda(), idx.cuda(), text.cuda(), 100.0,
                                        agg, True)
     check(full, logits, probs, want, T)
+
+
+def test_empty_and_ragged_edges(hip):
+    """The edges the reference reaches (clip_cls.py:139: `imgs[valid_masks]` may be empty for a sample, never for a batch;
+    an empty batch never reaches forward): a sample without a valid view gives zero logits rows / NaN-free probabilities
+    semantics of its own (sum over nothing: 0, mean: 0 / 0), B = 0 is a no-op, and a feature matrix with more rows than
+    row_idx uses (the full, un-compacted form) is indexed, not assumed compact."""
+    import torch
+    from eventclip_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    C, K, T = 64, 7, 3
+    feats = torch.randn(10, C, generator=g).cuda()
+    text = torch.nn.functional.normalize(torch.randn(K, C, generator=g), dim=-1).cuda()
+    idx = torch.tensor([[7, -1, 2], [-1, -1, -1]], dtype=torch.int32).cuda()          # rows 7 and 2 of a 10-row matrix; an empty sample
+    full, logits, probs = run_classify(feats, idx, text, 100.0, 'sum', False)
+    want0 = 100.0 * feats[[7, 2]] @ text.t()
+    torch.testing.assert_close(full[0, [0, 2]], want0, rtol=1e-5, atol=1e-4)
+    assert float(full[0, 1].abs().max()) == 0 and float(full[1].abs().max()) == 0
+    torch.testing.assert_close(logits[0], want0.sum(0), rtol=1e-5, atol=1e-3)
+    assert float(logits[1].abs().max()) == 0
+    # B = 0: nothing is launched, nothing is touched
+    e = torch.empty(0, device='cuda')
+    ws = torch.empty(256, dtype=torch.uint8, device='cuda')
+    assert lib.ec_classify(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(text.t().contiguous()), 0, T, C, K, 100.0, 0, 0, _lib.ptr(e),
+                           _lib.ptr(e), _lib.ptr(e), _lib.ptr(ws), 256, _lib.stream_ptr()) == 0
+    # a workspace that is too small is refused with the size that is needed
+    rc = lib.ec_classify(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(text.t().contiguous()), 2, T, C, K, 100.0, 0, 0, _lib.ptr(full),
+                         _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), 256, _lib.stream_ptr())
+    assert rc != 0 and b'ec_classify_workspace_bytes' in lib.ec_last_error()

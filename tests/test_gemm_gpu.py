@@ -362,3 +362,24 @@ def test_split_output_of_the_16_bit_epilogues(M, N, K, epilogue, hip):
     assert err < 2e-5, err
     with pytest.raises(RuntimeError, match='A_lo / W_lo'):       # the lo output exists in the segmented launches only
         ops.gemm(a_hi, w_hi, bias, epilogue, aux=out_lo)
+
+
+def test_split_operand_edges(hip):
+    """M = 0 is a no-op with split operands too; what the segmented launches do not take (splits, ws, resid, transposed
+    operands, a lo output outside STORE16 / GELU16) is refused, not ignored."""
+    import torch
+    from eventclip_amd import ops
+    a_hi, a_lo = _split(torch.randn(64, 128, device='cuda'), torch.float16)
+    w_hi, w_lo = _split(torch.randn(32, 128, device='cuda') / 11, torch.float16)
+    out = ops.gemm(a_hi[:0], w_hi, None, 'store32', A_lo=a_lo[:0], W_lo=w_lo)
+    assert out.shape == (0, 32)
+    with pytest.raises(RuntimeError, match='A_lo / W_lo'):
+        ops.gemm(a_hi, w_hi, None, 'resid32', out=torch.zeros(64, 32, device='cuda'), resid=torch.zeros(64, 32, device='cuda'), A_lo=a_lo)
+    with pytest.raises(RuntimeError, match='A_lo / W_lo'):
+        ops.gemm(a_hi, w_hi, None, 'store32', A_lo=a_lo, ws=torch.empty(1 << 20, dtype=torch.uint8, device='cuda'))
+    with pytest.raises(RuntimeError, match='A_lo / W_lo'):
+        ops.gemm(a_hi, w_hi, None, 'gelu16_save', aux=torch.empty(64, 32, dtype=torch.float16, device='cuda'), A_lo=a_lo)
+    # the three-product form against float64 on a shape that is one partial tile
+    want = (a_hi.double() + a_lo.double()) @ (w_hi.double() + w_lo.double()).t() - a_lo.double() @ w_lo.double().t()
+    got = ops.gemm(a_hi, w_hi, None, 'store32', A_lo=a_lo, W_lo=w_lo)
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6
