@@ -640,6 +640,9 @@ def main():
                                         f'{clip_model.image_precise_attn_blocks}: ec_vit_weights.precise_blocks / precise_attn_blocks)'
                                         if a.precise_blocks and not a.precise else '')
                                      + '; text tower split-precision (cached)'),
+                       # the EFFECTIVE tolerance-mode setting of the timed model (0 = the headline's 16-bit path; EVENTCLIP_PRECISE_BLOCKS
+                       # in the environment would change it without a flag on the command line)
+                       'precise_blocks_effective': [clip_model.image_precise_blocks, clip_model.image_precise_attn_blocks],
                        'last_block': ('every token' if clip_model.full_last_block else
                                       'keys/values for every token; query projection, attention, out_proj, '
                                       'MLP for the class token only (bit-identical encode_image output)'),
