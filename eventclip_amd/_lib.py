@@ -103,8 +103,8 @@ class EcVitWeights(ctypes.Structure):
                 ('ln_post_b', c_void_p), ('proj_w', c_void_p),
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
-                ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int), ('precise_blocks', c_int), ('precise_attn_blocks', c_int),
-                ('weights_exact16', c_int)]
+                ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int), ('precise_blocks', c_int), ('weights_exact16', c_int),
+                ('precise_attn_blocks', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):

@@ -497,18 +497,18 @@ typedef struct {
                                    where most of it is made (tools/rounding_budget.py).  (Rounds 1 - 4 ran
                                    these blocks as the fp32-stream chain of `precise`, three launches per GEMM and fp32
                                    attention everywhere: 2.0 x the step; this form costs 1.3 - 1.5 x.)  0 (default): off. */
-    int precise_attn_blocks;    /* <= precise_blocks: in the first precise_attn_blocks of the split-operand blocks the QKV
+    int weights_exact16;        /* != 0: the blocks' 16-bit matrices ARE the weights (a checkpoint stored in 16 bit, as
+                                   clip.load() returns one on a GPU): the qkv_w_lo / out_w_lo / fc1_w_lo / fc2_w_lo of a
+                                   split-precision block may be NULL, and the x_hi . w_lo product of such a matrix -- a sum
+                                   of zeros -- is skipped (two MFMA products per GEMM instead of three, the same bits).
+                                   0 (default): a split-precision block without its lo parts is an error. */
+    int precise_attn_blocks;    /* (round 5, appended) <= precise_blocks: in the first precise_attn_blocks of the split-operand blocks the QKV
                                    GEMM also writes the lo parts of q | k | v (ec_gemm_args.aux) and attention runs in fp32
                                    on hi + lo (ec_attention_split), its output entering out_proj as hi + lo, and c_fc writes
                                    QuickGELU's output as hi + lo into c_proj: where attention is sharp the 16-bit rounding
                                    of q and k in the FIRST blocks is the largest single error and that of the MLP activation
                                    the next (tools/rounding_budget.py; profiles/r5_tolerance_sweep.txt); behind them the
                                    16-bit attention kernel on a plain q with the scores scaled in fp32. */
-    int weights_exact16;        /* != 0: the blocks' 16-bit matrices ARE the weights (a checkpoint stored in 16 bit, as
-                                   clip.load() returns one on a GPU): the qkv_w_lo / out_w_lo / fc1_w_lo / fc2_w_lo of a
-                                   split-precision block may be NULL, and the x_hi . w_lo product of such a matrix -- a sum
-                                   of zeros -- is skipped (two MFMA products per GEMM instead of three, the same bits).
-                                   0 (default): a split-precision block without its lo parts is an error. */
 } ec_vit_weights;
 
 typedef struct {
