@@ -14,9 +14,9 @@
 // products in one ec_gemm launch (ec_gemm_args.A_lo / W_lo, EC_EPI_STORE32):
 //   classify_prep_rows   feats row -> (F.normalize,) x 2^e (e per row: the row's largest element lands in [2^10, 2^11),
 //                        so the lo parts are normal fp16 numbers) -> hi | lo, and the row's 2^-e
-//   classify_prep_text   text_t [C, K] -> [K16, C64] hi | lo, x 2^12 (unit rows)
+//   classify_prep_text   text_t [C, K] -> [K16, C64] hi | lo, each class row x its own 2^e'
 //   ec_gemm              raw [n_rows, K16] fp32
-//   classify_aggregate   per sample: logit = logit_scale 2^-e 2^-12 raw (powers of two: exact), softmax per view,
+//   classify_aggregate   per sample: logit = logit_scale 2^-e 2^-e' raw (powers of two: exact), softmax per view,
 //                        aggregation over the valid views.
 #include "common.h"
 
@@ -92,27 +92,39 @@ __global__ __launch_bounds__(256) void classify_prep_rows(const float *feats, in
     if (lane == 0) inv_scale[row] = ldexpf(1.f, -e);
 }
 
-// text_t fp32 [C, K] -> rows k of [Kp, Cp] fp16 hi | lo, x 2^12; rows K .. Kp - 1 and columns C .. Cp - 1 zero
-constexpr int CL_TEXT_SHIFT = 12;
+// text_t fp32 [C, K] -> rows k of [Kp, Cp] fp16 hi | lo, each class row scaled by its own power of two (largest element
+// into [2^10, 2^11), like the feature rows: the reference's text features are unit rows, but nothing here depends on it);
+// rows K .. Kp - 1 and columns C .. Cp - 1 zero.  One wave per class.
 __global__ __launch_bounds__(256) void classify_prep_text(const float *text_t, int C, int K, int Cp, int Kp, _Float16 *hi,
-                                                          _Float16 *lo)
+                                                          _Float16 *lo, float *inv_scale)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)Kp * Cp) return;
-    const int k = (int)(i / Cp), c = (int)(i - (long)k * Cp);
-    float v = 0.f;
-    if (k < K && c < C) v = ldexpf(text_t[(long)c * K + k], CL_TEXT_SHIFT);
-    const _Float16 h = (_Float16)v;
-    hi[i] = h;
-    lo[i] = (_Float16)(v - (float)h);
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= Kp) return;
+    float mx = 0.f;
+    if (k < K)
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, fabsf(text_t[(long)c * K + k]));
+    mx = wave_red_max(mx);
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) e = 10 - (int)floorf(log2f(mx));
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    for (int c = lane; c < Cp; c += 64) {
+        float v = 0.f;
+        if (k < K && c < C) v = ldexpf(text_t[(long)c * K + k], e);
+        const _Float16 h = (_Float16)v;
+        hi[(long)k * Cp + c] = h;
+        lo[(long)k * Cp + c] = (_Float16)(v - (float)h);
+    }
+    if (lane == 0) inv_scale[k] = ldexpf(1.f, -e);
 }
 
 struct AggArgs {
-    const float *raw;         // [n_rows, Kp] fp32: (feats 2^e) . (text 2^12)
-    const float *inv_scale;   // [n_rows] 2^-e
+    const float *raw;         // [n_rows, Kp] fp32: (feats 2^e) . (text 2^e')
+    const float *inv_scale;   // [n_rows] 2^-e of the feature rows
+    const float *inv_class;   // [Kp] 2^-e of the class rows
     const int *row_idx;
     int B, T, K, Kp;
-    float scale;              // logit_scale 2^-12
+    float scale;              // logit_scale
     int agg;
     float *full_logits, *logits, *probs;
 };
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(CL_THREADS) void classify_aggregate_kernel(const Ag
 #pragma unroll
         for (int t = 0; t < CL_MAXT; t++)
             if (t < T) {
-                const float l = s_row[t] >= 0 ? s_mul[t] * a.raw[(long)s_row[t] * a.Kp + k] : 0.f;
+                const float l = s_row[t] >= 0 ? s_mul[t] * (a.inv_class[k] * a.raw[(long)s_row[t] * a.Kp + k]) : 0.f;
                 fl[(long)t * K + k] = l;
                 vmax[t] = fmaxf(vmax[t], l);
             }
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(CL_THREADS) void classify_aggregate_kernel(const Ag
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct ClsCarve {
-    size_t a_hi, a_lo, w_hi, w_lo, inv, raw, total;
+    size_t a_hi, a_lo, w_hi, w_lo, inv, invk, raw, total;
     int Cp, Kp;
 };
 ClsCarve cls_carve(int n_rows, int C, int K)
@@ -189,7 +201,7 @@ ClsCarve cls_carve(int n_rows, int C, int K)
     auto take = [&](size_t b) { const size_t at = off; off += up256(b); return at; };
     c.a_hi = take((size_t)n_rows * c.Cp * 2), c.a_lo = take((size_t)n_rows * c.Cp * 2);
     c.w_hi = take((size_t)c.Kp * c.Cp * 2), c.w_lo = take((size_t)c.Kp * c.Cp * 2);
-    c.inv = take((size_t)n_rows * 4), c.raw = take((size_t)n_rows * c.Kp * 4);
+    c.inv = take((size_t)n_rows * 4), c.invk = take((size_t)c.Kp * 4), c.raw = take((size_t)n_rows * c.Kp * 4);
     c.total = off;
     return c;
 }
@@ -222,13 +234,11 @@ extern "C" EC_API int ec_classify(const float *feats, int n_rows, const int32_t 
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     _Float16 *a_hi = reinterpret_cast<_Float16 *>(ws + c.a_hi), *a_lo = reinterpret_cast<_Float16 *>(ws + c.a_lo);
     _Float16 *w_hi = reinterpret_cast<_Float16 *>(ws + c.w_hi), *w_lo = reinterpret_cast<_Float16 *>(ws + c.w_lo);
-    float *inv = reinterpret_cast<float *>(ws + c.inv), *raw = reinterpret_cast<float *>(ws + c.raw);
+    float *inv = reinterpret_cast<float *>(ws + c.inv), *invk = reinterpret_cast<float *>(ws + c.invk), *raw = reinterpret_cast<float *>(ws + c.raw);
     if (n_rows > 0) {
         hipLaunchKernelGGL(classify_prep_rows, dim3(ec::ceil_div(n_rows, 4)), dim3(256), 0, s, feats, n_rows, C, c.Cp, normalize,
                            a_hi, a_lo, inv);
-        const long nt = (long)c.Kp * c.Cp;
-        hipLaunchKernelGGL(classify_prep_text, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, text_t, C, K, c.Cp, c.Kp, w_hi,
-                           w_lo);
+        hipLaunchKernelGGL(classify_prep_text, dim3(ec::ceil_div(c.Kp, 4)), dim3(256), 0, s, text_t, C, K, c.Cp, c.Kp, w_hi, w_lo, invk);
         EC_CHECK_HIP(hipGetLastError());
         ec_gemm_args g = {};
         g.M = n_rows, g.N = c.Kp, g.K = c.Cp, g.dtype = EC_F16, g.epilogue = EC_EPI_STORE32, g.variant = 0;
@@ -236,8 +246,8 @@ extern "C" EC_API int ec_classify(const float *feats, int n_rows, const int32_t 
         if (int rc = ec_gemm(&g, stream)) return rc;
     }
     AggArgs a;
-    a.raw = raw, a.inv_scale = inv, a.row_idx = row_idx, a.B = B, a.T = T, a.K = K, a.Kp = c.Kp;
-    a.scale = ldexpf(logit_scale, -CL_TEXT_SHIFT), a.agg = agg;
+    a.raw = raw, a.inv_scale = inv, a.inv_class = invk, a.row_idx = row_idx, a.B = B, a.T = T, a.K = K, a.Kp = c.Kp;
+    a.scale = logit_scale, a.agg = agg;
     a.full_logits = full_logits, a.logits = logits, a.probs = probs;
     hipLaunchKernelGGL(classify_aggregate_kernel, dim3(B), dim3(CL_THREADS), 0, s, a);
     EC_CHECK_HIP(hipGetLastError());

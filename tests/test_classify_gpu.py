@@ -70,6 +70,21 @@ def test_few_shot_tail_matches_oracle(agg, hip):
     check(full, logits, probs, want, T)
 
 
+def test_unnormalised_text_and_tiny_features(hip):
+    """Nothing in the product depends on the text rows being unit vectors or on the features' magnitude: every feature row and
+    every class row is scaled by its own power of two before the fp16 split and the scales are taken out again exactly."""
+    import torch
+    g = torch.Generator().manual_seed(2)
+    B, T, C, K = 3, 2, 128, 20
+    feats = torch.randn(B * T, C, generator=g) * torch.tensor([1e-4, 1.0, 300.0, 1e-2, 5.0, 1e3])[:, None]
+    text = torch.randn(K, C, generator=g) * (10.0 ** torch.linspace(-3, 3, K))[:, None]
+    idx = torch.arange(B * T, dtype=torch.int32).view(B, T)
+    full, logits, probs = run_classify(feats.cuda(), idx.cuda(), text.cuda(), 1.0, 'sum', False)
+    want = (feats.double() @ text.double().t()).view(B, T, K)
+    scale = feats.double().abs().max(1).values.view(B, T, 1) * text.double().abs().max(1).values.view(1, 1, K) * C ** 0.5
+    assert float(((full.cpu().double() - want).abs() / scale).max()) < 2e-6
+
+
 def test_empty_and_ragged_edges(hip):
     """The edges the reference reaches (clip_cls.py:139: `imgs[valid_masks]` may be empty for a sample, never for a batch;
     an empty batch never reaches forward): a sample without a valid view gives zero logits rows / NaN-free probabilities
