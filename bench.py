@@ -354,7 +354,7 @@ def dist_init(a, world, rank, local, backend):
     exit (never a re-exec: the GPU is initialised)."""
     import datetime
     import threading
-    limit = float(os.environ.get('EVENTCLIP_DIST_TIMEOUT', '120'))
+    limit = float(os.environ.get('EVENTCLIP_DIST_TIMEOUT', '240'))
 
     def expired():
         dist_diag(rank, local, f'no answer from the {backend} first all-gather within {limit:.0f} s -- giving up '
