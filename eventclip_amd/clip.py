@@ -366,7 +366,7 @@ class CLIP(nn.Module):
         v.ln_pre_g, v.ln_pre_b = dev32(sd['visual.ln_pre.weight']), dev32(sd['visual.ln_pre.bias'])
         v.ln_post_g, v.ln_post_b = (dev32(sd['visual.ln_post.weight']),
                                     dev32(sd['visual.ln_post.bias']))
-        v.proj_w, v.proj_w_lo = dev16_pair(sd['visual.proj'].t())
+        v.proj_w, v.proj_w_lo = dev16_pair(sd['visual.proj'].t(), null_if_exact=True)
         v.precise = int(self.image_precise)
         v.full_last_block = int(self.full_last_block)
         v.low_latency = int(self.low_latency)
@@ -378,7 +378,7 @@ class CLIP(nn.Module):
                                  'ln_folded, float16 and no low_latency')
         v.precise_blocks = self.image_precise_blocks
         v.precise_attn_blocks = self.image_precise_attn_blocks
-        v.conv_w_lo = dev16_pair(conv_lo)[1]
+        v.conv_w_lo = dev16_pair(conv_lo, null_if_exact=True)[1]
         vb = blocks('visual.transformer', c['layers'], self.image_precise, q_scaled_all=bool(v.q_scaled),
                     ln_folded=bool(v.ln_folded), precise_first=self.image_precise_blocks)
         v.blocks = ctypes.cast(vb, ctypes.POINTER(_lib.EcBlockWeights))

@@ -119,6 +119,7 @@ inline int patch_embed(const ec_vit_weights *w, const void *patches, int rows, f
 {
     const int klo = ((3 * w->patch * w->patch + 63) / 64) * 64;
     EC_TRY(gemm(rows, w->width, w->kpad, w->dtype, EC_EPI_STORE32, patches, w->conv_w, nullptr, out, s));
+    if (!w->conv_w_lo) return EC_OK;   // conv1.weight IS its 16-bit value (weights_exact16): a sum of zeros skipped, the same bits
     return gemm(rows, w->width, klo, w->dtype, EC_EPI_RESID32, patches, w->conv_w_lo, nullptr, out, s, 0,
                 w->kpad);
 }

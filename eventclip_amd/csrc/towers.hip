@@ -313,8 +313,8 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     EC_REQUIRE(w->width == w->heads * 64, "ec_vit_encode: head dim must be 64");
     EC_REQUIRE(w->kpad % 64 == 0 && w->kpad >= 6 * w->patch * w->patch, "ec_vit_encode: bad kpad %d",
                w->kpad);
-    EC_REQUIRE(w->conv_w && w->conv_w_lo && w->proj_w && w->proj_w_lo,
-               "ec_vit_encode: conv / proj weights need their hi and lo parts");
+    EC_REQUIRE(w->conv_w && w->proj_w && (w->weights_exact16 || (w->conv_w_lo && w->proj_w_lo)),
+               "ec_vit_encode: conv / proj weights need their hi and lo parts (a lo part may be NULL with weights_exact16)");
     EC_REQUIRE(w->out_dim % 16 == 0, "ec_vit_encode: out_dim %d", w->out_dim);
     EC_REQUIRE(!(w->precise && w->q_scaled), "ec_vit_encode: the split-precision tower takes a plain q (q_scaled = 0)");
     const int g = w->image_size / w->patch, G = g * g, S = G + 1, W = w->width, dt = w->dtype;

@@ -456,8 +456,8 @@ typedef struct {
                                    ~fp32 results).  The patch embedding and ln_post @ proj always run
                                    split (hi + lo operands): they are 0.6 % of the flops and would be
                                    half of the logit error otherwise */
-    const void *conv_w_lo;      /* [W, roundup64(3 p^2)] = [w - w_hi rounded to 16 bits | 0] */
-    const void *proj_w_lo;      /* [out_dim, W] lo part of proj_w */
+    const void *conv_w_lo;      /* [W, roundup64(3 p^2)] = [w - w_hi rounded to 16 bits | 0]; NULL with weights_exact16 when all zero */
+    const void *proj_w_lo;      /* [out_dim, W] lo part of proj_w; NULL with weights_exact16 when all zero */
     int full_last_block;        /* encode_image returns ln_post(x[:, 0]) @ proj (openai/CLIP model.py), so
                                    of the last block's output only the class-token rows are ever read.
                                    0 (default): that block computes keys / values for every token but the

@@ -504,14 +504,18 @@ def test_weights_stored_in_16_bit_skip_the_lo_product(hip):
     cfg = eclip.arch_config('ViT-B/32', layers=3, text_layers=1, vocab_size=1024)
     sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in eclip.random_state_dict(cfg, seed=3).items()}
     img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
-    for kw in (dict(image_precise=True), dict(image_precise_blocks=2)):
+    for kw in (dict(image_precise=True), dict(image_precise_blocks=2), dict()):
         two = eclip.CLIP(cfg, sd, **kw).cuda().eval()
         three = eclip.CLIP(cfg, sd, **kw).cuda().eval()
         three.keep_zero_lo = True
         a, b = two.encode_image(img), three.encode_image(img)
         assert two._pack()['vit'].weights_exact16 == 1 and three._pack()['vit'].weights_exact16 == 0
-        field = 'qkv_w_lo' if 'image_precise' in kw else 'out_w_lo'
-        assert getattr(two._pack()['vb'][0], field) is None and getattr(three._pack()['vb'][0], field) is not None
+        if kw:
+            field = 'qkv_w_lo' if 'image_precise' in kw else 'out_w_lo'
+            assert getattr(two._pack()['vb'][0], field) is None and getattr(three._pack()['vb'][0], field) is not None
+        # conv1 and proj in every mode (the default chain included): no second patch-embedding launch, two products in proj
+        for field in ('conv_w_lo', 'proj_w_lo'):
+            assert getattr(two._pack()['vit'], field) is None and getattr(three._pack()['vit'], field) is not None
         assert torch.equal(a, b)
 
 
