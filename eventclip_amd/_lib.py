@@ -75,6 +75,7 @@ EC_EPI_RESID_HL, EC_EPI_STORE16_LN, EC_EPI_GELU16_LN = 6, 7, 8
 EC_STEP_LR0, EC_STEP_LR1, EC_STEP_BC1, EC_STEP_BC2_SQRT, EC_STEP_GRAD_SCALE, EC_STEP_INV_SCALE, EC_STEP_COUNT = 0, 1, 2, 3, 4, 5, 8
 EC_PRE_CHW_F32, EC_PRE_PATCHES16, EC_PRE_HWC_U8 = 0, 1, 2
 EC_AGG_SUM, EC_AGG_MEAN, EC_AGG_MAX = 0, 1, 2
+EC_OK, EC_ERR_INVALID, EC_ERR_HIP, EC_ERR_UNSUPPORTED, EC_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
 
 class EcBlockWeights(ctypes.Structure):
@@ -163,6 +164,7 @@ class EcVitLora(ctypes.Structure):
 SIGNATURES = {
     'ec_last_error': (ctypes.c_char_p, []),
     'ec_version': (c_int, []),
+    'ec_abi_check': (c_int, [c_int] + [ctypes.c_size_t] * 6),
     'ec_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
     'ec_profile_begin': (c_int, []),
     'ec_profile_end': (c_int, [ctypes.POINTER(EcProfileEntry), c_int, ctypes.POINTER(c_int)]),
@@ -229,9 +231,12 @@ SIGNATURES = {
     'ec_randaugment_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     'ec_randaugment': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                c_void_p, ctypes.c_size_t, c_void_p]),
-    'ec_classify_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
-    'ec_classify': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    'ec_classify_text_bytes': (ctypes.c_size_t, [c_int, c_int]),
+    'ec_classify_prep_text': (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
+    'ec_classify_v2_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
+    'ec_classify_v2': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                               c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    'ec_classify': (c_int, []),          # stub of the rounds 1 - 5 name: EC_ERR_UNSUPPORTED
     'ec_attention_train': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ec_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p]),
@@ -267,6 +272,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 600      # EC_ABI_VERSION of include/eventclip_hip.h these bindings mirror
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -292,6 +300,12 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        # the ctypes mirrors above against the library's own struct definitions (include/eventclip_hip.h, EC_ABI_CHECK)
+        rc = handle.ec_abi_check(ABI_VERSION, *(ctypes.sizeof(t) for t in (EcGemmArgs, EcBlockWeights, EcVitWeights,
+                                                                           EcTextWeights, EcEventsParams, EcAdapterWeights)))
+        if rc != 0:
+            raise HipLibraryError(f'{LIB_PATH}: {handle.ec_last_error().decode()} (eventclip_amd/_lib.py binds ABI '
+                                  f'{ABI_VERSION}; rebuild with `python -m eventclip_amd.build`)')
         _lib = handle
     return _lib
 

@@ -1565,6 +1565,15 @@ extern "C" EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out
     return EC_OK;
 }
 
+// EC_ATTN_SPLIT_F32 (tools/bench_attn_split.py, debug_attn_hl.py: force the fp32-MFMA kernel) is read by the diagnostic
+// build only: the product library's kernel choice -- numerics and speed of the tolerance mode -- never depends on the
+// process environment
+#ifdef EC_ATTN_DIAG
+static bool split_force_f32() { return getenv("EC_ATTN_SPLIT_F32") != nullptr; }
+#else
+static constexpr bool split_force_f32() { return false; }
+#endif
+
 extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
                                          int width, int heads, int q_prescaled, int dtype, ec_stream_t stream)
 {
@@ -1580,7 +1589,7 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
     // instruction (attention_hl_kernel); anything else: fp32 on v_mfma_f32_16x16x4_f32
     const int sp = 32 * ((S + 31) / 32);
     const int hl_lds = 4 * sp * 128 + (attn_lone_tile(S, 0, HL_WAVES) ? HL_WAVES * ATTN_PART * 4 : 0);
-    if (dtype == EC_F16 && !q_prescaled && hl_lds <= 160 * 1024 && !getenv("EC_ATTN_SPLIT_F32")) {
+    if (dtype == EC_F16 && !q_prescaled && hl_lds <= 160 * 1024 && !split_force_f32()) {
         AttnHlArgs h;
         h.qkv_hi = static_cast<const _Float16 *>(qkv_hi), h.qkv_lo = static_cast<const _Float16 *>(qkv_lo);
         h.out_hi = static_cast<_Float16 *>(out_hi), h.out_lo = static_cast<_Float16 *>(out_lo);
@@ -1595,7 +1604,7 @@ extern "C" EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo,
         const int split = (S / 2) & ~31, sl = S - split;
         const int spl = (sl & 31) == 1 ? ((sl + 15 + 15) / 16) * 16 : ((sl + 31) / 32) * 32;     // the odd key's 16 copies, else whole steps
         if (dtype == EC_F16 && !q_prescaled && split >= 32 && 4 * spl * 128 <= 160 * 1024 && (S + 15) / 16 <= HL_WAVES * HL2_TILES &&
-            !getenv("EC_ATTN_SPLIT_F32")) {
+            !split_force_f32()) {
             AttnHlArgs h;
             h.qkv_hi = static_cast<const _Float16 *>(qkv_hi), h.qkv_lo = static_cast<const _Float16 *>(qkv_lo);
             h.out_hi = static_cast<_Float16 *>(out_hi), h.out_lo = static_cast<_Float16 *>(out_lo);

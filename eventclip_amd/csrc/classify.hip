@@ -94,28 +94,47 @@ __global__ __launch_bounds__(256) void classify_prep_rows(const float *feats, in
 
 // text_t fp32 [C, K] -> rows k of [Kp, Cp] fp16 hi | lo, each class row scaled by its own power of two (largest element
 // into [2^10, 2^11), like the feature rows: the reference's text features are unit rows, but nothing here depends on it);
-// rows K .. Kp - 1 and columns C .. Cp - 1 zero.  One wave per class.
+// rows K .. Kp - 1 and columns C .. Cp - 1 zero.  One 256-thread workgroup per 64 classes: text_t is read with the lanes
+// along k (its contiguous dimension) and the transposed rows are written with the lanes along c, through a 64 x 64 LDS
+// tile (round 6; round 5 read text_t at stride K: one 4-byte element per 64-byte line).
 __global__ __launch_bounds__(256) void classify_prep_text(const float *text_t, int C, int K, int Cp, int Kp, _Float16 *hi,
                                                           _Float16 *lo, float *inv_scale)
 {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= Kp) return;
+    __shared__ float tile[64][65];
+    __shared__ float s_mx[4][64];
+    __shared__ int s_e[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 64, k = k0 + lane;
     float mx = 0.f;
     if (k < K)
-        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, fabsf(text_t[(long)c * K + k]));
-    mx = wave_red_max(mx);
-    int e = 0;
-    if (mx > 0.f && mx < INFINITY) e = 10 - (int)floorf(log2f(mx));
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    for (int c = lane; c < Cp; c += 64) {
-        float v = 0.f;
-        if (k < K && c < C) v = ldexpf(text_t[(long)c * K + k], e);
-        const _Float16 h = (_Float16)v;
-        hi[(long)k * Cp + c] = h;
-        lo[(long)k * Cp + c] = (_Float16)(v - (float)h);
+        for (int c = wave; c < C; c += 4) mx = fmaxf(mx, fabsf(text_t[(long)c * K + k]));
+    s_mx[wave][lane] = mx;
+    __syncthreads();
+    if (wave == 0) {
+        mx = fmaxf(fmaxf(s_mx[0][lane], s_mx[1][lane]), fmaxf(s_mx[2][lane], s_mx[3][lane]));
+        int e = 0;
+        if (mx > 0.f && mx < INFINITY) e = 10 - (int)floorf(log2f(mx));
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        s_e[lane] = e;
+        if (k < Kp) inv_scale[k] = ldexpf(1.f, -e);
     }
-    if (lane == 0) inv_scale[k] = ldexpf(1.f, -e);
+    __syncthreads();
+    const int e = s_e[lane];
+    for (int c0 = 0; c0 < Cp; c0 += 64) {
+        for (int cc = wave; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            tile[cc][lane] = (k < K && c < C) ? ldexpf(text_t[(long)c * K + k], e) : 0.f;
+        }
+        __syncthreads();
+        for (int kk = wave; kk < 64; kk += 4) {
+            if (k0 + kk >= Kp) break;
+            const float v = tile[lane][kk];
+            const _Float16 h = (_Float16)v;
+            hi[(long)(k0 + kk) * Cp + c0 + lane] = h;
+            lo[(long)(k0 + kk) * Cp + c0 + lane] = (_Float16)(v - (float)h);
+        }
+        __syncthreads();
+    }
 }
 
 struct AggArgs {
@@ -190,7 +209,8 @@ __global__ __launch_bounds__(CL_THREADS) void classify_aggregate_kernel(const Ag
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct ClsCarve {
-    size_t a_hi, a_lo, w_hi, w_lo, inv, invk, raw, total;
+    size_t a_hi, a_lo, inv, raw, total;          // per-call workspace (feature rows, raw products)
+    size_t w_hi, w_lo, invk, text_total;         // prepared text planes (ec_classify_prep_text)
     int Cp, Kp;
 };
 ClsCarve cls_carve(int n_rows, int C, int K)
@@ -200,45 +220,81 @@ ClsCarve cls_carve(int n_rows, int C, int K)
     size_t off = 0;
     auto take = [&](size_t b) { const size_t at = off; off += up256(b); return at; };
     c.a_hi = take((size_t)n_rows * c.Cp * 2), c.a_lo = take((size_t)n_rows * c.Cp * 2);
-    c.w_hi = take((size_t)c.Kp * c.Cp * 2), c.w_lo = take((size_t)c.Kp * c.Cp * 2);
-    c.inv = take((size_t)n_rows * 4), c.invk = take((size_t)c.Kp * 4), c.raw = take((size_t)n_rows * c.Kp * 4);
+    c.inv = take((size_t)n_rows * 4), c.raw = take((size_t)n_rows * c.Kp * 4);
     c.total = off;
+    off = 0;
+    c.w_hi = take((size_t)c.Kp * c.Cp * 2), c.w_lo = take((size_t)c.Kp * c.Cp * 2), c.invk = take((size_t)c.Kp * 4);
+    c.text_total = off;
     return c;
 }
 
 }  // namespace
 
-extern "C" EC_API size_t ec_classify_workspace_bytes(int n_rows, int C, int K)
+extern "C" EC_API size_t ec_classify_v2_workspace_bytes(int n_rows, int C, int K)
 {
     if (n_rows <= 0 || C <= 0 || K <= 0) return 0;
     return cls_carve(n_rows, C, K).total;
 }
 
-extern "C" EC_API int ec_classify(const float *feats, int n_rows, const int32_t *row_idx, const float *text_t,
-                                  int B, int T, int C, int K, float logit_scale, int agg,
-                                  int normalize, float *full_logits, float *logits, float *probs,
-                                  void *workspace, size_t workspace_bytes, ec_stream_t stream)
+extern "C" EC_API size_t ec_classify_text_bytes(int C, int K)
+{
+    if (C <= 0 || K <= 0) return 0;
+    return cls_carve(1, C, K).text_total;
+}
+
+extern "C" EC_API int ec_classify_prep_text(const float *text_t, int C, int K, void *text_ws, size_t text_ws_bytes,
+                                            ec_stream_t stream)
+{
+    EC_REQUIRE(C > 0 && K > 0 && text_t, "ec_classify_prep_text: bad arguments C=%d K=%d", C, K);
+    const ClsCarve c = cls_carve(1, C, K);
+    EC_REQUIRE(text_ws && ((uintptr_t)text_ws & 255) == 0, "ec_classify_prep_text: text_ws must be 256-byte aligned");
+    if (text_ws_bytes < c.text_total)
+        return ec::fail(EC_ERR_WORKSPACE, "ec_classify_prep_text: text_ws %zu < %zu bytes (ec_classify_text_bytes)", text_ws_bytes,
+                        c.text_total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char *ws = static_cast<unsigned char *>(text_ws);
+    hipLaunchKernelGGL(classify_prep_text, dim3(ec::ceil_div(c.Kp, 64)), dim3(256), 0, s, text_t, C, K, c.Cp, c.Kp,
+                       reinterpret_cast<_Float16 *>(ws + c.w_hi), reinterpret_cast<_Float16 *>(ws + c.w_lo),
+                       reinterpret_cast<float *>(ws + c.invk));
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+// The entry point of rounds 1 - 5 under this name took other arguments (round 4: no n_rows, no workspace; round 5: text_t
+// and one workspace): a caller built against an older header gets an error code from it, never a mis-read argument list.
+extern "C" EC_API int ec_classify(void)
+{
+    return ec::fail(EC_ERR_UNSUPPORTED, "ec_classify: removed in ABI 600 -- prepare the text planes once with ec_classify_prep_text "
+                                        "and call ec_classify_v2 (include/eventclip_hip.h)");
+}
+
+extern "C" EC_API int ec_classify_v2(const float *feats, int n_rows, const int32_t *row_idx, const void *text_ws,
+                                     int B, int T, int C, int K, float logit_scale, int agg,
+                                     int normalize, float *full_logits, float *logits, float *probs,
+                                     void *workspace, size_t workspace_bytes, ec_stream_t stream)
 {
     EC_REQUIRE(B >= 0 && T > 0 && T <= CL_MAXT && C > 0 && K > 0 && n_rows >= 0,
-               "ec_classify: bad shape n_rows=%d B=%d T=%d C=%d K=%d (T <= %d)", n_rows, B, T, C, K, CL_MAXT);
+               "ec_classify_v2: bad shape n_rows=%d B=%d T=%d C=%d K=%d (T <= %d)", n_rows, B, T, C, K, CL_MAXT);
     EC_REQUIRE(agg == EC_AGG_SUM || agg == EC_AGG_MEAN || agg == EC_AGG_MAX,
-               "ec_classify: unknown agg %d", agg);   // clip_cls.py:53
+               "ec_classify_v2: unknown agg %d", agg);   // clip_cls.py:53
     if (B == 0) return EC_OK;
-    EC_REQUIRE(row_idx && text_t && full_logits && logits && probs && (feats || n_rows == 0), "ec_classify: null buffer");
+    EC_REQUIRE(row_idx && text_ws && full_logits && logits && probs && (feats || n_rows == 0), "ec_classify_v2: null buffer");
+    EC_REQUIRE(((uintptr_t)text_ws & 255) == 0, "ec_classify_v2: text_ws must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ec::ProfScope prof(ec::PROF_CLASSIFY, s, 2.0 * n_rows * C * K, 0);
     const ClsCarve c = cls_carve(n_rows > 0 ? n_rows : 1, C, K);
-    EC_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "ec_classify: workspace must be 256-byte aligned");
+    EC_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "ec_classify_v2: workspace must be 256-byte aligned");
     if (workspace_bytes < c.total)
-        return ec::fail(EC_ERR_WORKSPACE, "ec_classify: workspace %zu < %zu bytes (ec_classify_workspace_bytes)", workspace_bytes, c.total);
+        return ec::fail(EC_ERR_WORKSPACE, "ec_classify_v2: workspace %zu < %zu bytes (ec_classify_v2_workspace_bytes)", workspace_bytes, c.total);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const unsigned char *tw = static_cast<const unsigned char *>(text_ws);
     _Float16 *a_hi = reinterpret_cast<_Float16 *>(ws + c.a_hi), *a_lo = reinterpret_cast<_Float16 *>(ws + c.a_lo);
-    _Float16 *w_hi = reinterpret_cast<_Float16 *>(ws + c.w_hi), *w_lo = reinterpret_cast<_Float16 *>(ws + c.w_lo);
-    float *inv = reinterpret_cast<float *>(ws + c.inv), *invk = reinterpret_cast<float *>(ws + c.invk), *raw = reinterpret_cast<float *>(ws + c.raw);
+    const _Float16 *w_hi = reinterpret_cast<const _Float16 *>(tw + c.w_hi), *w_lo = reinterpret_cast<const _Float16 *>(tw + c.w_lo);
+    const float *invk = reinterpret_cast<const float *>(tw + c.invk);
+    float *inv = reinterpret_cast<float *>(ws + c.inv), *raw = reinterpret_cast<float *>(ws + c.raw);
     if (n_rows > 0) {
         hipLaunchKernelGGL(classify_prep_rows, dim3(ec::ceil_div(n_rows, 4)), dim3(256), 0, s, feats, n_rows, C, c.Cp, normalize,
                            a_hi, a_lo, inv);
-        hipLaunchKernelGGL(classify_prep_text, dim3(ec::ceil_div(c.Kp, 4)), dim3(256), 0, s, text_t, C, K, c.Cp, c.Kp, w_hi, w_lo, invk);
         EC_CHECK_HIP(hipGetLastError());
         ec_gemm_args g = {};
         g.M = n_rows, g.N = c.Kp, g.K = c.Cp, g.dtype = EC_F16, g.epilogue = EC_EPI_STORE32, g.variant = 0;

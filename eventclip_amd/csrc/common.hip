@@ -144,7 +144,29 @@ EC_API int ec_profile_end(ec_profile_entry *out, int cap, int *n_out)
 
 EC_API const char *ec_last_error(void) { return ec::err_buf(); }
 
-EC_API int ec_version(void) { return 100; }
+EC_API int ec_version(void) { return EC_ABI_VERSION; }
+
+EC_API int ec_abi_check(int header_version, size_t gemm_args_bytes, size_t block_weights_bytes, size_t vit_weights_bytes,
+                        size_t text_weights_bytes, size_t events_params_bytes, size_t adapter_weights_bytes)
+{
+    if (header_version != EC_ABI_VERSION)
+        return ec::fail(EC_ERR_INVALID, "ec_abi_check: the caller was built against ABI %d, this library is ABI %d: rebuild the "
+                                        "caller against include/eventclip_hip.h of this library", header_version, EC_ABI_VERSION);
+    const struct { const char *name; size_t got, want; } s[] = {
+        {"ec_gemm_args", gemm_args_bytes, sizeof(ec_gemm_args)},
+        {"ec_block_weights", block_weights_bytes, sizeof(ec_block_weights)},
+        {"ec_vit_weights", vit_weights_bytes, sizeof(ec_vit_weights)},
+        {"ec_text_weights", text_weights_bytes, sizeof(ec_text_weights)},
+        {"ec_events_params", events_params_bytes, sizeof(ec_events_params)},
+        {"ec_adapter_weights", adapter_weights_bytes, sizeof(ec_adapter_weights)},
+    };
+    for (const auto &e : s)
+        if (e.got != e.want)
+            return ec::fail(EC_ERR_INVALID, "ec_abi_check: sizeof(%s) is %zu in the caller and %zu in this library (ABI %d): "
+                                            "the caller's struct definitions are not this library's", e.name, e.got, e.want,
+                            EC_ABI_VERSION);
+    return EC_OK;
+}
 
 EC_API int ec_device_info(int *cu_count, char *name, int name_len)
 {

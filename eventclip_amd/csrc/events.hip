@@ -1534,6 +1534,14 @@ extern "C" EC_API int ec_center_events(float *events, const int64_t *sample_rang
 }
 
 namespace {
+// EC_EVENTS_NO_BAND10 / EC_EVENTS_NO_PACK10 (fall back to the 32-bit band kernel: A/B timing) are read by the diagnostic build
+// only; the product library's kernel choice never depends on the process environment
+#ifdef EC_EVENTS_DIAG
+bool events_env_off(const char *name) { return getenv(name) != nullptr; }
+#else
+constexpr bool events_env_off(const char *) { return false; }
+#endif
+
 
 // LDS bytes of the whole-frame 10-bit histogram, and whether that path applies: the frame fits as packed
 // counts next to the reduction scratch and the LUT.  (Also for sensors whose 32-bit histogram would fit:
@@ -1632,7 +1640,7 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
     const B10Plan b10 = b10_plan(prm->H, prm->W, prm->max_frame_events);
     const int cus_now = ec::cu_count() > 0 ? ec::cu_count() : 256;
     const bool use_b10 = b10.ok && !raw_counts && !kept_counts && prm->sort_workspace &&
-                         prm->sort_workspace_bytes >= (size_t)B10_FLAG_BYTES + b10.region_bytes && !getenv("EC_EVENTS_NO_BAND10");
+                         prm->sort_workspace_bytes >= (size_t)B10_FLAG_BYTES + b10.region_bytes && !events_env_off("EC_EVENTS_NO_BAND10");
     unsigned char *sort_base = static_cast<unsigned char *>(prm->sort_workspace) + (use_b10 ? B10_FLAG_BYTES : 0);
     const size_t sort_bytes = prm->sort_workspace ? prm->sort_workspace_bytes - (use_b10 ? B10_FLAG_BYTES : 0) : 0;
     if (cache_events == 0 && prm->max_frame_events > 0 && prm->sort_workspace) {
@@ -1702,7 +1710,7 @@ int launch_events(const void *events, const int64_t *frame_range, int F, const e
         return EC_OK;
     }
     if (pack10_fits(prm->H, prm->W) && prm->sort_workspace && prm->sort_workspace_bytes >= 256 &&
-        !getenv("EC_EVENTS_NO_PACK10")) {
+        !events_env_off("EC_EVENTS_NO_PACK10")) {
         // whole-frame 10-bit path first, then the 32-bit kernel for the frames it flagged (none, for
         // ordinary data: its workgroups return at once).  The caller's workspace holds the flags.
         if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(events_pack10_kernel<EV>), lds))

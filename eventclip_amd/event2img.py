@@ -300,12 +300,6 @@ class HostFeeder:
         except Exception:   # noqa: BLE001 -- interpreter shutdown
             pass
 
-    def _take_free(self):
-        i = self._free.get()
-        if i < 0 or self._stop.is_set():
-            raise _FeederClosed()
-        return i
-
     # ---- producer side -------------------------------------------------------------------------------
     def _alloc(self, nbytes):
         cap = max(int(nbytes), int(self.capacity or 0))
@@ -331,16 +325,20 @@ class HostFeeder:
         total = sum(n_events) * esz
         if self._slots is None:
             self._alloc(total)
-        if total > self.capacity:
-            # a batch larger than any before it (pass capacity_bytes= to avoid this): wait until no slot is in
-            # use any more, then allocate the ring again
-            held = [self._take_free() for _ in range(self.depth)]
-            for j in held:
-                if self._slots[j]['consumed'] is not None:
-                    self._slots[j]['consumed'].synchronize()
-            self._slots = None
-            self._alloc(total + total // 4)
+        # (a batch larger than the ring: the producer collects every slot -- waiting on the queues alone, without a
+        # reference to the feeder -- and then calls _regrow)
         return dict(arrs=arrs, n_events=n_events, esz=esz, total=total, packed=packed)
+
+    def _regrow(self, total, held):
+        """a batch larger than any before it (pass capacity_bytes= to avoid this): every slot index is in `held`, i.e.
+        no batch is staged or being consumed; wait for the kernels that read the slots, then allocate the ring again"""
+        assert len(held) == self.depth
+        for j in held:
+            if self._slots[j]['consumed'] is not None:
+                self._slots[j]['consumed'].synchronize()
+        self._copy_stream.synchronize()
+        self._slots = None
+        self._alloc(total + total // 4)
 
     def _fill(self, prep, i):
         """copy the parsed batch into slot i's pinned buffer and issue its upload"""
@@ -415,7 +413,18 @@ class HostFeeder:
                     raise TypeError('HostFeeder: a batch is a LIST of per-sample event arrays (or a dict with such a '
                                     "list under 'events'); got a single array / tensor")
                 prep = feeder._parse(samples)
+                regrow, depth = prep['total'] > feeder.capacity, feeder.depth
                 del feeder
+                if regrow:
+                    # the wait for ALL slots runs here, on the queue and the stop flag, with no reference to the feeder
+                    # held: a consumer that drops the feeder meanwhile ends this thread (advisor, round 5 -- the wait used
+                    # to sit in _parse, under a strong reference and without a timeout)
+                    held = [take_free() for _ in range(depth)]
+                    feeder = ref()
+                    if feeder is None:
+                        break
+                    feeder._regrow(prep['total'], held)
+                    del feeder
                 i = take_free()
                 feeder = ref()
                 if feeder is None:

@@ -11,7 +11,7 @@ mirrors of the reference's interface (vis / preprocess / clip / adapter / clip_c
     torch.ops.eventclip_hip.vit_encode         ec_vit_encode                   models/clip_cls.py:101
     torch.ops.eventclip_hip.text_encode        ec_text_encode                  models/clip_cls.py:84
     torch.ops.eventclip_hip.adapter_fwd        ec_adapter_forward              models/adapter.py:82-105
-    torch.ops.eventclip_hip.classify           ec_classify                     models/clip_cls.py:139-154, :319-343
+    torch.ops.eventclip_hip.classify           ec_classify_v2                   models/clip_cls.py:139-154, :319-343
 
 Weights live in packed C structs owned by the Python modules; an op receives them as an integer
 handle into a registry of live modules (tensors-only signatures keep the ops traceable, and the
@@ -201,6 +201,31 @@ def _(feats, row_idx, adapter_handle):
     return feats.new_empty((row_idx.shape[0], row_idx.shape[1], feats.shape[-1]))
 
 
+# prepared text planes of ec_classify_prep_text, keyed on the identity and version of the text_t tensor: the text
+# features are constant across batches (cached prompts) or change once per optimiser step (learned parameter, a new
+# tensor each time: clip_cls.FSCLIPClassifier._text_transposed), so the transposed hi + lo planes are built once
+_TEXT_PLANES = {}
+_TEXT_PLANES_MAX = 8
+
+
+def _text_planes(text_t):
+    C, K = text_t.shape
+    key = (text_t.data_ptr(), text_t._version, C, K, text_t.device.index)
+    hit = _TEXT_PLANES.get(key)
+    if hit is not None and hit[1]() is text_t:
+        return hit[0]
+    import weakref
+    ws = torch.empty(max(int(_lib.lib().ec_classify_text_bytes(C, K)), 256), dtype=torch.uint8, device=text_t.device)
+    rc = _lib.lib().ec_classify_prep_text(_lib.ptr(text_t), C, K, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, 'ec_classify_prep_text')
+    for k in [k for k, v in _TEXT_PLANES.items() if v[1]() is None]:        # tensors that are gone
+        del _TEXT_PLANES[k]
+    while len(_TEXT_PLANES) >= _TEXT_PLANES_MAX:
+        del _TEXT_PLANES[next(iter(_TEXT_PLANES))]
+    _TEXT_PLANES[key] = (ws, weakref.ref(text_t))
+    return ws
+
+
 @custom_op(f'{NAMESPACE}::classify', mutates_args=(), device_types='cuda')
 def classify(feats: torch.Tensor, row_idx: torch.Tensor, text_t: torch.Tensor, logit_scale: float,
              agg: int, normalize: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -212,11 +237,12 @@ def classify(feats: torch.Tensor, row_idx: torch.Tensor, text_t: torch.Tensor, l
     logits = torch.empty((B, K), dtype=torch.float32, device=feats.device)
     probs = torch.empty((B, K), dtype=torch.float32, device=feats.device)
     n_rows = int(feats.shape[0])
-    ws = torch.empty(max(int(_lib.lib().ec_classify_workspace_bytes(n_rows, C, K)), 256), dtype=torch.uint8, device=feats.device)
-    rc = _lib.lib().ec_classify(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C, K,
-                                logit_scale, agg, int(normalize), _lib.ptr(full), _lib.ptr(logits),
-                                _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-    _lib.check(rc, 'ec_classify')
+    text_ws = _text_planes(text_t)
+    ws = torch.empty(max(int(_lib.lib().ec_classify_v2_workspace_bytes(n_rows, C, K)), 256), dtype=torch.uint8, device=feats.device)
+    rc = _lib.lib().ec_classify_v2(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(text_ws), B, T, C, K,
+                                   logit_scale, agg, int(normalize), _lib.ptr(full), _lib.ptr(logits),
+                                   _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, 'ec_classify_v2')
     return full, logits, probs
 
 

@@ -43,7 +43,23 @@ enum {
 enum { EC_F16 = 0, EC_BF16 = 1 };
 
 EC_API const char *ec_last_error(void);
+
+/* ABI version of THIS header; ec_version() returns the one the loaded library was built from.
+ *   100  rounds 1 - 5 (the number was never bumped; ec_classify changed its argument list twice and ec_gemm_args /
+ *        ec_vit_weights grew in that time -- a caller built against any of those headers must be rebuilt)
+ *   600  round 6: ec_classify -> ec_classify_prep_text + ec_classify_v2; ec_abi_check
+ * Structs are passed by pointer and only ever grow AT THE END; a library reads every field of ITS OWN struct
+ * definition, so a caller built against an older (shorter) struct would have the tail read from past its object.
+ * ec_abi_check(EC_ABI_VERSION, sizeof ...) -- EC_ABI_CHECK() below -- compares the caller's header version and struct
+ * sizes with the library's and returns EC_ERR_INVALID (message in ec_last_error()) on any difference: call it once
+ * after loading the library, before any other entry point.  (eventclip_amd/_lib.py does, with its ctypes mirrors.) */
+#define EC_ABI_VERSION 600
 EC_API int ec_version(void);
+EC_API int ec_abi_check(int header_version, size_t gemm_args_bytes, size_t block_weights_bytes, size_t vit_weights_bytes,
+                        size_t text_weights_bytes, size_t events_params_bytes, size_t adapter_weights_bytes);
+#define EC_ABI_CHECK()                                                                                              \
+    ec_abi_check(EC_ABI_VERSION, sizeof(ec_gemm_args), sizeof(ec_block_weights), sizeof(ec_vit_weights),            \
+                 sizeof(ec_text_weights), sizeof(ec_events_params), sizeof(ec_adapter_weights))
 /* number of CUs / name of the current device, for reports */
 EC_API int ec_device_info(int *cu_count, char *name, int name_len);
 
@@ -360,7 +376,8 @@ EC_API int ec_attention_f32(const float *qkv, void *out_hi, void *out_lo, int n_
  * EC_EPI_STORE16 leaves them with ec_gemm_args.aux; output as hi / lo parts [n_seq * S, width].  q_prescaled != 0: the q
  * columns already hold q * log2(e) / sqrt(64) (ec_vit_weights.q_scaled), else a plain q.  The attention of the first
  * split-operand blocks (ec_vit_weights.precise_attn_blocks).  A plain f16 q and a sequence whose K_hi, K_lo, V_hi, V_lo fit a CU's LDS in one pass
- * (S <= 288) or in two passes over the keys (S <= 608, the tiles' state in registers between them): three 16-bit MFMA products
+ * (4 * roundup32(S) * 128 bytes, plus 2 KB where a lone last query tile is split over the waves, within 160 KiB: S <= 320,
+ * S <= 288 for such sequences) or in two passes over the keys (S <= 608, the tiles' state in registers between them): three 16-bit MFMA products
  * per score and per P.V tile (the lo . lo terms left out), ~1e-6 from float64; otherwise scores, softmax and P.V in fp32 on
  * v_mfma_f32_16x16x4_f32. */
 EC_API int ec_attention_split(const void *qkv_hi, const void *qkv_lo, void *out_hi, void *out_lo, int n_seq, int S,
@@ -547,18 +564,27 @@ EC_API int ec_text_encode(const ec_text_weights *w, const int32_t *tokens, int n
  * ------------------------------------------------------------------------ */
 enum { EC_AGG_SUM = 0, EC_AGG_MEAN = 1, EC_AGG_MAX = 2 };
 
-/* feats:   fp32 [n_rows, C] image features (compact over valid views, or full).
+/* text_t:  fp32 [C, K] text features, transposed.  Prepared ONCE per set of text features (they are constant across
+ *          batches: cached zero-shot prompts, clip_cls.py:84-93; a learned parameter changes once per optimiser step):
+ *          ec_classify_prep_text writes the hi + lo fp16 planes of the K class rows (each scaled by its own power of
+ *          two so that the lo part is a normal number) and the scales into text_ws (ec_classify_text_bytes(C, K)
+ *          bytes, 256-byte aligned), which ec_classify_v2 reads.
+ * feats:   fp32 [n_rows, C] image features (compact over valid views, or full).
  * row_idx: int32 [B, T]: row of feats for view (b, t), or -1 for an invalid view.
- * text_t:  fp32 [C, K] text features, transposed.
  * normalize != 0: L2-normalise each view's features first (F.normalize, eps 1e-12).
  * Outputs fp32: full_logits [B, T, K] (invalid views 0), logits [B, K], probs [B, K].
- * The product runs on the matrix pipe at fp32 accuracy: both operands as hi + lo fp16 parts (scaled by powers of two so
- * that the lo parts are normal numbers), three MFMA products in one ec_gemm launch (ec_gemm_args.A_lo / W_lo), the
- * scales taken out again exactly.  workspace: ec_classify_workspace_bytes(n_rows, C, K) bytes, 256-byte aligned. */
-EC_API size_t ec_classify_workspace_bytes(int n_rows, int C, int K);
-EC_API int ec_classify(const float *feats, int n_rows, const int32_t *row_idx, const float *text_t, int B, int T,
-                       int C, int K, float logit_scale, int agg, int normalize, float *full_logits,
-                       float *logits, float *probs, void *workspace, size_t workspace_bytes, ec_stream_t stream);
+ * The product runs on the matrix pipe at fp32 accuracy: both operands as hi + lo fp16 parts, three MFMA products in
+ * one ec_gemm launch (ec_gemm_args.A_lo / W_lo), the scales taken out again exactly.
+ * workspace: ec_classify_v2_workspace_bytes(n_rows, C, K) bytes, 256-byte aligned (per call; no state survives).
+ * ec_classify: the name of rounds 1 - 5 (other argument lists); kept as a stub that returns EC_ERR_UNSUPPORTED so that a
+ * caller built against an older header gets an error code, not a mis-read argument list. */
+EC_API size_t ec_classify_text_bytes(int C, int K);
+EC_API int ec_classify_prep_text(const float *text_t, int C, int K, void *text_ws, size_t text_ws_bytes, ec_stream_t stream);
+EC_API size_t ec_classify_v2_workspace_bytes(int n_rows, int C, int K);
+EC_API int ec_classify_v2(const float *feats, int n_rows, const int32_t *row_idx, const void *text_ws, int B, int T,
+                          int C, int K, float logit_scale, int agg, int normalize, float *full_logits,
+                          float *logits, float *probs, void *workspace, size_t workspace_bytes, ec_stream_t stream);
+EC_API int ec_classify(void);
 
 /* ------------------------------------------------------------------------
  * Few-shot feature adapter.  Replaces TransformerAdapter.forward

@@ -242,6 +242,42 @@ def test_host_feeder_is_bit_identical_to_the_synchronous_path(hip):
         list(pipe.stream(iter([[make_events(0, g['resolution'])]])))
 
 
+def test_host_feeder_dropped_while_the_ring_regrows_ends_its_thread(hip):
+    """the wait for ALL slots that precedes a ring re-allocation (a batch larger than any before it) ran in
+    HostFeeder._parse under a strong reference to the feeder and without a timeout -- a consumer that dropped the
+    feeder at that moment left the thread, the pinned ring and the device ring alive for ever.  The wait now runs in
+    the producer loop on the queues alone: a regrown ring still delivers bit-identical batches, and a feeder dropped
+    while the producer waits for the slots is collected and its thread ends."""
+    import gc
+    import time
+    import weakref
+    import torch
+    from eventclip_amd.event2img import Event2ImagePipeline, HostFeeder
+    from eventclip_amd.synthetic import GEOMETRY, make_batch
+    g = GEOMETRY['n_cars']
+    qa = dict(max_imgs=2, N=g['N'], split_method='event_count', convert_method='event_histogram', grayscale=True,
+              count_non_zero=True, background_mask=False)
+    pipe = Event2ImagePipeline(g["resolution"], g["max_n"], qa, n_px=224, patch=32, kpad=6144)
+    small = [make_batch(2, 4000, g['resolution'], seed=i) for i in range(3)]
+    big = make_batch(2, 90000, g['resolution'], seed=9)                    # 2.9 MB against a 1 MB ring: regrow
+    feeder = HostFeeder(pipe, small + [big] + small[:1], depth=2)
+    outs = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in feeder]
+    assert len(outs) == 5 and feeder.capacity >= 2 * 90000 * 16
+    for o, batch in zip(outs, small + [big] + small[:1]):
+        want = pipe(batch)
+        assert torch.equal(o['patches'], want['patches']) and torch.equal(o['valid_mask'], want['valid_mask'])
+    # dropped while the producer waits for every slot (the consumer holds one: it never took the first batch's slot back)
+    feeder = HostFeeder(pipe, small[:2] + [big], depth=2)
+    next(feeder)                                       # one batch consumed, slot returned; the producer stages the second,
+    time.sleep(0.5)                                    # then waits for BOTH slots for the big one: one is held by 'ready'
+    th, ref = feeder._th, weakref.ref(feeder)
+    assert th.is_alive()
+    del feeder
+    gc.collect()
+    th.join(timeout=10)
+    assert ref() is None and not th.is_alive()
+
+
 def test_host_feeder_passes_ready_batches_through_and_closes(hip):
     """harness.evaluate wraps every batch stream in a HostFeeder when a pipeline is given.  Batches that carry the
     reference's img / valid_mask (no 'events' entry, test.py:60) pass through unchanged, in order, between batches

@@ -28,8 +28,32 @@ def test_binding_table_covers_header():
 
 def test_version_and_error_string():
     lib = _lib.lib()
-    assert lib.ec_version() >= 100
+    assert lib.ec_version() == _lib.ABI_VERSION == header_abi_version()
     assert isinstance(lib.ec_last_error(), bytes)
+
+
+def header_abi_version():
+    text = open(os.path.join(ROOT, 'include', 'eventclip_hip.h')).read()
+    return int(re.search(r'#define\s+EC_ABI_VERSION\s+(\d+)', text).group(1))
+
+
+def test_abi_check_rejects_older_headers_and_short_structs():
+    """ec_gemm_args / ec_vit_weights grew and ec_classify changed its argument list while ec_version() stayed
+    100.  ABI 600: ec_abi_check compares the caller's header version and struct sizes with the library's (the loader
+    of eventclip_amd/_lib.py calls it with its ctypes mirrors); a caller built against an older header is refused with a
+    message, and the old ec_classify name is a stub that returns an error code."""
+    lib = _lib.lib()
+    sizes = [ctypes.sizeof(t) for t in (_lib.EcGemmArgs, _lib.EcBlockWeights, _lib.EcVitWeights, _lib.EcTextWeights,
+                                        _lib.EcEventsParams, _lib.EcAdapterWeights)]
+    assert lib.ec_abi_check(_lib.ABI_VERSION, *sizes) == 0
+    assert lib.ec_abi_check(100, *sizes) == _lib.EC_ERR_INVALID and b'ABI 100' in lib.ec_last_error()
+    short = list(sizes)
+    short[0] = 176                                   # ec_gemm_args as round 4 had it (no A_lo / W_lo)
+    assert lib.ec_abi_check(_lib.ABI_VERSION, *short) == _lib.EC_ERR_INVALID and b'ec_gemm_args' in lib.ec_last_error()
+    short = list(sizes)
+    short[2] -= 8                                    # ec_vit_weights without its last field
+    assert lib.ec_abi_check(_lib.ABI_VERSION, *short) == _lib.EC_ERR_INVALID and b'ec_vit_weights' in lib.ec_last_error()
+    assert lib.ec_classify() == _lib.EC_ERR_UNSUPPORTED and b'ec_classify_v2' in lib.ec_last_error()
 
 
 def test_struct_layout_matches_header():

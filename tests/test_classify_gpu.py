@@ -15,10 +15,12 @@ def run_classify(feats, row_idx, text, scale, agg, normalize):
     text_t = text.t().contiguous()
     code = {'sum': _lib.EC_AGG_SUM, 'mean': _lib.EC_AGG_MEAN, 'max': _lib.EC_AGG_MAX}[agg]
     n_rows = feats.shape[0]
-    ws = torch.empty(_lib.lib().ec_classify_workspace_bytes(n_rows, C, K), dtype=torch.uint8, device='cuda')
-    _lib.check(_lib.lib().ec_classify(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(text_t), B, T, C,
-                                      K, scale, code, int(normalize), _lib.ptr(full),
-                                      _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    tws = torch.empty(_lib.lib().ec_classify_text_bytes(C, K), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().ec_classify_prep_text(_lib.ptr(text_t), C, K, _lib.ptr(tws), tws.numel(), _lib.stream_ptr()))
+    ws = torch.empty(max(_lib.lib().ec_classify_v2_workspace_bytes(n_rows, C, K), 256), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().ec_classify_v2(_lib.ptr(feats), n_rows, _lib.ptr(row_idx), _lib.ptr(tws), B, T, C,
+                                         K, scale, code, int(normalize), _lib.ptr(full),
+                                         _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return full, logits, probs
 
 
@@ -107,9 +109,40 @@ def test_empty_and_ragged_edges(hip):
     # B = 0: nothing is launched, nothing is touched
     e = torch.empty(0, device='cuda')
     ws = torch.empty(256, dtype=torch.uint8, device='cuda')
-    assert lib.ec_classify(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(text.t().contiguous()), 0, T, C, K, 100.0, 0, 0, _lib.ptr(e),
-                           _lib.ptr(e), _lib.ptr(e), _lib.ptr(ws), 256, _lib.stream_ptr()) == 0
-    # a workspace that is too small is refused with the size that is needed
-    rc = lib.ec_classify(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(text.t().contiguous()), 2, T, C, K, 100.0, 0, 0, _lib.ptr(full),
-                         _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), 256, _lib.stream_ptr())
-    assert rc != 0 and b'ec_classify_workspace_bytes' in lib.ec_last_error()
+    tws = torch.empty(lib.ec_classify_text_bytes(C, K), dtype=torch.uint8, device='cuda')
+    text_t = text.t().contiguous()
+    assert lib.ec_classify_prep_text(_lib.ptr(text_t), C, K, _lib.ptr(tws), tws.numel(), _lib.stream_ptr()) == 0
+    assert lib.ec_classify_v2(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(tws), 0, T, C, K, 100.0, 0, 0, _lib.ptr(e),
+                              _lib.ptr(e), _lib.ptr(e), _lib.ptr(ws), 256, _lib.stream_ptr()) == 0
+    # a workspace that is too small is refused with the size that is needed -- for the call and for the text planes
+    rc = lib.ec_classify_v2(_lib.ptr(feats), 10, _lib.ptr(idx), _lib.ptr(tws), 2, T, C, K, 100.0, 0, 0, _lib.ptr(full),
+                            _lib.ptr(logits), _lib.ptr(probs), _lib.ptr(ws), 256, _lib.stream_ptr())
+    assert rc != 0 and b'ec_classify_v2_workspace_bytes' in lib.ec_last_error()
+    rc = lib.ec_classify_prep_text(_lib.ptr(text_t), C, K, _lib.ptr(tws), 256, _lib.stream_ptr())
+    assert rc != 0 and b'ec_classify_text_bytes' in lib.ec_last_error()
+    # the entry point of rounds 1 - 5 answers with an error code whatever it is handed (ABI 600)
+    assert lib.ec_classify() == _lib.EC_ERR_UNSUPPORTED and b'ec_classify_v2' in lib.ec_last_error()
+
+
+def test_text_planes_are_prepared_once_per_text_tensor():
+    """torch.ops.eventclip_hip.classify builds the transposed hi + lo text planes once per text_t tensor (identity and
+    version): a second batch against the same text reuses them, an in-place update or a new tensor rebuilds them."""
+    import torch
+    from eventclip_amd import torch_ops
+    g = torch.Generator().manual_seed(3)
+    C, K = 96, 37
+    feats = torch.randn(6, C, generator=g).cuda()
+    idx = torch.arange(6, dtype=torch.int32).view(3, 2).cuda()
+    text_t = torch.nn.functional.normalize(torch.randn(K, C, generator=g), dim=-1).t().contiguous().cuda()
+    torch_ops._TEXT_PLANES.clear()
+    a = torch.ops.eventclip_hip.classify(feats, idx, text_t, 100.0, 1, False)
+    assert len(torch_ops._TEXT_PLANES) == 1
+    planes = next(iter(torch_ops._TEXT_PLANES.values()))[0]
+    b = torch.ops.eventclip_hip.classify(feats, idx, text_t, 100.0, 1, False)
+    assert len(torch_ops._TEXT_PLANES) == 1 and next(iter(torch_ops._TEXT_PLANES.values()))[0] is planes
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    text_t.mul_(2.0)                                             # in-place: new version, planes rebuilt
+    c = torch.ops.eventclip_hip.classify(feats, idx, text_t, 100.0, 1, False)
+    torch.testing.assert_close(c[0], 2 * a[0], rtol=1e-6, atol=1e-4)
+    want = 100.0 * feats.double() @ text_t.double()
+    torch.testing.assert_close(c[0].reshape(6, K).double(), want, rtol=1e-5, atol=1e-4)
