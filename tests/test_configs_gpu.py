@@ -16,99 +16,100 @@ seconds.  Every config runs twice:
             nine rounding groups of 3e-4 .. 6e-4 each), the reference's fp16 path 2.4e-3 .. 3.2e-3.
 
 The full batch sizes run through size-independent properties (test_config*_full_size_properties)."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
 
-def oracle_forward(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=None, emulate=None):
-    """Reference-order CPU chain; returns the out_dict of clip_cls.py.  emulate='fp16_reference': the towers
-    and the zero-shot logits in the arithmetic the reference runs on its GPU (oracle/clip_ref.py: fp16 weights
-    and activations, fp32 LayerNorm; clip_cls.py:148 then multiplies fp16 features; the few-shot classes cast the
-    features to fp32 first, clip_cls.py:286-288) -- the yardstick for the HIP path's error, not a target."""
-    import torch
-    from oracle import adapter as oa
-    from oracle import classify as oc
-    from oracle import clip_ref
-    from oracle import events as oe
-    from oracle import preprocess as op
-    kw = {k: v for k, v in qa.items() if k not in ('max_imgs', 'split_method', 'convert_method')}
-    frames, valid = [], torch.zeros(len(evs), T, dtype=torch.bool)
-    for b, ev in enumerate(evs):
-        f = oe.events2frames(ev, 'event_count', 'event_histogram', shape=geo, **kw)
-        assert len(f) <= T
-        valid[b, :len(f)] = True
-        frames.append(f)
-    imgs = torch.from_numpy(op.preprocess(np.concatenate(frames), cfg['image_size']))
-    feats = clip_ref.encode_image(sd, cfg, imgs, emulate=emulate)
-    h = (lambda x: x.half().float()) if emulate else (lambda x: x)
-    if adapter is None:
-        text = clip_ref.encode_text(sd, cfg, tokens, emulate=emulate)
-        text = h(text / h(text.norm(dim=-1, keepdim=True)))                 # F.normalize on the fp16 tensor
-        if emulate:
-            # logit_scale * img_feats @ text_feats.T on fp16 tensors: two rounded results (clip_cls.py:148)
-            out = oc.zs_forward(h(100.0 * feats), valid, text, 1.0, agg)
-            return {k: (h(v) if v.dtype.is_floating_point else v) for k, v in out.items()}, feats
-        return oc.zs_forward(feats, valid, text, 100.0, agg), feats
-    ad_sd, heads, residual, text_param = adapter
-    full = torch.zeros(len(evs), T, feats.shape[-1])
-    full[valid] = feats
-    ad = oa.transformer_adapter(ad_sd, full, valid, heads, residual)
-    text = torch.nn.functional.normalize(text_param, dim=-1)
-    return oc.fs_tail(ad, valid, text, 100.0, agg), feats
-
+from config_cases import (CASES, SIGNAL_GAINS, build_inputs, load_golden, fingerprint, make_events_batch,   # noqa: E402,F401
+                          make_weights, oracle_case, oracle_forward, quantize_args)
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3 relative of the reference's (fp32 oracle)
 # Input-dependent weights: the max-normalised error of full_logits against the fp32 oracle, per config, pinned at
 # 1.5 x what the HIP path measures (profiles/r5_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 4.9e-3 / 5.3e-3; the two N-ImageNet
 # cases were 3.1e-3 / 2.2e-3 on round 4's wide blobs, where 8 - 15 % of their features depended on the input: they now
 # carry 25 - 27 %, make_events_batch) -- a regression of 2 x fails.  north_star's 1e-3 is NOT met there with 16-bit GEMM
-# operands: ec_vit_weights.precise_blocks = 8 gets every config under it
-# (test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights); DESIGN.md 3.3 and the header say so.
+# operands: the tolerance mode (ec_vit_weights.precise_blocks) gets every config under it over the draws of
+# tests/config_cases.py (test_tolerance_mode_meets_1e3_over_draws); DESIGN.md 3.3 and the header say so.
 SIGNAL_TOL = {'n_caltech/ViT-B/32': 2.0e-3, 'n_caltech/ViT-L/14': 2.9e-3, 'n_cars/ViT-L/14': 2.0e-3,
               'n_imagenet/ViT-L/14@336px': 7.4e-3, 'n_imagenet/ViT-L/14': 8.0e-3}
-# (qk_gain, branch_gain, share of the feature norm that must vary with the input) per geometry: N-ImageNet frames
-# (70 000 events on 480 x 640 pixels under a background mask) are mostly white paper whatever the events, and the
-# gains that would force 30 % out of uniform-ish frames put the tower -- the fp32 one included -- into the chaotic
-# regime where one flipped attention maximum changes the answer (the emulation's error jumps from 5e-3 to 5e-2
-# between qk_gain 4 and 6); with the compact blobs of make_events_batch those two configs are held to 20 % (round 4:
-# 10 % / 8 % on the wide blobs).  (configs[0] is ONE sample: its five views show the same scene, 15 %)
-SIGNAL_GAINS = {'n_caltech/ViT-L/14': (2.5, 4.0, 0.3), 'n_caltech/ViT-B/32': (3.0, 4.0, 0.15),
-                'n_cars/ViT-L/14': (2.5, 4.0, 0.3), 'n_imagenet/ViT-L/14@336px': (4.0, 4.0, 0.2),
-                'n_imagenet/ViT-L/14': (4.0, 4.0, 0.2)}
 WEIGHTS = pytest.mark.parametrize('weights', ['init', 'signal'])
 LINE_TAG = ''      # appended to the config's name in the printed / recorded parity lines (the precise_blocks runs)
+# EC_LIVE_ORACLE=1: ignore tests/golden/configs_oracle_*.npz and recompute every oracle chain on this host
+LIVE_ORACLE = os.environ.get('EC_LIVE_ORACLE', '0') not in ('', '0')
 
 
-def make_weights(key, cfg, seed, weights):
+def hip_case(inp, **clip_kw):
+    """The HIP path on a case of config_cases.build_inputs: (out_dict, classifier, pipeline)."""
+    import torch
     from eventclip_amd import clip as eclip
-    qk, br = SIGNAL_GAINS[key][:2] if weights == 'signal' else (1.0, 1.0)
-    return eclip.random_state_dict(cfg, seed=seed, qk_gain=qk, branch_gain=br)
+    from eventclip_amd.clip_cls import FSCLIPClassifier, ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    case, g = inp['case'], inp['g']
+    m = eclip.CLIP(inp['cfg'], inp['sd'], **clip_kw).cuda().eval()
+    clip_dict = dict(clip_model=m, prompt='a point cloud image of a {}', class_names=[str(i) for i in range(case['K'])],
+                     agg_func='mean', class_tokens=inp['tokens'])
+    if case['kind'] == 'zs':
+        model = ZSCLIPClassifier(clip_dict=clip_dict).cuda().eval()
+    else:
+        model = FSCLIPClassifier(
+            adapter_dict=dict(adapter_type='text-trans', in_dim=768, d_model=256, num_heads=4, ffn_dim=1024,
+                              norm_first=True, num_layers=2, residual=case['residual']),
+            clip_dict=clip_dict, loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
+        model.adapter.load_state_dict(inp['adapter_sd'])
+        model = model.cuda().eval()
+    pipe = Event2ImagePipeline(g['resolution'], case['max_n'] or g['max_n'], inp['qa'], n_px=case['n_px'],
+                               patch=case['patch'], kpad=m.kpad)
+    with torch.no_grad():
+        out = model(pipe(inp['evs']))
+    return out, model, pipe
 
 
-def make_events_batch(batch, n_ev, resolution, seed, weights):
-    from eventclip_amd.synthetic import make_batch
-    if weights != 'signal':
-        return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.1)
-    if tuple(resolution) == (480, 640):
-        # N-ImageNet frames (70 000 events on 480 x 640 pixels under a background mask) stay 84 % white paper with the
-        # sigma = H / 8 blob of the other geometries, and the features then vary by 8 - 15 % only: a compact blob
-        # (95 % of the events within sigma = 24 pixels of a per-sample centre) puts 25 - 30 % of the feature norm into
-        # the input-dependent part at the same gains (round 5; CPU probe of the fp32 oracle: 0.27 / 0.27)
-        return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.95, blob_sigma=24)
-    return make_batch(batch, n_ev, resolution, seed=seed, blob_frac=0.7)
+def oracle_for(inp, live=False, need_emu=True):
+    """(want out_dict, image features, fp16-reference emulation out_dict or None, 'shipped' | 'live').  The fp32 oracle
+    chain of a full-depth ViT-L/14 costs tens of seconds of host time per case: its outputs are computed once in the
+    build container (tools/make_golden_configs.py) and shipped; they are used when the regenerated inputs carry the
+    fingerprint the file records, else (or with live=True / EC_LIVE_ORACLE=1) the chain runs here."""
+    import torch
+    gold = None if (live or LIVE_ORACLE) else load_golden(inp['c'], inp['weights'], inp['draw'])
+    if gold is not None and not np.allclose(gold['fingerprint'], fingerprint(inp), rtol=1e-9, atol=0):
+        import warnings
+        warnings.warn(f"configs[{inp['c']}] {inp['weights']} draw {inp['draw']}: this host regenerates different inputs "
+                      f"than the build container ({fingerprint(inp)} vs {gold['fingerprint']}); running the oracle live")
+        gold = None
+    if gold is not None:
+        vm = torch.from_numpy(gold['valid_masks'])
+        want = dict(full_logits=torch.from_numpy(gold['full_logits']), logits=torch.from_numpy(gold['logits']), valid_masks=vm)
+        emu = dict(full_logits=torch.from_numpy(gold['emu_full_logits']), logits=torch.from_numpy(gold['emu_logits']),
+                   valid_masks=vm)
+        return want, torch.from_numpy(gold['feats']), emu, 'shipped'
+    want, feats = oracle_case(inp)
+    emu = oracle_case(inp, emulate='fp16_reference')[0] if need_emu else None
+    return want, feats, emu, 'live'
 
 
-def compare(out, evs, geo, qa, cfg, sd, tokens, T, weights, name, adapter=None, key=None):
-    """HIP out_dict against the fp32 oracle chain; on the 'signal' weights also against the yardstick."""
-    want, feats = oracle_forward(evs, geo, qa, cfg, sd, tokens, T, 'mean', adapter=adapter)
-    if weights == 'signal':
-        emu, _ = oracle_forward(evs, geo, qa, cfg, sd, tokens, T, 'mean', adapter=adapter, emulate='fp16_reference')
-        check(out, want, feats=feats, emu=emu, logit_tol=SIGNAL_TOL[key], name=name, min_share=SIGNAL_GAINS[key][2])
+def run_config(c, weights, draw=0, live=False, tol=None, **clip_kw):
+    """One case of tests/config_cases.py through the HIP path and against the oracle (shipped outputs of the build
+    container's run unless live): on 'signal' weights also against the yardstick.  -> (inputs, out, want, pipe)."""
+    inp = build_inputs(c, weights, draw)
+    out, _, pipe = hip_case(inp, **clip_kw)
+    want, feats, emu, src = oracle_for(inp, live=live)
+    key = inp['case']['key']
+    name = f'configs[{c}]' + (f' draw {draw}' if draw else '') + (' (live oracle)' if src == 'live' else '')
+    if weights.startswith('signal'):
+        # the input-dependent share of the features is asserted on the historical draw (the gains were set on it);
+        # the other draws are held to 80 % of it (measured 0.17 .. 0.40, tools/make_golden_configs.py's log)
+        share = SIGNAL_GAINS[key][2] * (1.0 if draw == 0 else 0.8)
+        check(out, want, feats=feats, emu=emu, logit_tol=SIGNAL_TOL[key] if tol is None else tol, name=name, min_share=share)
     else:
         check(out, want)
-    return want
+    return inp, out, want, pipe
 
 
 def record_parity(line):
@@ -245,21 +246,7 @@ def test_config1_ncaltech_rgb_vitl14_full_depth(hip, weights):
     """configs[1] (the bench workload: N-Caltech101 zero-shot, ViT-L/14, RGB polarity, 10 views) at full
     depth against the fp32 oracle chain, ragged view counts included."""
     import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import ZSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    g, qa = quantize_args('n_caltech', 10, grayscale=False)
-    cfg = eclip.arch_config('ViT-L/14', text_layers=2)
-    sd = make_weights('n_caltech/ViT-L/14', cfg, 35, weights)
-    m = eclip.CLIP(cfg, sd).cuda().eval()
-    tokens = eclip.synthetic_tokens(101, seed=5)
-    evs = make_events_batch(3, [200000, 47000, 111000], g['resolution'], 5, weights)     # 10 + 2 + 6 views
-    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                                            class_names=[str(i) for i in range(101)],
-                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
-    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
-    out = model(pipe(evs))
-    want = compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 10, weights, 'configs[1]', key='n_caltech/ViT-L/14')
+    inp, out, want, pipe = run_config(1, weights)
     assert want['valid_masks'].sum(1).tolist() == [10, 2, 6]
     assert torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
 
@@ -275,31 +262,17 @@ def test_config1_signal_weights_other_tower_modes(hip, mode):
       first2 / first4   ec_vit_weights.precise_blocks: only the first 2 / 4 blocks as split-operand blocks (an early block's
                    rounding error is carried through every later block); held to the default path's bound, the lines
                    show what each count buys (bench.py --precise-blocks N prices it);
-      f16_weights  the default tower on the same weights ROUNDED TO 16 BIT FIRST (oracle included): what a released
-                   checkpoint is -- clip.load() on a GPU returns fp16 parameters (reference test.py:25-26) -- so the
-                   rounding of the fp32 random weights, which the other cases count as the HIP path's error, is not
-                   there: 1.40e-3 instead of 1.92e-3 (same bound as the default path)."""
+      f16_weights  the default tower on the same weights ROUNDED TO 16 BIT FIRST (oracle included; config_cases
+                   weights='signal16'): what a released checkpoint is -- clip.load() on a GPU returns fp16 parameters
+                   (reference test.py:25-26) -- so the rounding of the fp32 random weights, which the other cases count
+                   as the HIP path's error, is not there: 1.40e-3 instead of 1.92e-3 (same bound as the default path)."""
     import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import ZSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
     key = 'n_caltech/ViT-L/14'
-    g, qa = quantize_args('n_caltech', 10, grayscale=False)
-    cfg = eclip.arch_config('ViT-L/14', text_layers=2)
-    sd = make_weights(key, cfg, 35, 'signal')
-    if mode == 'f16_weights':
-        sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
     kw = dict(ln_folded=False, q_scaled=False) if mode == 'plain_chain' else dict(image_precise=True) if mode == 'precise' \
         else {} if mode == 'f16_weights' else dict(image_precise_blocks=int(mode[5:]))
-    m = eclip.CLIP(cfg, sd, **kw).cuda().eval()
-    tokens = eclip.synthetic_tokens(101, seed=5)
-    evs = make_events_batch(3, [200000, 47000, 111000], g['resolution'], 5, 'signal')
-    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                                            class_names=[str(i) for i in range(101)],
-                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
-    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
-    out = model(pipe(evs))
-    want, feats = oracle_forward(evs, g['resolution'], qa, cfg, sd, tokens, 10, 'mean')
+    inp = build_inputs(1, 'signal16' if mode == 'f16_weights' else 'signal', 0)
+    out, _, _ = hip_case(inp, **kw)
+    want, feats, _, _ = oracle_for(inp, need_emu=False)
     e = logit_errors({k: v.cpu() for k, v in out.items()}, want)
     line = (f'[configs[1] {mode}] full_logits error vs the fp32 oracle, max-normalised / centred: '
             f'{e["full_logits"][0]:.2e} / {e["full_logits"][1]:.2e}; aggregated logits {e["logits"][0]:.2e} / {e["logits"][1]:.2e}')
@@ -313,82 +286,36 @@ def test_config1_signal_weights_other_tower_modes(hip, mode):
 
 @WEIGHTS
 def test_config0_ncaltech_gray_vitb32_batch1(hip, weights):
-    """configs[0]: N-Caltech101 zero-shot, ViT-B/32 (full depth), gray event2img, batch = 1."""
+    """configs[0]: N-Caltech101 zero-shot, ViT-B/32 (full depth), gray event2img, batch = 1.  The oracle chain runs
+    LIVE on this host (12 blocks, 5 frames: seconds) and must reproduce the shipped outputs of the build container:
+    the shipped logits of the other configs are then this oracle's, not a stale file's."""
     import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import ZSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    g, qa = quantize_args('n_caltech', 10)
-    cfg = eclip.arch_config('ViT-B/32', text_layers=2)
-    sd = make_weights('n_caltech/ViT-B/32', cfg, 31, weights)
-    m = eclip.CLIP(cfg, sd).cuda().eval()
-    tokens = eclip.synthetic_tokens(101, seed=1)
-    evs = make_events_batch(1, [93000], g['resolution'], 1, weights)          # 4 chunks + overlap chunk = 5 views
-    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                                            class_names=[str(i) for i in range(101)],
-                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
-    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=32, kpad=m.kpad)
+    inp, out, want, pipe = run_config(0, weights, live=True)
     assert pipe.max_imgs == 10
-    out = model(pipe(evs))
-    want = compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 10, weights, 'configs[0]', key='n_caltech/ViT-B/32')
-    assert int(want['valid_masks'].sum()) == 5
+    assert int(want['valid_masks'].sum()) == 5                     # 4 chunks + overlap chunk = 5 views
     assert torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1))
+    gold = load_golden(0, weights, 0)
+    assert gold is not None, 'tests/golden/configs_oracle_0_*.npz missing: python tools/make_golden_configs.py'
+    np.testing.assert_allclose(fingerprint(inp), gold['fingerprint'], rtol=1e-9)
+    mag = float(want['full_logits'].abs().max())
+    assert float(np.abs(want['full_logits'].numpy() - gold['full_logits']).max()) < 2e-5 * mag   # fp32 GEMM order
 
 
 @WEIGHTS
 def test_config2_ncars_fewshot_adapter_vitl14(hip, weights):
     """configs[2]: N-Cars few-shot with the text-trans adapter, ViT-L/14 (all 24 blocks), one
     short view per sample (12 500 < N = 30 000 events), count_non_zero, no background mask."""
-    import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import FSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    g, qa = quantize_args('n_cars', 2)
-    cfg = eclip.arch_config('ViT-L/14', text_layers=1)
-    sd = make_weights('n_cars/ViT-L/14', cfg, 32, weights)
-    m = eclip.CLIP(cfg, sd).cuda().eval()
-    tokens = eclip.synthetic_tokens(2, seed=2)
-    evs = make_events_batch(6, 12500, g['resolution'], 2, weights)
-    torch.manual_seed(0)
-    model = FSCLIPClassifier(
-        adapter_dict=dict(adapter_type='text-trans', in_dim=768, d_model=256, num_heads=4,
-                          ffn_dim=1024, norm_first=True, num_layers=2, residual=0.8),
-        clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                       class_names=['car', 'background'], agg_func='mean', class_tokens=tokens),
-        loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
-    with torch.no_grad():
-        for p in model.adapter.parameters():
-            p.add_(torch.randn_like(p) * 0.02)
-    model = model.cuda().eval()
-    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=224, patch=14, kpad=m.kpad)
+    inp, out, want, pipe = run_config(2, weights)
     assert pipe.max_imgs == 1                                      # round(12500 / 30000) = 0 -> 1
-    out = model(pipe(evs))
-    ad_sd = {k: v.detach().cpu() for k, v in model.adapter.state_dict().items()}
-    compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 1, weights, 'configs[2]',
-            adapter=(ad_sd, 4, 0.8, model.text_feats.detach().cpu()), key='n_cars/ViT-L/14')
+    assert want['valid_masks'].shape == (6, 1)
 
 
 @WEIGHTS
 def test_config3_nimagenet_vitl14_336_k1000(hip, weights):
     """configs[3]: N-ImageNet zero-shot, ViT-L/14@336px (all 24 blocks, S = 577), 1000 classes, two views
     of 70 000 events on the 480 x 640 sensor (multi-band, uncached events path)."""
-    import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import ZSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    g, qa = quantize_args('n_imagenet', 2)
-    cfg = eclip.arch_config('ViT-L/14@336px', text_layers=1)
-    sd = make_weights('n_imagenet/ViT-L/14@336px', cfg, 33, weights)
-    m = eclip.CLIP(cfg, sd).cuda().eval()
-    tokens = eclip.synthetic_tokens(1000, seed=3)
-    evs = make_events_batch(2, [135000, 70000], g['resolution'], 3, weights)
-    model = ZSCLIPClassifier(clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                                            class_names=[str(i) for i in range(1000)],
-                                            agg_func='mean', class_tokens=tokens)).cuda().eval()
-    pipe = Event2ImagePipeline(g['resolution'], g['max_n'], qa, n_px=336, patch=14, kpad=m.kpad)
+    inp, out, want, pipe = run_config(3, weights)
     assert pipe.max_imgs == 2
-    out = model(pipe(evs))
-    want = compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 2, weights, 'configs[3]', key='n_imagenet/ViT-L/14@336px')
     assert want['valid_masks'].tolist() == [[True, True], [True, False]]
     top5 = out['logits'].topk(5, dim=-1).indices.cpu()              # test.py:76-81 top-5 path
     assert all(int(want['logits'][b].argmax()) in top5[b].tolist() for b in range(2))
@@ -397,33 +324,24 @@ def test_config3_nimagenet_vitl14_336_k1000(hip, weights):
 @WEIGHTS
 def test_config4_nimagenet_fewshot_t5_k1000(hip, weights):
     """configs[4]: N-ImageNet few-shot adapter, ViT-L/14 (all 24 blocks), T = 5 views, 1000
-    classes, residual 0.95; ragged view counts."""
-    import torch
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import FSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    g, qa = quantize_args('n_imagenet', 5)
-    cfg = eclip.arch_config('ViT-L/14', text_layers=1)
-    sd = make_weights('n_imagenet/ViT-L/14', cfg, 34, weights)
-    m = eclip.CLIP(cfg, sd).cuda().eval()
-    tokens = eclip.synthetic_tokens(1000, seed=4)
-    evs = make_events_batch(3, [350000, 150000, 69000], g['resolution'], 4, weights)
-    torch.manual_seed(1)
-    model = FSCLIPClassifier(
-        adapter_dict=dict(adapter_type='text-trans', in_dim=768, d_model=256, num_heads=4,
-                          ffn_dim=1024, norm_first=True, num_layers=2, residual=0.95),
-        clip_dict=dict(clip_model=m, prompt='a point cloud image of a {}',
-                       class_names=[str(i) for i in range(1000)], agg_func='mean',
-                       class_tokens=tokens),
-        loss_dict=dict(use_logits_loss=True, use_probs_loss=False)).cuda().eval()
-    # the reference derives max_imgs from max_n: round(135000 / 70000) = 2; T = 5 needs max_n = 350 k
-    pipe = Event2ImagePipeline(g['resolution'], 350000, qa, n_px=224, patch=14, kpad=m.kpad)
+    classes, residual 0.95; ragged view counts.  (The reference derives max_imgs from max_n:
+    round(135000 / 70000) = 2; T = 5 needs max_n = 350 k.)"""
+    inp, out, want, pipe = run_config(4, weights)
     assert pipe.max_imgs == 5
-    out = model(pipe(evs))
-    ad_sd = {k: v.detach().cpu() for k, v in model.adapter.state_dict().items()}
-    want = compare(out, evs, g['resolution'], qa, cfg, sd, tokens, 5, weights, 'configs[4]',
-                   adapter=(ad_sd, 4, 0.95, model.text_feats.detach().cpu()), key='n_imagenet/ViT-L/14')
     assert want['valid_masks'].sum(1).tolist() == [5, 2, 1]
+
+
+def test_shipped_oracle_is_reproduced_live_on_a_full_depth_vitl14(hip):
+    """One full-depth ViT-L/14 oracle chain per suite run stays LIVE on the GPU box's host (configs[2], 6 frames, the
+    few-shot tail included): it must reproduce tests/golden/configs_oracle_2_signal.npz draw 0."""
+    inp = build_inputs(2, 'signal', 0)
+    gold = load_golden(2, 'signal', 0)
+    assert gold is not None
+    np.testing.assert_allclose(fingerprint(inp), gold['fingerprint'], rtol=1e-9)
+    want, feats = oracle_case(inp)
+    mag = float(np.abs(gold['full_logits']).max())
+    assert float(np.abs(want['full_logits'].numpy() - gold['full_logits']).max()) < 2e-5 * mag
+    assert float(np.abs(feats.numpy() - gold['feats']).max()) < 2e-5 * float(np.abs(gold['feats']).max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -534,27 +452,21 @@ def test_config4_full_size_properties(hip):
     assert out['logits'].shape == (512, 1000) and out['valid_masks'].sum(1)[509:].tolist() == [1, 2, 4]
 
 
-@pytest.mark.parametrize('config', [0, 1, 2, 3, 4])
-def test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights(hip, config, monkeypatch):
-    """north_star's 1e-3 on the input-dependent weights of EVERY config with ec_vit_weights.precise_blocks = 8 (the
-    first eight blocks of the image tower as split-operand blocks, the first five of them (seven beyond 288 tokens) with fp32-class
-    attention, the rest
-    as the folded 16-bit chain; EVENTCLIP_PRECISE_BLOCKS sets it for the models the config tests build): the same five
-    tests with the absolute bound at 1e-3 instead of the per-config 16-bit bounds.  Measured (round 5, profiles/
-    r5_parity.txt): 4.1e-4 / 6.9e-4 / 9.3e-4 / 7.1e-4 / 8.3e-4 at 1.29 x the step on a checkpoint stored in 16 bit, the two
-    N-ImageNet cases on their round-5 inputs (25 - 27 % of the features input-dependent; rounds 1 - 4, the fp32-stream
-    chain in those blocks on the round-4 inputs: 3.4e-4 / 7.2e-4 / 5.9e-4 / 9.0e-4 / 7.5e-4 at 1.69 x).  The maximum over a
-    handful of frames is a noisy statistic (profiles/r5_tolerance_sweep.txt: +- 20 % between neighbouring settings); the
-    mode is the cheapest measured one with all five inside with some margin (7 : 5 and 8 : 5 without the MLP's lo part
-    are inside on four or at 9.5e-4)."""
-    import sys
-    mod = sys.modules[__name__]
-    fn = [test_config0_ncaltech_gray_vitb32_batch1, test_config1_ncaltech_rgb_vitl14_full_depth,
-          test_config2_ncars_fewshot_adapter_vitl14, test_config3_nimagenet_vitl14_336_k1000,
-          test_config4_nimagenet_fewshot_t5_k1000][config]
-    monkeypatch.setenv('EVENTCLIP_PRECISE_BLOCKS', '8')
-    for k in list(SIGNAL_TOL):
-        monkeypatch.setitem(SIGNAL_TOL, k, LOGIT_TOL)
-    monkeypatch.setattr(mod, 'LINE_TAG', ', precise_blocks = 8')
-    fn(hip, 'signal')
+# draws of tests/config_cases.py the tolerance mode is held to 1e-3 on, per config: the historical pair (0), and the two
+# WORST of the eight draws of profiles/r6_parity_seeds.txt (tools/sweep_tolerance.py --seeds 8) for the shipped settings
+TOLERANCE_DRAWS = {0: (0, 1, 2), 1: (0, 1, 2), 2: (0, 1, 2), 3: (0, 1, 2), 4: (0, 1, 2)}
 
+
+@pytest.mark.parametrize('config,draw', [(c, d) for c in range(5) for d in TOLERANCE_DRAWS[c]])
+def test_tolerance_mode_meets_1e3_over_draws(hip, config, draw, monkeypatch):
+    """north_star's 1e-3 on input-dependent weights with the tolerance mode (ec_vit_weights.precise_blocks /
+    precise_attn_blocks at eventclip_amd.clip.TOLERANCE_MODE's counts: the first blocks of the image tower as
+    split-operand blocks, the first few of them with fp32-class attention, the rest as the folded 16-bit chain), on
+    THREE (weight seed, event seed) draws per config against the oracle logits shipped in tests/golden/configs_oracle_*
+    (profiles/r6_parity_seeds.txt has all eight draws per config, default path and tolerance mode: median, worst case,
+    fraction inside 1e-3)."""
+    import sys
+    from eventclip_amd import clip as eclip
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, 'LINE_TAG', ', tolerance mode')
+    run_config(config, 'signal', draw, tol=LOGIT_TOL, **eclip.tolerance_mode_kwargs(CASES[config]['arch']))

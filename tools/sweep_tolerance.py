@@ -1,15 +1,23 @@
-"""Logit error of the five BASELINE configs (input-dependent weights) for combinations of the tolerance mode's knobs:
-EVENTCLIP_PRECISE_BLOCKS (split-operand blocks) x EVENTCLIP_PRECISE_ATTN_BLOCKS (of which fp32 attention).
+"""Logit error of the five BASELINE configs on input-dependent weights over the (weight seed, event seed) draws of
+tests/config_cases.py, for the default path and for settings of the tolerance mode
+(image_precise_blocks : image_precise_attn_blocks), against the fp32 oracle logits shipped in
+tests/golden/configs_oracle_*_signal.npz (tools/make_golden_configs.py, computed once in the build container).
 
-    python tools/sweep_tolerance.py 8:4 8:2 12:4 > profiles/r5_tolerance_sweep.txt
+    python tools/sweep_tolerance.py --seeds 8 default mode > profiles/r6_parity_seeds.txt
+    python tools/sweep_tolerance.py --seeds 8 --configs 3 8:7 10:7 12:9        # explicit settings
 
-Runs tests/test_configs_gpu.py's own config cases (same seeds, same oracle) with the bound lifted, prints one line per
-(combination, config): the max-normalised error of full_logits / logits against the fp32 oracle.
+'default' = the 16-bit path bench.py times; 'mode' = eventclip_amd.clip.TOLERANCE_MODE for the config's sequence
+length; 'B:A' = B split-operand blocks of which A with fp32-class attention.  One line per (setting, config, draw) with
+the max-normalised and the centred error of full_logits and the max-normalised error of the aggregated logits; then per
+(setting, config): median, worst draw and the fraction of draws inside north_star's 1e-3 (full_logits, max-normalised).
+--weights signal16: the same on weights rounded to 16 bit first (what a released checkpoint is).
 """
+import argparse
 import os
-import re
 import sys
-import tempfile
+import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,38 +25,53 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def main():
+    import torch
+    import config_cases as cc
     import test_configs_gpu as tc
-    fns = [tc.test_config0_ncaltech_gray_vitb32_batch1, tc.test_config1_ncaltech_rgb_vitl14_full_depth,
-           tc.test_config2_ncars_fewshot_adapter_vitl14, tc.test_config3_nimagenet_vitl14_336_k1000,
-           tc.test_config4_nimagenet_fewshot_t5_k1000]
-    configs = [int(c) for c in os.environ.get('SWEEP_CONFIGS', '0,1,2,3,4').split(',')]
-    for k in list(tc.SIGNAL_TOL):
-        tc.SIGNAL_TOL[k] = 1.0          # no bound: this tool reports
-    # the oracle chain of a config does not depend on the HIP mode: computed once per (config, arithmetic)
-    cache, plain = {}, tc.oracle_forward
-
-    def cached(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=None, emulate=None):
-        key = (tuple(geo), cfg['image_size'], cfg['width'], cfg['layers'], len(evs), sum(len(e) for e in evs), T, adapter is None, emulate)
-        if key not in cache:
-            cache[key] = plain(evs, geo, qa, cfg, sd, tokens, T, agg, adapter=adapter, emulate=emulate)
-        return cache[key]
-    tc.oracle_forward = cached
-    for combo in sys.argv[1:]:
-        pb, pa = combo.split(':')
-        os.environ['EVENTCLIP_PRECISE_BLOCKS'], os.environ['EVENTCLIP_PRECISE_ATTN_BLOCKS'] = pb, pa
-        for c in configs:
-            with tempfile.NamedTemporaryFile('r', suffix='.txt') as f:
-                os.environ['EC_PARITY_TABLE'] = f.name
-                tc.LINE_TAG = f', precise_blocks = {pb}, precise_attn_blocks = {pa}'
-                try:
-                    fns[c](None, 'signal')
-                    status = 'ok'
-                except AssertionError as e:
-                    status = 'assert: ' + str(e)[:80].replace('\n', ' ')
-                line = f.read().strip()
-            m = re.search(r'HIP ([0-9.e+-]+) / ([0-9.e+-]+),.*aggregated logits: HIP ([0-9.e+-]+)', line)
-            errs = f'full_logits {m.group(1)} (centred {m.group(2)}) logits {m.group(3)}' if m else line[:120]
-            print(f'precise_blocks={pb} attn={pa} configs[{c}]: {errs}  [{status}]', flush=True)
+    from eventclip_amd import clip as eclip
+    ap = argparse.ArgumentParser()
+    ap.add_argument('settings', nargs='+')
+    ap.add_argument('--seeds', type=int, default=8)
+    ap.add_argument('--configs', default='0,1,2,3,4')
+    ap.add_argument('--weights', default='signal')
+    ap.add_argument('--clip-kw', default='', help='extra CLIP(...) keyword arguments for the non-default settings, k=v,k=v')
+    a = ap.parse_args()
+    extra = {k: int(v) for k, v in (kv.split('=') for kv in a.clip_kw.split(',') if kv)}
+    configs = [int(c) for c in a.configs.split(',')]
+    rows = {}
+    t0 = time.time()
+    for c in configs:
+        for d in range(a.seeds):
+            inp = cc.build_inputs(c, a.weights, d)
+            want, feats, emu, src = tc.oracle_for(inp)
+            ee = tc.logit_errors(emu, want)
+            share = tc.signal_share(feats)
+            for s in a.settings:
+                if s == 'default':
+                    kw = {}
+                elif s == 'mode':
+                    kw = dict(eclip.tolerance_mode_kwargs(cc.CASES[c]['arch']), **extra)
+                else:
+                    pb, pa = (int(v) for v in s.split(':'))
+                    kw = dict(image_precise_blocks=min(pb, inp['cfg']['layers'] - 1), image_precise_attn_blocks=pa, **extra)
+                out, model, pipe = tc.hip_case(inp, **kw)
+                e = tc.logit_errors({k: v.cpu() for k, v in out.items()}, want)
+                top1 = bool(torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1)))
+                rows.setdefault((s, c), []).append(e['full_logits'][0])
+                tag = s if s in ('default',) else f'{s} {kw.get("image_precise_blocks")}:{kw.get("image_precise_attn_blocks")}'
+                print(f'[{tag}] configs[{c}] draw {d} (seeds {inp["wseed"]}, {inp["eseed"]}; share {share:.2f}; oracle {src}): '
+                      f'full_logits {e["full_logits"][0]:.2e} (centred {e["full_logits"][1]:.2e}), logits {e["logits"][0]:.2e}; '
+                      f'fp16-reference emulation {ee["full_logits"][0]:.2e} (centred {ee["full_logits"][1]:.2e}); top-1 '
+                      f'{"agrees" if top1 else "DIFFERS"}', flush=True)
+                del out, model, pipe
+                torch.cuda.empty_cache()
+    print()
+    print(f'summary over {a.seeds} draws per config, weights = {a.weights}: full_logits max |err| / max |logit| vs the fp32 oracle')
+    print('setting | config | median | worst | draws inside 1e-3')
+    for (s, c), v in rows.items():
+        v = np.asarray(v)
+        print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {int(v.argmax())}) | {int((v < 1e-3).sum())} / {len(v)}')
+    print(f'({time.time() - t0:.0f} s)')
 
 
 if __name__ == '__main__':
