@@ -80,6 +80,10 @@ def parse():
     ap.add_argument('--from-host', action='store_true',
                     help='also time the step with every batch starting in HOST memory (pinned staging ring + copy '
                          'stream, the upload of batch i + 1 under the tower of batch i): value_from_host')
+    ap.add_argument('--no-from-host', action='store_true', help='skip the host-fed steps of the default single-GPU line')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip BASELINE configs[2..4] at their per-GPU shards after the timed region: other_configs')
+    ap.add_argument('--no-strict-line', action='store_true', help='skip the 3 steps with pipe.strict = True: ms_per_step_strict')
     ap.add_argument('--no-dvfs', action='store_true', help='skip the clock / power sampling steps')
     ap.add_argument('--precise', action='store_true',
                     help='image tower with hi + lo operands in every GEMM (ec_vit_weights.precise, 3 x the MFMA work): '
@@ -92,7 +96,10 @@ def parse():
                          'n = 8 meets 1e-3 on the input-dependent weights of every config): a line of its own, never the headline')
     ap.add_argument('--no-tolerance-mode', action='store_true',
                     help='skip the extra steps (after the timed region) that price the 1e-3 mode: tolerance_mode')
+    ap.add_argument('--other-configs-batch', type=int, default=None,
+                    help='samples per step of each of other_configs (tests; default: the per-GPU shard of BASELINE\'s batch)')
     a = ap.parse_args()
+    a.arch_given, a.classes_given = a.arch, a.classes        # overrides (tests) also apply to other_configs
     c = CONFIGS[a.config]
     a.batch = a.batch or c['batch']
     a.arch = a.arch or c['arch']
@@ -103,39 +110,38 @@ def parse():
 def _cpu_event2img(args):
     """One sample through the CPU event2img stage (what a DataLoader worker of the reference does,
     datasets/event2img.py:114-128): events -> frames -> CLIP preprocess.  Returns the frame count."""
-    ev, qa, n_px = args
+    ev, qa, n_px, shape = args
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from oracle import events as oe
     from oracle import preprocess as op
-    frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
+    frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=tuple(shape), **qa)
     op.preprocess(frames, n_px)
     return frames.shape[0]
 
 
-TOLERANCE_BLOCKS = 8
-
-
 def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, frames_per_step, default_ms):
     """The price of north_star's 1e-3 on input-dependent weights, measured AFTER the timed region on the same box and
-    batch (never part of `value`): the image tower with its first TOLERANCE_BLOCKS blocks as split-operand blocks
-    (ec_vit_weights.precise_blocks -- the mode tests/test_configs_gpu.py::test_first_eight_blocks_in_split_precision_meet_
-    1e3_on_signal_weights holds to 1e-3 on all five BASELINE configs), a few steps each on the run's own weights and on
-    the same weights rounded to 16 bit first (what a released checkpoint is: the lo products of the exact matrices are
-    skipped), interleaved with steps of the default model."""
+    batch (never part of `value`): the image tower in the tolerance mode (eventclip_amd.clip.TOLERANCE_MODE: the first
+    blocks as split-operand blocks, ec_vit_weights.precise_blocks / precise_attn_blocks -- the settings
+    tests/test_configs_gpu.py::test_tolerance_mode_meets_1e3_over_draws holds to 1e-3 on three (weights, events) draws per
+    BASELINE config and profiles/r6_parity_seeds.txt measures on eight), a few steps each on the run's own weights and
+    on the same weights rounded to 16 bit first (what a released checkpoint is: the lo products of the exact matrices
+    are skipped), interleaved with steps of the default model."""
     from eventclip_amd import clip as eclip
     from eventclip_amd.clip_cls import ZSCLIPClassifier
     cdt = torch.float16 if a.dtype == 'float16' else torch.bfloat16
     if cdt != torch.float16:
         return None
     sd16 = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
-    out = {'precise_blocks': TOLERANCE_BLOCKS, 'steps': 3,
-           'configs_within_1e3': 'all five BASELINE configs on input-dependent weights '
-                                 '(tests/test_configs_gpu.py::test_first_eight_blocks_in_split_precision_meet_1e3_on_signal_weights; '
-                                 'measured errors in profiles/r5_parity.txt)',
-           'what': 'first 8 image-tower blocks as split-operand blocks: LayerNorm of both planes of the residual stream into '
+    kw = eclip.tolerance_mode_kwargs(cfg)
+    pb, pa = kw['image_precise_blocks'], kw['image_precise_attn_blocks']
+    out = {'precise_blocks': pb, 'precise_attn_blocks': pa, 'steps': 3,
+           'settings': {'up_to_288_tokens': list(eclip.TOLERANCE_MODE[0]), 'beyond': list(eclip.TOLERANCE_MODE[1])},
+           'configs_within_1e3': parity_seeds_summary(),
+           'what': f'first {pb} image-tower blocks as split-operand blocks: LayerNorm of both planes of the residual stream into '
                    'hi + lo parts, QKV / c_fc multiply both parts, every GEMM adds the product with its weight\'s lo part '
-                   '(one launch per GEMM; none where the matrix is its 16-bit value); the first 5 of them with attention in '
+                   f'(one launch per GEMM; none where the matrix is its 16-bit value); the first {pa} of them with attention in '
                    'fp32 on hi + lo q, k, v and the MLP activation as hi + lo into c_proj '
                    '(ec_vit_weights.precise_blocks / precise_attn_blocks)'}
 
@@ -151,7 +157,7 @@ def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, f
     for name, weights in (('as_run', sd), ('rounded_to_16_bit', sd16)):
         if name == 'as_run' and a.f16_weights:
             continue
-        m = eclip.CLIP(cfg, weights, dtype=a.dtype, chunk=a.chunk, image_precise_blocks=TOLERANCE_BLOCKS).cuda().eval()
+        m = eclip.CLIP(cfg, weights, dtype=a.dtype, chunk=a.chunk, **kw).cuda().eval()
         cls = ZSCLIPClassifier(clip_dict=dict(clip_dict, clip_model=m)).cuda().eval()
         cls.get_text_feats()
 
@@ -168,6 +174,17 @@ def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, f
     return out
 
 
+def parity_seeds_summary():
+    """What profiles/r6_parity_seeds.json (tools/sweep_tolerance.py --seeds 8 --json) measured for the shipped
+    tolerance-mode settings: per BASELINE config the median and the WORST of the eight (weight seed, event seed) draws of
+    full_logits' max-normalised error against the fp32 oracle, and how many draws are inside 1e-3 -- next to the same for
+    the default path.  A measurement made in the build round, quoted here; not re-measured by this run."""
+    path = os.path.join(ROOT, 'profiles', 'r6_parity_seeds.json')
+    if not os.path.exists(path):
+        return 'profiles/r6_parity_seeds.json missing: not measured'
+    return dict(json.load(open(path)), source='profiles/r6_parity_seeds.json (+ .txt: every draw)')
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -178,10 +195,13 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, workers=16):
+def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, workers=16, shape=(180, 240),
+                 pool=True):
     """The CPU oracle chain on a bounded sample of the same workload (rank 0, N=1 only), plus the
     event2img stage alone in one process and in a pool of `workers` processes, the way the
-    reference's DataLoader runs it (num_workers=16, configs/zsclip/zsclip_nin_params.py:15)."""
+    reference's DataLoader runs it (num_workers=16, configs/zsclip/zsclip_nin_params.py:15).
+    shape = the config's sensor (synthetic.GEOMETRY); the few-shot configs' adapter (0.01 % of the flops) is left out of the
+    CPU chain, the zero-shot tail stands in for it; pool=False skips the worker-pool number (other_configs)."""
     import multiprocessing as mp
     from oracle import classify as oc
     from oracle import clip_ref
@@ -197,7 +217,7 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, 
     n_frames = 0
     for ev in events[:n_samples]:
         ev = ev[:max_frames * qa['N']]
-        frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=(180, 240), **qa)
+        frames = oe.events2frames(ev, 'event_count', 'event_histogram', shape=tuple(shape), **qa)
         imgs = torch.from_numpy(op.preprocess(frames, cfg['image_size']))
         feats = clip_ref.encode_image(sd, cfg, imgs)
         valid = torch.ones(1, frames.shape[0], dtype=torch.bool)
@@ -212,11 +232,13 @@ def cpu_baseline(cfg, sd, tokens, events, quantize_args, n_samples, max_frames, 
     # event2img stage alone: one process, then a worker pool.  'spawn', not 'fork': the parent holds a HIP
     # context, runtime threads and a 64-thread OpenMP pool, and a forked child can inherit a lock one of those
     # threads held; every wait has a timeout, so a stuck worker costs the pool number, not the bench line
-    jobs = [(np.ascontiguousarray(ev[:max_frames * qa['N']]), qa, cfg['image_size'])
+    jobs = [(np.ascontiguousarray(ev[:max_frames * qa['N']]), qa, cfg['image_size'], tuple(shape))
             for ev in events[:max(n_samples, 2)]]
     t0 = time.perf_counter()
     single = sum(_cpu_event2img(j) for j in jobs)
     res['event2img_frames_per_s_1proc'] = single / (time.perf_counter() - t0)
+    if not pool:
+        return res
     try:
         workers = min(workers, os.cpu_count() or 1)
         pool_jobs = [jobs[i % len(jobs)] for i in range(2 * workers)]
@@ -381,6 +403,150 @@ def dist_init(a, world, rank, local, backend):
     dog.cancel()
 
 
+def build_workload(config, world, rank, batch=None, arch=None, classes=None, dtype='float16', chunk=2560,
+                   unique_samples=None, f16_weights=False, packed_events=False, clip_kw=None):
+    """Model + pipeline + this rank's share of one batch of BASELINE configs[config] as event streams resident in HBM."""
+    from eventclip_amd import clip as eclip
+    from eventclip_amd.clip_cls import FSCLIPClassifier, ZSCLIPClassifier
+    from eventclip_amd.event2img import Event2ImagePipeline
+    from eventclip_amd.harness import shard_range
+    from eventclip_amd.synthetic import GEOMETRY, make_events
+    c = CONFIGS[config]
+    batch, arch, classes = batch or c['batch'], arch or c['arch'], classes or c['K']
+    geo = GEOMETRY[c['geo']]
+    T, N = c['T'], geo['N']
+    quantize_args = dict(max_imgs=T, N=N, split_method='event_count',
+                         convert_method='event_histogram', grayscale=c['grayscale'],
+                         count_non_zero=geo['count_non_zero'],
+                         background_mask=geo['background_mask'])
+
+    # ---- model: seeded random CLIP, text features cached once ----
+    cfg = eclip.arch_config(arch)
+    sd = eclip.random_state_dict(cfg, seed=2)
+    if f16_weights:
+        cdt = torch.float16 if dtype == 'float16' else torch.bfloat16
+        sd = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    clip_model = eclip.CLIP(cfg, sd, dtype=dtype, chunk=chunk, **(clip_kw or {})).cuda().eval()
+    tokens = eclip.synthetic_tokens(classes, seed=2)
+    clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
+                     class_names=[f'class {i}' for i in range(classes)], agg_func='mean', class_tokens=tokens)
+    if c['adapter'] is None:
+        model = ZSCLIPClassifier(clip_dict=clip_dict)
+    else:
+        torch.manual_seed(2)
+        model = FSCLIPClassifier(adapter_dict=dict(adapter_type='text-trans', in_dim=cfg['embed_dim'], d_model=256,
+                                                   num_heads=4, ffn_dim=1024, norm_first=True, num_layers=2,
+                                                   residual=c['adapter']),
+                                 clip_dict=clip_dict, loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
+    model = model.cuda().eval()
+    model.get_text_feats()
+
+    # ---- data: this rank's share of the batch as event streams resident in HBM ----
+    if c['scaling'] == 'strong':       # a GLOBAL batch, contiguous shards (harness.shard_range)
+        shard_sizes = [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
+        local_batch, global_batch = shard_sizes[rank], batch
+    else:                              # the batch is per GPU
+        shard_sizes = [batch] * world
+        local_batch, global_batch = batch, batch * world
+    assert local_batch > 0, f'rank {rank} has no samples: batch {batch} over {world} ranks'
+    # config 1: every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
+    # then not flattered by a reuse pattern); the big configs tile a few distinct streams ON THE DEVICE
+    uniq_n = min(local_batch, unique_samples or (local_batch if config == 1 else 16))
+    # (generated on a few threads -- numpy releases the GIL in the generator and the sort: 256 streams of 200 000
+    # events are ~8 s of single-threaded host work per rank otherwise, and the ranks of a node do this at once)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(8, (os.cpu_count() or 8) // max(1, world)))) as ex:
+        evs = list(ex.map(lambda i: make_events(c['n_ev'], geo['resolution'], seed=2 * 100003 + rank * 1000 + i),
+                          range(uniq_n)))
+    if uniq_n == local_batch:
+        events = torch.from_numpy(np.concatenate(evs)).cuda()
+    else:
+        u = torch.from_numpy(np.stack(evs)).cuda()                                  # [uniq, n_ev, 4]
+        events = u[torch.arange(local_batch, device='cuda') % uniq_n].reshape(-1, 4).contiguous()
+        del u
+    n_events = [c['n_ev']] * local_batch
+    if packed_events:
+        from eventclip_amd.vis import pack_events_device
+        events = pack_events_device(events)
+    pipe = Event2ImagePipeline(geo['resolution'], c['max_n'] or geo['max_n'], quantize_args,
+                               n_px=cfg['image_size'], patch=cfg['patch'], kpad=clip_model.kpad,
+                               dtype=clip_model.compute_dtype)
+    pipe.strict = False   # no host sync inside the step (bounds are checked by the tests; ms_per_step_strict prices it)
+    views = T if c['n_ev'] >= N else 1          # frames per sample (vis.py:55-72: fewer than N events = one chunk)
+    return dict(c=c, geo=geo, cfg=cfg, sd=sd, T=T, N=N, clip_model=clip_model, model=model, tokens=tokens, clip_dict=clip_dict,
+                quantize_args=quantize_args, evs=evs, events=events, n_events=n_events, pipe=pipe, uniq_n=uniq_n,
+                shard_sizes=shard_sizes, local_batch=local_batch, global_batch=global_batch, views=views,
+                frames_per_step=local_batch * views, batch=batch, arch=arch, classes=classes)
+
+
+def dominant_kernel(prof, steps):
+    """(roofline dict of the kernel class with the largest summed duration, its record) from ec_profile records."""
+    dom = max(prof, key=lambda e: e['total_ms'])
+    avg_ms = dom['total_ms'] / dom['launches']
+    if dom['name'].startswith(MFMA_KERNELS):
+        achieved = dom['flops'] / dom['launches'] / (avg_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': achieved / PEAK_MFMA_TFLOPS}
+    else:
+        achieved = dom['bytes'] / dom['launches'] / (avg_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': achieved / PEAK_HBM_GBS}
+    roof.update(kernel=dom['name'], launches_per_step=dom['launches'] / steps, avg_launch_ms=avg_ms, traffic=None)
+    return roof, dom
+
+
+# per-GPU shard of BASELINE's batch on an 8-GPU node for the configs the default line does not time
+OTHER_CONFIG_BATCH = {2: 512, 3: 2048 // 8, 4: 4096 // 8}
+
+
+def other_configs(a, fence, cpu=True):
+    """BASELINE configs[2..4] on this one GPU, AFTER the timed region of the headline (never part of `value`): each at
+    the per-GPU shard of its BASELINE batch (configs[2]: 512 samples per GPU; configs[3] / [4]: their global batch over 8
+    GPUs = 256 x 2 / 512 x 5 views), one warm-up and two timed steps of the same step function (events resident in HBM
+    -> logits), with the dominant kernel class and its roofline fraction from the library's HIP-event records, and a
+    small CPU baseline on the config's own sensor shape (reference test.py:59-61 runs every config through the same
+    loop).  The builder-run full-size lines are profiles/r6_configs_bench.jsonl."""
+    from eventclip_amd import _lib
+    res = {}
+    for cid, batch in OTHER_CONFIG_BATCH.items():
+        t_all = time.perf_counter()
+        batch = a.other_configs_batch or batch
+        w = build_workload(cid, 1, 0, batch=batch, arch=a.arch_given, classes=a.classes_given, dtype=a.dtype, chunk=a.chunk)
+
+        def step():
+            return w['model'](w['pipe'](w['events'], w['n_events']))
+        step()
+        fence()
+        steps = 2
+        _lib.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        prof = _lib.profile_end()
+        assert int(out['valid_masks'].sum()) == w['frames_per_step']
+        roof, dom = dominant_kernel(prof, steps)
+        line = {'workload': f'{w["c"]["name"].format(arch=w["arch"])}, {batch} samples x {w["views"]} view(s) = the per-GPU '
+                            f'shard of BASELINE configs[{cid}] on 8 GPUs',
+                'value': w['frames_per_step'] / dt, 'unit': 'frames/s', 'ms_per_step': dt * 1e3, 'steps': steps,
+                'frames_per_step': w['frames_per_step'], 'dominant_kernel': roof['kernel'], 'bound': roof['bound'],
+                'frac': roof['frac'], 'dominant_ms_per_step': dom['total_ms'] / steps,
+                'kernel_ms_per_step': {e['name']: round(e['total_ms'] / steps, 3) for e in prof}}
+        if cpu:
+            try:
+                cb = cpu_baseline(w['cfg'], w['sd'], w['tokens'], w['evs'], w['quantize_args'], 1,
+                                  min(w['T'], 4 if cid != 3 else 2), shape=w['geo']['resolution'], pool=False)
+                line['cpu_baseline'] = {k: cb[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'event2img_frames_per_s_1proc')}
+            except Exception as e:   # noqa: BLE001 -- a baseline must never take the bench line down
+                line['cpu_baseline_error'] = repr(e)
+        line['wall_s'] = time.perf_counter() - t_all
+        res[str(cid)] = line
+        del w, out, step
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -420,75 +586,16 @@ def main():
         devices = devs
 
     from eventclip_amd import _lib
-    from eventclip_amd import clip as eclip
-    from eventclip_amd.clip_cls import FSCLIPClassifier, ZSCLIPClassifier
-    from eventclip_amd.event2img import Event2ImagePipeline
-    from eventclip_amd.harness import all_gather_rows, shard_range
-    from eventclip_amd.synthetic import GEOMETRY, make_events
+    from eventclip_amd.harness import all_gather_rows
 
-    c = CONFIGS[a.config]
-    geo = GEOMETRY[c['geo']]
-    T, N = c['T'], geo['N']
-    quantize_args = dict(max_imgs=T, N=N, split_method='event_count',
-                         convert_method='event_histogram', grayscale=c['grayscale'],
-                         count_non_zero=geo['count_non_zero'],
-                         background_mask=geo['background_mask'])
-
-    # ---- model: seeded random CLIP, text features cached once ----
-    cfg = eclip.arch_config(a.arch)
-    sd = eclip.random_state_dict(cfg, seed=2)
-    if a.f16_weights:
-        cdt = torch.float16 if a.dtype == 'float16' else torch.bfloat16
-        sd = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
-    clip_model = eclip.CLIP(cfg, sd, dtype=a.dtype, chunk=a.chunk, image_precise=a.precise,
-                            image_precise_blocks=0 if a.precise else a.precise_blocks).cuda().eval()
-    tokens = eclip.synthetic_tokens(a.classes, seed=2)
-    clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
-                     class_names=[f'class {i}' for i in range(a.classes)], agg_func='mean', class_tokens=tokens)
-    if c['adapter'] is None:
-        model = ZSCLIPClassifier(clip_dict=clip_dict)
-    else:
-        torch.manual_seed(2)
-        model = FSCLIPClassifier(adapter_dict=dict(adapter_type='text-trans', in_dim=cfg['embed_dim'], d_model=256,
-                                                   num_heads=4, ffn_dim=1024, norm_first=True, num_layers=2,
-                                                   residual=c['adapter']),
-                                 clip_dict=clip_dict, loss_dict=dict(use_logits_loss=True, use_probs_loss=False))
-    model = model.cuda().eval()
-    model.get_text_feats()
-
-    # ---- data: this rank's share of the batch as event streams resident in HBM ----
-    if c['scaling'] == 'strong':       # a GLOBAL batch, contiguous shards (harness.shard_range)
-        shard_sizes = [shard_range(a.batch, r, world)[1] - shard_range(a.batch, r, world)[0] for r in range(world)]
-        local_batch, global_batch = shard_sizes[rank], a.batch
-    else:                              # the batch is per GPU
-        shard_sizes = [a.batch] * world
-        local_batch, global_batch = a.batch, a.batch * world
-    assert local_batch > 0, f'rank {rank} has no samples: batch {a.batch} over {world} ranks'
-    # config 1: every sample of the batch is its own seeded stream (no tiling: the events kernel's HBM number is
-    # then not flattered by a reuse pattern); the big configs tile a few distinct streams ON THE DEVICE
-    uniq_n = min(local_batch, a.unique_samples or (local_batch if a.config == 1 else 16))
-    # (generated on a few threads -- numpy releases the GIL in the generator and the sort: 256 streams of 200 000
-    # events are ~8 s of single-threaded host work per rank otherwise, and the ranks of a node do this at once)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max(1, min(8, (os.cpu_count() or 8) // max(1, world)))) as ex:
-        evs = list(ex.map(lambda i: make_events(c['n_ev'], geo['resolution'], seed=2 * 100003 + rank * 1000 + i),
-                          range(uniq_n)))
-    if uniq_n == local_batch:
-        events = torch.from_numpy(np.concatenate(evs)).cuda()
-    else:
-        u = torch.from_numpy(np.stack(evs)).cuda()                                  # [uniq, n_ev, 4]
-        events = u[torch.arange(local_batch, device='cuda') % uniq_n].reshape(-1, 4).contiguous()
-        del u
-    n_events = [c['n_ev']] * local_batch
-    if a.packed_events:
-        from eventclip_amd.vis import pack_events_device
-        events = pack_events_device(events)
-    pipe = Event2ImagePipeline(geo['resolution'], c['max_n'] or geo['max_n'], quantize_args,
-                               n_px=cfg['image_size'], patch=cfg['patch'], kpad=clip_model.kpad,
-                               dtype=clip_model.compute_dtype)
-    pipe.strict = False   # no host sync inside the step (bounds are checked by the tests)
-    views = T if c['n_ev'] >= N else 1          # frames per sample (vis.py:55-72: fewer than N events = one chunk)
-    frames_per_step = local_batch * views       # this rank's
+    w = build_workload(a.config, world, rank, batch=a.batch, arch=a.arch, classes=a.classes, dtype=a.dtype, chunk=a.chunk,
+                       unique_samples=a.unique_samples, f16_weights=a.f16_weights, packed_events=a.packed_events,
+                       clip_kw=dict(image_precise=a.precise, image_precise_blocks=0 if a.precise else a.precise_blocks))
+    c, geo, cfg, sd, T, N = w['c'], w['geo'], w['cfg'], w['sd'], w['T'], w['N']
+    clip_model, model, tokens, clip_dict, quantize_args = w['clip_model'], w['model'], w['tokens'], w['clip_dict'], w['quantize_args']
+    evs, events, n_events, pipe, uniq_n = w['evs'], w['events'], w['n_events'], w['pipe'], w['uniq_n']
+    shard_sizes, local_batch, global_batch = w['shard_sizes'], w['local_batch'], w['global_batch']
+    views, frames_per_step = w['views'], w['frames_per_step']
     gather_events = []                          # HIP event pairs around the all-gather (rank-local stream)
 
     def step():
@@ -536,19 +643,23 @@ def main():
 
     # ---- the same steps with every batch starting in host memory (never part of `value`) ----
     host_line = None
-    if a.from_host:
+    # (on by default for the headline line on one GPU -- VERDICT r5 item 3: the host-fed number in the driver's record)
+    if a.from_host or (world == 1 and a.config == 1 and not a.no_from_host):
         host_samples = [evs[i % uniq_n] for i in range(local_batch)]      # numpy float32 [n_ev, 4] each
         if a.packed_events:
             from eventclip_amd.vis import pack_events
             packed = [pack_events(e) for e in evs]
             host_samples = [packed[i % uniq_n] for i in range(local_batch)]
 
-        def host_batches():
-            for _ in range(a.warmup + a.steps):
-                yield host_samples
         t0h = None
+        host_warm = min(a.warmup, 1) if not a.from_host else a.warmup
+        host_steps = min(a.steps, 5) if not a.from_host else a.steps
+
+        def host_batches():
+            for _ in range(host_warm + host_steps):
+                yield host_samples
         for i, batch in enumerate(pipe.stream(host_batches(), depth=2)):
-            if i == a.warmup:
+            if i == host_warm:
                 fence()
                 t0h = time.perf_counter()
             out_h = model(batch)
@@ -562,8 +673,8 @@ def main():
             dth = float(t.item())
         assert torch.equal(out_h['logits'], out['logits'])                 # same batch, same bits
         host_bytes = sum(e.nbytes for e in host_samples)
-        host_line = {'value_from_host': total_frames * a.steps / dth, 'ms_per_step_from_host': dth / a.steps * 1e3,
-                     'from_host': {'bytes_per_step_per_gpu': host_bytes,
+        host_line = {'value_from_host': total_frames * host_steps / dth, 'ms_per_step_from_host': dth / host_steps * 1e3,
+                     'from_host': {'bytes_per_step_per_gpu': host_bytes, 'steps': host_steps, 'warmup': host_warm,
                                    'path': 'per-sample copies into a pinned staging ring (8 threads), one async H2D '
                                            'copy per batch on a copy stream, batch i + 1 uploaded under the GPU work of '
                                            'batch i (eventclip_amd.event2img.HostFeeder)'}}
@@ -571,18 +682,7 @@ def main():
     if rank == 0:
         value = total_frames * a.steps / dt
         # ---- roofline of the dominant kernel, from the live HIP-event records ----
-        dom = max(prof, key=lambda e: e['total_ms'])
-        avg_ms = dom['total_ms'] / dom['launches']
-        if dom['name'].startswith(MFMA_KERNELS):
-            achieved = dom['flops'] / dom['launches'] / (avg_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_MFMA_TFLOPS}
-        else:
-            achieved = dom['bytes'] / dom['launches'] / (avg_ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': achieved / PEAK_HBM_GBS}
-        roof.update(kernel=dom['name'], launches_per_step=dom['launches'] / a.steps,
-                    avg_launch_ms=avg_ms, traffic=None)
+        roof, dom = dominant_kernel(prof, a.steps)
         # HBM-side bytes per launch come from the committed PMC passes (separate rocprofv3 --pmc runs
         # of this command, tools/profile_round.sh), not from this run: say which file and which commit
         traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -670,10 +770,31 @@ def main():
         if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks):
             res['tolerance_mode'] = tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
                                                    frames_per_step, res['ms_per_step'])
+        if world == 1 and not a.no_strict_line:
+            # Event2ImagePipeline's DEFAULT (strict = True) reads the events kernel's out-of-sensor count back to the
+            # host every batch (event2img.py:106-110; the reference syncs per batch too, test.py:66); the timed region
+            # runs strict = False: this is what the default costs on the same batch
+            pipe.strict = True
+            step()
+            fence()
+            t0s = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            res['ms_per_step_strict'] = (time.perf_counter() - t0s) / 3 * 1e3
+            res['strict_note'] = ('pipe.strict = True (the pipeline default: one 4-byte read-back of the dropped-event count per '
+                                  'batch), 3 steps after the timed region; `value` is timed with strict = False')
+            pipe.strict = False
         if world == 1 and not a.no_cpu_baseline:
-            if a.config == 1:
-                res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
-                                                   a.cpu_baseline_samples, a.cpu_baseline_frames)
+            res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
+                                               a.cpu_baseline_samples if a.config == 1 else 1,
+                                               min(a.cpu_baseline_frames, T) if a.config != 3 else 2,
+                                               shape=geo['resolution'], pool=(a.config == 1))
+        if world == 1 and a.config == 1 and not (a.no_other_configs or a.precise or a.precise_blocks or a.f16_weights):
+            # release the headline's model / workspace / events first: the other configs build their own
+            del w, model, clip_model, clip_dict, pipe, events, out, step
+            torch.cuda.empty_cache()
+            res['other_configs'] = other_configs(a, fence, cpu=not a.no_cpu_baseline)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -22,8 +22,8 @@ def last_json(text):
 
 
 def test_single_rank_line(hip):
-    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1'] + SMALL, cwd=ROOT, capture_output=True,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--other-configs-batch', '2'] + SMALL, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     assert REQUIRED <= set(d) and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
@@ -43,12 +43,26 @@ def test_single_rank_line(hip):
     assert abs(re_['frac'] - re_['achieved_GBps'] / re_['peak_GBps']) < 1e-9
     assert d['config']['unique_samples'] == 4
     # the price of the 1e-3 mode, measured behind the timed region on the same batch: never part of `value`
+    from eventclip_amd import clip as eclip
     tm = d['tolerance_mode']
-    assert tm['precise_blocks'] == 8 and 'configs_within_1e3' in tm and len(tm['lines']) == 2
+    assert [tm['precise_blocks'], tm['precise_attn_blocks']] == list(eclip.tolerance_mode_kwargs('ViT-B/32').values())
+    assert 'configs_within_1e3' in tm and len(tm['lines']) == 2
     for ln in tm['lines']:
         assert ln['weights'] in ('as_run', 'rounded_to_16_bit') and ln['ms_per_step'] > 0
         assert abs(ln['ratio_to_default'] - ln['ms_per_step'] / ln['default_ms_per_step_interleaved']) < 1e-9
         assert ln['ratio_to_default'] > 1.0          # it is a mode one pays for
+    # round 6: the host-fed number, the pipeline default's price and BASELINE configs[2..4] in the same record -- all
+    # measured after the timed region, none of them part of `value`
+    assert d['value_from_host'] > 0 and d['from_host']['bytes_per_step_per_gpu'] == 4 * 200000 * 16
+    assert d['ms_per_step_strict'] > 0
+    oc = d['other_configs']
+    assert sorted(oc) == ['2', '3', '4']
+    for cid, views in (('2', 1), ('3', 2), ('4', 5)):
+        ln = oc[cid]
+        assert ln['frames_per_step'] == 2 * views and f'configs[{cid}]' in ln['workload']
+        assert abs(ln['value'] - ln['frames_per_step'] * 1e3 / ln['ms_per_step']) < 1e-6 * ln['value']
+        assert ln['dominant_kernel'] in ln['kernel_ms_per_step'] and 0 < ln['frac'] < 1
+        assert ln['cpu_baseline']['value'] > 0 and ln['cpu_baseline']['kind'] == 'port'
 
 
 def test_two_ranks_share_the_gpu_over_gloo(hip):
@@ -160,7 +174,7 @@ def test_eight_ranks_over_gloo(hip, config, batch, expect):
 
 def test_config1_line_keeps_its_keys(hip):
     """--config 1 is the default line: same metric string and config keys as before the other configs existed."""
-    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--config', '1', '--no-cpu-baseline', '--no-dvfs'] + SMALL,
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--config', '1', '--no-cpu-baseline', '--no-dvfs', '--no-other-configs', '--no-from-host', '--no-strict-line'] + SMALL,
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
@@ -174,7 +188,7 @@ def test_config1_line_keeps_its_keys(hip):
 def test_split_precision_lines_are_labelled(hip, flags, tag):
     """--precise-blocks N / --precise / --f16-weights: lines of their own -- the metric string says which mode, the
     config says how the weights were made -- never to be mistaken for the headline."""
-    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--no-cpu-baseline', '--no-dvfs'] + flags + SMALL,
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--no-cpu-baseline', '--no-dvfs', '--no-from-host', '--no-strict-line'] + flags + SMALL,
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
