@@ -172,10 +172,17 @@ def _assign(root, key, tensor):
 # (up to 288 tokens, beyond) -- measured, profiles/r5_tolerance_sweep.txt: at S = 577 (configs[3], sharp attention over 2.2 x
 # the keys) five such blocks leave the logits at 1.0 - 1.4e-3, seven at 7e-4; at S = 257 five are enough
 DEFAULT_PRECISE_ATTN_BLOCKS = (5, 7)
-# THE TOLERANCE MODE: (image_precise_blocks, image_precise_attn_blocks) up to 288 tokens / beyond -- the counts
-# whose WORST of the eight (weight seed, event seed) draws per BASELINE config of tests/config_cases.py is inside
-# north_star's 1e-3 (profiles/r6_parity_seeds.txt, tools/sweep_tolerance.py --seeds 8); bench.py prices exactly these
-TOLERANCE_MODE = ((8, 5), (8, 7))
+# THE TOLERANCE MODE: (image_precise_blocks, image_precise_attn_blocks) up to 288 tokens / beyond.  Round 6 put the
+# claim on a distribution -- eight (weight seed, event seed) draws per BASELINE config (tests/config_cases.py), fp32 oracle logits
+# shipped, profiles/r6_parity_seeds.txt: round 5's (8, 5) / (8, 7) held 1e-3 on the ONE draw per config it was chosen on and on
+# 6 of 8 draws of configs[2], [3], [4] (worst 2.4e-3 / 1.05e-3 / 1.5e-3).  With every block split but only five with fp32-class
+# attention the error stays at 1.0e-3 (tools/tolerance_model.py: the 16-bit q and k of the later blocks are the largest
+# remaining term), so the attention count had to grow with the block count.  (12, 8) / (12, 12): the worst of the eight draws
+# is 3.1e-4 / 6.3e-4 / 7.6e-4 on configs[0] / [1] / [4], 7.8e-4 on configs[3]; configs[2] (two classes) is inside on seven
+# draws (worst 6.7e-4) and at 1.9e-3 on the eighth, whose largest |logit| is 1.5 of a possible 100 -- a denominator, not an
+# error, 5 x smaller than the other draws'; only all-but-one block (23 : 23, the `precise` tower's price) brings that draw
+# inside.  bench.py prices exactly these counts.
+TOLERANCE_MODE = ((12, 8), (12, 12))
 
 
 def tolerance_mode_kwargs(arch_or_cfg):

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--seeds', type=int, default=8)
     ap.add_argument('--configs', default='0,1,2,3,4')
     ap.add_argument('--weights', default='signal')
+    ap.add_argument('--json', default=None, help='write the per-(setting, config) summary there (bench.py quotes profiles/r6_parity_seeds.json)')
     ap.add_argument('--clip-kw', default='', help='extra CLIP(...) keyword arguments for the non-default settings, k=v,k=v')
     a = ap.parse_args()
     extra = {k: int(v) for k, v in (kv.split('=') for kv in a.clip_kw.split(',') if kv)}
@@ -72,6 +73,20 @@ def main():
         v = np.asarray(v)
         print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {int(v.argmax())}) | {int((v < 1e-3).sum())} / {len(v)}')
     print(f'({time.time() - t0:.0f} s)')
+    if a.json:
+        import json
+        summ = {}
+        for (s, c), v in rows.items():
+            v = np.asarray(v)
+            kw = eclip.tolerance_mode_kwargs(cc.CASES[c]['arch']) if s == 'mode' else None
+            summ.setdefault(s, {})[f'configs[{c}]'] = {
+                'median': float(np.median(v)), 'worst': float(v.max()), 'worst_draw': int(v.argmax()),
+                'inside_1e3': f'{int((v < 1e-3).sum())} / {len(v)}',
+                **({'blocks': [kw['image_precise_blocks'], kw['image_precise_attn_blocks']]} if kw else {})}
+        json.dump({'metric': 'full_logits max |err| / max |logit| vs the fp32 oracle, over the (weight seed, event seed) draws of '
+                             'tests/config_cases.py', 'draws_per_config': a.seeds, 'weights': a.weights, 'settings': summ,
+                   'note': 'configs[2] draw 5: max |logit| 1.53 (two classes, cosines below 0.016); see eventclip_amd/clip.py TOLERANCE_MODE'},
+                  open(a.json, 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634
+EXACT = {'qk', 'v', 'p', 'att', 'gelu'}
+EXACT_REST = set()
 
 
 def h16(x):
@@ -129,9 +131,22 @@ def attention_exact(q, k, v, heads):
     return ((q @ k.transpose(-1, -2)).softmax(dim=-1) @ v).transpose(1, 2).reshape(N, S, W)
 
 
+def parse_set(spec, L):
+    """'0-7,22-23' -> {0..7, 22, 23}; negative numbers count from the end ('-2--1' = the last two blocks)"""
+    out = set()
+    for part in [p for p in spec.split(',') if p]:
+        m = __import__('re').fullmatch(r'(-?\d+)(?:-(-?\d+))?', part)
+        lo = int(m.group(1))
+        hi = int(m.group(2)) if m.group(2) is not None else lo
+        lo, hi = (lo + L if lo < 0 else lo), (hi + L if hi < 0 else hi)
+        out |= set(range(lo, hi + 1))
+    return out
+
+
 @torch.no_grad()
 def tower(sd, cfg, image, B, A, var, exact16=False):
-    """encode_image in the tolerance mode (B split-operand blocks, A of them with exact attention) under `var`."""
+    """encode_image in the tolerance mode (B split-operand blocks, A of them with exact attention) under `var`.
+    B / A may be SETS of block indices (attribution experiments: which blocks' roundings matter)."""
     W, P, L = cfg['width'], cfg['patch'], cfg['layers']
     heads = W // 64
     x = F.conv2d(image, sd['visual.conv1.weight'], stride=P)
@@ -157,22 +172,26 @@ def tower(sd, cfg, image, B, A, var, exact16=False):
         wout, bout = sd[p + 'attn.out_proj.weight'], sd[p + 'attn.out_proj.bias']
         wfc1, bfc1 = sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias']
         wfc2, bfc2 = sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias']
-        if l < B:
-            pa = l < A
+        if (l in B) if isinstance(B, (set, frozenset)) else l < B:
+            pa = (l in A) if isinstance(A, (set, frozenset)) else l < A
             h_hi, h_lo = split16(F.layer_norm(x, (W,), g1, b1, 1e-5))
             qkv = gemm_split(h_hi, h_lo, 'h', wqkv, bqkv)
-            if pa:
-                qh, ql = split16(qkv)
-                qq, kk, vv = (qh + ql).split(W, dim=-1)
-                a_hi, a_lo = split16(attention_exact(qq, kk, vv, heads))
-            else:
-                qq, kk, vv = h16(qkv).split(W, dim=-1)
-                a_hi, a_lo = h16(attention16(qq, kk, vv, heads, ATTN_Q_SCALE)), None
+            # EXACT: which of the pa blocks' activations are carried as hi + lo / computed exactly (attribution experiments;
+            # the shipped mode: all of them).  qk / v: q, k / v as hi + lo; p: exact softmax probabilities; att / gelu: the
+            # attention output / the MLP activation as hi + lo into the next GEMM
+            ex = EXACT if pa else EXACT_REST
+            qq, kk, vv = qkv.split(W, dim=-1)
+            r2 = (lambda t: sum(split16(t)))
+            qq, kk = (r2(qq), r2(kk)) if 'qk' in ex else (h16(qq), h16(kk))
+            vv = r2(vv) if 'v' in ex else h16(vv)
+            att = attention_exact(qq, kk, vv, heads) if 'p' in ex else attention16(qq * 0.125, kk, vv, heads, 1.4426950408889634)
+            a_hi, a_lo = split16(att) if 'att' in ex else (h16(att), None)
             x = x + gemm_split(a_hi, a_lo, 'att', wout, bout)
             h_hi, h_lo = split16(F.layer_norm(x, (W,), g2, b2, 1e-5))
             m = gemm_split(h_hi, h_lo, 'h', wfc1, bfc1)
             m = m * torch.sigmoid(1.702 * m)
             m_hi, m_lo = split16(m)
+            pa = 'gelu' in ex
             x = x + gemm_split(m_hi, m_lo if pa else None, 'gelu', wfc2, bfc2)
             continue
         # ---- default chain: raw hi plane as the operand, LayerNorm finished behind the product ----
@@ -209,8 +228,13 @@ def main():
     ap.add_argument('--variants', default='f16,e4m3')
     ap.add_argument('--lo8', default='h,att,gelu,w')
     ap.add_argument('--weights', default='signal')
-    ap.add_argument('--blocks', default=None, help='B:A instead of eventclip_amd.clip.TOLERANCE_MODE')
+    ap.add_argument('--exact-rest', default='', help='the same for the split-operand blocks behind them (shipped: none)')
+    ap.add_argument('--exact', default='qk,v,p,att,gelu', help='activations carried exactly in the fp32-attention blocks (attribution)')
+    ap.add_argument('--blocks', default=None, help="B:A instead of eventclip_amd.clip.TOLERANCE_MODE; or block SETS '0-7,22-23:0-4'")
     a = ap.parse_args()
+    global EXACT, EXACT_REST
+    EXACT = set(x for x in a.exact.split(',') if x)
+    EXACT_REST = set(x for x in a.exact_rest.split(',') if x)
     variants = [Variant(k, a.lo8.split(',')) for k in a.variants.split(',')]
     rows = {}
     real = clip_ref.encode_image
@@ -222,7 +246,10 @@ def main():
             gold = cc.load_golden(c, a.weights, d)
             want = dict(full_logits=torch.from_numpy(gold['full_logits']), logits=torch.from_numpy(gold['logits']),
                         valid_masks=torch.from_numpy(gold['valid_masks']))
-            if a.blocks:
+            if a.blocks and ('-' in a.blocks or ',' in a.blocks):
+                Bs, As = a.blocks.split(':')
+                B, A = parse_set(Bs, inp['cfg']['layers']), parse_set(As, inp['cfg']['layers'])
+            elif a.blocks:
                 B, A = (int(v) for v in a.blocks.split(':'))
             else:
                 kw = eclip.tolerance_mode_kwargs(inp['cfg'])
@@ -238,7 +265,7 @@ def main():
                     clip_ref.encode_image = real
                 e = tc.logit_errors(out, want)
                 rows.setdefault((var.kind, c), []).append(e['full_logits'][0])
-                print(f'[model {var.kind} {B}:{A}] configs[{c}] draw {d}: full_logits {e["full_logits"][0]:.2e} '
+                print(f'[model {var.kind} {a.blocks or str(B) + ":" + str(A)}] configs[{c}] draw {d}: full_logits {e["full_logits"][0]:.2e} '
                       f'(centred {e["full_logits"][1]:.2e}), logits {e["logits"][0]:.2e}  ({time.time() - t0:.0f} s)', flush=True)
     print()
     print(f'CPU model of the tolerance mode, lo products as f16 / FP8 ({a.lo8}), weights = {a.weights}: full_logits max |err| / max |logit|')
