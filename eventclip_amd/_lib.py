@@ -66,7 +66,9 @@ class EcGemmArgs(ctypes.Structure):
                 ('ldw', c_long), ('resid', c_void_p), ('aux', c_void_p), ('splits', c_int),
                 ('split_stride', c_long), ('ws', c_void_p), ('ws_bytes', ctypes.c_size_t),
                 ('transposed', c_int), ('k_rows', c_int), ('row_stats', c_void_p), ('row_stats_stride', c_long),
-                ('col_sums', c_void_p), ('row_sums', c_void_p), ('A_lo', c_void_p), ('W_lo', c_void_p)]
+                ('col_sums', c_void_p), ('row_sums', c_void_p), ('A_lo', c_void_p), ('W_lo', c_void_p),
+                ('A_lo8', c_void_p), ('W8', c_void_p), ('A8', c_void_p), ('W_lo8', c_void_p),
+                ('a_lo8_exp', c_int), ('w8_exp', c_int), ('a8_exp', c_int), ('w_lo8_exp', c_int)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
@@ -216,6 +218,8 @@ SIGNATURES = {
     'ec_row_stats': (c_int, [c_void_p, c_long, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
     'ec_layernorm_hl': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
                                 c_long, c_int, c_void_p]),
+    'ec_layernorm_hl8': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_long, c_int, c_int, c_void_p]),
     'ec_attention_scaled_q': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     'ec_attention_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

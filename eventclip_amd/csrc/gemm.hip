@@ -23,6 +23,8 @@
 //  * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous
 //    range of tiles ordered N-fastest, so the N/BN tiles that share an
 //    activation row panel hit the same L2.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -65,6 +67,13 @@ struct GemmArgs {
     int nseg;
     long seg_da, seg_dw;        // bytes from A / W (the hi parts) to the lo parts
     unsigned seg_mask;          // bit s: segment s reads A's lo part; bit 4 + s: W's lo part
+    // FP8 lo products (SEG == 2, round 6): the FIRST nf8 (<= 2) segments multiply e4m3 operands -- 128 K elements per
+    // 128-byte LDS row instead of 64, one v_mfma_scale_f32_16x16x128_f8f6f4 where the 16-bit tile issues two
+    // v_mfma_f32_16x16x32 (the same matrix-pipe cycles per LDS tile, twice the K) -- stored at the SAME byte row pitch as the
+    // 16-bit operands (the first K bytes of each row), so that the staging DMA's per-lane offsets are unchanged.
+    int nf8;
+    long f8_oa[2], f8_ow[2];    // bytes from A / W to the e4m3 operands of fp8 segment s
+    int f8_scale[2];            // e8m0 byte (x 0x01010101) on the W side of segment s: 2^(byte - 127) undoes both operands' scales
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -352,6 +361,9 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
                                                 int lane, float *scratch, F &&between)
 {
     constexpr bool PIPE = (MODE & 1) != 0, GROW = (MODE & 2) != 0;
+    // cost-splitting forms of the diagnostic build (variants 34 .. 37, tools/bench_resid_split.py; WRONG results on purpose):
+    // bit 5 no residual loads (the planes read as zero), bit 6 no store of the lo plane, bit 7 no store at all
+    constexpr bool NOLOAD = (MODE & 32) != 0, NOLO = (MODE & 64) != 0, NOST = (MODE & 128) != 0;
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v8 v8;
     constexpr int PITCH = 68;
@@ -379,8 +391,12 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
     auto fetch = [&](int i) {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            xh[i][p] = bload16(rh, voff + (2 * i + p) * step8);
-            xl[i][p] = bload16(rl, voff + (2 * i + p) * step8);
+            if constexpr (NOLOAD) {
+                xh[i][p] = xl[i][p] = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                xh[i][p] = bload16(rh, voff + (2 * i + p) * step8);
+                xl[i][p] = bload16(rl, voff + (2 * i + p) * step8);
+            }
         }
     };
 #pragma unroll
@@ -449,8 +465,10 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
         }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            bstore16(oh[p], rh, voff + (2 * i + p) * step8);
-            bstore16(ol[p], rl, voff + (2 * i + p) * step8);
+            if constexpr (!NOST) bstore16(oh[p], rh, voff + (2 * i + p) * step8);
+            if constexpr (!NOST && !NOLO) bstore16(ol[p], rl, voff + (2 * i + p) * step8);
+            if constexpr (NOST) asm volatile("" ::"v"(oh[p]), "v"(ol[p]));      // keep the arithmetic
+            else if constexpr (NOLO) asm volatile("" ::"v"(ol[p]));
         }
         if (stats) {
 #pragma unroll
@@ -706,7 +724,7 @@ __device__ __forceinline__ void raster(int id, int tiles_m, int tiles_n, int &tm
 // change (2 - 3 times per tile, scalar work; the instruction's scalar offset is no way there: it IS part of the range
 // check on gfx950 -- offset + soffset >= num_records reads zeros -- so a range that covers it no longer ends at the
 // tile's last row).  Region 1 is requested one K tile apart from regions 0, 2, 3 and has a descriptor of its own.
-template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
+template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, int SEG = 0>
 __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 {
     typedef typename T16<DT>::v8 v8;
@@ -724,7 +742,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     const int ntiles_mn = g.tiles_m * g.tiles_n;
     const int ntiles = ntiles_mn * g.splits;   // K-batches are further tiles of the same launch
     static_assert(!SEG || !TN, "segments: row-major operands only");
-    const int nk = SEG ? g.nseg * (g.K / BK) : g.K / BK;
+    static_assert(SEG != 2 || DT == EC_F16, "fp8 lo products go with f16 hi products");
+    // SEG == 2: the first g.nf8 segments are e4m3 (K / 128 tiles each), the rest 16-bit (K / 64 tiles each)
+    const int nk8 = SEG == 2 ? g.nf8 * (g.K / (2 * BK)) : 0;
+    const int nk = SEG == 2 ? nk8 + (g.nseg - g.nf8) * (g.K / BK) : SEG ? g.nseg * (g.K / BK) : g.K / BK;
 
     auto key = [](int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); };
 
@@ -761,7 +782,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     const int kseg = g.K * 2;
     __amdgpu_buffer_rsrc_t rsAy = rsA;
     auto seg_rsrc = [&](int sg, bool w) {
-        const long d = ((g.seg_mask >> (w ? 4 + sg : sg)) & 1u) ? (w ? g.seg_dw : g.seg_da) : 0;
+        long d = ((g.seg_mask >> (w ? 4 + sg : sg)) & 1u) ? (w ? g.seg_dw : g.seg_da) : 0;
+        if constexpr (SEG == 2) {
+            if (sg < g.nf8) d = w ? (sg == 0 ? g.f8_ow[0] : g.f8_ow[1]) : (sg == 0 ? g.f8_oa[0] : g.f8_oa[1]);
+        }
         return w ? tile_rsrc(static_cast<const unsigned char *>(g.W) + (long)n0 * g.ldw * 2 + d, tile_span(g.N, n0, BN, g.ldw * 2))
                  : tile_rsrc(static_cast<const unsigned char *>(g.A) + (long)m0 * g.lda * 2 + d, tile_span(g.M, m0, BM, g.lda * 2));
     };
@@ -833,7 +857,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                                                          16, (r < 2 ? vbA : vbW) + (srow[r][i] + kb), 0, 0, 0);
             if (r == 1 || r == 3) {
                 kb += BK * 2;
-                if (kb == kseg) {
+                if (kb == ((SEG == 2 && sg < g.nf8) ? (kseg >> 1) : kseg)) {
                     kb = 0, sg++;
                     if (sg < g.nseg) {
                         if (r == 1) rsAy = seg_rsrc(sg, false);
@@ -893,6 +917,21 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 
     f32x4 acc[8][4];
     v8 fm[4][2], fn0[2][2], fn1[2][2];
+    // SEG == 2: a lane's two 16-byte pieces of a row live in ONE 8-register tuple (the operand of the e4m3 product as it
+    // stands; the 16-bit products read its halves) -- with separate 4-register values the allocator copied every operand of
+    // the e4m3 products into a fresh tuple and spilled
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    i32x8 gm[4], gn0[2], gn1[2];
+    auto ld8 = [&](int base, int off) {      // (LDS-typed addresses: an XOR on a generic pointer compiled to flat loads)
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(smem + base + off);
+        const i32x4 b = *reinterpret_cast<const i32x4 *>(smem + base + (off ^ 64));
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_m8 = [&](int buf, int mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) gm[mt] = ld8(buf * KT + mq * REGION, offM[mt]);
+    };
     auto load_m = [&](int buf, int mq) {
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -904,6 +943,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                     fm[mt][ks] = *reinterpret_cast<const v8 *>(smem + buf * KT + mq * REGION +
                                                                (offM[mt] ^ (ks << 6)));
             }
+    };
+    auto load_n8 = [&](i32x8(&gn)[2], int buf, int nq) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) gn[jj] = ld8(buf * KT + (2 + nq) * REGION, offN[jj]);
     };
     auto load_n = [&](v8(&fn)[2][2], int buf, int nq) {
 #pragma unroll
@@ -938,6 +981,26 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                         mfma16(fb[jj][ks], fm[mt][ks], acc[mq * 4 + mt][nqb * 2 + jj]);
             }
         __builtin_amdgcn_s_setprio(0);
+    };
+    // e4m3 tile: the SAME fragment reads (a lane's two 16-byte pieces of a row, chunks g and g + 4 of the 128-byte row) are
+    // the lane's 32 bytes of ONE 16x16x128 product -- which 32 of the 128 K elements a lane group holds does not matter as
+    // long as both operands hold the same ones, and both are read through the same layout.  scale_w: e8m0 x 4 (uniform).
+    auto mma2_g = [&](int mq, int nqa, i32x8(&ga)[2], int nqb, i32x8(&gb)[2], int scale_w) {
+        if constexpr (SEG == 2) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqa * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        ga[jj], gm[mt], acc[mq * 4 + mt][nqa * 2 + jj], 0, 0, 0, scale_w, 0, 0x7f7f7f7f);
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mq * 4 + mt][nqb * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        gb[jj], gm[mt], acc[mq * 4 + mt][nqb * 2 + jj], 0, 0, 0, scale_w, 0, 0x7f7f7f7f);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
     };
     auto bar_l = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1020,13 +1083,24 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int t = 0; t < nk; t++) {
+        // one K tile: two phases (32 16-bit MFMAs, or 16 e4m3 MFMAs of twice the cycles, each).  SEG == 2 runs the e4m3 tiles
+        // in a loop of their own in front of the 16-bit tiles: one MFMA kind per loop body, so that each loop is allocated
+        // like the plain kernel's (both kinds behind a branch in ONE body spilled fragments inside the loop)
+        auto ktile = [&](int t, auto f8tag) {
+            constexpr bool F8 = decltype(f8tag)::value;
             const int buf = t & 1, nxt = buf ^ 1;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            const int sc8 = F8 ? (t < (nk8 >> (g.nf8 >> 1)) ? g.f8_scale[0] : g.f8_scale[1]) : 0;
             // ---- phase A ----
-            load_m(buf, 0);
-            load_n(fn0, buf, 0);
-            load_n(fn1, buf, 1);
+            if constexpr (F8) {
+                load_m8(buf, 0);
+                load_n8(gn0, buf, 0);
+                load_n8(gn1, buf, 1);
+            } else {
+                load_m(buf, 0);
+                load_n(fn0, buf, 0);
+                load_n(fn1, buf, 1);
+            }
             if (has1) {
                 issue(1, nxt);
                 // behind a tile hand-over every piece of K tile 0 has landed already (waited for before the hand-over
@@ -1040,10 +1114,12 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
             bar_l();
-            mma2(0, 0, fn0, 1, fn1);
+            if constexpr (F8) mma2_g(0, 0, gn0, 1, gn1, sc8);
+            else mma2(0, 0, fn0, 1, fn1);
             bar();
             // ---- phase B ----
-            load_m(buf, 1);
+            if constexpr (F8) load_m8(buf, 1);
+            else load_m(buf, 1);
             if (has2) {
                 issue(0, buf);
                 issue(2, buf);
@@ -1053,9 +1129,14 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 EC_VMCNT(2);
             }
             bar_l();
-            mma2(1, 1, fn1, 0, fn0);
+            if constexpr (F8) mma2_g(1, 1, gn1, 0, gn0, sc8);
+            else mma2(1, 1, fn1, 0, fn0);
             bar();
-        }
+        };
+        int t = 0;
+        if constexpr (SEG == 2)
+            for (; t < nk8; t++) ktile(t, std::true_type{});
+        for (; t < nk; t++) ktile(t, std::false_type{});
         if (wm == 0) bar();   // balance the stagger barrier: every wave is out of the staging buffers
 
         const int cm0 = m0, cn0 = n0;
@@ -1092,7 +1173,8 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         constexpr bool BUF_EPI = EPI == EC_EPI_RESID_HL || EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI) ||
                                  EPI == EC_EPI_STORE32 || EPI == EC_EPI_RESID32;
         constexpr bool LOUT = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) && (HLM & 16) != 0;   // 16-bit output as hi + lo parts (args.aux)
-        constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? 48 : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : LOUT ? 32 : 16;
+        constexpr int TAIL_HL = ((HLM & 32) && (HLM & 128)) ? 0 : (HLM & (32 | 64 | 128)) ? 16 : 48;     // (diagnostic forms issue fewer operations)
+        constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? TAIL_HL : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : LOUT ? 32 : 16;
         constexpr int enc_tail = (TAIL & 15) | (7 << 4) | (15 << 8) | ((TAIL >> 4) << 14);
         if constexpr (EPI == EC_EPI_RESID_HL)
             epilogue_hl_buf<DT, 8, HLM>(ge, acc, wm0, wn0, elane,
@@ -1136,7 +1218,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     if constexpr (TL == 2) clock_stamp(g.diag, 2);
 }
 
-template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, bool SEG = false>
+template <int DT, int EPI, int TL = 0, bool TN = false, int HLM = HL_MODE_DEFAULT, int SEG = 0>
 int launch2pp(const GemmArgs &g0, hipStream_t stream)
 {
     GemmArgs g = g0;
@@ -1159,8 +1241,10 @@ int launch2pp(const GemmArgs &g0, hipStream_t stream)
     const int nseg = SEG ? g.nseg : 1;
     const unsigned full = (1u << nseg) - 1, ma = g.seg_mask & full, mw = (g.seg_mask >> 4) & full;
     const int parts_a = SEG && ma != 0 && ma != full ? 2 : 1, parts_w = SEG && mw != 0 && mw != full ? 2 : 1;
+    const int nf8 = SEG == 2 ? g.nf8 : 0;    // (an e4m3 product: the same flops, half the operand bytes)
     ec::ProfScope prof(g.splits > 1 ? (int)ec::PROF_GEMM_DW : cls, stream, 2.0 * g.M * g.N * g.K * g.splits * nseg,
-                       (2.0 * g.M * g.K * parts_a + 2.0 * g.N * g.K * parts_w + out_b * g.M * g.N) * g.splits);
+                       (2.0 * g.M * g.K * parts_a + 2.0 * g.N * g.K * parts_w + nf8 * (1.0 * g.M * g.K + 1.0 * g.N * g.K) +
+                        out_b * g.M * g.N) * g.splits);
     const int tiles = g.tiles_m * g.tiles_n * g.splits;
     hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), lds, stream, g);
     EC_CHECK_HIP(hipGetLastError());
@@ -1222,18 +1306,38 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
     if (g.nseg > 1) {
         // split-precision operands: the segmented main loop (default variant only)
         EC_REQUIRE(variant == 0, "ec_gemm: A_lo / W_lo need variant 0");
+        if (g.nf8 > 0) {
+            // ... with e4m3 lo products in front (f16 only; the epilogues the tolerance mode's blocks use)
+            if constexpr (DT == EC_F16) {
+                switch (epi) {
+                case EC_EPI_STORE16:
+                    return g.aux ? launch2pp<DT, EC_EPI_STORE16, false, false, HLO, 2>(g, s)
+                                 : launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, 2>(g, s);
+                case EC_EPI_GELU16:
+                    return g.aux ? launch2pp<DT, EC_EPI_GELU16, false, false, HLO, 2>(g, s)
+                                 : launch2pp<DT, EC_EPI_GELU16, false, false, HL_MODE_DEFAULT, 2>(g, s);
+                case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, 2>(g, s);
+                case EC_EPI_RESID_HL:
+                    EC_REQUIRE(g.aux, "ec_gemm: EC_EPI_RESID_HL needs args.aux (the lo plane)");
+                    return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, 2>(g, s);
+                default: return ec::fail(EC_ERR_INVALID, "ec_gemm: e4m3 lo products go with the STORE16, GELU16, STORE32 and RESID_HL epilogues (got %d)", epi);
+                }
+            } else {
+                return ec::fail(EC_ERR_INVALID, "ec_gemm: e4m3 lo products need dtype EC_F16");
+            }
+        }
         switch (epi) {
         case EC_EPI_STORE16:
-            return g.aux ? launch2pp<DT, EC_EPI_STORE16, false, false, HLO, true>(g, s)
-                         : launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, true>(g, s);
+            return g.aux ? launch2pp<DT, EC_EPI_STORE16, false, false, HLO, 1>(g, s)
+                         : launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, 1>(g, s);
         case EC_EPI_GELU16:
-            return g.aux ? launch2pp<DT, EC_EPI_GELU16, false, false, HLO, true>(g, s)
-                         : launch2pp<DT, EC_EPI_GELU16, false, false, HL_MODE_DEFAULT, true>(g, s);
-        case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, true>(g, s);
-        case EC_EPI_RESID32: return launch2pp<DT, EC_EPI_RESID32, false, false, HL_MODE_DEFAULT, true>(g, s);
+            return g.aux ? launch2pp<DT, EC_EPI_GELU16, false, false, HLO, 1>(g, s)
+                         : launch2pp<DT, EC_EPI_GELU16, false, false, HL_MODE_DEFAULT, 1>(g, s);
+        case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, 1>(g, s);
+        case EC_EPI_RESID32: return launch2pp<DT, EC_EPI_RESID32, false, false, HL_MODE_DEFAULT, 1>(g, s);
         case EC_EPI_RESID_HL:
             EC_REQUIRE(g.aux, "ec_gemm: EC_EPI_RESID_HL needs args.aux (the lo plane)");
-            return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, true>(g, s);
+            return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT, 1>(g, s);
         default: return ec::fail(EC_ERR_INVALID, "ec_gemm: A_lo / W_lo go with the STORE16, GELU16, STORE32, RESID32 and RESID_HL epilogues (got %d)", epi);
         }
     }
@@ -1261,6 +1365,12 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
         if (variant == 31 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 1>(g, s);
         if (variant == 32 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 2>(g, s);
         if (variant == 33 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, 3>(g, s);
+        // cost-splitting forms (wrong results on purpose; tools/bench_resid_split.py): no residual loads / no lo store /
+        // no store at all / neither loads nor stores
+        if (variant == 34 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 32>(g, s);
+        if (variant == 35 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 64>(g, s);
+        if (variant == 36 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 128>(g, s);
+        if (variant == 37 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 32 | 128>(g, s);
         if (variant == 13 && g.aux) return launch_b2p<DT, EC_EPI_RESID_HL>(g, s);   // two 4-wave workgroups per CU
 #endif
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");
@@ -1383,7 +1493,10 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.stat_out = nullptr, g.stat_groups = 0;
     g.nseg = 1;
     g.seg_da = g.seg_dw = g.seg_mask = 0;
-    if (a->A_lo || a->W_lo) {
+    g.nf8 = 0;
+    g.f8_oa[0] = g.f8_oa[1] = g.f8_ow[0] = g.f8_ow[1] = 0, g.f8_scale[0] = g.f8_scale[1] = 0x7f7f7f7f;
+    const bool l8 = a->A_lo8 != nullptr, w8 = a->W_lo8 != nullptr;
+    if (a->A_lo || a->W_lo || l8 || w8) {
         // split-precision operands: up to three products into the same accumulators, the small ones first
         // (a_lo . w + a . w_lo + a . w; a_lo . w_lo, ~2^-22 of the result, is left out)
         EC_REQUIRE(!a->transposed && a->splits <= 1 && !a->ws && !a->resid && a->variant == 0,
@@ -1392,6 +1505,25 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
         g.seg_da = a->A_lo ? (long)((intptr_t)a->A_lo - (intptr_t)a->A) : 0;
         g.seg_dw = a->W_lo ? (long)((intptr_t)a->W_lo - (intptr_t)a->W) : 0;
         int n = 0;
+        if (l8 || w8) {
+            // e4m3 lo products (the FIRST segments): A_lo8 . W8 in place of a_lo . w, A8 . W_lo8 in place of a . w_lo
+            EC_REQUIRE(a->dtype == EC_F16 && a->K % (2 * BK) == 0, "ec_gemm: e4m3 lo products need dtype EC_F16 and K %% 128 == 0 (K = %d)", a->K);
+            EC_REQUIRE(!(l8 && a->A_lo) && !(w8 && a->W_lo), "ec_gemm: a lo product is given as 16-bit (A_lo / W_lo) OR as e4m3 (A_lo8 / W_lo8), not both");
+            EC_REQUIRE((!l8 || a->W8) && (!w8 || a->A8), "ec_gemm: A_lo8 needs W8 (the e4m3 copy of W), W_lo8 needs A8 (the e4m3 copy of A)");
+            EC_REQUIRE((((uintptr_t)a->A_lo8 | (uintptr_t)a->W8 | (uintptr_t)a->A8 | (uintptr_t)a->W_lo8) & 15) == 0,
+                       "ec_gemm: e4m3 operands must be 16-byte aligned");
+            auto put = [&](const void *pa, const void *pw, int ea, int ew) {
+                const int byte = 127 - ea - ew;          // 2^(byte - 127) on the W side undoes both operands' scales
+                if (byte < 1 || byte > 254) return false;
+                g.f8_oa[n] = (long)((intptr_t)pa - (intptr_t)a->A), g.f8_ow[n] = (long)((intptr_t)pw - (intptr_t)a->W);
+                g.f8_scale[n] = byte * 0x01010101;
+                n++;
+                return true;
+            };
+            EC_REQUIRE(!l8 || put(a->A_lo8, a->W8, a->a_lo8_exp, a->w8_exp), "ec_gemm: a_lo8_exp + w8_exp = %d outside -127 .. 126", a->a_lo8_exp + a->w8_exp);
+            EC_REQUIRE(!w8 || put(a->A8, a->W_lo8, a->a8_exp, a->w_lo8_exp), "ec_gemm: a8_exp + w_lo8_exp = %d outside -127 .. 126", a->a8_exp + a->w_lo8_exp);
+            g.nf8 = n;
+        }
         if (a->A_lo) g.seg_mask |= 1u << n, n++;             // a_lo . w
         if (a->W_lo) g.seg_mask |= 1u << (4 + n), n++;       // a . w_lo
         n++;                                                 // a . w

@@ -66,11 +66,24 @@ __device__ __forceinline__ int units(int width, int lane)
 
 // HLIN: the row arrives as the two planes of the folded chain's residual stream (x = hi plane in DT, x_lo = fp16 lo plane,
 // both at row stride ldx) and is joined to fp32 on the way in: the LayerNorm of the split-operand blocks
-template <int DT, bool HLIN = false>
+// four fp32 -> four OCP e4m3 bytes (round to nearest even; clamped to +-448 first: e4m3fn has no infinity)
+__device__ __forceinline__ unsigned pack_e4m3(float a, float b, float c, float d, float scale)
+{
+    a = __builtin_amdgcn_fmed3f(a * scale, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(b * scale, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c * scale, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(d * scale, -448.f, 448.f);
+    unsigned r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0u, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
+// F8 (ec_layernorm_hl8): the lo part leaves as e4m3 of lo x lo_scale -- the A_lo8 operand of ec_gemm -- and, with out_hi8,
+// an e4m3 copy of the hi part x hi_scale (A8): one byte per element at the SAME byte row pitch as the 16-bit output (the
+// first `width` bytes of each 2 ldo-byte row; ec_gemm_args.A_lo8)
+template <int DT, bool HLIN = false, bool F8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void *x_v, const _Float16 *x_lo, long ldx,
                                                         const int *row_idx, const float *gamma,
                                                         const float *beta, int rows, int width,
-                                                        float eps, void *out, long ldo, void *out_lo)
+                                                        float eps, void *out, long ldo, void *out_lo,
+                                                        void *out_hi8 = nullptr, float lo_scale = 1.f, float hi_scale = 1.f)
 {
     typedef typename T16<DT>::elem elem;
     typedef typename T16<DT>::v4 v4;
@@ -100,7 +113,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void *x_v, const _
             v4 p = {to16(v[i].x, elem()), to16(v[i].y, elem()), to16(v[i].z, elem()),
                     to16(v[i].w, elem())};
             *reinterpret_cast<v4 *>(o + (i * 64 + lane) * 4) = p;
-            if (out_lo) {   // split precision: lo = 16-bit(x - hi), x ~ hi + lo to ~2^-22
+            if constexpr (F8) {
+                unsigned char *lo8 = static_cast<unsigned char *>(out_lo) + row * ldo * 2 + (i * 64 + lane) * 4;
+                *reinterpret_cast<unsigned *>(lo8) = pack_e4m3(v[i].x - (float)p[0], v[i].y - (float)p[1], v[i].z - (float)p[2],
+                                                               v[i].w - (float)p[3], lo_scale);
+                if (out_hi8) {
+                    unsigned char *hi8 = static_cast<unsigned char *>(out_hi8) + row * ldo * 2 + (i * 64 + lane) * 4;
+                    *reinterpret_cast<unsigned *>(hi8) = pack_e4m3((float)p[0], (float)p[1], (float)p[2], (float)p[3], hi_scale);
+                }
+            } else if (out_lo) {   // split precision: lo = 16-bit(x - hi), x ~ hi + lo to ~2^-22
                 v4 q = {to16(v[i].x - (float)p[0], elem()), to16(v[i].y - (float)p[1], elem()),
                         to16(v[i].z - (float)p[2], elem()), to16(v[i].w - (float)p[3], elem())};
                 *reinterpret_cast<v4 *>((elem *)out_lo + row * ldo + (i * 64 + lane) * 4) = q;
@@ -461,6 +482,26 @@ EC_API int ec_layernorm_hl(const void *x_hi, const void *x_lo, long ldx, const f
                            rows, width, eps, out16, ldo, out16_lo);
     else
         return ec::fail(EC_ERR_INVALID, "ec_layernorm_hl: unknown dtype %d", dtype);
+    EC_CHECK_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+EC_API int ec_layernorm_hl8(const void *x_hi, const void *x_lo, long ldx, const float *gamma, const float *beta, int rows,
+                            int width, float eps, void *out16, void *out_lo8, void *out_hi8, long ldo, int lo_exp, int hi_exp,
+                            ec_stream_t stream)
+{
+    EC_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && width <= LN_MAXV * 256,
+               "ec_layernorm_hl8: width=%d must be a multiple of 4 and <= %d", width, LN_MAXV * 256);
+    if (rows == 0) return EC_OK;
+    EC_REQUIRE(x_hi && x_lo && gamma && beta && out16 && out_lo8, "ec_layernorm_hl8: null buffer");
+    EC_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width, "ec_layernorm_hl8: strides must be multiples of 4 (ldo >= width)");
+    EC_REQUIRE(lo_exp >= -60 && lo_exp <= 60 && hi_exp >= -60 && hi_exp <= 60, "ec_layernorm_hl8: exponents outside -60 .. 60");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(ec::ceil_div(rows, 4)), block(256);
+    ec::ProfScope prof(ec::PROF_LAYERNORM, s, 0, (double)rows * width * (out_hi8 ? 8.0 : 7.0));
+    hipLaunchKernelGGL((layernorm_kernel<EC_F16, true, true>), grid, block, 0, s, x_hi, static_cast<const _Float16 *>(x_lo), ldx,
+                       (const int *)nullptr, gamma, beta, rows, width, eps, out16, ldo, out_lo8, out_hi8, ldexpf(1.f, lo_exp),
+                       ldexpf(1.f, hi_exp));
     EC_CHECK_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -19,7 +19,7 @@ def dtype_code(t):
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
          splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None,
-         A_lo=None, W_lo=None):
+         A_lo=None, W_lo=None, A_lo8=None, W8=None, A8=None, W_lo8=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
@@ -28,7 +28,9 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     updated in place: (hi, lo) <- split(hi + lo + acc + bias)); store16_ln / gelu16_ln (``row_stats`` fp32 [M, 2] =
     (rstd, -rstd mean) of A's rows from ``row_stats``, ``col_sums`` fp32 [N] = row sums of W as rounded).
     Split-precision operands in one launch: ``A_lo`` / ``W_lo`` (the lo parts, same shapes and strides):
-    out = epi(A_lo W^T + A W_lo^T + A W^T + bias); with them store16 / gelu16 take ``aux`` as the output's lo part."""
+    out = epi(A_lo W^T + A W_lo^T + A W^T + bias); with them store16 / gelu16 take ``aux`` as the output's lo part.
+    Lo products on the FP8 matrix path: ``A_lo8`` + ``W8`` in place of A_lo W^T, ``A8`` + ``W_lo8`` in place of A W_lo^T, each
+    a pair (uint8 tensor [rows, 2 K] whose first K bytes per row are e4m3, exponent) as quantize_e4m3 returns them."""
     import torch
     _lib.require_gpu()
     epi = {'store16': _lib.EC_EPI_STORE16, 'gelu16': _lib.EC_EPI_GELU16,
@@ -78,6 +80,12 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
     if W_lo is not None:
         assert W_lo.dtype == W.dtype and W_lo.shape == W.shape and W_lo.stride() == W.stride()
         a.W_lo = W_lo.data_ptr()
+    for name, part, ref, ld in (('A_lo8', A_lo8, A, a.lda), ('W8', W8, W, a.ldw), ('A8', A8, A, a.lda), ('W_lo8', W_lo8, W, a.ldw)):
+        if part is not None:
+            t, e = part
+            assert t.dtype == torch.uint8 and t.shape[0] == ref.shape[0] and t.stride(0) == 2 * ld and t.stride(1) == 1, name
+            setattr(a, name, t.data_ptr())
+            setattr(a, {'A_lo8': 'a_lo8_exp', 'W8': 'w8_exp', 'A8': 'a8_exp', 'W_lo8': 'w_lo8_exp'}[name], int(e))
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)
@@ -85,6 +93,29 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     _lib.check(_lib.lib().ec_gemm(ctypes.byref(a), _lib.stream_ptr()), 'ec_gemm')
     return out
+
+
+def quantize_e4m3(x, exp=None, pitch=None):
+    """x [rows, K] (any float dtype, any device) -> (uint8 [rows, pitch or 2 K] on x's device, exp): the first K bytes of each
+    row hold round_e4m3(x * 2^exp) (OCP e4m3fn, saturating at +-448), the layout of ec_gemm_args' e4m3 operands (the byte
+    row pitch of the 16-bit operand).  exp=None: the largest |x| lands in [128, 256)."""
+    import math
+    import torch
+    xf = x.detach().float()
+    if exp is None:
+        m = float(xf.abs().max())
+        exp = 8 - int(math.ceil(math.log2(m))) if m > 0 else 0
+    q = (xf * (2.0 ** exp)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    rows, K = q.shape
+    out = torch.zeros(rows, pitch or 2 * K, dtype=torch.uint8, device=x.device)
+    out[:, :K] = q
+    return out, exp
+
+
+def dequantize_e4m3(t, exp, K):
+    """the fp32 values an e4m3 operand of quantize_e4m3 / ec_layernorm_hl8 stands for"""
+    import torch
+    return t[:, :K].contiguous().view(torch.float8_e4m3fn).float() * (2.0 ** -exp)
 
 
 def gemm_rows(A, W, splits=1, out=None):

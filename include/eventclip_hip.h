@@ -330,6 +330,21 @@ typedef struct {
     /* ... and with them EC_EPI_STORE16 / EC_EPI_GELU16 take `aux` as a SECOND OUTPUT: C16 = hi = round16(v) and
      * aux16 = lo = round16(v - hi) of the epilogue's fp32 value v, [M, N] at stride ldc -- the operand pair of a
      * split-precision consumer (ec_attention_split; A_lo of the next GEMM). */
+    /* Lo products on the FP8 matrix path (round 6, ABI 600; appended).  A lo part is ~2^-11 of its hi part and its product
+     * needs ~2^-4 relative accuracy to cut the operand-rounding error of the 16-bit product 20-fold: e4m3 operands on
+     * v_mfma_scale_f32_16x16x128_f8f6f4 run at twice the f16 rate and are half the bytes.  dtype EC_F16, K % 128 == 0, the
+     * conditions of A_lo / W_lo; epilogues STORE16 / GELU16 (with or without the lo output) / STORE32 / RESID_HL.
+     *   A_lo8 + W8:  C += dq(A_lo8) . dq(W8)^T   in place of A_lo . W^T   (A_lo must be NULL)
+     *   A8 + W_lo8:  C += dq(A8) . dq(W_lo8)^T   in place of A . W_lo^T   (W_lo must be NULL)
+     * where dq(X8) = e4m3 value x 2^-x_exp: X8 holds round_e4m3(x . 2^x_exp), OCP e4m3fn, one power-of-two scale per tensor
+     * (producers: ec_layernorm_hl8 for activations; weights are quantised when they are packed).  LAYOUT: an e4m3 operand
+     * lies at the SAME BYTE ROW PITCH as its 16-bit counterpart -- row m of A_lo8 / A8 starts at byte m * 2 * lda and
+     * holds K bytes, row n of W8 / W_lo8 at byte n * 2 * ldw -- so that the staging DMA addresses all parts alike. */
+    const void *A_lo8;        /* e4m3 of (a_true - A) . 2^a_lo8_exp, or NULL */
+    const void *W8;           /* e4m3 of W . 2^w8_exp */
+    const void *A8;           /* e4m3 of A . 2^a8_exp */
+    const void *W_lo8;        /* e4m3 of (w_true - W) . 2^w_lo8_exp, or NULL */
+    int a_lo8_exp, w8_exp, a8_exp, w_lo8_exp;
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -366,6 +381,12 @@ EC_API int ec_layernorm_split(const float *x, long ldx, const int32_t *row_idx, 
 EC_API int ec_layernorm_hl(const void *x_hi, const void *x_lo, long ldx, const float *gamma, const float *beta, int rows,
                            int width, float eps, void *out16, void *out16_lo, long ldo, int dtype, ec_stream_t stream);
 /* fp32 [n] -> (QuickGELU if gelu) -> hi / lo 16-bit parts */
+/* ... with the lo part as the e4m3 operand of ec_gemm_args.A_lo8 (round 6): out_lo8 = round_e4m3((LN(x) - out16) . 2^lo_exp) and,
+ * when out_hi8 is given, out_hi8 = round_e4m3(out16 . 2^hi_exp) (ec_gemm_args.A8), one byte per element in the first `width`
+ * bytes of rows of 2 . ldo bytes (the byte row pitch of out16); values beyond +-448 . 2^-exp saturate.  f16 planes. */
+EC_API int ec_layernorm_hl8(const void *x_hi, const void *x_lo, long ldx, const float *gamma, const float *beta, int rows,
+                            int width, float eps, void *out16, void *out_lo8, void *out_hi8, long ldo, int lo_exp, int hi_exp,
+                            ec_stream_t stream);
 EC_API int ec_split16(const float *x, long n, int gelu, void *hi16, void *lo16, int dtype,
                       ec_stream_t stream);
 /* fp32 attention over fp32 qkv [n_seq * S, 3 * width]; output as hi / lo parts [n_seq * S, width] */

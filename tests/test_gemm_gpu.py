@@ -383,3 +383,126 @@ def test_split_operand_edges(hip):
     want = (a_hi.double() + a_lo.double()) @ (w_hi.double() + w_lo.double()).t() - a_lo.double() @ w_lo.double().t()
     got = ops.gemm(a_hi, w_hi, None, 'store32', A_lo=a_lo, W_lo=w_lo)
     assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('parts', ['l8', 'w8', 'both', 'l8+w_lo'])
+@pytest.mark.parametrize('epilogue', ['store32', 'store16', 'gelu16'])
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 1024, 1024), (513, 1024, 4096), (77, 768, 768), (5, 512, 128), (300, 48, 256)])
+def test_lo_products_on_the_fp8_matrix_path(M, N, K, epilogue, parts, hip):
+    """Round 6: the lo products as e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (ec_gemm_args.A_lo8 + W8 in place of
+    A_lo W^T, A8 + W_lo8 in place of A W_lo^T), in front of the 16-bit product(s) in the SAME launch and accumulators.
+    The kernel must compute EXACTLY the product of the dequantised operands (e4m3 x e4m3 products are exact in fp32; only
+    the summation order differs): against float64 of  A W^T + dq(A_lo8) dq(W8)^T [+ dq(A8) dq(W_lo8)^T | + A W_lo^T] + b."""
+    import torch
+    from eventclip_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + 3 * N + 5 * K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    bias = torch.randn(N, device='cuda', generator=g)
+    a_hi, a_lo = _split(a, torch.float16)
+    w_hi, w_lo = _split(w, torch.float16)
+    kw = {}
+    want = a_hi.double() @ w_hi.double().t() + bias.double()
+    if parts in ('l8', 'both', 'l8+w_lo'):
+        kw['A_lo8'] = ops.quantize_e4m3(a - a_hi.float(), exp=12)
+        kw['W8'] = ops.quantize_e4m3(w_hi)
+        want = want + ops.dequantize_e4m3(*kw['A_lo8'], K).double() @ ops.dequantize_e4m3(*kw['W8'], K).double().t()
+    if parts in ('w8', 'both'):
+        kw['A8'] = ops.quantize_e4m3(a_hi, exp=0)
+        kw['W_lo8'] = ops.quantize_e4m3(w - w_hi.float())
+        want = want + ops.dequantize_e4m3(*kw['A8'], K).double() @ ops.dequantize_e4m3(*kw['W_lo8'], K).double().t()
+    if parts == 'l8+w_lo':
+        kw['W_lo'] = w_lo
+        want = want + a_hi.double() @ w_lo.double().t()
+    if epilogue == 'gelu16':
+        want = want * torch.sigmoid(1.702 * want)
+    got = ops.gemm(a_hi, w_hi, bias, epilogue, **kw)
+    tol = 2e-6 if epilogue == 'store32' else 1e-3
+    err = float((got.double() - want).abs().max() / want.abs().max())
+    assert err < tol, err
+    if epilogue == 'store32':
+        # ... and with them the result is close to the product of the FULL operands: the e4m3 lo products remove most of the
+        # 16-bit operand rounding (3e-4 of the result without them; 2e-6 with 16-bit lo parts)
+        full = a.double() @ w.double().t() + bias.double()
+        plain = ops.gemm(a_hi, w_hi, bias, epilogue)
+        e8 = float((got.double() - full).abs().max() / full.abs().max())
+        e16 = float((plain.double() - full).abs().max() / full.abs().max())
+        if parts == 'both' and K >= 256:
+            assert e8 < 0.15 * e16, (e8, e16)
+
+
+def test_fp8_lo_products_edges(hip):
+    """What the e4m3 segments do not take is refused: bf16, K not a multiple of 128, a lo product given twice, a missing
+    partner operand; the lo output (aux) and RESID_HL work with them; many tiles (hand-over across the e4m3 -> 16-bit
+    segment change in the persistent loop)."""
+    import torch
+    from eventclip_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M, N, K = 70001, 512, 256
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    a_hi, a_lo = _split(a, torch.float16)
+    w_hi, w_lo = _split(w, torch.float16)
+    A_lo8, W8 = ops.quantize_e4m3(a - a_hi.float(), exp=12), ops.quantize_e4m3(w_hi)
+    want = a_hi.double() @ w_hi.double().t() + ops.dequantize_e4m3(*A_lo8, K).double() @ ops.dequantize_e4m3(*W8, K).double().t()
+    got = ops.gemm(a_hi, w_hi, None, 'store32', A_lo8=A_lo8, W8=W8)
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6
+    # RESID_HL: the planes updated by the two-product sum
+    hi = torch.randn(M, N, device='cuda', generator=g).half()
+    lo = (torch.randn(M, N, device='cuda', generator=g) * 1e-4).half()
+    ref = hi.double() + lo.double() + want
+    ops.gemm(a_hi, w_hi, None, 'resid_hl', out=hi, aux=lo, A_lo8=A_lo8, W8=W8)
+    assert float(((hi.double() + lo.double()) - ref).abs().max() / ref.abs().max()) < 2e-6
+    # the lo output of STORE16
+    out_lo = torch.empty(M, N, dtype=torch.float16, device='cuda')
+    out_hi = ops.gemm(a_hi, w_hi, None, 'store16', aux=out_lo, A_lo8=A_lo8, W8=W8)
+    assert float(((out_hi.double() + out_lo.double()) - want).abs().max() / want.abs().max()) < 2e-5
+    with pytest.raises(RuntimeError, match='not both'):
+        ops.gemm(a_hi, w_hi, None, 'store32', A_lo=a_lo, A_lo8=A_lo8, W8=W8)
+    with pytest.raises(RuntimeError, match='needs W8'):
+        ops.gemm(a_hi, w_hi, None, 'store32', A_lo8=A_lo8)
+    with pytest.raises(RuntimeError, match='K %% 128|K % 128'):
+        ops.gemm(a_hi[:, :192], w_hi[:, :192], None, 'store32', A_lo8=(A_lo8[0][:, :384], 12), W8=(W8[0][:, :384], W8[1]))
+    b_hi = a_hi.bfloat16()
+    with pytest.raises(RuntimeError, match='EC_F16'):
+        ops.gemm(b_hi, w_hi.bfloat16(), None, 'store32', A_lo8=A_lo8, W8=W8)
+
+
+@pytest.mark.parametrize('rows,width', [(771, 1024), (5, 768), (1030, 1280)])
+def test_layernorm_hl8_writes_e4m3_operands(rows, width, hip):
+    """ec_layernorm_hl8: LayerNorm of the hi + lo planes into the fp16 hi part (bit-identical to ec_layernorm_hl's), the lo
+    part as e4m3 of lo . 2^12 and an e4m3 copy of the hi part, one byte per element at the 16-bit row pitch -- exactly
+    torch's float8_e4m3fn rounding of the same fp32 values."""
+    import ctypes
+    import torch
+    from eventclip_amd import _lib, ops
+    g = torch.Generator(device='cuda').manual_seed(rows + width)
+    x = torch.randn(rows, width, device='cuda', generator=g) * 3 + 0.5
+    x[:, 7] *= 40                                                    # an outlier channel
+    x_hi = x.half()
+    x_lo = (x - x_hi.float()).half()
+    gamma = 1 + 0.1 * torch.randn(width, device='cuda', generator=g)
+    beta = 0.1 * torch.randn(width, device='cuda', generator=g)
+    o_hi = torch.empty(rows, width, dtype=torch.float16, device='cuda')
+    o_lo = torch.empty(rows, width, dtype=torch.float16, device='cuda')
+    lib = _lib.lib()
+    _lib.check(lib.ec_layernorm_hl(_lib.ptr(x_hi), _lib.ptr(x_lo), width, _lib.ptr(gamma), _lib.ptr(beta), rows, width, 1e-5,
+                                   _lib.ptr(o_hi), _lib.ptr(o_lo), width, _lib.EC_F16, _lib.stream_ptr()))
+    p_hi = torch.empty_like(o_hi)
+    lo8 = torch.full((rows, 2 * width), 0xAA, dtype=torch.uint8, device='cuda')
+    hi8 = torch.full((rows, 2 * width), 0xAA, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.ec_layernorm_hl8(_lib.ptr(x_hi), _lib.ptr(x_lo), width, _lib.ptr(gamma), _lib.ptr(beta), rows, width, 1e-5,
+                                    _lib.ptr(p_hi), _lib.ptr(lo8), _lib.ptr(hi8), width, 12, 0, _lib.stream_ptr()))
+    assert torch.equal(p_hi, o_hi)
+    assert bool((lo8[:, width:] == 0xAA).all()) and bool((hi8[:, width:] == 0xAA).all())      # the second half of a row is not touched
+    # the lo bytes: e4m3 of the SAME fp32 lo value the 16-bit kernel rounded to fp16 (o_lo is that value to 2^-11)
+    lo_ref = ops.dequantize_e4m3(lo8, 12, width)
+    err = (lo_ref - o_lo.float()).abs()
+    assert bool((err <= 2.0 ** -4 * o_lo.float().abs() + 2.0 ** -21).all())
+    want_hi8 = o_hi.float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(hi8[:, :width].contiguous(), want_hi8)
+    # without the hi copy
+    lo8b = torch.zeros_like(lo8)
+    _lib.check(lib.ec_layernorm_hl8(_lib.ptr(x_hi), _lib.ptr(x_lo), width, _lib.ptr(gamma), _lib.ptr(beta), rows, width, 1e-5,
+                                    _lib.ptr(p_hi), _lib.ptr(lo8b), None, width, 12, 0, _lib.stream_ptr()))
+    assert torch.equal(lo8b[:, :width], lo8[:, :width])
