@@ -94,6 +94,8 @@ def parse():
     ap.add_argument('--precise-blocks', type=int, default=0,
                     help='the FIRST n blocks of the image tower as split-operand blocks (ec_vit_weights.precise_blocks; '
                          'n = 8 meets 1e-3 on the input-dependent weights of every config): a line of its own, never the headline')
+    ap.add_argument('--tolerance-mode', action='store_true',
+                    help='time the headline config IN the tolerance mode (eventclip_amd.clip.TOLERANCE_MODE): a line of its own, never the headline')
     ap.add_argument('--no-tolerance-mode', action='store_true',
                     help='skip the extra steps (after the timed region) that price the 1e-3 mode: tolerance_mode')
     ap.add_argument('--other-configs-batch', type=int, default=None,
@@ -143,7 +145,10 @@ def tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events, f
                    'hi + lo parts, QKV / c_fc multiply both parts, every GEMM adds the product with its weight\'s lo part '
                    f'(one launch per GEMM; none where the matrix is its 16-bit value); the first {pa} of them with attention in '
                    'fp32 on hi + lo q, k, v and the MLP activation as hi + lo into c_proj '
-                   '(ec_vit_weights.precise_blocks / precise_attn_blocks)'}
+                   '(ec_vit_weights.precise_blocks / precise_attn_blocks)' +
+                   ('; the lo products of QKV / c_fc / c_proj as e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (ec_vit_weights.lo_fp8)'
+                    if eclip.DEFAULT_LO_FP8 else ''),
+           'lo_fp8': bool(eclip.DEFAULT_LO_FP8)}
 
     def timed(fn, n):
         fence()
@@ -404,7 +409,7 @@ def dist_init(a, world, rank, local, backend):
 
 
 def build_workload(config, world, rank, batch=None, arch=None, classes=None, dtype='float16', chunk=2560,
-                   unique_samples=None, f16_weights=False, packed_events=False, clip_kw=None):
+                   unique_samples=None, f16_weights=False, packed_events=False, clip_kw=None, tolerance_mode=False):
     """Model + pipeline + this rank's share of one batch of BASELINE configs[config] as event streams resident in HBM."""
     from eventclip_amd import clip as eclip
     from eventclip_amd.clip_cls import FSCLIPClassifier, ZSCLIPClassifier
@@ -426,7 +431,10 @@ def build_workload(config, world, rank, batch=None, arch=None, classes=None, dty
     if f16_weights:
         cdt = torch.float16 if dtype == 'float16' else torch.bfloat16
         sd = {k: (v.to(cdt).float() if v.dim() >= 2 else v) for k, v in sd.items()}
-    clip_model = eclip.CLIP(cfg, sd, dtype=dtype, chunk=chunk, **(clip_kw or {})).cuda().eval()
+    clip_kw = dict(clip_kw or {})
+    if tolerance_mode:
+        clip_kw.update(eclip.tolerance_mode_kwargs(cfg))
+    clip_model = eclip.CLIP(cfg, sd, dtype=dtype, chunk=chunk, **clip_kw).cuda().eval()
     tokens = eclip.synthetic_tokens(classes, seed=2)
     clip_dict = dict(clip_model=clip_model, prompt='a point cloud image of a {}',
                      class_names=[f'class {i}' for i in range(classes)], agg_func='mean', class_tokens=tokens)
@@ -590,7 +598,8 @@ def main():
 
     w = build_workload(a.config, world, rank, batch=a.batch, arch=a.arch, classes=a.classes, dtype=a.dtype, chunk=a.chunk,
                        unique_samples=a.unique_samples, f16_weights=a.f16_weights, packed_events=a.packed_events,
-                       clip_kw=dict(image_precise=a.precise, image_precise_blocks=0 if a.precise else a.precise_blocks))
+                       clip_kw=dict(image_precise=a.precise, image_precise_blocks=0 if a.precise else a.precise_blocks),
+                       tolerance_mode=a.tolerance_mode)
     c, geo, cfg, sd, T, N = w['c'], w['geo'], w['cfg'], w['sd'], w['T'], w['N']
     clip_model, model, tokens, clip_dict, quantize_args = w['clip_model'], w['model'], w['tokens'], w['clip_dict'], w['quantize_args']
     evs, events, n_events, pipe, uniq_n = w['evs'], w['events'], w['n_events'], w['pipe'], w['uniq_n']
@@ -709,6 +718,8 @@ def main():
             f'event-frames/sec (whole node), BASELINE configs[{a.config}]'
         if a.precise:
             metric += ' -- split-precision image tower (validation mode, not the headline)'
+        elif a.tolerance_mode:
+            metric += f' -- tolerance mode: first {clip_model.image_precise_blocks} blocks of the image tower as split-operand blocks (not the headline)'
         elif a.precise_blocks:
             metric += f' -- first {a.precise_blocks} blocks of the image tower as split-operand blocks (not the headline)'
         if c['scaling'] == 'weak':
@@ -734,11 +745,12 @@ def main():
                                       '16-bit MFMA operands, fp32 accumulate / softmax; residual stream as hi + lo '
                                       '16-bit planes (~2^-22), LayerNorm folded into the QKV / c_fc GEMMs (statistics '
                                       'of the 16-bit hi plane); patch embedding and ln_post @ proj with hi + lo operands')
-                                     + (f'; the first {a.precise_blocks} blocks as split-operand blocks (LayerNorm of both planes '
+                                     + (f'; the first {clip_model.image_precise_blocks} blocks as split-operand blocks (LayerNorm of both planes '
                                         'into hi + lo parts, QKV / c_fc multiply both, every GEMM adds its weight\'s lo product '
                                         f'in the same launch; fp32 attention on hi + lo q, k, v in the first '
                                         f'{clip_model.image_precise_attn_blocks}: ec_vit_weights.precise_blocks / precise_attn_blocks)'
-                                        if a.precise_blocks and not a.precise else '')
+                                        + (', their lo products as e4m3 operands on the FP8 matrix path (ec_vit_weights.lo_fp8)' if clip_model.image_lo_fp8 else '')
+                                        if clip_model.image_precise_blocks and not a.precise else '')
                                      + '; text tower split-precision (cached)'),
                        # the EFFECTIVE tolerance-mode setting of the timed model (0 = the headline's 16-bit path; EVENTCLIP_PRECISE_BLOCKS
                        # in the environment would change it without a flag on the command line)
@@ -767,7 +779,7 @@ def main():
             dv = sample_dvfs(step, fence, device=local)
             if dv:
                 res['dvfs'] = dv
-        if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks):
+        if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks or a.tolerance_mode):
             res['tolerance_mode'] = tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
                                                    frames_per_step, res['ms_per_step'])
         if world == 1 and not a.no_strict_line:
@@ -790,7 +802,7 @@ def main():
                                                a.cpu_baseline_samples if a.config == 1 else 1,
                                                min(a.cpu_baseline_frames, T) if a.config != 3 else 2,
                                                shape=geo['resolution'], pool=(a.config == 1))
-        if world == 1 and a.config == 1 and not (a.no_other_configs or a.precise or a.precise_blocks or a.f16_weights):
+        if world == 1 and a.config == 1 and not (a.no_other_configs or a.precise or a.precise_blocks or a.f16_weights or a.tolerance_mode):
             # release the headline's model / workspace / events first: the other configs build their own
             del w, model, clip_model, clip_dict, pipe, events, out, step
             torch.cuda.empty_cache()

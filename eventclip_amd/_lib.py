@@ -68,7 +68,8 @@ class EcGemmArgs(ctypes.Structure):
                 ('transposed', c_int), ('k_rows', c_int), ('row_stats', c_void_p), ('row_stats_stride', c_long),
                 ('col_sums', c_void_p), ('row_sums', c_void_p), ('A_lo', c_void_p), ('W_lo', c_void_p),
                 ('A_lo8', c_void_p), ('W8', c_void_p), ('A8', c_void_p), ('W_lo8', c_void_p),
-                ('a_lo8_exp', c_int), ('w8_exp', c_int), ('a8_exp', c_int), ('w_lo8_exp', c_int)]
+                ('a_lo8_exp', c_int), ('w8_exp', c_int), ('a8_exp', c_int), ('w_lo8_exp', c_int),
+                ('aux_e4m3', c_int), ('aux_exp', c_int)]
 
 
 EC_EPI_STORE16, EC_EPI_GELU16, EC_EPI_RESID32, EC_EPI_STORE32 = 0, 1, 2, 3
@@ -84,7 +85,8 @@ class EcBlockWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'ln1_g', 'ln1_b', 'qkv_w', 'qkv_b', 'out_w', 'out_b', 'ln2_g', 'ln2_b', 'fc1_w', 'fc1_b',
         'fc2_w', 'fc2_b', 'qkv_w_lo', 'out_w_lo', 'fc1_w_lo', 'fc2_w_lo', 'qkv_w_ln', 'qkv_cs', 'qkv_bf', 'fc1_w_ln',
-        'fc1_cs', 'fc1_bf')]
+        'fc1_cs', 'fc1_bf', 'qkv_w8', 'fc1_w8', 'fc2_w8', 'qkv_wlo8', 'fc1_wlo8')] + [
+        (n, c_int) for n in ('qkv_w8_exp', 'fc1_w8_exp', 'fc2_w8_exp', 'qkv_wlo8_exp', 'fc1_wlo8_exp')]
 
 
 class EcAdapterTrainLayer(ctypes.Structure):
@@ -107,7 +109,7 @@ class EcVitWeights(ctypes.Structure):
                 ('blocks', ctypes.POINTER(EcBlockWeights)), ('precise', c_int),
                 ('conv_w_lo', c_void_p), ('proj_w_lo', c_void_p), ('full_last_block', c_int),
                 ('low_latency', c_int), ('q_scaled', c_int), ('ln_folded', c_int), ('precise_blocks', c_int), ('weights_exact16', c_int),
-                ('precise_attn_blocks', c_int)]
+                ('precise_attn_blocks', c_int), ('lo_fp8', c_int)]
 
 
 class EcTextWeights(ctypes.Structure):

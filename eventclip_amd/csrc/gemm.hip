@@ -74,6 +74,7 @@ struct GemmArgs {
     int nf8;
     long f8_oa[2], f8_ow[2];    // bytes from A / W to the e4m3 operands of fp8 segment s
     int f8_scale[2];            // e8m0 byte (x 0x01010101) on the W side of segment s: 2^(byte - 127) undoes both operands' scales
+    float aux8_scale;           // STORE16 / GELU16 with the lo output as e4m3 (HLM bit 3): lo . aux8_scale, one byte per element
 };
 
 // sixteen zero bytes for the LDS-DMA lanes whose reduction row does not exist (transposed operands)
@@ -487,7 +488,7 @@ __device__ __forceinline__ void epilogue_hl_buf(const GemmArgs &g, f32x4 (&acc)[
 // 16-bit outputs (STORE16 / GELU16 and their folded-LayerNorm forms).  lds_rowstat: the wave row's 128 statistics
 // pairs in LDS (has_lds; always a pointer INTO the shared array, so that the reads compile to ds_read and not to
 // flat loads, whose s_waitcnt vmcnt(0) lgkmcnt(0) also waited for the next tile's first K tile), else g.rowstat
-template <int DT, int EPI, int TM, bool HAS_LDS, bool EARLY = false, bool LOUT = false, typename F>
+template <int DT, int EPI, int TM, bool HAS_LDS, bool EARLY = false, bool LOUT = false, bool LOUT8 = false, typename F>
 __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[TM][4], int m_base, int n_base,
                                                int lane, unsigned char *scratch, const float *lds_rowstat, F &&between)
 {
@@ -560,9 +561,14 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
         // mode only); twice the stores.
         const __amdgpu_buffer_rsrc_t rl = tile_rsrc(reinterpret_cast<char *>(g.aux) + ((long)m_base * g.ldc + n_base) * 2,
                                                     tile_span(g.M, m_base, TM * 16, g.ldc * 2));
+        // e4m3 lo output: row m of aux starts at byte m * 2 ldc (the 16-bit pitch), column n is byte n
+        const __amdgpu_buffer_rsrc_t rl8 = tile_rsrc(reinterpret_cast<char *>(g.aux) + (long)m_base * g.ldc * 2 + n_base,
+                                                     tile_span(g.M, m_base, TM * 16, g.ldc * 2));
+        const int voff8 = col_ok ? (lane >> 3) * (int)g.ldc * 2 + (lane & 7) * 8 : BUF_OOB;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             elem o[16], l[16];
+            float l32[16];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 f32x4 v;
@@ -576,29 +582,48 @@ __device__ __forceinline__ void epilogue16_buf(const GemmArgs &g, f32x4 (&acc)[T
                     float x = v[r];
                     asm volatile("" : "+v"(x));      // ONE rounded fp32 value for both parts (see attention_f32m_kernel)
                     o[4 * j + r] = to16(x, elem());
-                    l[4 * j + r] = to16(x - (float)o[4 * j + r], elem());
+                    l32[4 * j + r] = x - (float)o[4 * j + r];
+                    l[4 * j + r] = to16(l32[4 * j + r], elem());
                 }
             }
             unsigned char *b0 = scratch, *b1 = scratch + 16 * PITCH;
             *reinterpret_cast<u32x4 *>(b0 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&o[0]);
             *reinterpret_cast<u32x4 *>(b0 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&o[8]);
-            *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&l[0]);
-            *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&l[8]);
+            if constexpr (LOUT8) {
+                // the lo part as e4m3 of lo . aux8_scale (ec_gemm_args.aux_e4m3): 16 bytes per lane, a row of the 16 x 64 group =
+                // 64 bytes; aux rows lie at the byte pitch of C (the A_lo8 operand of the GEMM that follows)
+                u32x4 l8;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float d[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) d[r] = __builtin_amdgcn_fmed3f(l32[4 * j + r] * g.aux8_scale, -448.f, 448.f);
+                    unsigned w = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0u, false);
+                    l8[j] = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], w, true);
+                }
+                *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 16) = l8;
+            } else {
+                *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32) = *reinterpret_cast<const u32x4 *>(&l[0]);
+                *reinterpret_cast<u32x4 *>(b1 + lr * PITCH + q * 32 + 16) = *reinterpret_cast<const u32x4 *>(&l[8]);
+            }
             if (i == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 between();
                 __builtin_amdgcn_sched_barrier(0);
             }
             u32x4 t[2], u[2];
+            u32x2 u8[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 t[p] = *reinterpret_cast<const u32x4 *>(b0 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
-                u[p] = *reinterpret_cast<const u32x4 *>(b1 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
+                if constexpr (LOUT8) u8[p] = *reinterpret_cast<const u32x2 *>(b1 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 8);
+                else u[p] = *reinterpret_cast<const u32x4 *>(b1 + ((lane >> 3) + 8 * p) * PITCH + (lane & 7) * 16);
             }
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 bstore16(t[p], rc, voff + (2 * i + p) * step8);
-                bstore16(u[p], rl, voff + (2 * i + p) * step8);
+                if constexpr (LOUT8) __builtin_amdgcn_raw_buffer_store_b64(u8[p], rl8, voff8 + (2 * i + p) * step8, 0, 0);
+                else bstore16(u[p], rl, voff + (2 * i + p) * step8);
             }
         }
         return;
@@ -1173,6 +1198,7 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
         constexpr bool BUF_EPI = EPI == EC_EPI_RESID_HL || EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16 || epi_is_ln(EPI) ||
                                  EPI == EC_EPI_STORE32 || EPI == EC_EPI_RESID32;
         constexpr bool LOUT = (EPI == EC_EPI_STORE16 || EPI == EC_EPI_GELU16) && (HLM & 16) != 0;   // 16-bit output as hi + lo parts (args.aux)
+        constexpr bool LOUT8 = LOUT && (HLM & 8) != 0;                                              // ... the lo part as e4m3 bytes
         constexpr int TAIL_HL = ((HLM & 32) && (HLM & 128)) ? 0 : (HLM & (32 | 64 | 128)) ? 16 : 48;     // (diagnostic forms issue fewer operations)
         constexpr int TAIL = !BUF_EPI ? 0 : EPI == EC_EPI_RESID_HL ? TAIL_HL : EPI == EC_EPI_STORE32 ? 32 : EPI == EC_EPI_RESID32 ? 48 : LOUT ? 32 : 16;
         constexpr int enc_tail = (TAIL & 15) | (7 << 4) | (15 << 8) | ((TAIL >> 4) << 14);
@@ -1183,10 +1209,10 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             epilogue32_buf<EPI, 8, TN>(ge, acc, wm0, wn0, elane, reinterpret_cast<float *>(smem + KT) + wave * (16 * 68), next_tile);
         else if constexpr (BUF_EPI) {
             if (lds_stats)
-                epilogue16_buf<DT, EPI, 8, true, (HLM & 4) != 0, LOUT>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
+                epilogue16_buf<DT, EPI, 8, true, (HLM & 4) != 0, LOUT, LOUT8>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144),
                                                  side + slot * 512 + wm * 256, next_tile);
             else
-                epilogue16_buf<DT, EPI, 8, false, (HLM & 4) != 0, LOUT>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
+                epilogue16_buf<DT, EPI, 8, false, (HLM & 4) != 0, LOUT, LOUT8>(ge, acc, wm0, wn0, elane, smem + KT + wave * (2 * 16 * 144), nullptr, next_tile);
         }
         else {    // the training epilogues (second output / second input): the general form
             next_tile();
@@ -1314,6 +1340,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
                     return g.aux ? launch2pp<DT, EC_EPI_STORE16, false, false, HLO, 2>(g, s)
                                  : launch2pp<DT, EC_EPI_STORE16, false, false, HL_MODE_DEFAULT, 2>(g, s);
                 case EC_EPI_GELU16:
+                    if (g.aux && g.aux8_scale != 0.f) return launch2pp<DT, EC_EPI_GELU16, false, false, HLO | 8, 2>(g, s);
                     return g.aux ? launch2pp<DT, EC_EPI_GELU16, false, false, HLO, 2>(g, s)
                                  : launch2pp<DT, EC_EPI_GELU16, false, false, HL_MODE_DEFAULT, 2>(g, s);
                 case EC_EPI_STORE32: return launch2pp<DT, EC_EPI_STORE32, false, false, HL_MODE_DEFAULT, 2>(g, s);
@@ -1495,6 +1522,12 @@ extern "C" EC_API int ec_gemm(const ec_gemm_args *a, ec_stream_t stream)
     g.seg_da = g.seg_dw = g.seg_mask = 0;
     g.nf8 = 0;
     g.f8_oa[0] = g.f8_oa[1] = g.f8_ow[0] = g.f8_ow[1] = 0, g.f8_scale[0] = g.f8_scale[1] = 0x7f7f7f7f;
+    g.aux8_scale = 0.f;
+    if (a->aux_e4m3) {
+        EC_REQUIRE(a->epilogue == EC_EPI_GELU16 && a->aux && a->A_lo8 && a->dtype == EC_F16 && a->aux_exp >= -60 && a->aux_exp <= 60,
+                   "ec_gemm: aux_e4m3 goes with EC_EPI_GELU16, an aux buffer, e4m3 lo products (A_lo8) and -60 <= aux_exp <= 60");
+        g.aux8_scale = ldexpf(1.f, a->aux_exp);
+    }
     const bool l8 = a->A_lo8 != nullptr, w8 = a->W_lo8 != nullptr;
     if (a->A_lo || a->W_lo || l8 || w8) {
         // split-precision operands: up to three products into the same accumulators, the small ones first

@@ -78,6 +78,43 @@ inline int gemm_split16(int M, int N, int K, int dtype, int epi, const void *A, 
     return ec_gemm(&g, s);
 }
 
+// ... with the lo products on the FP8 matrix path (ec_vit_weights.lo_fp8): A_lo8 = the e4m3 lo part of A (ec_layernorm_hl8 /
+// the e4m3 lo output of c_fc), W8 = the e4m3 copy of W; where the weight has a lo part: A8 (e4m3 copy of A) with W_lo8, or the
+// 16-bit W_lo where no A8 exists (c_proj).  C_lo8: the output's lo part as e4m3 (GELU16; exponent LO8_EXP).
+constexpr int LO8_EXP = 12;    // lo parts of activations as e4m3 of lo . 2^12: saturates where the activation exceeds 256
+constexpr int HI8_EXP = 0;     // e4m3 copies of hi parts at scale 1: saturates beyond 448
+struct Fp8Parts {
+    const void *A_lo8, *W8, *A8, *W_lo8;
+    int w8_exp, w_lo8_exp;
+};
+inline void fp8_args(ec_gemm_args &g, const Fp8Parts &f)
+{
+    g.A_lo8 = f.A_lo8, g.W8 = f.W8, g.a_lo8_exp = LO8_EXP, g.w8_exp = f.w8_exp;
+    if (f.A8 && f.W_lo8) g.A8 = f.A8, g.W_lo8 = f.W_lo8, g.a8_exp = HI8_EXP, g.w_lo8_exp = f.w_lo8_exp;
+}
+inline int gemm_split16_f8(int M, int N, int K, int epi, const void *A, const void *W, const Fp8Parts &f, const float *bias, void *C,
+                           void *C_lo, bool C_lo_e4m3, ec_stream_t s)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = EC_F16, g.epilogue = epi, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = C, g.ldc = N;
+    fp8_args(g, f);
+    g.aux = C_lo;
+    if (C_lo && C_lo_e4m3) g.aux_e4m3 = 1, g.aux_exp = LO8_EXP;
+    return ec_gemm(&g, s);
+}
+inline int gemm_hl_f8(int M, int N, int K, const void *A, const void *W, const Fp8Parts &f, const void *W_lo, const float *bias,
+                      void *x_hi, void *x_lo, ec_stream_t s, float *row_sums = nullptr)
+{
+    ec_gemm_args g = {};
+    g.M = M, g.N = N, g.K = K, g.dtype = EC_F16, g.epilogue = EC_EPI_RESID_HL, g.variant = 0;
+    g.A = A, g.lda = K, g.W = W, g.bias = bias, g.C = x_hi, g.ldc = N, g.aux = x_lo;
+    g.row_sums = row_sums;
+    fp8_args(g, f);
+    g.W_lo = W_lo;
+    return ec_gemm(&g, s);
+}
+
 // layernorm.hip: ln_pre'd embedding straight into the hi / lo planes; class rows of the planes back to fp32
 int vit_embed_hl(const float *patch, const float *cls, const float *pos, const float *gamma, const float *beta,
                  int n_img, int seq, int width, float eps, void *x_hi, void *x_lo, int dtype, ec_stream_t stream);

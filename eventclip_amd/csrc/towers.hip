@@ -77,7 +77,7 @@ int run_blocks(const ec_block_weights *blocks, int layers, int n_seq, int S, int
 // rounding points.
 int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int S, int W, int heads, int dtype,
                       const BlockBufs &b, ec_stream_t s, bool first_only, bool q_scaled, int nsplit = 0, bool exact16 = false,
-                      int nattn = 0)
+                      int nattn = 0, bool lo_fp8 = false)
 {
     const int rows = n_seq * S;
     void *x_hi = b.x;
@@ -100,6 +100,12 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
         EC_REQUIRE(blocks[l].qkv_w && blocks[l].fc1_w && blocks[l].ln1_g && blocks[l].ln2_g, "folded chain: split-operand block %d lacks its plain weights", l);
         EC_REQUIRE(exact16 || (blocks[l].qkv_w_lo && blocks[l].out_w_lo && blocks[l].fc1_w_lo && blocks[l].fc2_w_lo),
                    "folded chain: split-operand block %d has no lo weight parts (and weights_exact16 is not set)", l);
+        if (lo_fp8) {
+            EC_REQUIRE(blocks[l].qkv_w8 && blocks[l].fc1_w8 && blocks[l].fc2_w8, "folded chain: lo_fp8 needs the e4m3 weights (*_w8) of split-operand block %d", l);
+            EC_REQUIRE((!blocks[l].qkv_w_lo || blocks[l].qkv_wlo8) && (!blocks[l].fc1_w_lo || blocks[l].fc1_wlo8),
+                       "folded chain: lo_fp8 needs the e4m3 lo parts (qkv_wlo8 / fc1_wlo8) of split-operand block %d", l);
+            EC_REQUIRE(b.mlp_lo && W % 128 == 0, "folded chain: lo_fp8 needs the mlp_lo buffer and a width that is a multiple of 128");
+        }
     }
     if (nsplit == 0) EC_TRY(ec_row_stats(x_hi, W, rows, W, LN_EPS, b.stats, dtype, s));
     for (int l = 0; l < layers; l++) {
@@ -132,6 +138,35 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             unsigned char *mlp8 = static_cast<unsigned char *>(b.mlp);
             void *h_lo1 = mlp8 + (size_t)rows * 3 * W * esz, *qkv_lo = mlp8, *att_lo = h_lo1, *h_lo2 = b.qkv;
             const bool pa = l < nattn, next_default = l + 1 >= nsplit && l + 1 < layers;
+            if (lo_fp8) {
+                // ---- the same block with its lo products on the FP8 matrix path (ec_vit_weights.lo_fp8) ----
+                // e4m3 parts at the 16-bit byte pitch in the same dead buffers; the e4m3 copy of LN(x)'s hi part (needed where the
+                // weight has a lo part) in the mlp_lo buffer (ln_1: dead until c_fc writes it) / behind the lo part in the qkv buffer (ln_2)
+                unsigned char *qkv8 = static_cast<unsigned char *>(b.qkv);
+                void *h8_1 = w.qkv_wlo8 ? b.mlp_lo : nullptr, *h8_2 = w.fc1_wlo8 ? qkv8 + (size_t)rows * W * esz : nullptr;
+                EC_TRY(ec_layernorm_hl8(x_hi, x_lo, W, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, h_lo1, h8_1, W, LO8_EXP, HI8_EXP, s));
+                const Fp8Parts fq = {h_lo1, w.qkv_w8, h8_1, w.qkv_wlo8, w.qkv_w8_exp, w.qkv_wlo8_exp};
+                EC_TRY(gemm_split16_f8(rows, 3 * W, W, EC_EPI_STORE16, b.h, w.qkv_w, fq, w.qkv_b, b.qkv, pa ? qkv_lo : nullptr, false, s));
+                if (pa) {
+                    EC_TRY(ec_attention_split(b.qkv, qkv_lo, b.h, att_lo, n_seq, S, W, heads, 0, dtype, s));
+                } else {
+                    EC_TRY(attention_exact_scale(b.qkv, b.h, n_seq, S, W, heads, dtype, s));
+                }
+                EC_TRY(gemm_hl(rows, W, W, dtype, b.h, w.out_w, w.out_b, x_hi, x_lo, s, 0, nullptr, w.out_w_lo, pa ? att_lo : nullptr));
+                EC_TRY(ec_layernorm_hl8(x_hi, x_lo, W, w.ln2_g, w.ln2_b, rows, W, LN_EPS, b.h, h_lo2, h8_2, W, LO8_EXP, HI8_EXP, s));
+                const Fp8Parts f1 = {h_lo2, w.fc1_w8, h8_2, w.fc1_wlo8, w.fc1_w8_exp, w.fc1_wlo8_exp};
+                void *m_lo8 = pa ? b.mlp_lo : nullptr;
+                EC_TRY(gemm_split16_f8(rows, 4 * W, W, EC_EPI_GELU16, b.h, w.fc1_w, f1, w.fc1_b, b.mlp, m_lo8, true, s));
+                if (pa) {
+                    // c_proj: the activation's e4m3 lo part with the e4m3 copy of fc2_w; the weight's lo part (no e4m3 copy of the
+                    // activation's hi part exists) as a 16-bit product
+                    const Fp8Parts f2 = {m_lo8, w.fc2_w8, nullptr, nullptr, w.fc2_w8_exp, 0};
+                    EC_TRY(gemm_hl_f8(rows, W, 4 * W, b.mlp, w.fc2_w, f2, w.fc2_w_lo, w.fc2_b, x_hi, x_lo, s, next_default ? sums : nullptr));
+                } else {
+                    EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, next_default ? sums : nullptr, w.fc2_w_lo,
+                                   nullptr));
+                }
+            } else {
             EC_TRY(ec_layernorm_hl(x_hi, x_lo, W, w.ln1_g, w.ln1_b, rows, W, LN_EPS, b.h, h_lo1, W, dtype, s));
             EC_TRY(gemm_split16(rows, 3 * W, W, dtype, EC_EPI_STORE16, b.h, h_lo1, w.qkv_w, w.qkv_w_lo, w.qkv_b, b.qkv,
                                 pa ? qkv_lo : nullptr, s));
@@ -149,6 +184,7 @@ int run_blocks_folded(const ec_block_weights *blocks, int layers, int n_seq, int
             // the first default block behind the split-operand blocks takes its statistics from this epilogue's sums
             EC_TRY(gemm_hl(rows, W, 4 * W, dtype, b.mlp, w.fc2_w, w.fc2_b, x_hi, x_lo, s, 0, next_default ? sums : nullptr,
                            w.fc2_w_lo, m_lo));
+            }
             if (next_default) {
                 if (fused)
                     EC_TRY(ec_row_stats_merge(sums, rows, groups, W, LN_EPS, b.stats, s));
@@ -283,7 +319,7 @@ EC_API size_t ec_vit_workspace_bytes(const ec_vit_weights *w, int chunk)
         return carve_precise(sc, chunk, g * g + 1, w->width, pb, &s16, &s16b, &idx);
     }
     BlockBufs b;
-    carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx, nullptr, w->precise_blocks > 0 && w->precise_attn_blocks > 0);
+    carve(sc, chunk, g * g + 1, w->width, 0, b, &s16, &idx, nullptr, w->precise_blocks > 0 && (w->precise_attn_blocks > 0 || w->lo_fp8));
     return sc.off + (w->low_latency ? LATENCY_WS_BYTES : 0);
 }
 
@@ -346,7 +382,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
     BlockBufs b;
     void *cls16, *cls16_lo;
     int *idx;
-    size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo, w->precise_blocks > 0 && w->precise_attn_blocks > 0);
+    size_t need = carve(sc, chunk, S, W, 0, b, &cls16, &idx, &cls16_lo, w->precise_blocks > 0 && (w->precise_attn_blocks > 0 || w->lo_fp8));
     // precise_blocks: the first blocks of the folded chain multiply both planes of the residual stream and the
     // weights' lo parts (run_blocks_folded)
     const int pblocks = w->precise_blocks;
@@ -385,7 +421,7 @@ EC_API int ec_vit_encode(const ec_vit_weights *w, const void *patches, int n_img
             EC_TRY(vit_embed_hl(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, n, S, W, LN_EPS, x_hi, x_lo, dt, stream));
             EC_TRY(run_blocks_folded(w->blocks, w->layers, n, S, W, w->heads, dt, b, stream, w->full_last_block == 0,
                                      w->q_scaled != 0, pblocks, w->weights_exact16 != 0,
-                                     w->precise_attn_blocks < pblocks ? w->precise_attn_blocks : pblocks));
+                                     w->precise_attn_blocks < pblocks ? w->precise_attn_blocks : pblocks, pblocks > 0 && w->lo_fp8 != 0));
             // the class rows back to fp32 (x = hi + lo) for ln_post; patch_out (the mlp buffer) is free by now
             EC_TRY(join_hl_rows(x_hi, x_lo, (long)S * W, n, W, patch_out, dt, stream));
             EC_TRY(ec_layernorm_split(patch_out, W, nullptr, w->ln_post_g, w->ln_post_b, n, W, LN_EPS, cls16, cls16_lo, W,

@@ -19,7 +19,7 @@ def dtype_code(t):
 
 def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, resid=None, aux=None,
          splits=1, K=None, ws=None, row_stats=None, col_sums=None, row_stats_stride=0, row_sums=None,
-         A_lo=None, W_lo=None, A_lo8=None, W8=None, A8=None, W_lo8=None):
+         A_lo=None, W_lo=None, A_lo8=None, W8=None, A8=None, W_lo8=None, aux8=None):
     """out = epi(A[M,K] @ W[N,K]^T + bias).  epilogue: store16 | gelu16 | resid32 | store32 |
     gelu16_save (aux receives the pre-activation) | gelu_bwd16 (out = acc * QuickGELU'(aux)).
     resid32 accumulates into ``out`` (fp32) in place, or computes out = resid + ... when ``resid`` is given.
@@ -86,6 +86,10 @@ def gemm(A, W, bias=None, epilogue='store16', out=None, variant=0, diag=None, re
             assert t.dtype == torch.uint8 and t.shape[0] == ref.shape[0] and t.stride(0) == 2 * ld and t.stride(1) == 1, name
             setattr(a, name, t.data_ptr())
             setattr(a, {'A_lo8': 'a_lo8_exp', 'W8': 'w8_exp', 'A8': 'a8_exp', 'W_lo8': 'w_lo8_exp'}[name], int(e))
+    if aux8 is not None:          # gelu16 with e4m3 lo products: the lo output as e4m3 (uint8 [M, 2 N], exponent)
+        t, e = aux8
+        assert t.dtype == torch.uint8 and tuple(t.shape) == (M, 2 * N) and t.stride(0) == 2 * out.stride(-2) and aux is None
+        a.aux, a.aux_e4m3, a.aux_exp = t.data_ptr(), 1, int(e)
     if splits > 1:
         a.splits, a.split_stride = splits, out.stride(0)
     if ws is not None:                       # fp32 scratch: an under-filled launch runs K-batched (low latency)

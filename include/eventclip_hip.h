@@ -345,6 +345,9 @@ typedef struct {
     const void *A8;           /* e4m3 of A . 2^a8_exp */
     const void *W_lo8;        /* e4m3 of (w_true - W) . 2^w_lo8_exp, or NULL */
     int a_lo8_exp, w8_exp, a8_exp, w_lo8_exp;
+    int aux_e4m3;             /* != 0 (EC_EPI_GELU16 with aux and A_lo8): the lo output leaves as e4m3 of lo . 2^aux_exp, one byte per
+                                 element in the first N bytes of rows of 2 . ldc bytes -- the A_lo8 operand of the GEMM that follows */
+    int aux_exp;
 } ec_gemm_args;
 
 EC_API int ec_gemm(const ec_gemm_args *args, ec_stream_t stream);
@@ -477,6 +480,12 @@ typedef struct {
     const float *qkv_cs, *qkv_bf;
     const void *fc1_w_ln;
     const float *fc1_cs, *fc1_bf;
+    /* (round 6, ABI 600; appended) e4m3 operands of the split-operand blocks' lo products (ec_vit_weights.lo_fp8; ec_gemm_args.W8 /
+     * W_lo8): round_e4m3(w16 . 2^exp) of the PLAIN 16-bit matrices qkv_w / fc1_w / fc2_w and round_e4m3(w_lo . 2^exp) of the lo
+     * parts of qkv_w / fc1_w, each [N, K] bytes at the 16-bit byte row pitch (rows of 2 K bytes, the first K used); NULL = not packed
+     * (a lo part that is NULL stays NULL). */
+    const void *qkv_w8, *fc1_w8, *fc2_w8, *qkv_wlo8, *fc1_wlo8;
+    int qkv_w8_exp, fc1_w8_exp, fc2_w8_exp, qkv_wlo8_exp, fc1_wlo8_exp;
 } ec_block_weights;
 
 typedef struct {
@@ -547,6 +556,14 @@ typedef struct {
                                    of q and k in the FIRST blocks is the largest single error and that of the MLP activation
                                    the next (tools/rounding_budget.py; profiles/r5_tolerance_sweep.txt); behind them the
                                    16-bit attention kernel on a plain q with the scores scaled in fp32. */
+    int lo_fp8;                 /* (round 6, appended) != 0 with precise_blocks: the lo products of the split-operand blocks' QKV, c_fc and
+                                   c_proj GEMMs run on the FP8 matrix path -- LayerNorm writes its lo part (and, where the weight has
+                                   a lo part, a copy of its hi part) as e4m3 (ec_layernorm_hl8), c_fc writes the MLP activation's lo
+                                   part as e4m3 (ec_gemm_args.aux_e4m3), and the GEMMs multiply them with the e4m3 weights of
+                                   ec_block_weights (*_w8 / *_wlo8) at twice the f16 rate and half the operand bytes: an e4m3 lo
+                                   product measures 0.58 - 0.60 of the f16 one.  The lo part is ~2^-11 of its hi part, so e4m3's 2^-4
+                                   still removes ~95 % of the 16-bit operand-rounding error (profiles/r6_fp8_model_8_5.txt, r6_parity_seeds.txt).
+                                   out_proj (the attention output's lo part) stays 16-bit.  Needs the *_w8 fields of every split-operand block. */
 } ec_vit_weights;
 
 typedef struct {

@@ -59,7 +59,7 @@ def test_abi_check_rejects_older_headers_and_short_structs():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.EcFrameStats) == 40
     assert ctypes.sizeof(_lib.EcEventsParams) == 80
-    assert ctypes.sizeof(_lib.EcGemmArgs) == 240     # (+ A_lo, W_lo: round 5; + the four e4m3 operands and their exponents: round 6)
+    assert ctypes.sizeof(_lib.EcGemmArgs) == 248     # (+ A_lo, W_lo: round 5; + the four e4m3 operands and their exponents: round 6)
 
 
 def test_attention_kernels_have_no_unpadded_asm_hazards():
