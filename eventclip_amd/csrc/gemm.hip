@@ -1137,6 +1137,25 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                 // (satisfied already; tells hipcc's wait-count pass that no staging DMA is pending behind the main
                 // loop, so that it does not put a vmcnt(0) of its own in front of the epilogue's first LDS read)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
+                if constexpr (EPI == EC_EPI_RESID_HL && (HLM & 256) != 0) {
+                    // A / B (diagnostic variant 38, round 6): touch the wave tile's residual planes one K tile ahead of the
+                    // epilogue that reads them -- one dword of each 128-byte line by LDS-DMA into a dump area (no register
+                    // destination; issued as inline asm: requests OLDER than anything the epilogue issues only make its
+                    // counted waits conservative), so that the epilogue's loads find the lines in L2 / on their way
+                    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const int tm0 = m0 + wm * 128, tn0 = n0 + wn * 64;
+                    const long torg = ((long)tm0 * g.ldc + tn0) * 2, tspan = tile_span(g.M, tm0, 128, g.ldc * 2);
+                    const __amdgpu_buffer_rsrc_t th = tile_rsrc(reinterpret_cast<const char *>(g.C) + torg, tspan);
+                    const __amdgpu_buffer_rsrc_t tlo = tile_rsrc(reinterpret_cast<const char *>(g.aux) + torg, tspan);
+                    const int dump = 2 * KT + 4608 + wave * 256;
+                    const int v0 = tn0 < g.N ? ln * (int)g.ldc * 2 : BUF_OOB, v1 = tn0 < g.N ? (ln + 64) * (int)g.ldc * 2 : BUF_OOB;
+                    asm volatile("s_mov_b32 m0, %4\n\t"
+                                 "buffer_load_dword %0, %2, 0 offen lds\n\t"
+                                 "buffer_load_dword %1, %2, 0 offen lds\n\t"
+                                 "buffer_load_dword %0, %3, 0 offen lds\n\t"
+                                 "buffer_load_dword %1, %3, 0 offen lds"
+                                 :: "v"(v0), "v"(v1), "s"(th), "s"(tlo), "s"(dump) : "memory");
+                }
             }
             bar_l();
             if constexpr (F8) mma2_g(0, 0, gn0, 1, gn1, sc8);
@@ -1252,7 +1271,8 @@ int launch2pp(const GemmArgs &g0, hipStream_t stream)
     g.tiles_n = ec::ceil_div(g.N, 256);
     // two staging buffers + the row-statistics side area (LN epilogues) / the tail of the hi-lo epilogue's double
     // scratch (8 waves x 2 x 16 rows x 68 floats = 68 KiB from the second staging buffer on)
-    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 : 0);
+    constexpr int lds = 2 * 4 * 128 * 128 + (epi_is_ln(EPI) ? 2 * 2048 : 0) + (EPI == EC_EPI_RESID_HL ? 4608 : 0) +
+                        (EPI == EC_EPI_RESID_HL && (HLM & 256) ? 2048 : 0);      // (+ the dump area of the prefetch A / B)
     auto kern = gemm2pp_kernel<DT, EPI, TL, TN, HLM, SEG>;
     if (int rc = ec::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     const int cus = ec::cu_count();
@@ -1398,6 +1418,7 @@ template <int DT> int dispatch_epi(const GemmArgs &g, int epi, int variant, hipS
         if (variant == 35 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 64>(g, s);
         if (variant == 36 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 128>(g, s);
         if (variant == 37 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 32 | 128>(g, s);
+        if (variant == 38 && g.aux) return launch2pp<DT, EC_EPI_RESID_HL, false, false, HL_MODE_DEFAULT | 256>(g, s);   // residual planes touched a K tile ahead
         if (variant == 13 && g.aux) return launch_b2p<DT, EC_EPI_RESID_HL>(g, s);   // two 4-wave workgroups per CU
 #endif
         EC_REQUIRE(variant == 0 && g.aux, "ec_gemm: EC_EPI_RESID_HL needs variant 0 and args.aux (the lo plane)");

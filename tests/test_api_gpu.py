@@ -255,9 +255,10 @@ def test_host_feeder_dropped_while_the_ring_regrows_ends_its_thread(hip):
     from eventclip_amd.event2img import Event2ImagePipeline, HostFeeder
     from eventclip_amd.synthetic import GEOMETRY, make_batch
     g = GEOMETRY['n_cars']
-    qa = dict(max_imgs=2, N=g['N'], split_method='event_count', convert_method='event_histogram', grayscale=True,
+    qa = dict(max_imgs=4, N=g['N'], split_method='event_count', convert_method='event_histogram', grayscale=True,
               count_non_zero=True, background_mask=False)
-    pipe = Event2ImagePipeline(g["resolution"], g["max_n"], qa, n_px=224, patch=32, kpad=6144)
+    pipe = Event2ImagePipeline(g["resolution"], 4 * g["N"], qa, n_px=224, patch=32, kpad=6144)   # 4 views: no random view subsampling
+    assert pipe.max_imgs == 4
     small = [make_batch(2, 4000, g['resolution'], seed=i) for i in range(3)]
     big = make_batch(2, 90000, g['resolution'], seed=9)                    # 2.9 MB against a 1 MB ring: regrow
     feeder = HostFeeder(pipe, small + [big] + small[:1], depth=2)

@@ -61,7 +61,7 @@ def test_single_rank_line(hip):
         ln = oc[cid]
         assert ln['frames_per_step'] == 2 * views and f'configs[{cid}]' in ln['workload']
         assert abs(ln['value'] - ln['frames_per_step'] * 1e3 / ln['ms_per_step']) < 1e-6 * ln['value']
-        assert ln['dominant_kernel'] in ln['kernel_ms_per_step'] and 0 < ln['frac'] < 1
+        assert ln['dominant_kernel'] in ln['kernel_ms_per_step'] and 0 <= ln['frac'] < 1      # (two samples: a latency-bound kernel may dominate)
         assert ln['cpu_baseline']['value'] > 0 and ln['cpu_baseline']['kind'] == 'port'
 
 

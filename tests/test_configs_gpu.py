@@ -453,10 +453,11 @@ def test_config4_full_size_properties(hip):
 
 
 # draws of tests/config_cases.py the tolerance mode is held to 1e-3 on, per config: the historical pair (0) and the two
-# WORST of the other draws inside the bound at the shipped settings (profiles/r6_parity_seeds.txt, tools/sweep_tolerance.py
-# --seeds 8: worst-of-eight 3.1e-4 / 6.3e-4 / 7.8e-4 / 7.6e-4 on configs[0] / [1] / [3] / [4]).  configs[2] is inside on seven
-# of its eight draws (worst 6.7e-4); draw 5 is the one outside, held by test_tolerance_mode_configs2_small_logits_draw
-TOLERANCE_DRAWS = {0: (0, 3, 2), 1: (0, 4, 2), 2: (0, 6, 3), 3: (0, 2, 1), 4: (0, 2, 5)}
+# WORST of the other draws at the shipped settings (profiles/r6_parity_seeds.txt, tools/sweep_tolerance.py --seeds 8 default mode:
+# worst-of-eight 2.6e-4 / 5.5e-4 / 7.5e-4 / 7.7e-4 on configs[0] / [1] / [3] / [4]).  configs[2] is inside on seven of its eight
+# draws (worst of those 6.9e-4, the historical pair); draw 5 is the one outside, held by
+# test_tolerance_mode_configs2_small_logits_draw
+TOLERANCE_DRAWS = {0: (0, 4, 3), 1: (0, 2, 5), 2: (0, 6, 4), 3: (0, 3, 6), 4: (0, 2, 6)}
 
 
 @pytest.mark.parametrize('config,draw', [(c, d) for c in range(5) for d in TOLERANCE_DRAWS[c]])
@@ -479,7 +480,7 @@ def test_tolerance_mode_configs2_small_logits_draw(hip):
     configs[2] draw 5 (two classes, few-shot head: logits = 100 cos).  Its largest |logit| is 1.53 -- every cosine of the
     batch below 0.016, five times smaller than the other draws' -- so the same absolute error (2.9e-3 logit units = 2.9e-5 in
     the cosine) reads as 1.9e-3 of max |logit|.  Held here at what it measures, so that the number in the docs stays true:
-    below 2.5e-3 in the mode (default path: 2.5e-3), absolute error below 4e-3 logit units, classes ranked as the oracle
+    1.5 - 1.9e-3 in the mode by setting (default path: 2.5e-3): below 2.5e-3, absolute error below 4e-3 logit units, classes ranked as the oracle
     ranks them wherever the oracle separates them by more than the error."""
     import torch
     from eventclip_amd import clip as eclip

@@ -27,7 +27,7 @@ from eventclip_amd import ops  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
 M = frames * 257
-FORMS = [('default', dict(variant=0), True), ('no row sums', dict(variant=0), False), ('no residual loads', dict(variant=34), True),
+FORMS = [('default', dict(variant=0), True), ('planes touched one K tile ahead (variant 38)', dict(variant=38), True), ('no row sums', dict(variant=0), False), ('no residual loads', dict(variant=34), True),
          ('no lo store', dict(variant=35), True), ('no stores', dict(variant=36), True), ('no loads, no stores', dict(variant=37), True),
          ('no loads, no stores, no row sums', dict(variant=37), False), ('store16 (plain 16-bit store)', None, False)]
 for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
@@ -49,6 +49,13 @@ for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
     for f in FORMS:
         run(f[1], f[2])
     torch.cuda.synchronize()
+    # (variant 38 must give the product kernel's bits)
+    h0, l0 = hi.clone(), lo.clone()
+    run(dict(variant=0), True)
+    r0 = (hi.clone(), lo.clone(), rs.clone())
+    hi.copy_(h0), lo.copy_(l0)
+    run(dict(variant=38), True)
+    assert torch.equal(hi, r0[0]) and torch.equal(lo, r0[1]) and torch.equal(rs, r0[2]), 'variant 38 differs'
     for _ in range(7):
         for tag, kw, stats in FORMS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,6 +70,6 @@ for name, N, K in (('out_proj', 1024, 1024), ('c_proj', 1024, 4096)):
     base = sorted(times['default'])[3]
     for tag, t in times.items():
         t = sorted(t)[3]
-        print(f'{name:9s} M={M} N={N} K={K}  {tag:36s}: median {t:.3f} ms = {2.0 * M * N * K / t / 1e9:6.0f} TFLOP/s  ({t - base:+.3f} ms vs default)',
+        print(f'{name:9s} M={M} N={N} K={K}  {tag:46s}: median {t:.3f} ms = {2.0 * M * N * K / t / 1e9:6.0f} TFLOP/s  ({t - base:+.3f} ms vs default)',
               flush=True)
     del A, W, hi, lo, out16, rs
