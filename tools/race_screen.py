@@ -11,10 +11,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eventclip_amd import ops  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+_args = [a for a in sys.argv[1:] if not a.startswith('--')]
+reps = int(_args[0]) if _args else 60
+ONLY_FP8 = '--only-fp8' in sys.argv        # round 6: the new kernel forms alone (the others: profiles/r5_race_screen.txt)
 shapes = [(65792, 3072, 1024), (65792, 1024, 1024), (65792, 4096, 1024), (65792, 1024, 4096), (70001, 768, 640),
           (33333, 1024, 64), (257 * 300, 512, 512), (9999, 1536, 2048), (300000, 256, 128)]
 bad = 0
+if ONLY_FP8:
+    shapes = []
 noise = torch.empty(64 << 20, device='cuda')          # a copy kernel between launches perturbs L2 / HBM timing
 for (M, N, K) in shapes:
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
@@ -73,7 +77,7 @@ def repeat(label, fn, check):
 
 
 # transposed operands: C = A^T W over the rows, in row batches (ragged last K tile)
-for (rows, M, N, splits) in ((16448, 1024, 3072, 5), (16448, 1024, 1024, 16), (16448, 4096, 1024, 4), (70001, 768, 768, 8),
+for (rows, M, N, splits) in () if ONLY_FP8 else ((16448, 1024, 3072, 5), (16448, 1024, 1024, 16), (16448, 4096, 1024, 4), (70001, 768, 768, 8),
                              (3001, 256, 512, 2), (16448, 1024, 4096, 4)):
     g = torch.Generator(device='cuda').manual_seed(rows + M + N)
     A = torch.randn(rows, M, device='cuda', generator=g).half()
@@ -88,7 +92,7 @@ for (rows, M, N, splits) in ((16448, 1024, 3072, 5), (16448, 1024, 1024, 16), (1
 
 # a few frames: K-batched launches + fixup (ec_gemm_args.ws), every epilogue the fixup implements
 ws = torch.empty(80 << 20, dtype=torch.uint8, device='cuda')
-for (M, N, K) in ((257, 1024, 1024), (257, 3072, 1024), (514, 1024, 4096), (50, 768, 3072), (2570, 4096, 1024)):
+for (M, N, K) in () if ONLY_FP8 else ((257, 1024, 1024), (257, 3072, 1024), (514, 1024, 4096), (50, 768, 3072), (2570, 4096, 1024)):
     g = torch.Generator(device='cuda').manual_seed(M * 7 + N + K)
     A = torch.randn(M, K, device='cuda', generator=g).half()
     W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).half()
@@ -112,7 +116,7 @@ for (M, N, K) in ((257, 1024, 1024), (257, 3072, 1024), (514, 1024, 4096), (50, 
         repeat(('ws', M, N, K, epi), run, check)
 
 # LayerNorm folded into the GEMMs (round 3): hi / lo residual planes, row statistics, LN-finishing epilogues
-for (M, N, K) in ((65792, 1024, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
+for (M, N, K) in () if ONLY_FP8 else ((65792, 1024, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
     g = torch.Generator(device='cuda').manual_seed(M + N * 5 + K)
     A = torch.randn(M, K, device='cuda', generator=g).half()
     W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).half()
@@ -130,7 +134,7 @@ for (M, N, K) in ((65792, 1024, 1024), (65792, 1024, 4096), (70001, 768, 640), (
         e = float((hi.float() + lo.float() - want).abs().max() / want.abs().max())
         return e if e > 2e-6 else None
     repeat(('resid_hl', M, N, K), run_hl, check_hl)
-for (M, N, K) in ((65792, 3072, 1024), (65792, 4096, 1024), (70001, 768, 640), (514, 3072, 1024)):
+for (M, N, K) in () if ONLY_FP8 else ((65792, 3072, 1024), (65792, 4096, 1024), (70001, 768, 640), (514, 3072, 1024)):
     g = torch.Generator(device='cuda').manual_seed(M + N * 3 + K * 7)
     X = (torch.randn(M, K, device='cuda', generator=g) * 2 + 0.3).half()
     gamma, beta = 1 + 0.2 * torch.randn(K, device='cuda', generator=g), 0.3 * torch.randn(K, device='cuda', generator=g)
@@ -153,7 +157,7 @@ for (M, N, K) in ((65792, 3072, 1024), (65792, 4096, 1024), (70001, 768, 640), (
 
 # split-precision products in one launch (round 5): segments a_lo . w / a . w_lo / a . w, every epilogue the tower runs on
 # them, the 16-bit ones with and without the lo output
-for (M, N, K) in ((65792, 3072, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
+for (M, N, K) in () if ONLY_FP8 else ((65792, 3072, 1024), (65792, 1024, 4096), (70001, 768, 640), (257, 1024, 1024)):
     g = torch.Generator(device='cuda').manual_seed(M * 3 + N + K * 11)
     a = torch.randn(M, K, device='cuda', generator=g)
     w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
@@ -183,6 +187,58 @@ for (M, N, K) in ((65792, 3072, 1024), (65792, 1024, 4096), (70001, 768, 640), (
             e = float((got - ref).abs().max() / ref.abs().max())
             return e if not e <= tol else None
         repeat(('segments', epi, 'lo out' if with_lo else '', M, N, K), run_seg, check_seg)
+
+# lo products on the FP8 matrix path (round 6): e4m3 segments in front of the 16-bit ones, every epilogue the tolerance mode runs
+# on them (STORE16 with the 16-bit lo output, GELU16 with the e4m3 lo output, RESID_HL), one and two e4m3 segments, + a 16-bit W_lo
+for (M, N, K) in ((65792, 3072, 1024), (65792, 1024, 4096), (70001, 768, 768), (257, 1024, 1024)):
+    g = torch.Generator(device='cuda').manual_seed(M * 3 + N + K * 13)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    a_hi, w_hi = a.half(), w.half()
+    w_lo = (w - w_hi.float()).half()
+    A_lo8, W8 = ops.quantize_e4m3(a - a_hi.float(), exp=12), ops.quantize_e4m3(w_hi)
+    A8, W_lo8 = ops.quantize_e4m3(a_hi, exp=0), ops.quantize_e4m3(w - w_hi.float())
+    bias = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g) * 3
+    hi0, lo0 = x.half(), (x - x.half().float()).half()
+    base = a_hi.double() @ w_hi.double().t() + bias.double() + ops.dequantize_e4m3(*A_lo8, K).double() @ ops.dequantize_e4m3(*W8, K).double().t()
+    two = base + ops.dequantize_e4m3(*A8, K).double() @ ops.dequantize_e4m3(*W_lo8, K).double().t()
+    mixed = base + a_hi.double() @ w_lo.double().t()
+    del a, w
+    for epi, parts, lo_out in (('store32', 'one', ''), ('store16', 'two', 'f16'), ('store16', 'one', ''), ('gelu16', 'two', 'e4m3'),
+                               ('gelu16', 'one', 'e4m3'), ('gelu16', 'one', ''), ('resid_hl', 'one', ''), ('resid_hl', 'mixed', '')):
+        kw = dict(A_lo8=A_lo8, W8=W8)
+        if parts == 'two':
+            kw.update(A8=A8, W_lo8=W_lo8)
+        if parts == 'mixed':
+            kw.update(W_lo=w_lo)
+        full = two if parts == 'two' else mixed if parts == 'mixed' else base
+
+        def run_f8(epi=epi, kw=kw, lo_out=lo_out):
+            if epi == 'resid_hl':
+                hi, lo = hi0.clone(), lo0.clone()
+                ops.gemm(a_hi, w_hi, bias, epi, out=hi, aux=lo, **kw)
+                return hi, lo
+            out = torch.full((M, N), float('nan'), dtype=torch.float32 if epi == 'store32' else torch.float16, device='cuda')
+            if lo_out == 'f16':
+                aux = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda')
+                return ops.gemm(a_hi, w_hi, bias, epi, out=out, aux=aux, **kw), aux
+            if lo_out == 'e4m3':
+                aux8 = torch.full((M, 2 * N), 0x7f, dtype=torch.uint8, device='cuda')
+                return ops.gemm(a_hi, w_hi, bias, epi, out=out, aux8=(aux8, 12), **kw), aux8
+            return ops.gemm(a_hi, w_hi, bias, epi, out=out, **kw)
+
+        def check_f8(out, *rest, epi=epi, full=full, lo_out=lo_out):
+            ref = full + x.double() if epi == 'resid_hl' else (full * torch.sigmoid(1.702 * full) if epi == 'gelu16' else full)
+            got = out.double()
+            if epi == 'resid_hl' or lo_out == 'f16':
+                got = got + rest[0].double()
+            if lo_out == 'e4m3':
+                got = got + ops.dequantize_e4m3(rest[0], 12, N).double()
+            tol = 2e-5 if (epi in ('resid_hl', 'store32') or lo_out == 'f16') else (2e-4 if lo_out == 'e4m3' else 2e-3)
+            e = float((got - ref).abs().max() / ref.abs().max())
+            return e if not e <= tol else None
+        repeat(('e4m3 segments', epi, parts, lo_out, M, N, K), run_f8, check_f8)
 
 print('race screen:', 'CLEAN' if bad == 0 else f'{bad} problems', f'({reps} repeats per case)')
 sys.exit(1 if bad else 0)
