@@ -493,6 +493,43 @@ def test_precise_blocks_tower(dt, hip):
             eclip.CLIP(cfg, sd, dtype=dt, **kw).cuda().encode_image(img.cuda())
 
 
+@pytest.mark.parametrize('f16_weights', [False, True])
+def test_split_operand_blocks_with_e4m3_lo_products(f16_weights, hip):
+    """ec_vit_weights.lo_fp8 (round 6): the lo products of the split-operand blocks' QKV / c_fc / c_proj GEMMs as e4m3
+    operands.  On a 4-block ViT-B/32 with three split-operand blocks (two of them with fp32-class attention): the features stay
+    within 3e-5 of the 16-bit-lo form's (relative to the largest feature: an e4m3 lo product is a 2^-15 perturbation of its
+    GEMM) and as close to the fp32 oracle; the e4m3 weights are packed exactly where the C side needs them (lo parts only
+    where the matrix has one: none on a checkpoint stored in 16 bit); chunked and whole-batch calls agree bit for bit."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-B/32', layers=4, text_layers=1, vocab_size=1024)
+    sd = eclip.random_state_dict(cfg, seed=3, qk_gain=2.0, branch_gain=3.0)
+    if f16_weights:
+        sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    img = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    want = clip_ref.encode_image(sd, cfg, img)
+    kw = dict(image_precise_blocks=3, image_precise_attn_blocks=2)
+    m8 = eclip.CLIP(cfg, sd, image_lo_fp8=True, **kw).cuda().eval()
+    m16 = eclip.CLIP(cfg, sd, image_lo_fp8=False, **kw).cuda().eval()
+    f8, f16 = m8.encode_image(img.cuda()).cpu(), m16.encode_image(img.cuda()).cpu()
+    assert m8._pack()['vit'].lo_fp8 == 1 and m16._pack()['vit'].lo_fp8 == 0
+    b8, b16 = m8._pack()['vb'], m16._pack()['vb']
+    for l in range(4):
+        split = l < 3
+        assert (b8[l].qkv_w8 is not None) == split and (b8[l].fc1_w8 is not None) == split and (b8[l].fc2_w8 is not None) == split
+        assert (b8[l].qkv_wlo8 is not None) == (split and not f16_weights) and (b8[l].fc1_wlo8 is not None) == (split and not f16_weights)
+        assert b16[l].qkv_w8 is None and b16[l].qkv_wlo8 is None
+    e8, e16 = rel_err(f8, want), rel_err(f16, want)
+    d = float((f8 - f16).abs().max() / f16.abs().max())
+    print(f'\n[lo_fp8 on 3 of 4 blocks, f16 weights {f16_weights}] error vs fp32: e4m3 lo {e8:.2e}, 16-bit lo {e16:.2e}; e4m3 vs 16-bit {d:.2e}')
+    assert d < 3e-5 and e8 < 1.25 * e16 + 1e-5, (d, e8, e16)
+    e0 = rel_err(eclip.CLIP(cfg, sd).cuda().eval().encode_image(img.cuda()).cpu(), want)
+    assert e8 < 0.6 * e0, (e8, e0)
+    a = eclip.CLIP(cfg, sd, image_lo_fp8=True, chunk=2, **kw).cuda().eval().encode_image(img.cuda()).cpu()
+    assert torch.equal(a, f8)
+
+
 def test_weights_stored_in_16_bit_skip_the_lo_product(hip):
     """ec_vit_weights.weights_exact16: on a checkpoint whose matrices are 16-bit values already (what clip.load() returns
     on a GPU) the split-precision blocks pass NULL lo parts and run one MFMA product per GEMM less; the skipped product

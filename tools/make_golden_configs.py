@@ -34,7 +34,7 @@ def main():
     a = ap.parse_args()
     for c in [int(x) for x in a.configs.split(',')]:
         for weights in a.weights.split(','):
-            draws = [int(x) for x in a.draws.split(',')] if a.draws else (list(range(cc.N_DRAWS)) if weights == 'signal' else [0])
+            draws = [int(x) for x in a.draws.split(',')] if a.draws else (list(range(cc.N_DRAWS)) if weights.startswith('signal') else [0])
             path = cc.golden_path(c, weights)
             z = dict(np.load(path, allow_pickle=False)) if os.path.exists(path) else {}
             for d in draws:

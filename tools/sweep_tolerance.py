@@ -39,7 +39,7 @@ def main():
     a = ap.parse_args()
     extra = {k: int(v) for k, v in (kv.split('=') for kv in a.clip_kw.split(',') if kv)}
     configs = [int(c) for c in a.configs.split(',')]
-    rows = {}
+    rows, rows_c = {}, {}
     t0 = time.time()
     for c in configs:
         for d in range(a.seeds):
@@ -59,6 +59,7 @@ def main():
                 e = tc.logit_errors({k: v.cpu() for k, v in out.items()}, want)
                 top1 = bool(torch.equal(out['logits'].argmax(-1).cpu(), want['logits'].argmax(-1)))
                 rows.setdefault((s, c), []).append(e['full_logits'][0])
+                rows_c.setdefault((s, c), []).append(e['full_logits'][1])
                 tag = s if s in ('default',) else f'{s} {kw.get("image_precise_blocks")}:{kw.get("image_precise_attn_blocks")}'
                 print(f'[{tag}] configs[{c}] draw {d} (seeds {inp["wseed"]}, {inp["eseed"]}; share {share:.2f}; oracle {src}): '
                       f'full_logits {e["full_logits"][0]:.2e} (centred {e["full_logits"][1]:.2e}), logits {e["logits"][0]:.2e}; '
@@ -68,10 +69,11 @@ def main():
                 torch.cuda.empty_cache()
     print()
     print(f'summary over {a.seeds} draws per config, weights = {a.weights}: full_logits max |err| / max |logit| vs the fp32 oracle')
-    print('setting | config | median | worst | draws inside 1e-3')
+    print('setting | config | median | worst | draws inside 1e-3 | centred (error / largest input-dependent part of a logit): median | worst')
     for (s, c), v in rows.items():
-        v = np.asarray(v)
-        print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {int(v.argmax())}) | {int((v < 1e-3).sum())} / {len(v)}')
+        v, vc = np.asarray(v), np.asarray(rows_c[(s, c)])
+        print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {int(v.argmax())}) | {int((v < 1e-3).sum())} / {len(v)} | '
+              f'{np.median(vc):.2e} | {vc.max():.2e} (draw {int(vc.argmax())})')
     print(f'({time.time() - t0:.0f} s)')
     if a.json:
         import json
@@ -82,6 +84,7 @@ def main():
             summ.setdefault(s, {})[f'configs[{c}]'] = {
                 'median': float(np.median(v)), 'worst': float(v.max()), 'worst_draw': int(v.argmax()),
                 'inside_1e3': f'{int((v < 1e-3).sum())} / {len(v)}',
+                'centred_median': float(np.median(rows_c[(s, c)])), 'centred_worst': float(np.max(rows_c[(s, c)])),
                 **({'blocks': [kw['image_precise_blocks'], kw['image_precise_attn_blocks']]} if kw else {})}
         json.dump({'metric': 'full_logits max |err| / max |logit| vs the fp32 oracle, over the (weight seed, event seed) draws of '
                              'tests/config_cases.py', 'draws_per_config': a.seeds, 'weights': a.weights, 'settings': summ,
