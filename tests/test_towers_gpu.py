@@ -496,9 +496,10 @@ def test_precise_blocks_tower(dt, hip):
 @pytest.mark.parametrize('f16_weights', [False, True])
 def test_split_operand_blocks_with_e4m3_lo_products(f16_weights, hip):
     """ec_vit_weights.lo_fp8 (round 6): the lo products of the split-operand blocks' QKV / c_fc / c_proj GEMMs as e4m3
-    operands.  On a 4-block ViT-B/32 with three split-operand blocks (two of them with fp32-class attention): the features stay
-    within 3e-5 of the 16-bit-lo form's (relative to the largest feature: an e4m3 lo product is a 2^-15 perturbation of its
-    GEMM) and as close to the fp32 oracle; the e4m3 weights are packed exactly where the C side needs them (lo parts only
+    operands.  On a 4-block ViT-B/32 with three split-operand blocks (two of them with fp32-class attention): the features are as
+    close to the fp32 oracle as the 16-bit-lo form's (the two forms differ from EACH OTHER by about that error: the 16-bit
+    block behind them rounds a slightly different input differently, so its rounding errors decorrelate -- the reason why
+    the max-normalised error moves by +- 15 % between forms of equal accuracy); the e4m3 weights are packed exactly where the C side needs them (lo parts only
     where the matrix has one: none on a checkpoint stored in 16 bit); chunked and whole-batch calls agree bit for bit."""
     import torch
     from eventclip_amd import clip as eclip
@@ -523,7 +524,7 @@ def test_split_operand_blocks_with_e4m3_lo_products(f16_weights, hip):
     e8, e16 = rel_err(f8, want), rel_err(f16, want)
     d = float((f8 - f16).abs().max() / f16.abs().max())
     print(f'\n[lo_fp8 on 3 of 4 blocks, f16 weights {f16_weights}] error vs fp32: e4m3 lo {e8:.2e}, 16-bit lo {e16:.2e}; e4m3 vs 16-bit {d:.2e}')
-    assert d < 3e-5 and e8 < 1.25 * e16 + 1e-5, (d, e8, e16)
+    assert d < 2 * e16 and e8 < 1.25 * e16 + 1e-5, (d, e8, e16)
     e0 = rel_err(eclip.CLIP(cfg, sd).cuda().eval().encode_image(img.cuda()).cpu(), want)
     assert e8 < 0.6 * e0, (e8, e0)
     a = eclip.CLIP(cfg, sd, image_lo_fp8=True, chunk=2, **kw).cuda().eval().encode_image(img.cuda()).cpu()
