@@ -187,7 +187,11 @@ def parity_seeds_summary():
     path = os.path.join(ROOT, 'profiles', 'r6_parity_seeds.json')
     if not os.path.exists(path):
         return 'profiles/r6_parity_seeds.json missing: not measured'
-    return dict(json.load(open(path)), source='profiles/r6_parity_seeds.json (+ .txt: every draw)')
+    out = dict(json.load(open(path)), source='profiles/r6_parity_seeds.json (+ .txt: every draw)')
+    p16 = os.path.join(ROOT, 'profiles', 'r6_parity_seeds_16bit_weights.json')
+    if os.path.exists(p16):      # the same draws on weights rounded to 16 bit first (what a released checkpoint is)
+        out['on_weights_rounded_to_16_bit'] = dict(json.load(open(p16))['settings'], source='profiles/r6_parity_seeds_16bit_weights.json')
+    return out
 
 
 def cpu_model():
