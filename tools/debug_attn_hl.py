@@ -1,5 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, '/root/repo')
+# EC_ATTN_SPLIT_F32 is read by the DIAGNOSTIC build only since round 6 (the product library's kernel choice never depends on the environment)
+os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join('/root/repo', 'eventclip_amd', 'libeventclip_hip_diag.so'))
 from eventclip_amd import _lib
 lib = _lib.lib()
 heads, W = 4, 256

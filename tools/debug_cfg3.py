@@ -2,6 +2,8 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+# EC_ATTN_SPLIT_F32 is read by the DIAGNOSTIC build only since round 6 (the product library's kernel choice never depends on the environment)
+os.environ.setdefault('EVENTCLIP_HIP_LIB', os.path.join(ROOT, 'eventclip_amd', 'libeventclip_hip_diag.so'))
 import torch
 import test_configs_gpu as tc
 from eventclip_amd import clip as eclip
