@@ -121,3 +121,34 @@ def test_f16_operands_do_not_overflow_at_large_activations(hip):
     f = m.encode_image(imgs.cuda()).cpu()
     assert torch.isfinite(f).all()
     assert float((f - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+def test_e4m3_lo_products_saturate_gracefully_at_large_activations(hip):
+    """The tolerance mode's e4m3 lo parts carry one power-of-two scale per tensor (lo . 2^12: values beyond +-448 . 2^-12
+    saturate, i.e. activations beyond +-256 are corrected only in part; the e4m3 copy of a hi part saturates beyond +-448).
+    With LayerNorm gains of 30 and QuickGELU inputs in the thousands -- far outside what either scale covers -- the
+    split-operand blocks must stay finite, agree with the oracle like the 16-bit-lo form does, and never do worse than the
+    default 16-bit path: a saturated lo part degrades to the uncorrected 16-bit product for that element, no further."""
+    import torch
+    from eventclip_amd import clip as eclip
+    from oracle import clip_ref
+    cfg = eclip.arch_config('ViT-L/14', layers=3, text_layers=1)
+    sd = eclip.random_state_dict(cfg, seed=78)
+    for l in range(3):
+        p = f'visual.transformer.resblocks.{l}.'
+        sd[p + 'ln_1.weight'] *= 30.
+        sd[p + 'attn.in_proj_weight'] /= 30.
+        sd[p + 'ln_2.weight'] *= 30.
+        sd[p + 'mlp.c_fc.weight'] *= 8.
+        sd[p + 'mlp.c_proj.weight'] /= 240.
+    imgs = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    ref = clip_ref.encode_image(sd, cfg, imgs)
+    err = {}
+    for name, kw in (('default', {}), ('lo16', dict(image_precise_blocks=2, image_precise_attn_blocks=2, image_lo_fp8=False)),
+                     ('lo8', dict(image_precise_blocks=2, image_precise_attn_blocks=2, image_lo_fp8=True))):
+        f = eclip.CLIP(cfg, sd, dtype='float16', **kw).cuda().eval().encode_image(imgs.cuda()).cpu()
+        assert torch.isfinite(f).all(), name
+        err[name] = float((f - ref).abs().max() / ref.abs().max())
+    print('\n[large activations, 2 of 3 blocks split] error vs fp32:', {k: f'{v:.2e}' for k, v in err.items()})
+    assert err['lo8'] < 2e-3 and err['lo16'] < 2e-3
+    assert err['lo8'] <= 1.2 * err['default'], err
