@@ -46,3 +46,23 @@ def test_classify_workspace_size_is_a_host_function():
     assert b % 256 == 0 and int(lib.ec_classify_v2_workspace_bytes(0, C, K)) == 0
     t = int(lib.ec_classify_text_bytes(C, K))
     assert t >= 2 * 112 * C * 2 + 112 * 4 and t % 256 == 0 and int(lib.ec_classify_text_bytes(0, K)) == 0
+
+
+def test_tolerance_mode_settings(monkeypatch):
+    """eventclip_amd.clip.TOLERANCE_MODE is the one place the tolerance mode's counts live (bench.py prices them, the config tests
+    hold them to 1e-3, profiles/r6_parity_seeds.json records them): by sequence length, clamped to the depth of the tower."""
+    from eventclip_amd import clip as eclip
+    short, long_ = eclip.TOLERANCE_MODE
+    assert eclip.tolerance_mode_kwargs('ViT-L/14') == dict(image_precise_blocks=short[0], image_precise_attn_blocks=short[1])
+    assert eclip.tolerance_mode_kwargs('ViT-L/14@336px') == dict(image_precise_blocks=long_[0], image_precise_attn_blocks=long_[1])
+    kw = eclip.tolerance_mode_kwargs('ViT-B/32')                                  # 12 layers: at most 11 split-operand blocks
+    assert kw['image_precise_blocks'] == min(short[0], 11) and kw['image_precise_attn_blocks'] <= kw['image_precise_blocks']
+    cfg = eclip.arch_config('ViT-B/32', layers=4, text_layers=1, vocab_size=64)
+    sd = eclip.random_state_dict(cfg, seed=0)
+    m = eclip.CLIP(cfg, sd, **eclip.tolerance_mode_kwargs(cfg))
+    assert m.image_precise_blocks == 3 and m.image_lo_fp8 == eclip.DEFAULT_LO_FP8
+    assert eclip.CLIP(cfg, sd).image_lo_fp8 is False                              # no split-operand blocks: nothing to run on e4m3
+    monkeypatch.setenv('EVENTCLIP_LO_FP8', '0')
+    assert eclip.CLIP(cfg, sd, image_precise_blocks=2).image_lo_fp8 is False
+    monkeypatch.setenv('EVENTCLIP_TOLERANCE_MODE', '2:1')
+    assert eclip.tolerance_mode_kwargs(cfg) == dict(image_precise_blocks=2, image_precise_attn_blocks=1)
