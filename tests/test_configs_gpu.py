@@ -32,7 +32,8 @@ from config_cases import (CASES, SIGNAL_GAINS, build_inputs, load_golden, finger
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3 relative of the reference's (fp32 oracle)
 # Input-dependent weights: the max-normalised error of full_logits against the fp32 oracle, per config, pinned at
-# 1.5 x what the HIP path measures (profiles/r5_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 4.9e-3 / 5.3e-3; the two N-ImageNet
+# 1.5 x what the HIP path measures on draw 0 (profiles/r5_parity.txt: 1.3e-3 / 1.9e-3 / 1.3e-3 / 4.9e-3 / 5.3e-3; all eight draws:
+# profiles/r6_parity_seeds.txt, worst 2.4e-3 / 1.9e-3 / 2.5e-3 / 6.7e-3 / 7.2e-3; the two N-ImageNet
 # cases were 3.1e-3 / 2.2e-3 on round 4's wide blobs, where 8 - 15 % of their features depended on the input: they now
 # carry 25 - 27 %, make_events_batch) -- a regression of 2 x fails.  north_star's 1e-3 is NOT met there with 16-bit GEMM
 # operands: the tolerance mode (ec_vit_weights.precise_blocks) gets every config under it over the draws of
