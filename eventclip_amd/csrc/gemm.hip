@@ -875,11 +875,16 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
             for (int i = 0; i < 2; i++) glds16(src[r][i], smem + buf * KT + r * REGION + (i * 8 + wave) * 1024);
         } else if constexpr (SEG) {
             int &kb = r == 1 ? ky : kx, &sg = r == 1 ? sy : sx;
+            int vb = r < 2 ? vbA : vbW;
+            // SEG == 2: the per-lane base stays ONE register per operand (opaque here): hoisted as eight `base + row offset`
+            // sums they did not fit beside the two loops' fragments and came back from scratch behind s_waitcnt vmcnt(0) at
+            // every tile hand-over
+            if constexpr (SEG == 2) asm volatile("" : "+v"(vb));
 #pragma unroll
             for (int i = 0; i < 2; i++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r == 1 ? rsAy : r == 0 ? rsA : rsW,
                                                          (__attribute__((address_space(3))) void *)(smem + buf * KT + r * REGION + (i * 8 + wave) * 1024),
-                                                         16, (r < 2 ? vbA : vbW) + (srow[r][i] + kb), 0, 0, 0);
+                                                         16, vb + (srow[r][i] + kb), 0, 0, 0);
             if (r == 1 || r == 3) {
                 kb += BK * 2;
                 if (kb == ((SEG == 2 && sg < g.nf8) ? (kseg >> 1) : kseg)) {
