@@ -524,7 +524,8 @@ def other_configs(a, fence, cpu=True):
     loop).  The builder-run full-size lines are profiles/r6_configs_bench.jsonl."""
     from eventclip_amd import _lib
     res = {}
-    for cid, batch in OTHER_CONFIG_BATCH.items():
+
+    def one(cid, batch):
         t_all = time.perf_counter()
         batch = a.other_configs_batch or batch
         w = build_workload(cid, 1, 0, batch=batch, arch=a.arch_given, classes=a.classes_given, dtype=a.dtype, chunk=a.chunk)
@@ -560,8 +561,13 @@ def other_configs(a, fence, cpu=True):
                 line['cpu_baseline_error'] = repr(e)
         line['wall_s'] = time.perf_counter() - t_all
         line['setup_s'] = t_setup
-        res[str(cid)] = line
-        del w, out, step
+        return line
+
+    for cid, batch in OTHER_CONFIG_BATCH.items():
+        try:
+            res[str(cid)] = one(cid, batch)
+        except Exception as e:   # noqa: BLE001 -- one config's failure costs that config's entry only
+            res[str(cid)] = {'error': repr(e)}
         torch.cuda.empty_cache()
     return res
 
@@ -665,39 +671,45 @@ def main():
     host_line = None
     # (on by default for the headline line on one GPU -- VERDICT r5 item 3: the host-fed number in the driver's record)
     if a.from_host or (world == 1 and a.config == 1 and not a.no_from_host):
-        host_samples = [evs[i % uniq_n] for i in range(local_batch)]      # numpy float32 [n_ev, 4] each
-        if a.packed_events:
-            from eventclip_amd.vis import pack_events
-            packed = [pack_events(e) for e in evs]
-            host_samples = [packed[i % uniq_n] for i in range(local_batch)]
+        # (measured after the timed region: a failure here must not cost the line its `value`; an explicit --from-host run raises)
+        try:
+            host_samples = [evs[i % uniq_n] for i in range(local_batch)]      # numpy float32 [n_ev, 4] each
+            if a.packed_events:
+                from eventclip_amd.vis import pack_events
+                packed = [pack_events(e) for e in evs]
+                host_samples = [packed[i % uniq_n] for i in range(local_batch)]
 
-        t0h = None
-        host_warm = min(a.warmup, 1) if not a.from_host else a.warmup
-        host_steps = min(a.steps, 5) if not a.from_host else a.steps
+            t0h = None
+            host_warm = min(a.warmup, 1) if not a.from_host else a.warmup
+            host_steps = min(a.steps, 5) if not a.from_host else a.steps
 
-        def host_batches():
-            for _ in range(host_warm + host_steps):
-                yield host_samples
-        for i, batch in enumerate(pipe.stream(host_batches(), depth=2)):
-            if i == host_warm:
-                fence()
-                t0h = time.perf_counter()
-            out_h = model(batch)
+            def host_batches():
+                for _ in range(host_warm + host_steps):
+                    yield host_samples
+            for i, batch in enumerate(pipe.stream(host_batches(), depth=2)):
+                if i == host_warm:
+                    fence()
+                    t0h = time.perf_counter()
+                out_h = model(batch)
+                if world > 1:
+                    out_h['logits'] = all_gather_rows(out_h['logits'], shard_sizes)
+            fence()
+            dth = time.perf_counter() - t0h
             if world > 1:
-                out_h['logits'] = all_gather_rows(out_h['logits'], shard_sizes)
-        fence()
-        dth = time.perf_counter() - t0h
-        if world > 1:
-            t = torch.tensor([dth], device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dth = float(t.item())
-        assert torch.equal(out_h['logits'], out['logits'])                 # same batch, same bits
-        host_bytes = sum(e.nbytes for e in host_samples)
-        host_line = {'value_from_host': total_frames * host_steps / dth, 'ms_per_step_from_host': dth / host_steps * 1e3,
-                     'from_host': {'bytes_per_step_per_gpu': host_bytes, 'steps': host_steps, 'warmup': host_warm,
-                                   'path': 'per-sample copies into a pinned staging ring (8 threads), one async H2D '
-                                           'copy per batch on a copy stream, batch i + 1 uploaded under the GPU work of '
-                                           'batch i (eventclip_amd.event2img.HostFeeder)'}}
+                t = torch.tensor([dth], device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dth = float(t.item())
+            assert torch.equal(out_h['logits'], out['logits'])                 # same batch, same bits
+            host_bytes = sum(e.nbytes for e in host_samples)
+            host_line = {'value_from_host': total_frames * host_steps / dth, 'ms_per_step_from_host': dth / host_steps * 1e3,
+                         'from_host': {'bytes_per_step_per_gpu': host_bytes, 'steps': host_steps, 'warmup': host_warm,
+                                       'path': 'per-sample copies into a pinned staging ring (8 threads), one async H2D '
+                                               'copy per batch on a copy stream, batch i + 1 uploaded under the GPU work of '
+                                               'batch i (eventclip_amd.event2img.HostFeeder)'}}
+        except Exception as e:   # noqa: BLE001
+            if a.from_host or world > 1:
+                raise
+            host_line = {'from_host_error': repr(e)}
 
     if rank == 0:
         value = total_frames * a.steps / dt
@@ -790,34 +802,45 @@ def main():
             dv = sample_dvfs(step, fence, device=local)
             if dv:
                 res['dvfs'] = dv
+        def extra(key, fn):
+            """the measurements behind the timed region never take the line down: a failure is recorded under key_error"""
+            try:
+                res[key] = fn()
+            except Exception as e:   # noqa: BLE001
+                res[key + '_error'] = repr(e)
+                sys.stderr.write(f'[bench] {key} failed: {e!r}\n')
         if world == 1 and a.config == 1 and not (a.no_tolerance_mode or a.precise or a.precise_blocks or a.tolerance_mode):
-            res['tolerance_mode'] = tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
-                                                   frames_per_step, res['ms_per_step'])
+            extra('tolerance_mode', lambda: tolerance_mode(a, cfg, sd, clip_dict, step, fence, pipe, events, n_events,
+                                                           frames_per_step, res['ms_per_step']))
         if world == 1 and not a.no_strict_line:
             # Event2ImagePipeline's DEFAULT (strict = True) reads the events kernel's out-of-sensor count back to the
             # host every batch (event2img.py:106-110; the reference syncs per batch too, test.py:66); the timed region
             # runs strict = False: this is what the default costs on the same batch
-            pipe.strict = True
-            step()
-            fence()
-            t0s = time.perf_counter()
-            for _ in range(3):
-                step()
-            fence()
-            res['ms_per_step_strict'] = (time.perf_counter() - t0s) / 3 * 1e3
+            def strict_ms():
+                pipe.strict = True
+                try:
+                    step()
+                    fence()
+                    t0s = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    fence()
+                    return (time.perf_counter() - t0s) / 3 * 1e3
+                finally:
+                    pipe.strict = False
+            extra('ms_per_step_strict', strict_ms)
             res['strict_note'] = ('pipe.strict = True (the pipeline default: one 4-byte read-back of the dropped-event count per '
                                   'batch), 3 steps after the timed region; `value` is timed with strict = False')
-            pipe.strict = False
         if world == 1 and not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, sd, tokens, evs, quantize_args,
-                                               a.cpu_baseline_samples if a.config == 1 else 1,
-                                               min(a.cpu_baseline_frames, T) if a.config != 3 else 2,
-                                               shape=geo['resolution'], pool=(a.config == 1))
+            extra('cpu_baseline', lambda: cpu_baseline(cfg, sd, tokens, evs, quantize_args,
+                                                       a.cpu_baseline_samples if a.config == 1 else 1,
+                                                       min(a.cpu_baseline_frames, T) if a.config != 3 else 2,
+                                                       shape=geo['resolution'], pool=(a.config == 1)))
         if world == 1 and a.config == 1 and not (a.no_other_configs or a.precise or a.precise_blocks or a.f16_weights or a.tolerance_mode):
             # release the headline's model / workspace / events first: the other configs build their own
             del w, model, clip_model, clip_dict, pipe, events, out, step
             torch.cuda.empty_cache()
-            res['other_configs'] = other_configs(a, fence, cpu=not a.no_cpu_baseline)
+            extra('other_configs', lambda: other_configs(a, fence, cpu=not a.no_cpu_baseline))
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
