@@ -506,3 +506,35 @@ def test_layernorm_hl8_writes_e4m3_operands(rows, width, hip):
     _lib.check(lib.ec_layernorm_hl8(_lib.ptr(x_hi), _lib.ptr(x_lo), width, _lib.ptr(gamma), _lib.ptr(beta), rows, width, 1e-5,
                                     _lib.ptr(p_hi), _lib.ptr(lo8b), None, width, 12, 0, _lib.stream_ptr()))
     assert torch.equal(lo8b[:, :width], lo8[:, :width])
+
+
+@pytest.mark.parametrize('M,N,K', [(257 * 3, 4096, 1024), (77, 768, 768), (300, 48, 256)])
+def test_gelu16_writes_its_lo_part_as_e4m3(M, N, K, hip):
+    """EC_EPI_GELU16 with ec_gemm_args.aux_e4m3 (the c_fc GEMM of a split-operand block under lo_fp8): C = hi = round16(v),
+    aux = round_e4m3((v - hi) . 2^12), one byte per element in the first N bytes of rows of 2 N bytes -- the A_lo8 operand of
+    c_proj.  hi is bit-identical to the same launch with a 16-bit lo output, the e4m3 bytes are the rounding of that launch's
+    lo part (to the 2^-11 the fp16 lo itself carries), the second half of every aux row is not touched, and hi + dq(lo8)
+    reproduces QuickGELU(a w^T + b) of the dequantised operands to 2^-4 of a 16-bit ulp."""
+    import torch
+    from eventclip_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    bias = 0.1 * torch.randn(N, device='cuda', generator=g)
+    a_hi, w_hi = a.half(), w.half()
+    A_lo8, W8 = ops.quantize_e4m3(a - a_hi.float(), exp=12), ops.quantize_e4m3(w_hi)
+    lo16 = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda')
+    hi_a = ops.gemm(a_hi, w_hi, bias, 'gelu16', aux=lo16, A_lo8=A_lo8, W8=W8)
+    lo8 = torch.full((M, 2 * N), 0x55, dtype=torch.uint8, device='cuda')
+    hi_b = ops.gemm(a_hi, w_hi, bias, 'gelu16', aux8=(lo8, 12), A_lo8=A_lo8, W8=W8)
+    assert torch.equal(hi_a, hi_b)
+    assert bool((lo8[:, N:] == 0x55).all())
+    dq = ops.dequantize_e4m3(lo8, 12, N)
+    assert bool(((dq - lo16.float()).abs() <= 2.0 ** -4 * lo16.float().abs() + 2.0 ** -20).all())
+    ref = a_hi.double() @ w_hi.double().t() + bias.double() + ops.dequantize_e4m3(*A_lo8, K).double() @ ops.dequantize_e4m3(*W8, K).double().t()
+    ref = ref * torch.sigmoid(1.702 * ref)
+    e8 = float(((hi_b.double() + dq.double()) - ref).abs().max() / ref.abs().max())
+    e16 = float((hi_b.double() - ref).abs().max() / ref.abs().max())
+    assert e8 < 0.12 * e16 + 2e-6, (e8, e16)
+    with pytest.raises(RuntimeError, match='aux_e4m3'):        # the e4m3 lo output exists with e4m3 lo products and GELU16 only
+        ops.gemm(a_hi, w_hi, bias, 'store16', aux8=(lo8, 12), A_lo8=A_lo8, W8=W8)
