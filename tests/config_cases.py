@@ -18,6 +18,9 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 N_DRAWS = 8
+# eight more draws per config that no setting was ever chosen on: the tolerance mode's counts were picked on draws 0 .. 7, these
+# validate them (profiles/r6_parity_seeds_held_out.txt; tools/sweep_tolerance.py --draws 8-15)
+HELD_OUT_DRAWS = tuple(range(8, 16))
 
 # key = the SIGNAL_GAINS / SIGNAL_TOL key; counts = events per sample (ragged view counts on purpose)
 CASES = {
@@ -50,6 +53,8 @@ def draw_seeds(c, d):
     """(weight seed, event seed) of draw d of config c; draw 0 = the historical pair."""
     if d == 0:
         return CASES[c]['wseed'], CASES[c]['eseed']
+    if d >= N_DRAWS:          # the held-out draws (HELD_OUT_DRAWS): never used to pick a setting
+        return 3000 + 100 * c + d, 4000 + 100 * c + d
     return 1000 + 10 * c + d, 2000 + 10 * c + d
 
 

@@ -22,8 +22,13 @@ def test_every_config_ships_its_draws():
                 assert g['emu_full_logits'].shape == (B, T, K) and g['feats'].shape[0] == int(g['valid_masks'].sum())
                 assert np.isfinite(g['full_logits']).all() and g['fingerprint'].shape == (6,)
     assert cc.load_golden(1, 'signal16', 0) is not None
-    seeds = {cc.draw_seeds(c, d) for c in range(5) for d in range(cc.N_DRAWS)}
-    assert len(seeds) == 5 * cc.N_DRAWS                       # no (weights, events) pair is used twice
+    all_draws = list(range(cc.N_DRAWS)) + list(cc.HELD_OUT_DRAWS)
+    seeds = {cc.draw_seeds(c, d) for c in range(5) for d in all_draws}
+    assert len(seeds) == 5 * len(all_draws)                   # no (weights, events) pair is used twice
+    assert len({s[0] for s in seeds}) == len(seeds) and len({s[1] for s in seeds}) == len(seeds)
+    for c in range(5):                                        # the held-out draws (never used to pick a setting) ship too
+        for d in cc.HELD_OUT_DRAWS:
+            assert cc.load_golden(c, 'signal', d) is not None, (c, d)
 
 
 def test_configs0_oracle_reproduces_the_shipped_outputs():

@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('settings', nargs='+')
     ap.add_argument('--seeds', type=int, default=8)
+    ap.add_argument('--draws', default=None, help="'8-15': these draws instead of 0 .. seeds - 1 (the held-out draws of tests/config_cases.py)")
     ap.add_argument('--configs', default='0,1,2,3,4')
     ap.add_argument('--weights', default='signal')
     ap.add_argument('--json', default=None, help='write the per-(setting, config) summary there (bench.py quotes profiles/r6_parity_seeds.json)')
@@ -40,9 +41,14 @@ def main():
     extra = {k: int(v) for k, v in (kv.split('=') for kv in a.clip_kw.split(',') if kv)}
     configs = [int(c) for c in a.configs.split(',')]
     rows, rows_c = {}, {}
+    if a.draws:
+        lo, _, hi = a.draws.partition('-')
+        draws = list(range(int(lo), int(hi or lo) + 1))
+    else:
+        draws = list(range(a.seeds))
     t0 = time.time()
     for c in configs:
-        for d in range(a.seeds):
+        for d in draws:
             inp = cc.build_inputs(c, a.weights, d)
             want, feats, emu, src = tc.oracle_for(inp)
             ee = tc.logit_errors(emu, want)
@@ -68,12 +74,12 @@ def main():
                 del out, model, pipe
                 torch.cuda.empty_cache()
     print()
-    print(f'summary over {a.seeds} draws per config, weights = {a.weights}: full_logits max |err| / max |logit| vs the fp32 oracle')
+    print(f'summary over draws {draws[0]} .. {draws[-1]} per config, weights = {a.weights}: full_logits max |err| / max |logit| vs the fp32 oracle')
     print('setting | config | median | worst | draws inside 1e-3 | centred (error / largest input-dependent part of a logit): median | worst')
     for (s, c), v in rows.items():
         v, vc = np.asarray(v), np.asarray(rows_c[(s, c)])
-        print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {int(v.argmax())}) | {int((v < 1e-3).sum())} / {len(v)} | '
-              f'{np.median(vc):.2e} | {vc.max():.2e} (draw {int(vc.argmax())})')
+        print(f'{s} | configs[{c}] | {np.median(v):.2e} | {v.max():.2e} (draw {draws[int(v.argmax())]}) | {int((v < 1e-3).sum())} / {len(v)} | '
+              f'{np.median(vc):.2e} | {vc.max():.2e} (draw {draws[int(vc.argmax())]})')
     print(f'({time.time() - t0:.0f} s)')
     if a.json:
         import json
@@ -82,12 +88,12 @@ def main():
             v = np.asarray(v)
             kw = eclip.tolerance_mode_kwargs(cc.CASES[c]['arch']) if s == 'mode' else None
             summ.setdefault(s, {})[f'configs[{c}]'] = {
-                'median': float(np.median(v)), 'worst': float(v.max()), 'worst_draw': int(v.argmax()),
+                'median': float(np.median(v)), 'worst': float(v.max()), 'worst_draw': draws[int(v.argmax())],
                 'inside_1e3': f'{int((v < 1e-3).sum())} / {len(v)}',
                 'centred_median': float(np.median(rows_c[(s, c)])), 'centred_worst': float(np.max(rows_c[(s, c)])),
                 **({'blocks': [kw['image_precise_blocks'], kw['image_precise_attn_blocks']]} if kw else {})}
         json.dump({'metric': 'full_logits max |err| / max |logit| vs the fp32 oracle, over the (weight seed, event seed) draws of '
-                             'tests/config_cases.py', 'draws_per_config': a.seeds, 'weights': a.weights, 'settings': summ,
+                             'tests/config_cases.py', 'draws_per_config': len(draws), 'draws': [draws[0], draws[-1]], 'weights': a.weights, 'settings': summ,
                    'note': 'configs[2] draw 5: max |logit| 1.53 (two classes, cosines below 0.016); see eventclip_amd/clip.py TOLERANCE_MODE'},
                   open(a.json, 'w'), indent=1)
 
