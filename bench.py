@@ -183,7 +183,8 @@ def parity_seeds_summary():
     """What profiles/r6_parity_seeds.json (tools/sweep_tolerance.py --seeds 8 --json) measured for the shipped
     tolerance-mode settings: per BASELINE config the median and the WORST of the eight (weight seed, event seed) draws of
     full_logits' max-normalised error against the fp32 oracle, and how many draws are inside 1e-3 -- next to the same for
-    the default path.  A measurement made in the build round, quoted here; not re-measured by this run."""
+    the default path, for the same draws on weights rounded to 16 bit, and for eight HELD-OUT draws per config that no setting
+    was chosen on.  A measurement made in the build round, quoted here; not re-measured by this run."""
     path = os.path.join(ROOT, 'profiles', 'r6_parity_seeds.json')
     if not os.path.exists(path):
         return 'profiles/r6_parity_seeds.json missing: not measured'
@@ -191,6 +192,9 @@ def parity_seeds_summary():
     p16 = os.path.join(ROOT, 'profiles', 'r6_parity_seeds_16bit_weights.json')
     if os.path.exists(p16):      # the same draws on weights rounded to 16 bit first (what a released checkpoint is)
         out['on_weights_rounded_to_16_bit'] = dict(json.load(open(p16))['settings'], source='profiles/r6_parity_seeds_16bit_weights.json')
+    ph = os.path.join(ROOT, 'profiles', 'r6_parity_seeds_held_out.json')
+    if os.path.exists(ph):       # eight more draws per config that no setting was chosen on
+        out['held_out_draws_8_to_15'] = dict(json.load(open(ph))['settings'], source='profiles/r6_parity_seeds_held_out.json')
     return out
 
 

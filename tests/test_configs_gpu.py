@@ -453,12 +453,12 @@ def test_config4_full_size_properties(hip):
     assert out['logits'].shape == (512, 1000) and out['valid_masks'].sum(1)[509:].tolist() == [1, 2, 4]
 
 
-# draws of tests/config_cases.py the tolerance mode is held to 1e-3 on, per config: the historical pair (0) and the two
-# WORST of the other draws at the shipped settings (profiles/r6_parity_seeds.txt, tools/sweep_tolerance.py --seeds 8 default mode:
-# worst-of-eight 2.6e-4 / 5.5e-4 / 7.5e-4 / 7.7e-4 on configs[0] / [1] / [3] / [4]).  configs[2] is inside on seven of its eight
-# draws (worst of those 6.9e-4, the historical pair); draw 5 is the one outside, held by
-# test_tolerance_mode_configs2_small_logits_draw
-TOLERANCE_DRAWS = {0: (0, 4, 3), 1: (0, 2, 5), 2: (0, 6, 4), 3: (0, 3, 6), 4: (0, 2, 6)}
+# draws of tests/config_cases.py the tolerance mode is held to 1e-3 on, per config: the historical pair (0), the WORST of draws
+# 1 .. 7 (the draws the counts were picked on) and the worst of the HELD-OUT draws 8 .. 15, at the shipped settings
+# (profiles/r6_parity_seeds.txt / r6_parity_seeds_held_out.txt: worst 2.4e-4 / 4.8e-4 / 8.0e-4 / 6.1e-4 and 2.9e-4 / 4.8e-4 / 7.2e-4 /
+# 5.5e-4 / 7.2e-4).  configs[2] draw 5 (fp32 weights) is the one pair of 120 outside, held by
+# test_tolerance_mode_configs2_small_logits_draw; the worst of configs[2]'s other selection draws is draw 3
+TOLERANCE_DRAWS = {0: (0, 3, 14), 1: (0, 4, 12), 2: (0, 3, 12), 3: (0, 6, 9), 4: (0, 2, 9)}
 
 
 @pytest.mark.parametrize('config,draw', [(c, d) for c in range(5) for d in TOLERANCE_DRAWS[c]])
@@ -466,9 +466,9 @@ def test_tolerance_mode_meets_1e3_over_draws(hip, config, draw, monkeypatch):
     """north_star's 1e-3 on input-dependent weights with the tolerance mode (ec_vit_weights.precise_blocks /
     precise_attn_blocks at eventclip_amd.clip.TOLERANCE_MODE's counts: the first blocks of the image tower as
     split-operand blocks, the first few of them with fp32-class attention, the rest as the folded 16-bit chain), on
-    THREE (weight seed, event seed) draws per config against the oracle logits shipped in tests/golden/configs_oracle_*
-    (profiles/r6_parity_seeds.txt has all eight draws per config, default path and tolerance mode: median, worst case,
-    fraction inside 1e-3)."""
+    THREE (weight seed, event seed) draws per config -- one of them held out when the counts were picked -- against the oracle
+    logits shipped in tests/golden/configs_oracle_* (profiles/r6_parity_seeds.txt / _held_out.txt / _16bit_weights.txt have every
+    draw, default path and tolerance mode: median, worst case, fraction inside 1e-3)."""
     import sys
     from eventclip_amd import clip as eclip
     mod = sys.modules[__name__]
@@ -477,11 +477,11 @@ def test_tolerance_mode_meets_1e3_over_draws(hip, config, draw, monkeypatch):
 
 
 def test_tolerance_mode_configs2_small_logits_draw(hip):
-    """The one (config, draw) of the forty in profiles/r6_parity_seeds.txt on which the tolerance mode is NOT inside 1e-3:
+    """The one (config, draw) of the 120 in profiles/r6_parity_seeds*.txt on which the tolerance mode is NOT inside 1e-3:
     configs[2] draw 5 (two classes, few-shot head: logits = 100 cos).  Its largest |logit| is 1.53 -- every cosine of the
-    batch below 0.016, five times smaller than the other draws' -- so the same absolute error (2.9e-3 logit units = 2.9e-5 in
-    the cosine) reads as 1.9e-3 of max |logit|.  Held here at what it measures, so that the number in the docs stays true:
-    1.5 - 1.9e-3 in the mode by setting (default path: 2.5e-3): below 2.5e-3, absolute error below 4e-3 logit units, classes ranked as the oracle
+    batch below 0.016, five times smaller than the other draws' -- so the same absolute error (2e-3 logit units = 2e-5 in
+    the cosine) reads as 1.3e-3 of max |logit| (7.9e-4, inside, on the same draw with the weights rounded to 16 bit).  Held here at what it measures, so that the number in the docs stays true:
+    1.3 - 1.9e-3 in the mode by setting (default path: 2.5e-3): below 2.5e-3, absolute error below 4e-3 logit units, classes ranked as the oracle
     ranks them wherever the oracle separates them by more than the error."""
     import torch
     from eventclip_amd import clip as eclip
