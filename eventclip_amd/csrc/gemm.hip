@@ -1029,6 +1029,14 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
                     acc[mq * 4 + mt][nqb * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                         gb[jj], gm[mt], acc[mq * 4 + mt][nqb * 2 + jj], 0, 0, 0, scale_w, 0, 0x7f7f7f7f);
             }
+            // The products are pinned HERE: without it hipcc sank the sixteen MFMAs of phase A out of their slot between the two
+            // barriers (sched_barrier does not stop the IR-level code motion of a pure intrinsic whose results are only read
+            // an iteration later) down in front of phase B's -- an empty `s_setprio 1; s_setprio 0` was left where the matrix pipe
+            // should have been busy, and both waves of a SIMD ran their products in the same interval: an e4m3 K tile took 3900
+            // cycles against the 16-bit tile's 2400 (profiles/r6_gemm.md 1)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                asm volatile("" : "+v"(acc[mq * 4 + mt][0]), "+v"(acc[mq * 4 + mt][1]), "+v"(acc[mq * 4 + mt][2]), "+v"(acc[mq * 4 + mt][3]));
             __builtin_amdgcn_s_setprio(0);
         }
     };

@@ -77,3 +77,19 @@ def test_attention_kernels_have_no_unpadded_asm_hazards():
     sys.path.insert(0, os.path.join(root, 'tools'))
     import check_attn_isa
     assert check_attn_isa.main() == 0
+
+
+def test_gemm_kernels_keep_their_schedule_and_have_no_scratch():
+    """csrc/gemm.hip's persistent kernel issues the MFMAs of a phase between `s_setprio 1` / `s_setprio 0`, closed by barriers,
+    and counts its vmcnt waits: tools/check_gemm_isa.py compiles the file and checks every instantiation for scratch, for an
+    empty matrix-pipe slot (round 6: hipcc had sunk the e4m3 MFMAs of a phase in front of the next phase's) and for phases
+    whose MFMA count is neither 32 (16-bit) nor 16 (e4m3)."""
+    import shutil
+    import sys
+    import pytest
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_gemm_isa
+    assert check_gemm_isa.main() == 0

@@ -15,6 +15,8 @@ ap.add_argument('--k', type=int, default=1024)
 ap.add_argument('--frames', type=int, default=256)
 ap.add_argument('--epi', default='store16')
 ap.add_argument('--iters', type=int, default=3)
+ap.add_argument('--lo', default='none', choices=['none', 'f16', 'e4m3'],
+                help='add the lo product A_lo W^T as 16-bit or as e4m3 operands (round 6: the split-operand blocks of the tolerance mode)')
 a = ap.parse_args()
 M = a.frames * 257
 A = torch.randn(M, a.k, device='cuda').half()
@@ -26,6 +28,14 @@ if a.epi == 'resid_hl':      # the tower's residual GEMMs: hi / lo planes + row 
     kw = dict(aux=torch.zeros(M, a.n, device='cuda', dtype=torch.float16), row_sums=torch.zeros(M, a.n // 64, 2, device='cuda'))
 elif a.epi.endswith('_ln'):  # ... its LayerNorm-finishing GEMMs
     kw = dict(row_stats=ops.row_stats(A), col_sums=W.float().sum(1).contiguous())
+if a.lo != 'none':
+    full = torch.randn(M, a.k, device='cuda')
+    A = full.half()
+    if a.lo == 'f16':
+        kw['A_lo'] = (full - A.float()).half()
+    else:
+        kw['A_lo8'], kw['W8'] = ops.quantize_e4m3(full - A.float(), exp=12), ops.quantize_e4m3(W)
+    del full
 for _ in range(a.iters):
     ops.gemm(A, W, bias, a.epi, out=out, variant=a.variant, **kw)
 torch.cuda.synchronize()
