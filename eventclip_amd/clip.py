@@ -185,11 +185,11 @@ DEFAULT_PRECISE_ATTN_BLOCKS = (5, 7)
 #     at 8.0e-4 (profiles/r6_parity_seeds*.txt).  The pair outside is configs[2] draw 5 on fp32 weights (1.3e-3): two classes, its
 #     largest |logit| is 1.5 of a possible 100 -- a denominator 5 x smaller than the other draws', not a larger error; the same draw on
 #     16-bit weights is inside (7.9e-4).
-# Price on the bench config (profiles/r6_tolerance_price.txt): 1.46 x the default step on a checkpoint stored in 16 bit, 1.83 x on
+# Price on the bench config (profiles/r6_g_bench.json): 1.43 x the default step on a checkpoint stored in 16 bit, 1.77 x on
 # fp32 weights; with 16-bit lo products 1.64 x / 2.09 x.  bench.py prices exactly these counts.
 TOLERANCE_MODE = ((16, 12), (16, 12))
-# ... with the lo products of those blocks as e4m3 operands (ec_vit_weights.lo_fp8, round 6): an e4m3 lo product costs 0.58 - 0.60 of
-# the f16 one (66 / 99 ms of the mode's step on 16-bit / fp32 weights) and costs the mode's error + 4 % on average, + 17 % on
+# ... with the lo products of those blocks as e4m3 operands (ec_vit_weights.lo_fp8, round 6): an e4m3 lo product costs 0.51 - 0.52 of
+# the f16 one (~80 / ~125 ms of the mode's step on 16-bit / fp32 weights) and costs the mode's error + 4 % on average, + 17 % on
 # configs[4] (profiles/r6_tolerance_sweep_fp8.txt; profiles/r6_parity_seeds*.txt measure the mode as shipped)
 DEFAULT_LO_FP8 = True
 

@@ -561,7 +561,7 @@ typedef struct {
                                    a lo part, a copy of its hi part) as e4m3 (ec_layernorm_hl8), c_fc writes the MLP activation's lo
                                    part as e4m3 (ec_gemm_args.aux_e4m3), and the GEMMs multiply them with the e4m3 weights of
                                    ec_block_weights (*_w8 / *_wlo8) at twice the f16 rate and half the operand bytes: an e4m3 lo
-                                   product measures 0.58 - 0.60 of the f16 one.  The lo part is ~2^-11 of its hi part, so e4m3's 2^-4
+                                   product measures 0.51 - 0.52 of the f16 one.  The lo part is ~2^-11 of its hi part, so e4m3's 2^-4
                                    still removes ~95 % of the 16-bit operand-rounding error (profiles/r6_fp8_model_8_5.txt, r6_parity_seeds.txt).
                                    out_proj (the attention output's lo part) stays 16-bit.  Needs the *_w8 fields of every split-operand block. */
 } ec_vit_weights;
