@@ -1017,17 +1017,24 @@ __global__ __launch_bounds__(512) void gemm2pp_kernel(const GemmArgs g)
     // long as both operands hold the same ones, and both are read through the same layout.  scale_w: e8m0 x 4 (uniform).
     auto mma2_g = [&](int mq, int nqa, i32x8(&ga)[2], int nqb, i32x8(&gb)[2], int scale_w) {
         if constexpr (SEG == 2) {
+            // operand format code of the scaled product: 0 = e4m3.  -DEC_LO_FMT=2 (e2m3, FP6) / 4 (e2m1, FP4) in a diagnostic
+            // build reads the SAME bytes as that format -- a rate experiment with meaningless results (tools/build_lo_fmt_probe.sh)
+#if defined(EC_GEMM_DIAG) && defined(EC_LO_FMT)
+            constexpr int FMT = EC_LO_FMT;
+#else
+            constexpr int FMT = 0;
+#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
                     acc[mq * 4 + mt][nqa * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                        ga[jj], gm[mt], acc[mq * 4 + mt][nqa * 2 + jj], 0, 0, 0, scale_w, 0, 0x7f7f7f7f);
+                        ga[jj], gm[mt], acc[mq * 4 + mt][nqa * 2 + jj], FMT, FMT, 0, scale_w, 0, 0x7f7f7f7f);
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
                     acc[mq * 4 + mt][nqb * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                        gb[jj], gm[mt], acc[mq * 4 + mt][nqb * 2 + jj], 0, 0, 0, scale_w, 0, 0x7f7f7f7f);
+                        gb[jj], gm[mt], acc[mq * 4 + mt][nqb * 2 + jj], FMT, FMT, 0, scale_w, 0, 0x7f7f7f7f);
             }
             // The products are pinned HERE: without it hipcc sank the sixteen MFMAs of phase A out of their slot between the two
             // barriers (sched_barrier does not stop the IR-level code motion of a pure intrinsic whose results are only read
