@@ -195,6 +195,10 @@ def parity_seeds_summary():
     ph = os.path.join(ROOT, 'profiles', 'r6_parity_seeds_held_out.json')
     if os.path.exists(ph):       # eight more draws per config that no setting was chosen on
         out['held_out_draws_8_to_15'] = dict(json.load(open(ph))['settings'], source='profiles/r6_parity_seeds_held_out.json')
+    ph16 = os.path.join(ROOT, 'profiles', 'r6_parity_seeds_16bit_weights_held_out.json')
+    if os.path.exists(ph16):     # ... and those held-out draws on weights rounded to 16 bit
+        out['held_out_draws_8_to_15_on_16_bit_weights'] = dict(json.load(open(ph16))['settings'],
+                                                               source='profiles/r6_parity_seeds_16bit_weights_held_out.json')
     return out
 
 
