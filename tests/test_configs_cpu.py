@@ -29,6 +29,8 @@ def test_every_config_ships_its_draws():
     for c in range(5):                                        # the held-out draws (never used to pick a setting) ship too
         for d in cc.HELD_OUT_DRAWS:
             assert cc.load_golden(c, 'signal', d) is not None, (c, d)
+        for d in all_draws:                                   # ... and every draw on weights rounded to 16 bit
+            assert cc.load_golden(c, 'signal16', d) is not None, (c, d)
 
 
 def test_configs0_oracle_reproduces_the_shipped_outputs():
